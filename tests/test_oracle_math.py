@@ -202,6 +202,7 @@ def test_cg_h_semantics():
     assert k2 == k - 1 and rn2 >= 1e-16
     k3, u3, _ = zo.cg(P.rowptr, P.cols, P.vals, P.b, kmax=5, rtol=1e-8)
     assert k3 == 5
-    # warm start at the solution converges in one step
-    k4, _, _ = zo.cg(P.rowptr, P.cols, P.vals, P.b, x0=u, kmax=50, rtol=1e-3)
-    assert k4 == 1
+    # the test is relative to the INITIAL residual (rnorm0, src/cg.h:53,78): a warm start from a
+    # partly converged x needs further iterations for the same rtol and stays a solution
+    k4, u4, _ = zo.cg(P.rowptr, P.cols, P.vals, P.b, x0=u3, kmax=1000, rtol=1e-8)
+    assert 1 < k4 <= k and np.linalg.norm(u4 - u) < 1e-6 * np.linalg.norm(u)
