@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): DoF/s for `ZZZ Assemble matrix` + `ZZZ Assemble vector` + `ZZZ Solve`,
+and the CG-SpMV achieved HBM GB/s against the 8 TB/s peak.
+
+One "step" = one pass of the hot path over the synthetic cube problem: assemble A, assemble b,
+solve A u = b with Jacobi-preconditioned CG to rtol 1e-8 (the reference run
+`--problem_type poisson --order 1 --scaling_type strong --ndofs 10000000 -ksp_type cg
+-pc_type jacobi -ksp_rtol 1e-8`, BASELINE.json configs[1]; mesh 108x103x111 refined once ==
+216x206x222, 10 016 937 dofs, src/mesh.cpp:78-151).  Inputs (mesh, dofmap, coefficients, sparsity
+pattern) are resident in HBM before the timed region, as in the reference where they are built
+before the ZZZ Assemble matrix timer starts (src/poisson_problem.cpp:33-123).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+For N > 1 the cube is cut into N z-slabs, one per GPU (strong scaling: the total problem is
+fixed); halo exchange and the CG all-reduces run on RCCL inside libzzz_hip; torch.distributed
+(gloo) is plumbing only: unique-id broadcast, barrier, max over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "performance-test_amd"))
+
+import numpy as np  # noqa: E402
+
+import zzz  # noqa: E402  (ctypes mirror of include/zzz_abi.h; loads libzzz_hip.so, fails loudly if absent)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def spmv_algorithmic_bytes(n, nnz):
+    # fp64 values + int32 columns + int32 row pointers + x read once + y written
+    return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def cpu_baseline(P, ctx, iters_gpu, sample_iters=20):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample
+    of the same workload: full matrix + vector assembly, then `sample_iters` Jacobi-PCG iterations,
+    extrapolated to the iteration count the GPU solve needed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import zzz_oracle as zo
+
+    cores = os.cpu_count() or 1
+    zo.set_num_threads(cores)
+    rowptr32, cols, _ = ctx.csr_download(values=False)
+    rowptr = rowptr32.astype(np.int64)
+    bc = P.bc_marker()
+    t0 = time.perf_counter()
+    vals = zo.assemble_matrix(P.form, P.order, P.x, P.cells, P.cell_dofs, bc, rowptr, cols)
+    t1 = time.perf_counter()
+    b = zo.assemble_vector(P.form, P.order, P.x, P.cells, P.cell_dofs, P.f, P.g,
+                           P.facets if P.form == 0 else None, bc)
+    t2 = time.perf_counter()
+    zo.pcg(rowptr, cols, vals, b, rtol=1e-8, max_it=2)  # touch pages
+    t3 = time.perf_counter()
+    zo.pcg(rowptr, cols, vals, b, rtol=1e-8, max_it=sample_iters)
+    t4 = time.perf_counter()
+    t_iter = (t4 - t3) / sample_iters
+    t_total = (t2 - t0) + t_iter * iters_gpu
+    n = P.n_owned * P.bs
+    return {
+        "value": n / t_total, "unit": "DoF/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/zzz_oracle.c with OpenMP on {cores} threads, same {n}-dof problem: full matrix assembly "
+                   f"{t1 - t0:.2f} s + vector assembly {t2 - t1:.2f} s + {sample_iters} Jacobi-PCG iterations at "
+                   f"{t_iter * 1e3:.1f} ms each, extrapolated to the {iters_gpu} iterations of the GPU solve"),
+        "assemble_s": t2 - t0, "ms_per_cg_iteration": t_iter * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ndofs", type=int, default=10000000)
+    ap.add_argument("--problem_type", default="poisson")
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--scaling_type", default="strong")
+    ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none"])
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1:
+        # libzzz_hip (and its HIP runtime, /opt/rocm) is already loaded; torch is used for gloo only
+        import torch
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    bs = 3 if a.problem_type == "elasticity" else 1
+    strong = a.scaling_type == "strong"
+    nx, ny, nz, r = zzz.mesh_size(a.ndofs, strong, world, bs, a.order)
+    nx, ny, nz = nx << r, ny << r, nz << r
+    P = zzz.Part(a.problem_type, a.order, nx, ny, nz, world, rank)
+    ctx = zzz.Context(local_rank)
+    if world > 1:
+        import torch
+
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(zzz.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, src=0)
+        ctx.comm_init(world, rank, bytes(uid.numpy().tobytes()))
+    ctx.upload_part(P)
+    if world > 1:
+        ctx.upload_halo(P)
+    ctx.pattern_build()  # fem::petsc::create_matrix: outside ZZZ Assemble matrix (src/poisson_problem.cpp:122-123)
+    nrows, ncols, nnz = ctx.csr_sizes()
+    pc = zzz.PC_JACOBI if a.pc == "jacobi" else zzz.PC_NONE
+
+    def step(profile=False):
+        t = {}
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.assemble_matrix(P.form)
+        ctx.sync()
+        t["assemble_matrix"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        ctx.assemble_vector(P.form)
+        ctx.sync()
+        t["assemble_vector"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        it, rn, r0 = ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, profile=profile)
+        ctx.sync()
+        t["solve"] = time.perf_counter() - t2
+        t["iters"] = it
+        t["rel"] = rn / r0 if r0 else 0.0
+        return t
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ctx.sync()
+    t_begin = time.perf_counter()
+    phases = []
+    for _ in range(a.steps):
+        phases.append(step(profile=True))
+    ctx.sync()
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    spmv_ms, spmv_n = ctx.profile()
+    unorm = ctx.vec_norm(zzz.VEC_U)
+    ndofs_global = P.global_dofs_total
+    ms_per_step = elapsed / a.steps * 1e3
+    iters = phases[-1]["iters"]
+
+    out = None
+    if rank == 0:
+        alg_bytes = spmv_algorithmic_bytes(nrows, nnz)
+        achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+        avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
+        out = {
+            "metric": "DoF/s for ZZZ Assemble + ZZZ Solve; CG-SpMV achieved HBM GB/s vs peak",
+            "value": ndofs_global / (elapsed / a.steps),
+            "unit": "DoF/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": (f"--problem_type {a.problem_type} --order {a.order} --scaling_type {a.scaling_type} "
+                             f"--ndofs {a.ndofs} -ksp_type cg -pc_type {a.pc} -ksp_rtol {a.rtol:g}"),
+                "mesh": f"{nx}x{ny}x{nz} sub-cubes x 6 tetrahedra", "dofs": ndofs_global,
+                "cells": P.global_cells, "nnz_rank0": nnz, "rows_rank0": nrows,
+                "partition": f"{world} z-slab(s)", "krylov_iterations": iters,
+                "relative_residual": phases[-1]["rel"], "solution_norm": unorm,
+            },
+            "phases_ms": {"ZZZ Assemble matrix": avg("assemble_matrix") * 1e3,
+                          "ZZZ Assemble vector": avg("assemble_vector") * 1e3, "ZZZ Solve": avg("solve") * 1e3},
+            "dofs_per_s": {"ZZZ Assemble matrix": ndofs_global / avg("assemble_matrix"),
+                           "ZZZ Assemble vector": ndofs_global / avg("assemble_vector"),
+                           "ZZZ Solve": ndofs_global / avg("solve"),
+                           "iterations x dofs / ZZZ Solve": iters * ndofs_global / avg("solve")},
+            "roofline": {"bound": "hbm", "kernel": "spmv_tile_kernel (CG SpMV + <p,Ap> partials)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, ctx, iters)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,228 @@
+/*
+ * zzz_abi.h -- C-ABI of libzzz_hip.so: the MI355X (gfx950) implementation of the hot path of
+ * FEniCS/performance-test (`ZZZ Assemble matrix`, `ZZZ Assemble vector`, `ZZZ Solve`).
+ *
+ * Plain C, POD arguments, opaque context handle.  No exceptions cross this boundary: every
+ * function returns 0 on success or a ZZZ_ERR_* code; zzz_last_error() gives the message.
+ * The host owns host arrays; every upload copies; the library owns all device memory behind the
+ * context; downloads write into caller-provided buffers.  One driving host thread per context;
+ * one context per GPU (one process or thread per GPU).  Work is enqueued asynchronously on the
+ * context's HIP stream except the *_download functions, zzz_sync and zzz_cg_solve.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository, FEniCS/performance-test @ 2025-10-24).
+ *
+ * Data model at the boundary (one mesh partition = one context, DOLFINx's per-rank view):
+ *   - block dofs [0, n_owned) are owned, [n_owned, n_owned + n_ghost) are ghosts
+ *     (the la::Vector layout, src/cgpoisson_problem.cpp:212-215); scalar dof = bs*block + comp.
+ *   - the partition holds every cell that touches an owned dof (one ghost-cell layer), so each
+ *     owned matrix row and vector entry is complete locally and MatAssemblyBegin/End's row
+ *     exchange (src/poisson_problem.cpp:132-133) and b.scatter_rev (:154) have nothing to ship.
+ *   - cell_dofs follows the Basix local ordering of the P_k gll_warped tetrahedron
+ *     (src/poisson_problem.cpp:35-38): vertices 0-3; edges e0=(2,3) e1=(1,3) e2=(1,2) e3=(0,3)
+ *     e4=(0,2) e5=(0,1), k-1 dofs each, counted from the edge's first local vertex; faces
+ *     f0=(1,2,3) f1=(0,2,3) f2=(0,1,3) f3=(0,1,2).  Edge orientation is resolved by the dofmap
+ *     (the caller permutes an edge's sub-dofs when the global direction opposes the local one),
+ *     so the kernels apply no dof transformation -- DOLFINx's convention for Lagrange.
+ *   - the matrix is scalar CSR (PETSc AIJ): fp64 values, int32 columns (local scalar indices,
+ *     ascending within a row), int32 row pointers; rows = owned scalar dofs.
+ */
+#ifndef ZZZ_ABI_H
+#define ZZZ_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zzz_ctx zzz_ctx;
+
+/* error classes */
+enum
+{
+  ZZZ_OK = 0,
+  ZZZ_ERR_ARG = 1,     /* bad argument / call order (std::runtime_error in the reference) */
+  ZZZ_ERR_HIP = 2,     /* HIP runtime error */
+  ZZZ_ERR_RCCL = 3,    /* RCCL error / librccl not loadable */
+  ZZZ_ERR_NO_GPU = 4,  /* no usable device: the library has no CPU fallback */
+  ZZZ_ERR_LIMIT = 5,   /* size exceeds an int32 index range */
+  ZZZ_ERR_DIVERGED = 6 /* Krylov breakdown (non-finite scalar) */
+};
+
+/* forms: form_Poisson_{a,L,M}{1,2,3}, form_Elasticity_{a,L}{1,2,3}
+ * (src/poisson_problem.cpp:110-119, src/elasticity_problem.cpp:184-191) */
+enum
+{
+  ZZZ_FORM_POISSON = 0,
+  ZZZ_FORM_ELASTICITY = 1
+};
+
+enum
+{
+  ZZZ_COEFF_F = 0, /* "w0" of L (src/poisson_problem.cpp:117, src/elasticity_problem.cpp:189) */
+  ZZZ_COEFF_G = 1  /* "w1" of the Poisson L (src/poisson_problem.cpp:117) */
+};
+
+enum
+{
+  ZZZ_VEC_B = 0, /* right-hand side b */
+  ZZZ_VEC_U = 1  /* solution u (u->x() of the reference) */
+};
+
+/* Krylov options: what "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-8" selects through
+ * solver.set_from_options() (src/poisson_problem.cpp:169), or the arguments of linalg::cg
+ * (src/cg.h:39-40). */
+enum
+{
+  ZZZ_PC_NONE = 0,
+  ZZZ_PC_JACOBI = 1
+};
+enum
+{
+  ZZZ_NORM_PRECONDITIONED = 0, /* PETSc KSPCG default: ||M^-1 r|| */
+  ZZZ_NORM_UNPRECONDITIONED = 1,
+  ZZZ_NORM_NATURAL = 2
+};
+enum
+{
+  ZZZ_CG_PETSC = 0, /* KSPCG: zero initial guess, test dp <= max(rtol*dp0, atol) */
+  ZZZ_CG_CGH = 1    /* src/cg.h:38-86: x is the initial guess, test <r,r>/<r0,r0> < rtol^2 */
+};
+enum
+{
+  ZZZ_OP_CSR = 0,    /* assembled operator (poisson, elasticity) */
+  ZZZ_OP_MATFREE = 1 /* cgpoisson's action(a, un) (src/cgpoisson_problem.cpp:193-230) */
+};
+
+typedef struct
+{
+  int32_t variant;  /* ZZZ_CG_PETSC | ZZZ_CG_CGH */
+  int32_t pc;       /* ZZZ_PC_* (ZZZ_CG_CGH requires ZZZ_PC_NONE) */
+  int32_t norm;     /* ZZZ_NORM_* (ZZZ_CG_PETSC only) */
+  int32_t op;       /* ZZZ_OP_* */
+  int32_t max_it;   /* -ksp_max_it (PETSc default 10000) / kmax */
+  int32_t profile;  /* != 0: record HIP events around the SpMV launches (see zzz_profile_get) */
+  double rtol;      /* -ksp_rtol / rtol */
+  double atol;      /* -ksp_atol (PETSc default 1e-50); unused by ZZZ_CG_CGH */
+} zzz_solver_opts;
+
+/* ---- library / device ------------------------------------------------------------------ */
+
+/* Number of visible GPUs; 0 when there is none (then zzz_ctx_create fails with ZZZ_ERR_NO_GPU). */
+int zzz_device_count(void);
+
+/* Creates a context on `device`.  Replaces MPI_Init/PetscInitialize as far as this path needs
+ * them (src/main.cpp:245-258). */
+int zzz_ctx_create(int device, zzz_ctx** out);
+void zzz_ctx_destroy(zzz_ctx* ctx);
+
+/* Message of the last error on ctx (or of the last context-less error when ctx == NULL).
+ * The pointer stays valid until the next call on that context. */
+const char* zzz_last_error(const zzz_ctx* ctx);
+
+/* Blocks until all enqueued work is done (the driver calls it before stopping a ZZZ timer). */
+int zzz_sync(zzz_ctx* ctx);
+
+/* ---- problem data (feed) --------------------------------------------------------------- */
+
+/* mesh::Geometry::x() and the geometry dofmap of the mesh handed to problem()
+ * (src/poisson_problem.h:19-23; created at src/mesh.cpp:184-186).
+ * x: nverts*3 row-major; cell_verts: ncells*4 local vertex indices. */
+int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncells, const int32_t* cell_verts);
+
+/* fem::create_functionspace's DofMap + IndexMap (src/poisson_problem.cpp:43-44,
+ * src/elasticity_problem.cpp:108-111).  order 1..3 (form_*.at(order-1),
+ * src/poisson_problem.cpp:117); bs 1 or 3; cell_dofs: ncells*nd block indices, nd = 4/10/20. */
+int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs, int64_t n_owned, int64_t n_ghost);
+
+/* fem::DirichletBC(u0 == 0, bdofs) (src/poisson_problem.cpp:53-77, src/elasticity_problem.cpp:119-145).
+ * bc_dofs: local SCALAR dof indices, owned and ghost, all with value 0. */
+int zzz_bc_upload(zzz_ctx* ctx, int64_t nbc, const int32_t* bc_dofs);
+
+/* Exterior facets integrated by the `ds` term of L (src/Poisson.py:32); what
+ * create_entities(2)/create_connectivity(2,3) prepare (src/main.cpp:147-148).
+ * pairs: nfacets*(cell, local facet 0..3); local facet f is opposite local vertex f. */
+int zzz_facets_upload(zzz_ctx* ctx, int64_t nfacets, const int32_t* cell_facet_pairs);
+
+/* Nodal values of a coefficient Function (f->interpolate / g->interpolate,
+ * src/poisson_problem.cpp:83-106, src/elasticity_problem.cpp:153-176): (n_owned+n_ghost)*bs. */
+int zzz_coeff_upload(zzz_ctx* ctx, int which, const double* values);
+
+/* ---- matrix ---------------------------------------------------------------------------- */
+
+/* fem::petsc::create_matrix(*a) (src/poisson_problem.cpp:122-123): sparsity pattern of the
+ * owned rows + the dof->cell adjacency the assembly kernels walk.  Outside `ZZZ Assemble
+ * matrix`, inside `ZZZ Assemble`, as in the reference. */
+int zzz_csr_pattern_build(zzz_ctx* ctx);
+
+/* Sizes of the local matrix: owned scalar rows, local scalar columns (owned+ghost), nonzeros. */
+int zzz_csr_sizes(const zzz_ctx* ctx, int64_t* nrows, int64_t* ncols, int64_t* nnz);
+
+/* Copies the CSR arrays to the host (parity checks; MatView-like).  NULL pointers are skipped.
+ * rowptr: nrows+1, cols/vals: nnz. */
+int zzz_csr_download(zzz_ctx* ctx, int32_t* rowptr, int32_t* cols, double* vals);
+
+/* Replaces the matrix values (testing the solver on a given operator). vals: nnz. */
+int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals);
+
+/* The `ZZZ Assemble matrix` block (src/poisson_problem.cpp:125-139,
+ * src/elasticity_problem.cpp:199-213): tabulate_tensor of form a per cell, constrained rows and
+ * columns zeroed, ADD into A, then set_diagonal = 1.0 on constrained rows. */
+int zzz_assemble_matrix(zzz_ctx* ctx, int form);
+
+/* The `ZZZ Assemble vector` block (src/poisson_problem.cpp:146-157,
+ * src/elasticity_problem.cpp:220-231): cell (+ exterior-facet) integrals of L into b,
+ * apply_lifting (identically zero: u0 == 0), bc->set. */
+int zzz_assemble_vector(zzz_ctx* ctx, int form);
+
+/* ---- vectors --------------------------------------------------------------------------- */
+
+/* Host <-> device copies of b or u; n_owned*bs entries (owned part). */
+int zzz_vec_download(zzz_ctx* ctx, int which, double* out);
+int zzz_vec_upload(zzz_ctx* ctx, int which, const double* in);
+
+/* la::norm(*u->x()) (src/main.cpp:229): l2 norm over owned entries, summed over all ranks. */
+int zzz_vec_norm(zzz_ctx* ctx, int which, double* out);
+
+/* y = A x on host vectors of the owned size (ghost values of x are exchanged first when a
+ * communicator is attached).  MatMult; for parity checks of the SpMV kernel alone. */
+int zzz_spmv(zzz_ctx* ctx, const double* x, double* y);
+
+/* ---- solve ----------------------------------------------------------------------------- */
+
+/* solver_function(u, b) (src/poisson_problem.cpp:164-179; src/cgpoisson_problem.cpp:178-244;
+ * called under `ZZZ Solve` at src/main.cpp:208-211).  Solves A u = b with the vectors held by
+ * the context; returns the Krylov iteration count like KSPGetIterationNumber / cg()'s k.
+ * rnorm[0] = final norm, rnorm[1] = initial norm (variant CGH: <r,r> and <r0,r0>). */
+int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* opts, int* iters, double* rnorm);
+
+/* Residual-norm history of the last solve (KSPGetResidualHistory): copies min(n, iters+1). */
+int zzz_cg_history(zzz_ctx* ctx, int n, double* out);
+
+/* Average duration (ms) and count of the SpMV launches event-timed during the last
+ * zzz_cg_solve with opts.profile != 0. */
+int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);
+
+/* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */
+
+#define ZZZ_UNIQUE_ID_BYTES 128
+
+/* ncclGetUniqueId on the root; ship the bytes to the other ranks out of band (the driver's
+ * threads share memory; bench.py broadcasts them).  Replaces MPI_COMM_WORLD bootstrap. */
+int zzz_comm_unique_id(void* id /* ZZZ_UNIQUE_ID_BYTES */);
+
+/* ncclCommInitRank: attaches this context as `rank` of `nranks`. */
+int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id);
+
+/* The forward scatter of common::Scatterer / IndexMap (src/cgpoisson_problem.cpp:187-190,
+ * 225-229): for neighbour k, this rank sends x[send_idx[send_off[k]..send_off[k+1])] (owned
+ * block dofs) and receives recv_cnt[k] block values into the next ghost slots; the ghost block
+ * range is ordered by neighbour, then by the sender's send order. */
+int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const int64_t* send_off,
+                    const int32_t* send_idx, const int64_t* recv_cnt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZZZ_ABI_H */

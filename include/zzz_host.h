@@ -1,0 +1,88 @@
+/*
+ * zzz_host.h -- C API of libzzz_host.so: the host-side "feed" of the hot path (pure C++, no GPU).
+ *
+ * It produces, per mesh partition, exactly the arrays the device library (zzz_abi.h) consumes:
+ * what DOLFINx hands to fem::assemble_* in the reference -- geometry, cell connectivity, dofmap,
+ * Dirichlet dofs, exterior facets, interpolated coefficients and the ghost-exchange plan.
+ * Reference code it replaces (paths relative to FEniCS/performance-test):
+ *   mesh size search .............. src/mesh.cpp:44-151 (restated exactly)
+ *   create_box + partitioning ..... src/mesh.cpp:153-186 (own structured z-slab partitioner;
+ *                                   ParMETIS/SCOTCH/KaHIP and Plaza refinement are out of scope:
+ *                                   a mesh "refined r times" is generated directly at its
+ *                                   effective size (Nx<<r) x (Ny<<r) x (Nz<<r), which has the same
+ *                                   entity and dof counts, src/mesh.cpp:44-54)
+ *   create_functionspace .......... src/poisson_problem.cpp:35-44, src/elasticity_problem.cpp:103-111
+ *   locate_entities/locate_dofs ... src/poisson_problem.cpp:58-75, src/elasticity_problem.cpp:125-142
+ *   Function::interpolate ......... src/poisson_problem.cpp:83-106, src/elasticity_problem.cpp:153-176
+ *   create_entities(2) / ds facets  src/main.cpp:147-148
+ *   IndexMap / Scatterer plan ..... src/cgpoisson_problem.cpp:187-190
+ */
+#ifndef ZZZ_HOST_H
+#define ZZZ_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zzzh_part zzzh_part;
+
+/* src/mesh.cpp:56-74; -1 for an unsupported order */
+int64_t zzzh_num_pdofs(int64_t i, int64_t j, int64_t k, int nrefine, int order);
+/* src/mesh.cpp:44-54: out = {vertices, edges, faces, cells} */
+void zzzh_num_entities(int64_t i, int64_t j, int64_t k, int nrefine, int64_t out[4]);
+/* src/mesh.cpp:78-151: out = {Nx, Ny, Nz, r}. strong != 0: ndofs is the total; else per process. */
+void zzzh_mesh_size(int64_t ndofs, int strong, int64_t num_processes, int64_t dofs_per_node, int order,
+                    int64_t out[4]);
+
+enum
+{
+  ZZZH_POISSON = 0,   /* scalar P_k, Dirichlet on x = 0 and x = 1, coefficients f and g */
+  ZZZH_ELASTICITY = 1 /* vector P_k (bs 3), Dirichlet on y = 0, coefficient f */
+};
+
+/* indices into the sizes array of zzzh_part_sizes */
+enum
+{
+  ZZZH_NVERTS = 0,
+  ZZZH_NCELLS,      /* local cells (owned layers + one ghost layer) */
+  ZZZH_NOWNED,      /* owned block dofs */
+  ZZZH_NGHOST,      /* ghost block dofs */
+  ZZZH_ND,          /* dofs per cell */
+  ZZZH_BS,
+  ZZZH_NFACETS,     /* exterior facets among the local cells */
+  ZZZH_NBC,         /* constrained local scalar dofs */
+  ZZZH_NNEIGH,
+  ZZZH_NSEND,       /* total block dofs sent per forward scatter */
+  ZZZH_GLOBAL_DOFS, /* index_map.size_global() * bs (src/main.cpp:178-180) */
+  ZZZH_GLOBAL_CELLS,
+  ZZZH_OWNED_CELLS, /* cells of this partition's own layers (sum over parts = global cells) */
+  ZZZH_OWN_OFFSET,  /* global block index of local owned dof 0 (owned range is contiguous) */
+  ZZZH_NSIZES
+};
+
+/* Partition `part` of `nparts` z-slabs of the nx*ny*nz unit cube (6 tetrahedra per sub-cube).
+ * Returns NULL on bad arguments (message via zzzh_last_error). */
+zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part);
+void zzzh_part_destroy(zzzh_part* p);
+const char* zzzh_last_error(void);
+
+void zzzh_part_sizes(const zzzh_part* p, int64_t sizes[ZZZH_NSIZES]);
+const double* zzzh_part_x(const zzzh_part* p);             /* nverts*3 */
+const int32_t* zzzh_part_cells(const zzzh_part* p);        /* ncells*4, vertices ascending */
+const int32_t* zzzh_part_cell_dofs(const zzzh_part* p);    /* ncells*nd */
+const int32_t* zzzh_part_facets(const zzzh_part* p);       /* nfacets*2 */
+const int32_t* zzzh_part_bc_dofs(const zzzh_part* p);      /* nbc local scalar dofs */
+const double* zzzh_part_dof_x(const zzzh_part* p);         /* (nowned+nghost)*3 */
+const int64_t* zzzh_part_global_dofs(const zzzh_part* p);  /* (nowned+nghost) global block index */
+const double* zzzh_part_coeff(const zzzh_part* p, int which); /* 0: f, 1: g (Poisson only) */
+const int32_t* zzzh_part_neigh(const zzzh_part* p);        /* nneigh ranks */
+const int64_t* zzzh_part_send_off(const zzzh_part* p);     /* nneigh+1 */
+const int32_t* zzzh_part_send_idx(const zzzh_part* p);     /* nsend owned block dofs */
+const int64_t* zzzh_part_recv_cnt(const zzzh_part* p);     /* nneigh */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

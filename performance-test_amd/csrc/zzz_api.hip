@@ -1,0 +1,556 @@
+// C-ABI entry points of libzzz_hip.so (declared, with the reference interfaces they replace, in
+// include/zzz_abi.h).  There is no CPU fallback: without a usable GPU every entry point fails.
+#include "zzz_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+
+namespace zzz
+{
+static std::mutex g_err_mutex;
+static std::string g_err;
+
+void set_global_error(const char* msg)
+{
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  g_err = msg;
+}
+
+int fail(zzz_ctx* ctx, int code, const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    set_global_error(buf);
+  return code;
+}
+
+static int ndofs_cell(int order) { return order == 1 ? 4 : order == 2 ? 10 : order == 3 ? 20 : -1; }
+
+template <typename T>
+static int upload(zzz_ctx* ctx, DevBuf<T>& d, const T* h, size_t n, size_t pad = 0)
+{
+  ZZZ_HIP(ctx, d.alloc(n + pad));
+  if (pad)
+    ZZZ_HIP(ctx, hipMemsetAsync(d.p + n, 0, pad * sizeof(T), ctx->stream));
+  if (n)
+    ZZZ_HIP(ctx, hipMemcpyAsync(d.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+} // namespace zzz
+
+using namespace zzz;
+
+extern "C" {
+
+int zzz_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int zzz_ctx_create(int device, zzz_ctx** out)
+{
+  if (!out)
+    return fail(nullptr, ZZZ_ERR_ARG, "zzz_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, ZZZ_ERR_NO_GPU, "no HIP device available (%s); libzzz_hip has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return fail(nullptr, ZZZ_ERR_ARG, "device %d out of range [0, %d)", device, n);
+  e = hipSetDevice(device);
+  if (e != hipSuccess)
+    return fail(nullptr, ZZZ_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+  zzz_ctx* ctx = new zzz_ctx();
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess)
+  {
+    delete ctx;
+    return fail(nullptr, ZZZ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  if (ctx->state.alloc(1) != hipSuccess || ctx->red.alloc(16) != hipSuccess
+      || hipHostMalloc((void**)&ctx->h_state, 8 * sizeof(zzz::CgState), hipHostMallocDefault) != hipSuccess)
+  {
+    zzz_ctx_destroy(ctx);
+    return fail(nullptr, ZZZ_ERR_HIP, "context allocation failed");
+  }
+  memset(ctx->h_state, 0, 8 * sizeof(zzz::CgState));
+  *out = ctx;
+  return ZZZ_OK;
+}
+
+void zzz_ctx_destroy(zzz_ctx* ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream)
+    (void)hipStreamSynchronize(ctx->stream);
+  comm_destroy(ctx);
+  for (hipEvent_t ev : ctx->ev)
+    (void)hipEventDestroy(ev);
+  if (ctx->h_state)
+    (void)hipHostFree(ctx->h_state);
+  if (ctx->stream)
+    (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* zzz_last_error(const zzz_ctx* ctx)
+{
+  if (ctx)
+    return ctx->err.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  static thread_local std::string copy;
+  copy = g_err;
+  return copy.c_str();
+}
+
+int zzz_sync(zzz_ctx* ctx)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  ZZZ_HIP(ctx, hipSetDevice(ctx->device));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
+#define ZZZ_ENTER(ctx)                                          \
+  do                                                            \
+  {                                                             \
+    if (!(ctx))                                                 \
+      return fail(nullptr, ZZZ_ERR_ARG, "NULL context");        \
+    ZZZ_HIP(ctx, hipSetDevice((ctx)->device));                  \
+  } while (0)
+
+int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncells, const int32_t* cell_verts)
+{
+  ZZZ_ENTER(ctx);
+  if (nverts <= 0 || ncells <= 0 || !x || !cell_verts)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_mesh_upload: empty mesh or NULL array");
+  if (nverts > INT32_MAX / 4 || ncells > INT32_MAX / 32)
+    return fail(ctx, ZZZ_ERR_LIMIT, "mesh too large for int32 indexing (%lld vertices, %lld cells)", (long long)nverts,
+                (long long)ncells);
+  for (int64_t i = 0; i < 4 * ncells; ++i)
+    if (cell_verts[i] < 0 || cell_verts[i] >= nverts)
+      return fail(ctx, ZZZ_ERR_ARG, "cell_verts[%lld] = %d out of range", (long long)i, cell_verts[i]);
+  ctx->nverts = nverts;
+  ctx->ncells = ncells;
+  ctx->h_cell_verts.assign(cell_verts, cell_verts + 4 * ncells);
+  int rc = upload(ctx, ctx->x, x, (size_t)(3 * nverts));
+  if (rc)
+    return rc;
+  rc = upload(ctx, ctx->cell_verts, cell_verts, (size_t)(4 * ncells));
+  ctx->have_pattern = ctx->have_matrix = false;
+  return rc;
+}
+
+int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs, int64_t n_owned, int64_t n_ghost)
+{
+  ZZZ_ENTER(ctx);
+  const int nd = ndofs_cell(order);
+  if (nd < 0) // form_poisson_a.at(order - 1) throws std::out_of_range in the reference
+    return fail(ctx, ZZZ_ERR_ARG, "order %d not supported (1..3)", order);
+  if (bs != 1 && bs != 3)
+    return fail(ctx, ZZZ_ERR_ARG, "block size %d not supported (1 or 3)", bs);
+  if (ctx->ncells == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_dofmap_upload before zzz_mesh_upload");
+  if (n_owned <= 0 || n_ghost < 0 || !cell_dofs)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_dofmap_upload: bad sizes");
+  const int64_t nloc = n_owned + n_ghost;
+  if (nloc * bs > INT32_MAX - 8)
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld local scalar dofs exceed int32", (long long)(nloc * bs));
+  for (int64_t i = 0; i < ctx->ncells * nd; ++i)
+    if (cell_dofs[i] < 0 || cell_dofs[i] >= nloc)
+      return fail(ctx, ZZZ_ERR_ARG, "cell_dofs[%lld] = %d out of range", (long long)i, cell_dofs[i]);
+  ctx->order = order;
+  ctx->bs = bs;
+  ctx->nd = nd;
+  ctx->n_owned = n_owned;
+  ctx->n_ghost = n_ghost;
+  ctx->h_cell_dofs.assign(cell_dofs, cell_dofs + ctx->ncells * nd);
+  int rc = upload(ctx, ctx->cell_dofs, cell_dofs, (size_t)(ctx->ncells * nd));
+  if (rc)
+    return rc;
+  const size_t nv = (size_t)ctx->nloc();
+  // bc marker: nothing constrained until zzz_bc_upload; facet mask: no exterior facets until uploaded
+  ZZZ_HIP(ctx, ctx->bc.alloc(nv));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bc.p, 0, nv, ctx->stream));
+  ZZZ_HIP(ctx, ctx->facet_mask.alloc((size_t)ctx->ncells));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->facet_mask.p, 0, (size_t)ctx->ncells, ctx->stream));
+  ctx->nfacets = 0;
+  DevBuf<double>* vecs[] = {&ctx->b, &ctx->u, &ctx->r, &ctx->z, &ctx->p, &ctx->w, &ctx->dinv, &ctx->coeff[0], &ctx->coeff[1]};
+  for (DevBuf<double>* v : vecs)
+  {
+    ZZZ_HIP(ctx, v->alloc(nv));
+    ZZZ_HIP(ctx, hipMemsetAsync(v->p, 0, nv * sizeof(double), ctx->stream));
+  }
+  ZZZ_HIP(ctx, ctx->part_a.alloc(4096));
+  ZZZ_HIP(ctx, ctx->part_b.alloc(4096));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_bc = false;
+  ctx->have_coeff[0] = ctx->have_coeff[1] = false;
+  ctx->have_pattern = ctx->have_matrix = false;
+  return ZZZ_OK;
+}
+
+int zzz_bc_upload(zzz_ctx* ctx, int64_t nbc, const int32_t* bc_dofs)
+{
+  ZZZ_ENTER(ctx);
+  if (ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_bc_upload before zzz_dofmap_upload");
+  if (nbc < 0 || (nbc > 0 && !bc_dofs))
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_bc_upload: bad arguments");
+  std::vector<uint8_t> m((size_t)ctx->nloc(), 0);
+  for (int64_t i = 0; i < nbc; ++i)
+  {
+    if (bc_dofs[i] < 0 || bc_dofs[i] >= ctx->nloc())
+      return fail(ctx, ZZZ_ERR_ARG, "bc_dofs[%lld] = %d out of range", (long long)i, bc_dofs[i]);
+    m[bc_dofs[i]] = 1;
+  }
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->bc.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_bc = true;
+  return ZZZ_OK;
+}
+
+int zzz_facets_upload(zzz_ctx* ctx, int64_t nfacets, const int32_t* pairs)
+{
+  ZZZ_ENTER(ctx);
+  if (ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_facets_upload before zzz_dofmap_upload");
+  if (nfacets < 0 || (nfacets > 0 && !pairs))
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_facets_upload: bad arguments");
+  std::vector<uint8_t> m((size_t)ctx->ncells, 0);
+  for (int64_t i = 0; i < nfacets; ++i)
+  {
+    const int32_t c = pairs[2 * i], f = pairs[2 * i + 1];
+    if (c < 0 || c >= ctx->ncells || f < 0 || f > 3)
+      return fail(ctx, ZZZ_ERR_ARG, "facet %lld = (%d, %d) out of range", (long long)i, c, f);
+    m[c] |= (uint8_t)(1u << f);
+  }
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->facet_mask.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->nfacets = nfacets;
+  return ZZZ_OK;
+}
+
+int zzz_coeff_upload(zzz_ctx* ctx, int which, const double* values)
+{
+  ZZZ_ENTER(ctx);
+  if (ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_coeff_upload before zzz_dofmap_upload");
+  if ((which != ZZZ_COEFF_F && which != ZZZ_COEFF_G) || !values)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_coeff_upload: bad arguments");
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->coeff[which].p, values, (size_t)ctx->nloc() * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_coeff[which] = true;
+  return ZZZ_OK;
+}
+
+int zzz_csr_pattern_build(zzz_ctx* ctx)
+{
+  ZZZ_ENTER(ctx);
+  if (ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_pattern_build before zzz_dofmap_upload");
+  const int nd = ctx->nd, bs = ctx->bs;
+  const int64_t nb = ctx->n_owned, nc = ctx->ncells;
+  const int32_t* cd = ctx->h_cell_dofs.data();
+  // owned block dof -> incident cells, ascending (counting sort over cells)
+  std::vector<int32_t> off((size_t)nb + 1, 0);
+  for (int64_t c = 0; c < nc; ++c)
+    for (int i = 0; i < nd; ++i)
+    {
+      const int32_t d = cd[c * nd + i];
+      if (d < nb)
+        off[(size_t)d + 1]++;
+    }
+  for (int64_t i = 0; i < nb; ++i)
+  {
+    if ((int64_t)off[i] + off[i + 1] > INT32_MAX)
+      return fail(ctx, ZZZ_ERR_LIMIT, "dof->cell adjacency exceeds int32");
+    off[i + 1] += off[i];
+  }
+  std::vector<int32_t> adj((size_t)off[nb]);
+  {
+    std::vector<int32_t> pos(off.begin(), off.end() - 1);
+    for (int64_t c = 0; c < nc; ++c)
+      for (int i = 0; i < nd; ++i)
+      {
+        const int32_t d = cd[c * nd + i];
+        if (d < nb)
+          adj[(size_t)pos[d]++] = (int32_t)c;
+      }
+  }
+  // block pattern: per owned block dof, the sorted union of the dofs of its cells
+  std::vector<int32_t> bptr((size_t)nb + 1, 0);
+  std::vector<std::vector<int32_t>> chunks;
+  const int64_t CH = 1 << 16;
+  const int64_t nch = (nb + CH - 1) / CH;
+  chunks.resize((size_t)nch);
+  bool overflow = false;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t ch = 0; ch < nch; ++ch)
+  {
+    std::vector<int32_t> tmp;
+    std::vector<int32_t>& out = chunks[(size_t)ch];
+    const int64_t lo = ch * CH, hi = std::min(nb, lo + CH);
+    for (int64_t r = lo; r < hi; ++r)
+    {
+      tmp.clear();
+      for (int32_t a = off[r]; a < off[r + 1]; ++a)
+        tmp.insert(tmp.end(), cd + (int64_t)adj[a] * nd, cd + (int64_t)adj[a] * nd + nd);
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      bptr[(size_t)r + 1] = (int32_t)tmp.size();
+      out.insert(out.end(), tmp.begin(), tmp.end());
+    }
+  }
+  int64_t nblk = 0;
+  for (int64_t r = 0; r < nb; ++r)
+    nblk += bptr[r + 1];
+  const int64_t nnz = nblk * bs * bs;
+  if (nnz > INT32_MAX - 8)
+    overflow = true;
+  if (overflow)
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range", (long long)nnz);
+  const int64_t nrows = nb * bs;
+  std::vector<int32_t> rowptr((size_t)nrows + 1);
+  std::vector<int32_t> cols((size_t)nnz);
+  rowptr[0] = 0;
+  for (int64_t r = 0; r < nb; ++r)
+    for (int c = 0; c < bs; ++c)
+      rowptr[(size_t)(r * bs + c) + 1] = rowptr[(size_t)(r * bs + c)] + bptr[r + 1] * bs;
+  int maxrow = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(max : maxrow)
+  for (int64_t ch = 0; ch < nch; ++ch)
+  {
+    const std::vector<int32_t>& in = chunks[(size_t)ch];
+    const int64_t lo = ch * CH, hi = std::min(nb, lo + CH);
+    size_t q = 0;
+    for (int64_t r = lo; r < hi; ++r)
+    {
+      const int nbc = bptr[r + 1];
+      maxrow = std::max(maxrow, nbc * bs);
+      for (int c = 0; c < bs; ++c)
+      {
+        int32_t* dst = cols.data() + rowptr[(size_t)(r * bs + c)];
+        for (int k = 0; k < nbc; ++k)
+          for (int d = 0; d < bs; ++d)
+            dst[k * bs + d] = in[q + k] * bs + d;
+      }
+      q += (size_t)nbc;
+    }
+  }
+  chunks.clear();
+  ctx->nrows = nrows;
+  ctx->ncols = ctx->nloc();
+  ctx->nnz = nnz;
+  ctx->max_row_nnz = maxrow;
+  int rc = upload(ctx, ctx->rowptr, rowptr.data(), rowptr.size());
+  if (!rc)
+    rc = upload(ctx, ctx->cols, cols.data(), cols.size(), 8);
+  if (!rc)
+    rc = upload(ctx, ctx->adj_off, off.data(), off.size());
+  if (!rc)
+    rc = upload(ctx, ctx->adj_cells, adj.data(), adj.size());
+  if (rc)
+    return rc;
+  ZZZ_HIP(ctx, ctx->vals.alloc((size_t)nnz + 8));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->vals.p, 0, ((size_t)nnz + 8) * sizeof(double), ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = build_spmv_tiles(ctx, rowptr);
+  if (!rc)
+    rc = build_asm_tiles(ctx, rowptr);
+  if (rc)
+    return rc;
+  ctx->have_pattern = true;
+  ctx->have_matrix = false;
+  return ZZZ_OK;
+}
+
+int zzz_csr_sizes(const zzz_ctx* ctx, int64_t* nrows, int64_t* ncols, int64_t* nnz)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  if (!ctx->have_pattern)
+    return fail(const_cast<zzz_ctx*>(ctx), ZZZ_ERR_ARG, "no sparsity pattern yet");
+  if (nrows)
+    *nrows = ctx->nrows;
+  if (ncols)
+    *ncols = ctx->ncols;
+  if (nnz)
+    *nnz = ctx->nnz;
+  return ZZZ_OK;
+}
+
+int zzz_csr_download(zzz_ctx* ctx, int32_t* rowptr, int32_t* cols, double* vals)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "no sparsity pattern yet");
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rowptr)
+    ZZZ_HIP(ctx, hipMemcpy(rowptr, ctx->rowptr.p, ((size_t)ctx->nrows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (cols)
+    ZZZ_HIP(ctx, hipMemcpy(cols, ctx->cols.p, (size_t)ctx->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (vals)
+    ZZZ_HIP(ctx, hipMemcpy(vals, ctx->vals.p, (size_t)ctx->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  return ZZZ_OK;
+}
+
+int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_pattern || !vals)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_upload_values: no pattern or NULL values");
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->vals.p, vals, (size_t)ctx->nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_matrix = true;
+  return ZZZ_OK;
+}
+
+int zzz_assemble_matrix(zzz_ctx* ctx, int form)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_assemble_matrix before zzz_csr_pattern_build");
+  if (form != ZZZ_FORM_POISSON && form != ZZZ_FORM_ELASTICITY)
+    return fail(ctx, ZZZ_ERR_ARG, "unknown form %d", form);
+  int rc = launch_assemble_matrix(ctx, form);
+  if (!rc)
+    ctx->have_matrix = true;
+  return rc;
+}
+
+int zzz_assemble_vector(zzz_ctx* ctx, int form)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_assemble_vector before zzz_csr_pattern_build");
+  if (form != ZZZ_FORM_POISSON && form != ZZZ_FORM_ELASTICITY)
+    return fail(ctx, ZZZ_ERR_ARG, "unknown form %d", form);
+  if (!ctx->have_coeff[ZZZ_COEFF_F] || (form == ZZZ_FORM_POISSON && !ctx->have_coeff[ZZZ_COEFF_G]))
+    return fail(ctx, ZZZ_ERR_ARG, "coefficient(s) of L not uploaded");
+  return launch_assemble_vector(ctx, form);
+}
+
+static zzz::DevBuf<double>* pick_vec(zzz_ctx* ctx, int which)
+{
+  return which == ZZZ_VEC_B ? &ctx->b : which == ZZZ_VEC_U ? &ctx->u : nullptr;
+}
+
+int zzz_vec_download(zzz_ctx* ctx, int which, double* out)
+{
+  ZZZ_ENTER(ctx);
+  DevBuf<double>* v = pick_vec(ctx, which);
+  if (!v || !v->p || !out)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_vec_download: bad vector / not allocated");
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZZZ_HIP(ctx, hipMemcpy(out, v->p, (size_t)(ctx->n_owned * ctx->bs) * sizeof(double), hipMemcpyDeviceToHost));
+  return ZZZ_OK;
+}
+
+int zzz_vec_upload(zzz_ctx* ctx, int which, const double* in)
+{
+  ZZZ_ENTER(ctx);
+  DevBuf<double>* v = pick_vec(ctx, which);
+  if (!v || !v->p || !in)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_vec_upload: bad vector / not allocated");
+  ZZZ_HIP(ctx, hipMemcpyAsync(v->p, in, (size_t)(ctx->n_owned * ctx->bs) * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
+int zzz_vec_norm(zzz_ctx* ctx, int which, double* out)
+{
+  ZZZ_ENTER(ctx);
+  DevBuf<double>* v = pick_vec(ctx, which);
+  if (!v || !v->p || !out)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_vec_norm: bad vector / not allocated");
+  return vec_norm_local(ctx, v->p, ctx->n_owned * ctx->bs, out);
+}
+
+int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_matrix || !x || !y)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv: no matrix or NULL vector");
+  const size_t n = (size_t)(ctx->n_owned * ctx->bs);
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, ctx->p.n * sizeof(double), ctx->stream));
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->p.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->comm)
+  {
+    int rc = comm_halo_forward(ctx, ctx->p.p);
+    if (rc)
+      return rc;
+  }
+  int rc = launch_spmv(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
+  if (rc)
+    return rc;
+  ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
+int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
+{
+  ZZZ_ENTER(ctx);
+  if (!o)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_solve: NULL options");
+  if (o->op == ZZZ_OP_CSR && !ctx->have_matrix)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_solve: matrix not assembled");
+  if (o->op != ZZZ_OP_CSR && o->op != ZZZ_OP_MATFREE)
+    return fail(ctx, ZZZ_ERR_ARG, "unknown operator kind %d", o->op);
+  if (o->variant != ZZZ_CG_PETSC && o->variant != ZZZ_CG_CGH)
+    return fail(ctx, ZZZ_ERR_ARG, "unknown CG variant %d", o->variant);
+  if (o->variant == ZZZ_CG_CGH && o->pc != ZZZ_PC_NONE)
+    return fail(ctx, ZZZ_ERR_ARG, "src/cg.h has no preconditioner: use pc = ZZZ_PC_NONE");
+  if (o->pc != ZZZ_PC_NONE && o->pc != ZZZ_PC_JACOBI)
+    return fail(ctx, ZZZ_ERR_ARG, "unsupported preconditioner %d (none, jacobi)", o->pc);
+  if (o->pc == ZZZ_PC_JACOBI && o->op != ZZZ_OP_CSR)
+    return fail(ctx, ZZZ_ERR_ARG, "Jacobi needs the assembled operator");
+  if (o->norm < 0 || o->norm > 2)
+    return fail(ctx, ZZZ_ERR_ARG, "unknown norm type %d", o->norm);
+  if (o->max_it < 0 || o->max_it > (1 << 24))
+    return fail(ctx, ZZZ_ERR_ARG, "max_it %d out of range", o->max_it);
+  return cg_solve(ctx, o, iters, rnorm);
+}
+
+int zzz_cg_history(zzz_ctx* ctx, int n, double* out)
+{
+  if (!ctx || !out || n < 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_history: bad arguments");
+  const size_t m = std::min((size_t)n, ctx->history.size());
+  std::copy(ctx->history.begin(), ctx->history.begin() + (long)m, out);
+  return ZZZ_OK;
+}
+
+int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  if (spmv_avg_ms)
+    *spmv_avg_ms = ctx->prof_spmv_ms;
+  if (spmv_count)
+    *spmv_count = ctx->prof_spmv_n;
+  return ZZZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,340 @@
+// FE assembly on gfx950 (K1-K5 of SURVEY.md 2c): replaces the FFCx tabulate_tensor kernels plus
+// fem::assemble_matrix / assemble_vector / set_diagonal / DirichletBC::set
+// (src/poisson_problem.cpp:125-157, src/elasticity_problem.cpp:199-231).
+//
+// Row-gather formulation: one thread owns one scalar matrix row (vector entry) and walks the cells
+// incident to its dof in ascending cell order, evaluating only ITS row of each element tensor.
+//   * no atomics, no colouring: every CSR value is written exactly once, by one thread, and the
+//     per-entry summation order (ascending cell index) is the serial CPU order => reproducible;
+//   * the workgroup's CSR segment (values + column indices) lives in LDS while it is accumulated,
+//     so the column search never touches HBM, and it leaves as one contiguous coalesced store;
+//   * geometry / dof indices of a cell are re-read by its nd owners, but those reads hit L2 (the
+//     rows of a workgroup are neighbours); flops are redundant by nd and free (fp64 VALU, no MFMA:
+//     the path is bound by the 8 B/nonzero it must write, not by arithmetic).
+// Constrained rows and columns are zeroed as the element tensor is produced, and the diagonal of a
+// constrained row is set to 1.0 (fem::set_diagonal) by the thread that owns the row.
+#include "zzz_device.h"
+#include "zzz_internal.h"
+
+namespace zzz
+{
+constexpr int ASM_BLOCK = 256;
+constexpr int ASM_NNZ = 4096; // LDS: 32 KiB values + 16 KiB columns per workgroup
+
+struct Geom
+{
+  double adet;    // |det J|
+  double K[3][3]; // J^-1: K[al][a] = dX_al/dx_a
+};
+
+__device__ inline void load_cell(const double* __restrict__ x, const int4 v, double p[4][3])
+{
+  const int vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const double* q = x + 3 * (int64_t)vv[k];
+    p[k][0] = q[0];
+    p[k][1] = q[1];
+    p[k][2] = q[2];
+  }
+}
+
+__device__ inline void geometry(const double p[4][3], Geom& G)
+{
+  double J[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int al = 0; al < 3; ++al)
+      J[a][al] = p[al + 1][a] - p[0][a];
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+  const double id = 1.0 / det;
+  G.adet = fabs(det);
+  G.K[0][0] = c00 * id;
+  G.K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+  G.K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+  G.K[1][0] = -c01 * id;
+  G.K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+  G.K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+  G.K[2][0] = c02 * id;
+  G.K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+  G.K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+}
+
+// physical gradients of the four P1 hat functions: g[i][a] = sum_al K[al][a] * dphi_i/dX_al
+__device__ inline void p1_grads(const Geom& G, double g[4][3])
+{
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    g[1][a] = G.K[0][a];
+    g[2][a] = G.K[1][a];
+    g[3][a] = G.K[2][a];
+    g[0][a] = -(G.K[0][a] + G.K[1][a] + G.K[2][a]);
+  }
+}
+
+__device__ inline double sel3(double a0, double a1, double a2, int c) { return c == 0 ? a0 : (c == 1 ? a1 : a2); }
+
+__device__ inline int find_pos(const int32_t* __restrict__ c, int len, int32_t col)
+{
+  int lo = 0, hi = len - 1;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (c[mid] < col)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ---- matrix, P1, BS = 1 (Poisson a1, src/Poisson.py:31) or 3 (Elasticity a1, src/Elasticity.py:39)
+template <int BS>
+__global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restrict__ x,
+                                                           const int32_t* __restrict__ cell_verts,
+                                                           const int32_t* __restrict__ cell_dofs,
+                                                           const int32_t* __restrict__ adj_off,
+                                                           const int32_t* __restrict__ adj_cells,
+                                                           const uint8_t* __restrict__ bc,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ cols, double* __restrict__ vals,
+                                                           const int32_t* __restrict__ tiles)
+{
+  __shared__ double vals_s[ASM_NNZ];
+  __shared__ int32_t cols_s[ASM_NNZ];
+  const int d0 = tiles[blockIdx.x], d1 = tiles[blockIdx.x + 1];
+  const int row0 = d0 * BS, row1 = d1 * BS;
+  const int s = rowptr[row0], e = rowptr[row1];
+  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+  {
+    cols_s[k] = cols[s + k];
+    vals_s[k] = 0.0;
+  }
+  __syncthreads();
+  const int r = row0 + (int)threadIdx.x;
+  if (r < row1)
+  {
+    const int i = r / BS, c = r % BS;
+    const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
+    const bool bcr = bc[r] != 0;
+    constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
+    constexpr double mu = Ey / (2.0 * (1.0 + nu));
+    constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+    {
+      const int cell = adj_cells[a];
+      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
+      const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
+      const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
+      double p[4][3], g[4][3];
+      Geom G;
+      load_cell(x, v, p);
+      geometry(p, G);
+      p1_grads(G, g);
+      const int li = (dofs[0] == i) ? 0 : (dofs[1] == i) ? 1 : (dofs[2] == i) ? 2 : 3;
+      const double w = G.adet / 6.0; // reference volume
+      double gi[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k == li)
+        {
+          gi[0] = g[k][0];
+          gi[1] = g[k][1];
+          gi[2] = g[k][2];
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        const int pos = find_pos(cols_s + a0, len, dofs[j] * BS);
+        const double gg = gi[0] * g[j][0] + gi[1] * g[j][1] + gi[2] * g[j][2];
+        if (BS == 1)
+        {
+          double val = w * gg;
+          if (bcr || bc[dofs[j]])
+            val = 0.0;
+          vals_s[a0 + pos] += val;
+        }
+        else
+        {
+          const double gic = sel3(gi[0], gi[1], gi[2], c), gjc = sel3(g[j][0], g[j][1], g[j][2], c);
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+          {
+            // mu (delta_cd g_i.g_j + d_d phi_i d_c phi_j) + lambda d_c phi_i d_d phi_j
+            double val = w * (mu * ((c == d ? gg : 0.0) + gi[d] * gjc) + lmbda * gic * g[j][d]);
+            if (bcr || bc[dofs[j] * 3 + d])
+              val = 0.0;
+            vals_s[a0 + pos + d] += val;
+          }
+        }
+      }
+    }
+    if (bcr) // fem::set_diagonal: 1.0 on constrained rows
+      vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+    vals[s + k] = vals_s[k];
+}
+
+// ---- vector, P1: Poisson L1 = f v dx + g v ds (src/Poisson.py:32), Elasticity L1 = f.v dx (:40)
+template <int BS>
+__global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restrict__ x,
+                                                           const int32_t* __restrict__ cell_verts,
+                                                           const int32_t* __restrict__ cell_dofs,
+                                                           const int32_t* __restrict__ adj_off,
+                                                           const int32_t* __restrict__ adj_cells,
+                                                           const uint8_t* __restrict__ bc,
+                                                           const uint8_t* __restrict__ facet_mask,
+                                                           const double* __restrict__ f, const double* __restrict__ gc,
+                                                           double* __restrict__ b, int64_t nrows)
+{
+  const int64_t r = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x;
+  if (r >= nrows)
+    return;
+  const int i = (int)(r / BS), c = (int)(r % BS);
+  double sum = 0.0;
+  for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+  {
+    const int cell = adj_cells[a];
+    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
+    const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
+    const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
+    double p[4][3];
+    Geom G;
+    load_cell(x, v, p);
+    geometry(p, G);
+    const int li = (dofs[0] == i) ? 0 : (dofs[1] == i) ? 1 : (dofs[2] == i) ? 2 : 3;
+    double fl[4], fs = 0.0, fi = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      fl[j] = f[(int64_t)dofs[j] * BS + c];
+      fs += fl[j];
+      if (j == li)
+        fi = fl[j];
+    }
+    sum += G.adet * ((fs + fi) / 120.0); // |detJ| * sum_j (1+delta_ij)/120 f_j
+    if (BS == 1)
+    {
+      const unsigned m = facet_mask[cell];
+      if (m)
+      {
+        double gl[4], gi = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          gl[j] = gc[dofs[j]];
+          if (j == li)
+            gi = gl[j];
+        }
+#pragma unroll
+        for (int lf = 0; lf < 4; ++lf)
+          if (((m >> lf) & 1u) && lf != li)
+          {
+            // facet lf = the three vertices other than lf
+            const int q0 = lf == 0 ? 1 : 0, q1 = lf <= 1 ? 2 : 1, q2 = lf == 3 ? 2 : 3;
+            double e1[3], e2[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+            {
+              e1[k] = p[q1][k] - p[q0][k];
+              e2[k] = p[q2][k] - p[q0][k];
+            }
+            const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2],
+                         cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const double scale = sqrt(cx * cx + cy * cy + cz * cz); // 2 * area
+            const double gs = gl[q0] + gl[q1] + gl[q2];
+            sum += scale * ((gs + gi) / 24.0); // 2 area * sum_j (1+delta_ij)/24 g_j
+          }
+      }
+    }
+  }
+  b[r] = bc[r] ? 0.0 : sum; // bc->set(b), u0 == 0
+}
+
+int build_asm_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr)
+{
+  const int bs = ctx->bs;
+  const int64_t nb = ctx->n_owned;
+  std::vector<int32_t> tiles;
+  tiles.push_back(0);
+  int64_t d = 0;
+  while (d < nb)
+  {
+    int64_t q = d;
+    const int64_t s = h_rowptr[d * bs];
+    while (q < nb && (q + 1 - d) * bs <= ASM_BLOCK && h_rowptr[(q + 1) * bs] - s <= ASM_NNZ)
+      ++q;
+    if (q == d)
+      return fail(ctx, ZZZ_ERR_LIMIT, "rows of block dof %lld exceed the assembly tile (%d nonzeros)", (long long)d,
+                  ASM_NNZ);
+    tiles.push_back((int32_t)q);
+    d = q;
+  }
+  ctx->n_asm_tiles = (int64_t)tiles.size() - 1;
+  ZZZ_HIP(ctx, ctx->asm_tile.alloc(tiles.size()));
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->asm_tile.p, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
+int launch_assemble_matrix(zzz_ctx* ctx, int form)
+{
+  const int bs = form == ZZZ_FORM_ELASTICITY ? 3 : 1;
+  if (bs != ctx->bs)
+    return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
+  const dim3 grid((unsigned)ctx->n_asm_tiles), block(ASM_BLOCK);
+  if (ctx->order == 1)
+  {
+    if (bs == 1)
+      hipLaunchKernelGGL(asm_matrix_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                         ctx->asm_tile.p);
+    else
+      hipLaunchKernelGGL(asm_matrix_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                         ctx->asm_tile.p);
+  }
+  else
+    return fail(ctx, ZZZ_ERR_ARG, "order %d matrix assembly is not built yet", ctx->order);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+
+int launch_assemble_vector(zzz_ctx* ctx, int form)
+{
+  const int bs = form == ZZZ_FORM_ELASTICITY ? 3 : 1;
+  if (bs != ctx->bs)
+    return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
+  const int64_t nrows = ctx->n_owned * bs;
+  const dim3 grid((unsigned)((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+  if (ctx->order == 1)
+  {
+    if (bs == 1)
+      hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
+                         ctx->coeff[1].p, ctx->b.p, nrows);
+    else
+      hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
+                         (const double*)nullptr, ctx->b.p, nrows);
+  }
+  else
+    return fail(ctx, ZZZ_ERR_ARG, "order %d vector assembly is not built yet", ctx->order);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+
+int launch_matfree_action(zzz_ctx* ctx, const double*, double*, double*, int*)
+{
+  return fail(ctx, ZZZ_ERR_ARG, "matrix-free operator is not built yet");
+}
+} // namespace zzz

@@ -1,0 +1,454 @@
+// Conjugate gradients on the GPU: linalg::cg of src/cg.h:38-86 (variant CGH) and PETSc's KSPCG with
+// PCJACOBI / PCNONE as the reference selects it at src/poisson_problem.cpp:168-177 (variant PETSC).
+//
+// All Krylov scalars live in device memory; the host only enqueues.  One iteration is
+//   k_update_p : p = z + (beta_k / beta_{k-1}) p                       (axpy, src/cg.h:82)
+//   [halo]     : ghost values of p from their owners                   (scatter_fwd)
+//   spmv       : w = A p, per-workgroup partials of <p, w>             (action, src/cg.h:62)
+//   k_reduce   : <p,w> -> alpha = beta_k / <p,w>   [+ RCCL all-reduce]  (inner_product, src/cg.h:65)
+//   k_update_xr: x += alpha p; r -= alpha w; z = D^-1 r; partials of <r,z> and the test norm
+//                                                                      (axpy x2, src/cg.h:68,71)
+//   k_reduce   : beta_{k+1}, norm, convergence test  [+ all-reduce]     (squared_norm, src/cg.h:74-79)
+// Every kernel returns at once when the device-side `converged` flag is set; the host polls that
+// flag a few iterations behind the queue, so the returned iteration count is exact.
+// Reductions use fixed trees (per-workgroup partials, then one workgroup) => reproducible runs.
+// HBM traffic per iteration beyond the SpMV: 24 B/row (p update) + 56 B/row (x, r, z update).
+#include "zzz_device.h"
+#include "zzz_internal.h"
+
+#include <cmath>
+
+namespace zzz
+{
+constexpr int VB = 256;        // threads per workgroup of the vector kernels
+constexpr int VGRID_MAX = 2048; // 8 workgroups per CU
+
+struct CgParams
+{
+  int variant, pc, norm;
+  double rtol, atol;
+};
+
+__global__ void k_extract_dinv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                               const double* __restrict__ vals, double* __restrict__ dinv, int64_t n, int jacobi)
+{
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+  {
+    double d = 1.0;
+    if (jacobi)
+    {
+      d = 0.0;
+      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (cols[k] == (int32_t)r)
+          d = vals[k];
+      if (d == 0.0)
+        d = 1.0; // PCJACOBI replaces zero diagonal entries by one
+    }
+    dinv[r] = 1.0 / d;
+  }
+}
+
+// r = b - w (w = A x0, or nothing when x0 == 0); z = dinv r; partials: pa = <r,z>, pb = test norm^2
+__global__ __launch_bounds__(VB) void k_init_residual(const double* __restrict__ b, const double* __restrict__ w,
+                                                      const double* __restrict__ dinv, double* __restrict__ r,
+                                                      double* __restrict__ z, int64_t n, int norm,
+                                                      double* __restrict__ pa, double* __restrict__ pb)
+{
+  __shared__ double sh[VB / 64];
+  double sa = 0, sb = 0;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    const double ri = w ? (-1.0 * w[i] + b[i]) : b[i]; // axpy(r, -1, y, b), src/cg.h:47
+    const double zi = dinv[i] * ri;
+    r[i] = ri;
+    z[i] = zi;
+    sa += ri * zi;
+    sb += (norm == ZZZ_NORM_UNPRECONDITIONED) ? ri * ri : zi * zi;
+  }
+  const double ta = block_reduce_sum(sa, sh);
+  const double tb = block_reduce_sum(sb, sh);
+  if (threadIdx.x == 0)
+  {
+    pa[blockIdx.x] = ta;
+    pb[blockIdx.x] = tb;
+  }
+}
+
+__global__ __launch_bounds__(VB) void k_update_p(const CgState* __restrict__ st, const double* __restrict__ beta_hist,
+                                                 int it, const double* __restrict__ z, double* __restrict__ p, int64_t n)
+{
+  if (st->converged)
+    return;
+  const double bcoef = (it == 0) ? 0.0 : beta_hist[it] / beta_hist[it - 1];
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+    p[i] = (it == 0) ? z[i] : bcoef * p[i] + z[i];
+}
+
+__global__ __launch_bounds__(VB) void k_update_xr(const CgState* __restrict__ st, const double* __restrict__ alpha_p,
+                                                  const double* __restrict__ p, const double* __restrict__ w,
+                                                  const double* __restrict__ dinv, double* __restrict__ x,
+                                                  double* __restrict__ r, double* __restrict__ z, int64_t n, int norm,
+                                                  double* __restrict__ pa, double* __restrict__ pb)
+{
+  if (st->converged)
+    return;
+  __shared__ double sh[VB / 64];
+  const double alpha = *alpha_p;
+  double sa = 0, sb = 0;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    x[i] = alpha * p[i] + x[i];           // src/cg.h:68
+    const double ri = -alpha * w[i] + r[i]; // src/cg.h:71
+    const double zi = dinv[i] * ri;
+    r[i] = ri;
+    z[i] = zi;
+    sa += ri * zi;
+    sb += (norm == ZZZ_NORM_UNPRECONDITIONED) ? ri * ri : zi * zi;
+  }
+  const double ta = block_reduce_sum(sa, sh);
+  const double tb = block_reduce_sum(sb, sh);
+  if (threadIdx.x == 0)
+  {
+    pa[blockIdx.x] = ta;
+    pb[blockIdx.x] = tb;
+  }
+}
+
+// one workgroup: out[j] = sum(parts_j[0..np)), j < nvec
+__device__ inline double reduce_parts(const double* __restrict__ parts, int np, double* sh)
+{
+  double s = 0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x)
+    s += parts[i];
+  return block_reduce_sum(s, sh);
+}
+
+// scalar logic after <p,w>: alpha = beta_it / <p,w>
+__device__ inline void scalar_alpha(CgState* st, const double* beta_hist, int it, double pw, double* alpha)
+{
+  const double a = beta_hist[it] / pw;
+  *alpha = a;
+  if (!isfinite(a) && st->converged == 0)
+  {
+    st->converged = 2;
+    st->iters = it;
+  }
+}
+
+// scalar logic after <r,z> and the norm partial: `it` = number of completed iterations
+__device__ inline void scalar_beta(CgState* st, double* beta_hist, double* dp_hist, int it, double rz, double nn,
+                                   CgParams P)
+{
+  beta_hist[it] = rz;
+  if (P.variant == ZZZ_CG_CGH)
+  {
+    // src/cg.h:53-55,74-79: rnorm = <r,r>; break when rnorm/rnorm0 < rtol^2 (strict), no test at k = 0
+    dp_hist[it] = rz;
+    st->dp = rz;
+    if (it == 0)
+    {
+      st->dp0 = rz;
+      st->ttol = P.rtol * P.rtol;
+    }
+    else if (rz / st->dp0 < P.rtol * P.rtol)
+    {
+      st->converged = 1;
+      st->iters = it;
+    }
+    return;
+  }
+  const double dp = (P.norm == ZZZ_NORM_NATURAL) ? sqrt(fabs(rz)) : sqrt(nn);
+  dp_hist[it] = dp;
+  st->dp = dp;
+  if (it == 0)
+  {
+    st->dp0 = dp;
+    st->ttol = fmax(P.rtol * dp, P.atol);
+  }
+  if (!isfinite(dp))
+  {
+    st->converged = 2;
+    st->iters = it;
+  }
+  else if (dp <= st->ttol) // KSPConvergedDefault
+  {
+    st->converged = 1;
+    st->iters = it;
+  }
+}
+
+// mode 0: reduce + scalar logic (single rank); mode 1: reduce only, sums to out[] (multi rank)
+__global__ __launch_bounds__(1024) void k_reduce_alpha(CgState* st, const double* __restrict__ parts, int np,
+                                                       const double* beta_hist, int it, double* alpha, double* out,
+                                                       int mode)
+{
+  if (st->converged)
+    return;
+  __shared__ double sh[16];
+  const double pw = reduce_parts(parts, np, sh);
+  if (threadIdx.x == 0)
+  {
+    if (mode == 0)
+      scalar_alpha(st, beta_hist, it, pw, alpha);
+    else
+      out[0] = pw;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_beta(CgState* st, const double* __restrict__ pa,
+                                                      const double* __restrict__ pb, int np, double* beta_hist,
+                                                      double* dp_hist, int it, CgParams P, double* out, int mode)
+{
+  if (st->converged)
+    return;
+  __shared__ double sh[16];
+  const double rz = reduce_parts(pa, np, sh);
+  const double nn = reduce_parts(pb, np, sh);
+  if (threadIdx.x == 0)
+  {
+    if (mode == 0)
+      scalar_beta(st, beta_hist, dp_hist, it, rz, nn, P);
+    else
+    {
+      out[0] = rz;
+      out[1] = nn;
+    }
+  }
+}
+
+// multi-rank: scalar logic on the all-reduced sums
+__global__ void k_scalar_alpha(CgState* st, const double* red, const double* beta_hist, int it, double* alpha)
+{
+  if (st->converged)
+    return;
+  scalar_alpha(st, beta_hist, it, red[0], alpha);
+}
+__global__ void k_scalar_beta(CgState* st, const double* red, double* beta_hist, double* dp_hist, int it, CgParams P)
+{
+  if (st->converged)
+    return;
+  scalar_beta(st, beta_hist, dp_hist, it, red[0], red[1], P);
+}
+
+__global__ __launch_bounds__(VB) void k_sqnorm(const double* __restrict__ v, int64_t n, double* __restrict__ parts)
+{
+  __shared__ double sh[VB / 64];
+  double s = 0;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+    s += v[i] * v[i];
+  const double t = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0)
+    parts[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(1024) void k_reduce_plain(const double* __restrict__ parts, int np, double* out)
+{
+  __shared__ double sh[16];
+  const double s = reduce_parts(parts, np, sh);
+  if (threadIdx.x == 0)
+    out[0] = s;
+}
+
+static int vgrid(int64_t n)
+{
+  int64_t g = (n + VB - 1) / VB;
+  if (g > VGRID_MAX)
+    g = VGRID_MAX;
+  if (g < 1)
+    g = 1;
+  return (int)g;
+}
+
+// sum of squares over the owned entries, all-reduced over ranks when a communicator is attached
+int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out)
+{
+  const int g = vgrid(n);
+  hipLaunchKernelGGL(k_sqnorm, dim3(g), dim3(VB), 0, ctx->stream, v, n, ctx->part_b.p);
+  hipLaunchKernelGGL(k_reduce_plain, dim3(1), dim3(1024), 0, ctx->stream, ctx->part_b.p, g, ctx->red.p);
+  ZZZ_HIP(ctx, hipGetLastError());
+  if (ctx->comm)
+  {
+    int rc = comm_allreduce_sum(ctx, ctx->red.p, 1);
+    if (rc)
+      return rc;
+  }
+  double s = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&s, ctx->red.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = std::sqrt(s);
+  return ZZZ_OK;
+}
+
+int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
+{
+  const int64_t n = ctx->n_owned * ctx->bs; // owned scalar rows
+  const int max_it = o->max_it;
+  CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol};
+  const bool multi = ctx->comm != nullptr;
+  const int mode = multi ? 1 : 0;
+  const int g = vgrid(n);
+  hipStream_t s = ctx->stream;
+
+  ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
+  double* alpha = ctx->red.p + 4;
+
+  // PCSetUp(PCJACOBI): inverse diagonal (inside `ZZZ Solve`, as KSPSetUp is in the reference)
+  if (o->op == ZZZ_OP_CSR)
+    hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n,
+                       o->pc == ZZZ_PC_JACOBI ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                       (const double*)nullptr, ctx->dinv.p, n, 0);
+
+  auto apply = [&](double* x, double* y, double* parts, int* np) -> int {
+    if (multi)
+    {
+      int rc = comm_halo_forward(ctx, x);
+      if (rc)
+        return rc;
+    }
+    if (o->op == ZZZ_OP_CSR)
+      return launch_spmv(ctx, x, y, parts, np);
+    return launch_matfree_action(ctx, x, y, parts, np);
+  };
+
+  // initial residual
+  const double* w0 = nullptr;
+  if (o->variant == ZZZ_CG_CGH)
+  {
+    int rc = apply(ctx->u.p, ctx->w.p, nullptr, nullptr); // action(x, y), src/cg.h:46
+    if (rc)
+      return rc;
+    w0 = ctx->w.p;
+  }
+  else
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
+  hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(VB), 0, s, ctx->b.p, w0, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm,
+                     ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
+  auto reduce_beta = [&](int it) -> int {
+    hipLaunchKernelGGL(k_reduce_beta, dim3(1), dim3(1024), 0, s, ctx->state.p, ctx->part_b.p,
+                       ctx->part_b.p + VGRID_MAX, g, ctx->beta_hist.p, ctx->dp_hist.p, it, P, ctx->red.p, mode);
+    if (multi)
+    {
+      int rc = comm_allreduce_sum(ctx, ctx->red.p, 2);
+      if (rc)
+        return rc;
+      hipLaunchKernelGGL(k_scalar_beta, dim3(1), dim3(1), 0, s, ctx->state.p, ctx->red.p, ctx->beta_hist.p,
+                         ctx->dp_hist.p, it, P);
+    }
+    return ZZZ_OK;
+  };
+  {
+    int rc = reduce_beta(0);
+    if (rc)
+      return rc;
+  }
+
+  // profiling events around the SpMV launches
+  const int max_prof = o->profile ? 512 : 0;
+  if ((int)ctx->ev.size() < 2 * max_prof)
+  {
+    size_t old = ctx->ev.size();
+    ctx->ev.resize(2 * max_prof);
+    for (size_t i = old; i < ctx->ev.size(); ++i)
+      ZZZ_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+  }
+  int nprof = 0;
+
+  // host polling: copy the state every CHECK iterations, look at it two batches later
+  constexpr int CHECK = 8, NSLOT = 4;
+  hipEvent_t chk_ev[NSLOT];
+  for (int i = 0; i < NSLOT; ++i)
+    ZZZ_HIP(ctx, hipEventCreateWithFlags(&chk_ev[i], hipEventDisableTiming));
+  int nchk = 0;
+  bool stop = false;
+
+  int it = 0;
+  for (; it < max_it && !stop; ++it)
+  {
+    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, it, ctx->z.p, ctx->p.p, n);
+    int np = 0;
+    if (nprof < max_prof)
+      (void)hipEventRecord(ctx->ev[2 * nprof], s);
+    {
+      int rc = apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+      if (rc)
+        return rc;
+    }
+    if (nprof < max_prof)
+    {
+      (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
+      ++nprof;
+    }
+    hipLaunchKernelGGL(k_reduce_alpha, dim3(1), dim3(1024), 0, s, ctx->state.p, ctx->part_a.p, np, ctx->beta_hist.p, it,
+                       alpha, ctx->red.p, mode);
+    if (multi)
+    {
+      int rc = comm_allreduce_sum(ctx, ctx->red.p, 1);
+      if (rc)
+        return rc;
+      hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, s, ctx->state.p, ctx->red.p, ctx->beta_hist.p, it, alpha);
+    }
+    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, alpha, ctx->p.p, ctx->w.p, ctx->dinv.p,
+                       ctx->u.p, ctx->r.p, ctx->z.p, n, P.norm, ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
+    {
+      int rc = reduce_beta(it + 1);
+      if (rc)
+        return rc;
+    }
+    if ((it + 1) % CHECK == 0)
+    {
+      const int slot = nchk % NSLOT;
+      if (nchk >= NSLOT - 1)
+      {
+        // wait for the check issued NSLOT-1 batches ago
+        const int old = (nchk - (NSLOT - 1)) % NSLOT;
+        ZZZ_HIP(ctx, hipEventSynchronize(chk_ev[old]));
+        if (ctx->h_state[old].converged)
+          stop = true;
+      }
+      ZZZ_HIP(ctx, hipMemcpyAsync(&ctx->h_state[slot], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+      ZZZ_HIP(ctx, hipEventRecord(chk_ev[slot], s));
+      ++nchk;
+    }
+  }
+  ZZZ_HIP(ctx, hipGetLastError());
+  CgState fin;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  for (int i = 0; i < NSLOT; ++i)
+    (void)hipEventDestroy(chk_ev[i]);
+
+  const int its = fin.converged ? fin.iters : max_it;
+  ctx->last_iters = its;
+  if (iters)
+    *iters = its;
+  if (rnorm)
+  {
+    rnorm[0] = fin.dp;
+    rnorm[1] = fin.dp0;
+  }
+  ctx->history.resize((size_t)its + 1);
+  ZZZ_HIP(ctx, hipMemcpy(ctx->history.data(), ctx->dp_hist.p, sizeof(double) * ((size_t)its + 1), hipMemcpyDeviceToHost));
+
+  ctx->prof_spmv_ms = 0.0;
+  ctx->prof_spmv_n = 0;
+  const int used = nprof < its ? nprof : its; // launches past convergence return at once: not counted
+  for (int i = 0; i < used; ++i)
+  {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess)
+    {
+      ctx->prof_spmv_ms += ms;
+      ctx->prof_spmv_n++;
+    }
+  }
+  if (ctx->prof_spmv_n)
+    ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
+  if (fin.converged == 2)
+    return fail(ctx, ZZZ_ERR_DIVERGED, "CG broke down: non-finite scalar at iteration %d", fin.iters);
+  return ZZZ_OK;
+}
+} // namespace zzz

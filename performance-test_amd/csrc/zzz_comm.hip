@@ -1,0 +1,228 @@
+// Inter-GPU communication over RCCL (xGMI): the 8-byte all-reduces of the CG dot products
+// (MPI_Allreduce inside la::inner_product / la::squared_norm, src/cg.h:53,65,74) and the forward
+// halo scatter (common::Scatterer::scatter_fwd, src/cgpoisson_problem.cpp:225-229).
+//
+// librccl is loaded with dlopen the first time a communicator is asked for, so single-GPU runs do
+// not depend on it.  All calls are enqueued on the context's stream: the CG loop stays free of
+// host synchronisation.  The halo is a grouped ncclSend/ncclRecv per neighbour (<= 7 peers on one
+// node = one xGMI link each); owned values are packed by a gather kernel, received values land
+// directly in the ghost segment, which the partitioner orders by (neighbour, sender order).
+#include "zzz_internal.h"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+namespace zzz
+{
+typedef struct ncclComm* ncclComm_t;
+typedef struct
+{
+  char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+enum
+{
+  ncclFloat64 = 8,
+  ncclSum = 0
+};
+static_assert(sizeof(ncclUniqueId) == ZZZ_UNIQUE_ID_BYTES, "unique id size");
+
+struct Rccl
+{
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl g_rccl;
+
+static const char* load_rccl()
+{
+  if (g_rccl.h)
+    return nullptr;
+  const char* names[] = {"librccl.so.1", "librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+      break;
+  if (!h)
+    return "cannot dlopen librccl.so.1";
+#define ZZZ_SYM(field, name)                                   \
+  *(void**)(&g_rccl.field) = dlsym(h, name);                   \
+  if (!g_rccl.field)                                           \
+    return "librccl lacks " name;
+  ZZZ_SYM(GetUniqueId, "ncclGetUniqueId")
+  ZZZ_SYM(CommInitRank, "ncclCommInitRank")
+  ZZZ_SYM(CommDestroy, "ncclCommDestroy")
+  ZZZ_SYM(AllReduce, "ncclAllReduce")
+  ZZZ_SYM(Send, "ncclSend")
+  ZZZ_SYM(Recv, "ncclRecv")
+  ZZZ_SYM(GroupStart, "ncclGroupStart")
+  ZZZ_SYM(GroupEnd, "ncclGroupEnd")
+  ZZZ_SYM(GetErrorString, "ncclGetErrorString")
+#undef ZZZ_SYM
+  g_rccl.h = h;
+  return nullptr;
+}
+
+struct Comm
+{
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+
+#define ZZZ_NCCL(ctx, call)                                                                                    \
+  do                                                                                                           \
+  {                                                                                                            \
+    ncclResult_t r_ = (call);                                                                                  \
+    if (r_ != 0)                                                                                               \
+      return fail(ctx, ZZZ_ERR_RCCL, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+__global__ void k_pack(const double* __restrict__ v, const int32_t* __restrict__ idx, double* __restrict__ out,
+                       int64_t n, int bs)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * bs; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = v[(int64_t)idx[i / bs] * bs + i % bs]; // pack_fn, src/cgpoisson_problem.cpp:32-37
+}
+
+int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n)
+{
+  if (!ctx->comm)
+    return ZZZ_OK;
+  ZZZ_NCCL(ctx, g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, ctx->comm->comm, ctx->stream));
+  return ZZZ_OK;
+}
+
+int comm_halo_forward(zzz_ctx* ctx, double* vec)
+{
+  if (!ctx->comm || ctx->nneigh == 0)
+    return ZZZ_OK;
+  const int bs = ctx->bs;
+  const int64_t nsend = ctx->send_off[ctx->nneigh];
+  if (nsend > 0)
+  {
+    int64_t g = (nsend * bs + 255) / 256;
+    if (g > 1024)
+      g = 1024;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)g), dim3(256), 0, ctx->stream, vec, ctx->send_idx.p, ctx->send_buf.p, nsend,
+                       bs);
+  }
+  ZZZ_NCCL(ctx, g_rccl.GroupStart());
+  int64_t ghost = ctx->n_owned;
+  for (int k = 0; k < ctx->nneigh; ++k)
+  {
+    const int64_t ns = ctx->send_off[k + 1] - ctx->send_off[k], nr = ctx->recv_cnt[k];
+    if (ns > 0)
+      ZZZ_NCCL(ctx, g_rccl.Send(ctx->send_buf.p + ctx->send_off[k] * bs, (size_t)(ns * bs), ncclFloat64,
+                                ctx->neigh_rank[k], ctx->comm->comm, ctx->stream));
+    if (nr > 0)
+      ZZZ_NCCL(ctx, g_rccl.Recv(vec + ghost * bs, (size_t)(nr * bs), ncclFloat64, ctx->neigh_rank[k], ctx->comm->comm,
+                                ctx->stream));
+    ghost += nr;
+  }
+  ZZZ_NCCL(ctx, g_rccl.GroupEnd());
+  return ZZZ_OK;
+}
+
+void comm_destroy(zzz_ctx* ctx)
+{
+  if (ctx->comm)
+  {
+    if (ctx->comm->comm && g_rccl.CommDestroy)
+      (void)g_rccl.CommDestroy(ctx->comm->comm);
+    delete ctx->comm;
+    ctx->comm = nullptr;
+  }
+}
+} // namespace zzz
+
+using namespace zzz;
+
+extern "C" {
+
+int zzz_comm_unique_id(void* id)
+{
+  if (!id)
+    return fail(nullptr, ZZZ_ERR_ARG, "zzz_comm_unique_id: NULL buffer");
+  if (const char* e = load_rccl())
+    return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, dlerror() ? dlerror() : "");
+  ncclUniqueId u;
+  ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != 0)
+    return fail(nullptr, ZZZ_ERR_RCCL, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
+  memcpy(id, &u, sizeof(u));
+  return ZZZ_OK;
+}
+
+int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  ZZZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (nranks < 1 || rank < 0 || rank >= nranks || !id)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_init: bad rank %d of %d", rank, nranks);
+  if (const char* e = load_rccl())
+    return fail(ctx, ZZZ_ERR_RCCL, "%s", e);
+  comm_destroy(ctx);
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  Comm* c = new Comm();
+  c->nranks = nranks;
+  c->rank = rank;
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  if (r != 0)
+  {
+    delete c;
+    return fail(ctx, ZZZ_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+  }
+  ctx->comm = c;
+  return ZZZ_OK;
+}
+
+int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const int64_t* send_off,
+                    const int32_t* send_idx, const int64_t* recv_cnt)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  ZZZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_halo_upload before zzz_dofmap_upload");
+  if (nneigh < 0 || (nneigh > 0 && (!neigh_rank || !send_off || !recv_cnt)))
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_halo_upload: bad arguments");
+  int64_t nrecv = 0;
+  for (int k = 0; k < nneigh; ++k)
+  {
+    if (send_off[k + 1] < send_off[k] || recv_cnt[k] < 0)
+      return fail(ctx, ZZZ_ERR_ARG, "zzz_halo_upload: negative count for neighbour %d", k);
+    nrecv += recv_cnt[k];
+  }
+  if (nrecv != ctx->n_ghost)
+    return fail(ctx, ZZZ_ERR_ARG, "halo receives %lld block dofs but the dofmap has %lld ghosts", (long long)nrecv,
+                (long long)ctx->n_ghost);
+  const int64_t nsend = nneigh ? send_off[nneigh] : 0;
+  for (int64_t i = 0; i < nsend; ++i)
+    if (send_idx[i] < 0 || send_idx[i] >= ctx->n_owned)
+      return fail(ctx, ZZZ_ERR_ARG, "send_idx[%lld] = %d is not an owned block dof", (long long)i, send_idx[i]);
+  ctx->nneigh = nneigh;
+  ctx->neigh_rank.assign(neigh_rank, neigh_rank + nneigh);
+  ctx->send_off.assign(send_off, send_off + nneigh + 1);
+  ctx->recv_cnt.assign(recv_cnt, recv_cnt + nneigh);
+  if (nneigh == 0)
+    ctx->send_off.assign(1, 0);
+  ZZZ_HIP(ctx, ctx->send_idx.alloc((size_t)nsend));
+  ZZZ_HIP(ctx, ctx->send_buf.alloc((size_t)(nsend * ctx->bs)));
+  if (nsend)
+    ZZZ_HIP(ctx, hipMemcpy(ctx->send_idx.p, send_idx, (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+  return ZZZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,161 @@
+// Internal declarations of libzzz_hip.so (not part of the ABI; see include/zzz_abi.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/zzz_abi.h"
+
+namespace zzz
+{
+// ---- device buffer -------------------------------------------------------------------------
+template <typename T>
+struct DevBuf
+{
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count)
+  {
+    release();
+    if (count == 0)
+      count = 1;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess)
+      n = count;
+    return e;
+  }
+};
+
+struct Comm; // zzz_comm.cpp
+
+// CG scalars kept on the device so the iteration loop never waits for the host.
+struct CgState
+{
+  int converged; // 0 running, 1 converged, 2 broke down (non-finite)
+  int iters;     // iteration count at convergence
+  double dp0;    // initial norm (variant PETSC) or <r0,r0> (variant CGH)
+  double ttol;   // max(rtol*dp0, atol)
+  double dp;     // last norm
+};
+
+} // namespace zzz
+
+struct zzz_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // mesh
+  int64_t nverts = 0, ncells = 0;
+  zzz::DevBuf<double> x;         // nverts*3
+  zzz::DevBuf<int32_t> cell_verts; // ncells*4
+  std::vector<int32_t> h_cell_verts;
+
+  // dofmap
+  int order = 0, bs = 0, nd = 0;
+  int64_t n_owned = 0, n_ghost = 0; // block dofs
+  zzz::DevBuf<int32_t> cell_dofs;   // ncells*nd
+  std::vector<int32_t> h_cell_dofs;
+
+  // bc marker per local scalar dof (owned + ghost)
+  zzz::DevBuf<uint8_t> bc;
+  bool have_bc = false;
+
+  // exterior-facet mask per cell (bit f = local facet f is exterior)
+  zzz::DevBuf<uint8_t> facet_mask;
+  int64_t nfacets = 0;
+
+  // coefficients
+  zzz::DevBuf<double> coeff[2];
+  bool have_coeff[2] = {false, false};
+
+  // pattern (owned rows) + adjacency
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  zzz::DevBuf<int32_t> rowptr, cols;
+  zzz::DevBuf<double> vals;
+  zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
+  int max_row_nnz = 0;
+  // SpMV tiling (row-aligned tiles of the nonzero stream)
+  zzz::DevBuf<int32_t> tile_row;
+  int64_t ntiles = 0;
+  // assembly tiling: contiguous owned block-dof ranges whose CSR segment fits LDS
+  zzz::DevBuf<int32_t> asm_tile;
+  int64_t n_asm_tiles = 0;
+  bool have_pattern = false, have_matrix = false;
+
+  // vectors, (n_owned+n_ghost)*bs each
+  zzz::DevBuf<double> b, u, r, z, p, w, dinv;
+  // reductions
+  zzz::DevBuf<double> part_a, part_b, red; // block partials; reduced scalars
+  zzz::DevBuf<double> beta_hist, dp_hist;
+  zzz::DevBuf<zzz::CgState> state;
+  zzz::CgState* h_state = nullptr; // pinned
+  std::vector<double> history;
+  int last_iters = 0;
+
+  // profiling
+  std::vector<hipEvent_t> ev;
+  double prof_spmv_ms = 0.0;
+  int64_t prof_spmv_n = 0;
+
+  // multi-GPU
+  zzz::Comm* comm = nullptr;
+  int nneigh = 0;
+  std::vector<int32_t> neigh_rank;
+  std::vector<int64_t> send_off, recv_cnt;
+  zzz::DevBuf<int32_t> send_idx;
+  zzz::DevBuf<double> send_buf;
+
+  int64_t nloc() const { return (n_owned + n_ghost) * bs; }
+};
+
+namespace zzz
+{
+int fail(zzz_ctx* ctx, int code, const char* fmt, ...);
+void set_global_error(const char* msg);
+
+#define ZZZ_HIP(ctx, call)                                                                                            \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    hipError_t e_ = (call);                                                                                           \
+    if (e_ != hipSuccess)                                                                                             \
+      return zzz::fail(ctx, ZZZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// kernels_spmv
+int build_spmv_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr);
+// y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
+int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+
+// kernels_assemble
+int build_asm_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr);
+int launch_assemble_matrix(zzz_ctx* ctx, int form);
+int launch_assemble_vector(zzz_ctx* ctx, int form);
+int launch_matfree_action(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+
+// kernels_cg
+int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);
+int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out);
+
+// comm
+int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n);
+int comm_halo_forward(zzz_ctx* ctx, double* vec);
+void comm_destroy(zzz_ctx* ctx);
+} // namespace zzz

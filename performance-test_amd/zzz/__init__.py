@@ -1,0 +1,356 @@
+"""ctypes mirror of the two C ABIs of this package (include/zzz_abi.h, include/zzz_host.h).
+
+Used by tests/ and bench.py to drive the same entry points the C++ driver
+(host/main.cpp, the `dolfinx-scaling-test` binary) calls.  No compute happens in Python and there
+is no CPU fallback: `Context()` raises when the HIP library or a GPU is missing.
+Never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(PKG)
+
+FORM_POISSON, FORM_ELASTICITY = 0, 1
+COEFF_F, COEFF_G = 0, 1
+VEC_B, VEC_U = 0, 1
+PC_NONE, PC_JACOBI = 0, 1
+NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL = 0, 1, 2
+CG_PETSC, CG_CGH = 0, 1
+OP_CSR, OP_MATFREE = 0, 1
+ERR_NO_GPU = 4
+
+ABI_SYMBOLS = [
+    "zzz_device_count", "zzz_ctx_create", "zzz_ctx_destroy", "zzz_last_error", "zzz_sync", "zzz_mesh_upload",
+    "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_csr_pattern_build",
+    "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
+    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_cg_solve", "zzz_cg_history",
+    "zzz_profile_get", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload",
+]
+HOST_SYMBOLS = [
+    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_part_create", "zzzh_part_destroy",
+    "zzzh_last_error", "zzzh_part_sizes", "zzzh_part_x", "zzzh_part_cells", "zzzh_part_cell_dofs",
+    "zzzh_part_facets", "zzzh_part_bc_dofs", "zzzh_part_dof_x", "zzzh_part_global_dofs", "zzzh_part_coeff",
+    "zzzh_part_neigh", "zzzh_part_send_off", "zzzh_part_send_idx", "zzzh_part_recv_cnt",
+]
+
+(NVERTS, NCELLS, NOWNED, NGHOST, ND, BS, NFACETS, NBC, NNEIGH, NSEND, GLOBAL_DOFS, GLOBAL_CELLS, OWNED_CELLS,
+ OWN_OFFSET, NSIZES) = range(15)
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("pc", C.c_int32), ("norm", C.c_int32), ("op", C.c_int32),
+                ("max_it", C.c_int32), ("profile", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double)]
+
+
+class ZzzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libzzz_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose=False):
+    """make -C performance-test_amd (hipcc --offload-arch=gfx950; cross-compiles without a GPU)"""
+    subprocess.check_call(["make", "-C", PKG, "-j4"], stdout=None if verbose else subprocess.DEVNULL)
+
+
+def hip_lib_path():
+    return os.path.join(PKG, "libzzz_hip.so")
+
+
+def host_lib_path():
+    return os.path.join(PKG, "libzzz_host.so")
+
+
+_HIP = None
+_HOST = None
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def hip():
+    """Loads libzzz_hip.so; raises (never falls back) when it is missing."""
+    global _HIP
+    if _HIP is None:
+        path = hip_lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C performance-test_amd` (no CPU fallback exists)")
+        L = C.CDLL(path)
+        L.zzz_last_error.restype = C.c_char_p
+        L.zzz_last_error.argtypes = [C.c_void_p]
+        L.zzz_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.zzz_ctx_destroy.argtypes = [C.c_void_p]
+        L.zzz_ctx_destroy.restype = None
+        L.zzz_sync.argtypes = [C.c_void_p]
+        L.zzz_mesh_upload.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int64, _i32p]
+        L.zzz_dofmap_upload.argtypes = [C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int64, C.c_int64]
+        L.zzz_bc_upload.argtypes = [C.c_void_p, C.c_int64, _i32p]
+        L.zzz_facets_upload.argtypes = [C.c_void_p, C.c_int64, _i32p]
+        L.zzz_coeff_upload.argtypes = [C.c_void_p, C.c_int, _f64p]
+        L.zzz_csr_pattern_build.argtypes = [C.c_void_p]
+        L.zzz_csr_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
+        L.zzz_csr_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zzz_csr_upload_values.argtypes = [C.c_void_p, _f64p]
+        L.zzz_assemble_matrix.argtypes = [C.c_void_p, C.c_int]
+        L.zzz_assemble_vector.argtypes = [C.c_void_p, C.c_int]
+        L.zzz_vec_download.argtypes = [C.c_void_p, C.c_int, _f64p]
+        L.zzz_vec_upload.argtypes = [C.c_void_p, C.c_int, _f64p]
+        L.zzz_vec_norm.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.zzz_spmv.argtypes = [C.c_void_p, _f64p, _f64p]
+        L.zzz_cg_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
+        L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.zzz_comm_unique_id.argtypes = [C.c_void_p]
+        L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.zzz_halo_upload.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, _i32p, _i64p]
+        _HIP = L
+    return _HIP
+
+
+def host():
+    global _HOST
+    if _HOST is None:
+        path = host_lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C performance-test_amd`")
+        L = C.CDLL(path)
+        L.zzzh_num_pdofs.restype = C.c_int64
+        L.zzzh_num_pdofs.argtypes = [C.c_int64] * 3 + [C.c_int, C.c_int]
+        L.zzzh_num_entities.argtypes = [C.c_int64] * 3 + [C.c_int, _i64p]
+        L.zzzh_mesh_size.argtypes = [C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, _i64p]
+        L.zzzh_part_create.restype = C.c_void_p
+        L.zzzh_part_create.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int]
+        L.zzzh_part_destroy.argtypes = [C.c_void_p]
+        L.zzzh_part_destroy.restype = None
+        L.zzzh_last_error.restype = C.c_char_p
+        L.zzzh_part_sizes.argtypes = [C.c_void_p, _i64p]
+        for name, ty in (("x", C.c_double), ("cells", C.c_int32), ("cell_dofs", C.c_int32), ("facets", C.c_int32),
+                         ("bc_dofs", C.c_int32), ("dof_x", C.c_double), ("global_dofs", C.c_int64),
+                         ("neigh", C.c_int32), ("send_off", C.c_int64), ("send_idx", C.c_int32),
+                         ("recv_cnt", C.c_int64)):
+            f = getattr(L, "zzzh_part_" + name)
+            f.restype = C.POINTER(ty)
+            f.argtypes = [C.c_void_p]
+        L.zzzh_part_coeff.restype = C.POINTER(C.c_double)
+        L.zzzh_part_coeff.argtypes = [C.c_void_p, C.c_int]
+        _HOST = L
+    return _HOST
+
+
+def device_count():
+    return int(hip().zzz_device_count())
+
+
+# ------------------------------------------------------------------------------------------------
+def mesh_size(ndofs, strong, nproc, dofs_per_node, order):
+    out = np.zeros(4, np.int64)
+    host().zzzh_mesh_size(int(ndofs), 1 if strong else 0, int(nproc), int(dofs_per_node), int(order), out)
+    return tuple(int(v) for v in out)
+
+
+def _arr(ptr, n, dtype, shape=None):
+    if n == 0:
+        a = np.zeros(0, dtype)
+    else:
+        a = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    return a.reshape(shape) if shape is not None else a
+
+
+class Part:
+    """One z-slab partition of the cube problem (host/mesh_part.cpp)."""
+
+    def __init__(self, problem, order, nx, ny, nz, nparts=1, part=0):
+        H = host()
+        pid = FORM_ELASTICITY if problem == "elasticity" else FORM_POISSON
+        h = H.zzzh_part_create(pid, order, nx, ny, nz, nparts, part)
+        if not h:
+            raise ValueError(H.zzzh_last_error().decode())
+        try:
+            s = np.zeros(NSIZES, np.int64)
+            H.zzzh_part_sizes(h, s)
+            self.sizes = s
+            self.problem, self.order, self.form = problem, order, pid
+            self.dims = (nx, ny, nz)
+            self.nparts, self.part = nparts, part
+            self.nverts, self.ncells = int(s[NVERTS]), int(s[NCELLS])
+            self.n_owned, self.n_ghost = int(s[NOWNED]), int(s[NGHOST])
+            self.nd, self.bs = int(s[ND]), int(s[BS])
+            self.nloc = self.n_owned + self.n_ghost
+            self.global_dofs_total, self.global_cells = int(s[GLOBAL_DOFS]), int(s[GLOBAL_CELLS])
+            self.owned_cells, self.own_offset = int(s[OWNED_CELLS]), int(s[OWN_OFFSET])
+            self.x = _arr(H.zzzh_part_x(h), 3 * self.nverts, np.float64, (-1, 3))
+            self.cells = _arr(H.zzzh_part_cells(h), 4 * self.ncells, np.int32, (-1, 4))
+            self.cell_dofs = _arr(H.zzzh_part_cell_dofs(h), self.nd * self.ncells, np.int32, (-1, self.nd))
+            self.facets = _arr(H.zzzh_part_facets(h), 2 * int(s[NFACETS]), np.int32, (-1, 2))
+            self.bc_dofs = _arr(H.zzzh_part_bc_dofs(h), int(s[NBC]), np.int32)
+            self.dof_x = _arr(H.zzzh_part_dof_x(h), 3 * self.nloc, np.float64, (-1, 3))
+            self.global_dofs = _arr(H.zzzh_part_global_dofs(h), self.nloc, np.int64)
+            self.f = _arr(H.zzzh_part_coeff(h, 0), self.nloc * self.bs, np.float64)
+            self.g = _arr(H.zzzh_part_coeff(h, 1), self.nloc, np.float64) if pid == FORM_POISSON else None
+            nn = int(s[NNEIGH])
+            self.neigh = _arr(H.zzzh_part_neigh(h), nn, np.int32)
+            self.send_off = _arr(H.zzzh_part_send_off(h), nn + 1, np.int64)
+            self.send_idx = _arr(H.zzzh_part_send_idx(h), int(s[NSEND]), np.int32)
+            self.recv_cnt = _arr(H.zzzh_part_recv_cnt(h), nn, np.int64)
+        finally:
+            H.zzzh_part_destroy(h)
+
+    def bc_marker(self):
+        m = np.zeros(self.nloc * self.bs, np.uint8)
+        m[self.bc_dofs] = 1
+        return m
+
+
+# ------------------------------------------------------------------------------------------------
+class Context:
+    """RAII wrapper of zzz_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        self.L = hip()
+        h = C.c_void_p()
+        rc = self.L.zzz_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise ZzzError(rc, self.L.zzz_last_error(None).decode())
+        self.h = h
+        self.bs = 1
+        self.n_owned = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zzz_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc:
+            raise ZzzError(rc, self.L.zzz_last_error(self.h).decode())
+
+    def sync(self):
+        self._ck(self.L.zzz_sync(self.h))
+
+    def upload_mesh(self, x, cells):
+        x = np.ascontiguousarray(x, np.float64)
+        cells = np.ascontiguousarray(cells, np.int32)
+        self._ck(self.L.zzz_mesh_upload(self.h, x.shape[0], x, cells.shape[0], cells))
+
+    def upload_dofmap(self, order, bs, cell_dofs, n_owned, n_ghost=0):
+        cd = np.ascontiguousarray(cell_dofs, np.int32)
+        self._ck(self.L.zzz_dofmap_upload(self.h, order, bs, cd, n_owned, n_ghost))
+        self.bs, self.n_owned, self.n_ghost = bs, n_owned, n_ghost
+
+    def upload_bc(self, bc_dofs):
+        b = np.ascontiguousarray(bc_dofs, np.int32)
+        self._ck(self.L.zzz_bc_upload(self.h, b.shape[0], b if b.size else np.zeros(1, np.int32)))
+
+    def upload_facets(self, facets):
+        f = np.ascontiguousarray(facets, np.int32).reshape(-1)
+        self._ck(self.L.zzz_facets_upload(self.h, f.shape[0] // 2, f if f.size else np.zeros(2, np.int32)))
+
+    def upload_coeff(self, which, values):
+        self._ck(self.L.zzz_coeff_upload(self.h, which, np.ascontiguousarray(values, np.float64)))
+
+    def upload_part(self, P):
+        """everything problem() sets up before `ZZZ Assemble matrix` (src/poisson_problem.cpp:33-123)"""
+        self.upload_mesh(P.x, P.cells)
+        self.upload_dofmap(P.order, P.bs, P.cell_dofs, P.n_owned, P.n_ghost)
+        self.upload_bc(P.bc_dofs)
+        self.upload_facets(P.facets)
+        self.upload_coeff(COEFF_F, P.f)
+        if P.g is not None:
+            self.upload_coeff(COEFF_G, P.g)
+
+    def pattern_build(self):
+        self._ck(self.L.zzz_csr_pattern_build(self.h))
+
+    def csr_sizes(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.L.zzz_csr_sizes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def csr_download(self, values=True):
+        nrows, _, nnz = self.csr_sizes()
+        rowptr = np.zeros(nrows + 1, np.int32)
+        cols = np.zeros(nnz, np.int32)
+        vals = np.zeros(nnz) if values else None
+        self._ck(self.L.zzz_csr_download(self.h, rowptr.ctypes.data, cols.ctypes.data,
+                                         vals.ctypes.data if values else None))
+        return rowptr, cols, vals
+
+    def csr_upload_values(self, vals):
+        self._ck(self.L.zzz_csr_upload_values(self.h, np.ascontiguousarray(vals, np.float64)))
+
+    def assemble_matrix(self, form):
+        self._ck(self.L.zzz_assemble_matrix(self.h, form))
+
+    def assemble_vector(self, form):
+        self._ck(self.L.zzz_assemble_vector(self.h, form))
+
+    def vec_download(self, which):
+        out = np.zeros(self.n_owned * self.bs)
+        self._ck(self.L.zzz_vec_download(self.h, which, out))
+        return out
+
+    def vec_upload(self, which, v):
+        v = np.ascontiguousarray(v, np.float64)
+        assert v.shape[0] == self.n_owned * self.bs
+        self._ck(self.L.zzz_vec_upload(self.h, which, v))
+
+    def vec_norm(self, which):
+        out = C.c_double()
+        self._ck(self.L.zzz_vec_norm(self.h, which, C.byref(out)))
+        return out.value
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.zeros_like(x)
+        self._ck(self.L.zzz_spmv(self.h, x, y))
+        return y
+
+    def cg_solve(self, variant=CG_PETSC, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, op=OP_CSR, rtol=1e-8, atol=1e-50,
+                 max_it=10000, profile=False):
+        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, rtol, atol)
+        it = C.c_int()
+        rn = (C.c_double * 2)()
+        self._ck(self.L.zzz_cg_solve(self.h, C.byref(o), C.byref(it), rn))
+        return it.value, rn[0], rn[1]
+
+    def cg_history(self, n):
+        out = np.zeros(n)
+        self._ck(self.L.zzz_cg_history(self.h, n, out))
+        return out
+
+    def profile(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.L.zzz_profile_get(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def comm_init(self, nranks, rank, uid_bytes):
+        buf = C.create_string_buffer(bytes(uid_bytes), 128)
+        self._ck(self.L.zzz_comm_init(self.h, nranks, rank, buf))
+
+    def upload_halo(self, P):
+        nn = len(P.neigh)
+        z32, z64 = np.zeros(1, np.int32), np.zeros(1, np.int64)
+        self._ck(self.L.zzz_halo_upload(self.h, nn, P.neigh if nn else z32, P.send_off if nn else z64,
+                                        P.send_idx if P.send_idx.size else z32, P.recv_cnt if nn else z64))
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = hip().zzz_comm_unique_id(buf)
+    if rc:
+        raise ZzzError(rc, hip().zzz_last_error(None).decode())
+    return buf.raw

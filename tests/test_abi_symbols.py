@@ -1,0 +1,58 @@
+"""The C-ABI libraries load on a machine without a GPU and export every symbol that include/*.h
+declares; without a GPU the compute entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import zzz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", src)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    names = _declared("zzz_abi.h", "zzz_")
+    assert len(names) >= 26
+    assert sorted(names) == sorted(zzz.ABI_SYMBOLS)
+    lib = ctypes.CDLL(zzz.hip_lib_path())
+    for n in names:
+        assert hasattr(lib, n), f"libzzz_hip.so does not export {n}"
+
+
+def test_host_library_exports_every_declared_symbol():
+    names = _declared("zzz_host.h", "zzzh_")
+    assert sorted(names) == sorted(zzz.HOST_SYMBOLS)
+    lib = ctypes.CDLL(zzz.host_lib_path())
+    for n in names:
+        assert hasattr(lib, n), f"libzzz_host.so does not export {n}"
+
+
+def test_no_cpu_fallback():
+    if zzz.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(zzz.ZzzError) as e:
+        zzz.Context(0)
+    assert e.value.code == zzz.ERR_NO_GPU
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under performance-test_amd/ or include/ may name it."""
+    bad = []
+    for base in ("performance-test_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"zzz_oracle|zo_[a-z]+\(|oracle/", txt) and "Never imports anything from oracle" not in txt \
+                        and "no oracle" not in txt:
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

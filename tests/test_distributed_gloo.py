@@ -1,0 +1,132 @@
+"""N > 1 path on CPU: two processes (gloo), each holding one z-slab produced by the host feed.
+The data path follows the product's plan exactly -- owned rows assembled locally from the slab plus
+its ghost-cell layer, forward halo per the send/recv lists, all-reduced dot products -- with the
+oracle's kernels standing in for the HIP ones (no GPU here).  The distributed Jacobi-PCG must
+reproduce the serial oracle solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, problem, order, dims, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "performance-test_amd")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    import zzz
+    import zzz_oracle as zo
+
+    zo.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    P = zzz.Part(problem, order, *dims, world, rank)
+    bs = P.bs
+    rp, cl = zo.pattern(P.nloc, P.cell_dofs, bs)
+    bc = P.bc_marker()
+    vals = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, bc, rp, cl)
+    b = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g,
+                           P.facets if problem == "poisson" else None, bc)
+    no = P.n_owned * bs
+    # owned rows only (the device matrix): rows [0, no), columns local incl. ghosts
+    rp_o, cl_o, v_o = rp[:no + 1].copy(), cl[:rp[no]].copy(), vals[:rp[no]].copy()
+    diag = np.array([v_o[rp_o[r] + np.searchsorted(cl_o[rp_o[r]:rp_o[r + 1]], r)] for r in range(no)])
+
+    def halo(v):
+        # forward scatter per the plan: owners -> ghosts (zzz_halo_upload contract)
+        reqs, bufs = [], []
+        g = P.n_owned
+        for k, nb in enumerate(P.neigh):
+            idx = P.send_idx[P.send_off[k]:P.send_off[k + 1]]
+            sb = torch.from_numpy(np.ascontiguousarray(v.reshape(-1, bs)[idx].reshape(-1)))
+            rb = torch.zeros(int(P.recv_cnt[k]) * bs, dtype=torch.float64)
+            reqs.append(dist.isend(sb, int(nb)))
+            reqs.append(dist.irecv(rb, int(nb)))
+            bufs.append((g, rb))
+            g += int(P.recv_cnt[k])
+        for r in reqs:
+            r.wait()
+        for g0, rb in bufs:
+            v[g0 * bs:g0 * bs + rb.numel()] = rb.numpy()
+
+    def allsum(*xs):
+        t = torch.tensor(xs, dtype=torch.float64)
+        dist.all_reduce(t)
+        return [float(v) for v in t]
+
+    def matvec(pfull):
+        halo(pfull)
+        y = np.zeros(no)
+        # CSR rows over local columns
+        y[:] = np.add.reduceat(v_o * pfull[cl_o], rp_o[:-1]) if no else 0
+        return y
+
+    # PETSc-style Jacobi PCG (as zo_pcg), distributed
+    x = np.zeros(no)
+    r = b[:no].copy()
+    z = r / diag
+    beta, zz = allsum(r @ z, z @ z)
+    dp0 = dp = np.sqrt(zz)
+    ttol = max(1e-8 * dp0, 1e-50)
+    pf = np.zeros(P.nloc * bs)
+    it, betaold = 0, 1.0
+    while it < 10000 and dp > ttol:
+        pf[:no] = z if it == 0 else (beta / betaold) * pf[:no] + z
+        w = matvec(pf)
+        (pw,) = allsum(pf[:no] @ w)
+        a = beta / pw
+        x += a * pf[:no]
+        r -= a * w
+        z = r / diag
+        betaold = beta
+        beta, zz = allsum(r @ z, z @ z)
+        dp = np.sqrt(zz)
+        it += 1
+    q.put((rank, it, P.own_offset, x))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (4, 3, 6)), ("poisson", 2, (2, 2, 4)),
+                                                ("elasticity", 1, (3, 3, 4))])
+def test_two_rank_pcg_matches_serial_oracle(problem, order, dims):
+    import multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "performance-test_amd"))
+    import zzz
+    import zzz_oracle as zo
+
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, problem, order, dims, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    zo.set_num_threads(1)
+    G = zzz.Part(problem, order, *dims)
+    rp, cl = zo.pattern(G.nloc, G.cell_dofs, G.bs)
+    v = zo.assemble_matrix(G.form, order, G.x, G.cells, G.cell_dofs, G.bc_marker(), rp, cl)
+    b = zo.assemble_vector(G.form, order, G.x, G.cells, G.cell_dofs, G.f, G.g,
+                           G.facets if problem == "poisson" else None, G.bc_marker())
+    it, u, _, _ = zo.pcg(rp, cl, v, b, rtol=1e-8)
+    ug = np.concatenate([r[3] for r in res])  # owned ranges are contiguous and ordered by rank
+    assert res[0][2] == 0 and res[1][2] * G.bs == res[0][3].size
+    assert abs(res[0][1] - it) <= 2 and res[0][1] == res[1][1]
+    assert np.linalg.norm(ug - u) <= 1e-7 * np.linalg.norm(u)

@@ -1,0 +1,110 @@
+"""Host feed (performance-test_amd/host/mesh_part.cpp, C++) against the oracle's independent,
+generic (sort-based, topological) restatement: same problem up to a dof permutation."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import zzz
+import zzz_oracle as zo
+
+
+@pytest.fixture(autouse=True)
+def _one_thread():
+    zo.set_num_threads(1)
+
+
+def test_mesh_size_search_equals_oracle_and_survey():
+    cases = [(500000, True, 1, 1, 1), (10000000, True, 1, 1, 1), (10000000, True, 8, 1, 1), (500000, False, 8, 3, 1),
+             (500000, False, 1, 3, 1), (50000000, True, 8, 1, 3), (50000, False, 1, 1, 1), (50000, False, 2, 1, 3),
+             (100000, False, 2, 3, 3), (1000000, True, 2, 1, 2), (70000000, True, 1, 1, 1)]
+    for c in cases:
+        assert zzz.mesh_size(*c) == zo.mesh_size(*c), c
+    assert zzz.mesh_size(10000000, True, 1, 1, 1) == (108, 103, 111, 1)
+
+
+def _oracle_on(P):
+    rp, cl = zo.pattern(P.nloc, P.cell_dofs, P.bs)
+    bc = P.bc_marker()
+    v = zo.assemble_matrix(P.form, P.order, P.x, P.cells, P.cell_dofs, bc, rp, cl)
+    b = zo.assemble_vector(P.form, P.order, P.x, P.cells, P.cell_dofs, P.f, P.g,
+                           P.facets if P.problem == "poisson" else None, bc)
+    n = P.nloc * P.bs
+    return sp.csr_matrix((v, cl, rp), shape=(n, n)), b
+
+
+@pytest.mark.parametrize("problem", ["poisson", "elasticity"])
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_single_partition_equals_oracle_problem(problem, order):
+    dims = (3, 2, 4)
+    P = zzz.Part(problem, order, *dims)
+    O = zo.Problem(problem, order, *dims).assemble()
+    assert P.n_owned == O.nblock == zo.num_pdofs(*dims, 0, order) and P.n_ghost == 0
+    assert P.ncells == O.cells.shape[0] and P.global_cells == P.ncells
+    assert np.all(np.diff(P.cells, axis=1) > 0)  # vertex-sorted cells
+    A1, b1 = _oracle_on(P)
+    key = lambda X: [tuple(np.round(r, 9)) for r in X]  # noqa: E731
+    mp = {k: i for i, k in enumerate(key(O.dof_x))}
+    perm = np.array([mp[k] for k in key(P.dof_x)])
+    assert len(set(perm)) == P.n_owned
+    sperm = (perm[:, None] * P.bs + np.arange(P.bs)[None, :]).reshape(-1)
+    A2 = sp.csr_matrix((O.vals, O.cols, O.rowptr), shape=(O.n, O.n))[sperm][:, sperm]
+    assert A1.nnz == A2.nnz
+    assert abs(A1 - A2).max() <= 1e-13 * abs(A2).max()
+    assert np.abs(b1 - O.b[sperm]).max() <= 1e-13 * np.abs(O.b).max()
+    # BCs, facets, coefficients restated topologically by the oracle on the host's mesh
+    bcm = zo.locate_bc(1 if problem == "elasticity" else 0, order, P.x, P.cells, P.cell_dofs, P.nloc)
+    np.testing.assert_array_equal(np.repeat(bcm, P.bs), P.bc_marker())
+    if problem == "poisson":
+        np.testing.assert_array_equal(zo.exterior_facets(P.cells), P.facets)
+        assert np.abs(zo.interpolate(0, P.dof_x) - P.f).max() < 1e-14
+        assert np.abs(zo.interpolate(1, P.dof_x) - P.g).max() < 1e-15
+    else:
+        assert np.abs(zo.interpolate(2, P.dof_x) - P.f).max() < 1e-15
+
+
+@pytest.mark.parametrize("problem,order", [("poisson", 1), ("poisson", 3), ("elasticity", 1), ("elasticity", 2)])
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_partitions_reproduce_global_rows(problem, order, nparts):
+    """One ghost-cell layer makes every owned row complete: owned rows of each partition equal the
+    global rows (what MatAssemblyBegin/End would otherwise have to exchange)."""
+    dims = (3, 2, 5)
+    G = zzz.Part(problem, order, *dims)
+    A, bg = _oracle_on(G)
+    bs = G.bs
+    tot_owned = tot_cells = 0
+    for part in range(nparts):
+        P = zzz.Part(problem, order, *dims, nparts, part)
+        tot_owned += P.n_owned
+        tot_cells += P.owned_cells
+        np.testing.assert_array_equal(P.global_dofs[:P.n_owned], P.own_offset + np.arange(P.n_owned))
+        Al, b = _oracle_on(P)
+        gs = (P.global_dofs[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        no = P.n_owned * bs
+        Ag = A[gs[:no]][:, gs]
+        np.testing.assert_array_equal(np.diff(Al[:no].indptr), np.diff(Ag.indptr))
+        assert abs(Al[:no] - Ag).max() <= 1e-14 * abs(A).max()
+        assert np.abs(b[:no] - bg[gs[:no]]).max() <= 1e-14 * np.abs(bg).max()
+    assert tot_owned == G.n_owned and tot_cells == G.global_cells
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_halo_plan_is_consistent(order):
+    parts = [zzz.Part("poisson", order, 3, 2, 7, 3, p) for p in range(3)]
+    for p, P in enumerate(parts):
+        g = P.n_owned
+        for k, nb in enumerate(P.neigh):
+            Q = parts[nb]
+            kk = list(Q.neigh).index(p)
+            sent = Q.global_dofs[Q.send_idx[Q.send_off[kk]:Q.send_off[kk + 1]]]
+            np.testing.assert_array_equal(sent, P.global_dofs[g:g + P.recv_cnt[k]])
+            g += P.recv_cnt[k]
+        assert g == P.nloc
+
+
+def test_bad_arguments():
+    with pytest.raises(ValueError):
+        zzz.Part("poisson", 4, 2, 2, 2)  # form_*.at(order-1) throws in the reference
+    with pytest.raises(ValueError):
+        zzz.Part("poisson", 1, 2, 2, 2, 3, 0)  # fewer layers than parts
+    with pytest.raises(ValueError):
+        zzz.Part("poisson", 1, 0, 2, 2)
