@@ -259,8 +259,256 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   b[r] = bc[r] ? 0.0 : sum; // bc->set(b), u0 == 0
 }
 
+
+// ---- generic P2/P3 kernels: the element tensor row is a contraction of per-cell geometry with the
+// reference tensors of element_tables.inc, staged in LDS next to the workgroup's CSR segment.
+// LPR lanes share one matrix row and split the columns j of each incident cell between them; a
+// cell's columns are distinct, the lanes of a row sit in one wavefront and walk the cells in
+// lockstep, so the per-entry summation order is still the serial ascending-cell order, no atomics.
+#include "element_tables.inc"
+
+template <int ND, int BS, int LPR>
+__global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restrict__ x,
+                                                           const int32_t* __restrict__ cell_verts,
+                                                           const int32_t* __restrict__ cell_dofs,
+                                                           const int32_t* __restrict__ adj_off,
+                                                           const int32_t* __restrict__ adj_cells,
+                                                           const uint8_t* __restrict__ bc,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ cols, double* __restrict__ vals,
+                                                           const int32_t* __restrict__ tiles,
+                                                           const double* __restrict__ tab)
+{
+  constexpr int NT = (BS == 1) ? 6 : 9;
+  constexpr int NN = ND * ND;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* vals_s = reinterpret_cast<double*>(lds_raw);
+  double* T_s = vals_s + ASM_NNZ;
+  int32_t* cols_s = reinterpret_cast<int32_t*>(T_s + NT * NN);
+  for (int k = threadIdx.x; k < NT * NN; k += ASM_BLOCK)
+  {
+    if (BS == 1)
+    {
+      // symmetrised pieces: G is symmetric, so S^{ab} + S^{ba} is all a < b needs
+      const int t = k / NN, ij = k % NN;
+      const int a = t < 3 ? t : (t == 3 ? 0 : (t == 4 ? 0 : 1)), b = t < 3 ? t : (t == 3 ? 1 : 2);
+      T_s[k] = (t < 3) ? tab[(a * 3 + a) * NN + ij] : tab[(a * 3 + b) * NN + ij] + tab[(b * 3 + a) * NN + ij];
+    }
+    else
+      T_s[k] = tab[k];
+  }
+  const int d0 = tiles[blockIdx.x], d1 = tiles[blockIdx.x + 1];
+  const int row0 = d0 * BS, row1 = d1 * BS;
+  const int s = rowptr[row0], e = rowptr[row1];
+  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+  {
+    cols_s[k] = cols[s + k];
+    vals_s[k] = 0.0;
+  }
+  __syncthreads();
+  const int rl = (int)threadIdx.x / LPR, lane = (int)threadIdx.x % LPR;
+  const int r = row0 + rl;
+  if (r < row1)
+  {
+    const int i = r / BS, c = r % BS;
+    const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
+    const bool bcr = bc[r] != 0;
+    constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
+    constexpr double mu = Ey / (2.0 * (1.0 + nu));
+    constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+    {
+      const int cell = adj_cells[a];
+      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
+      const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
+      double p[4][3];
+      Geom G;
+      load_cell(x, v, p);
+      geometry(p, G);
+      int li = 0;
+      for (int jj = 0; jj < ND; ++jj)
+        if (cd[jj] == i)
+          li = jj;
+      const double* Tl = T_s + li * ND;
+      if (BS == 1)
+      {
+        // |detJ| (K K^T): 00 11 22 01 02 12
+        double GG[6];
+        GG[0] = G.adet * (G.K[0][0] * G.K[0][0] + G.K[0][1] * G.K[0][1] + G.K[0][2] * G.K[0][2]);
+        GG[1] = G.adet * (G.K[1][0] * G.K[1][0] + G.K[1][1] * G.K[1][1] + G.K[1][2] * G.K[1][2]);
+        GG[2] = G.adet * (G.K[2][0] * G.K[2][0] + G.K[2][1] * G.K[2][1] + G.K[2][2] * G.K[2][2]);
+        GG[3] = G.adet * (G.K[0][0] * G.K[1][0] + G.K[0][1] * G.K[1][1] + G.K[0][2] * G.K[1][2]);
+        GG[4] = G.adet * (G.K[0][0] * G.K[2][0] + G.K[0][1] * G.K[2][1] + G.K[0][2] * G.K[2][2]);
+        GG[5] = G.adet * (G.K[1][0] * G.K[2][0] + G.K[1][1] * G.K[2][1] + G.K[1][2] * G.K[2][2]);
+        for (int j = lane; j < ND; j += LPR)
+        {
+          const int dj = cd[j];
+          const int pos = find_pos(cols_s + a0, len, dj);
+          double val = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            val += GG[t] * Tl[t * NN + j];
+          if (bcr || bc[dj])
+            val = 0.0;
+          vals_s[a0 + pos] += val;
+        }
+      }
+      else
+      {
+        for (int j = lane; j < ND; j += LPR)
+        {
+          const int dj = cd[j];
+          const int pos = find_pos(cols_s + a0, len, dj * 3);
+          // D[cc][d] = |detJ| sum_{al,be} K[al][cc] K[be][d] S^[al][be]_{li,j} = int d_cc phi_i d_d phi_j
+          double D[3][3];
+          {
+            double tmp[3][3];
+#pragma unroll
+            for (int al = 0; al < 3; ++al)
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                tmp[al][d] = Tl[(al * 3 + 0) * NN + j] * G.K[0][d] + Tl[(al * 3 + 1) * NN + j] * G.K[1][d]
+                             + Tl[(al * 3 + 2) * NN + j] * G.K[2][d];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                D[cc][d] = G.adet * (G.K[0][cc] * tmp[0][d] + G.K[1][cc] * tmp[1][d] + G.K[2][cc] * tmp[2][d]);
+          }
+          const double tr = D[0][0] + D[1][1] + D[2][2];
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+          {
+            const double Dcd = sel3(D[0][d], D[1][d], D[2][d], c), Ddc = sel3(D[d][0], D[d][1], D[d][2], c);
+            double val = mu * ((c == d ? tr : 0.0) + Ddc) + lmbda * Dcd;
+            if (bcr || bc[dj * 3 + d])
+              val = 0.0;
+            vals_s[a0 + pos + d] += val;
+          }
+        }
+      }
+    }
+    if (bcr && lane == 0) // fem::set_diagonal
+      vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+    vals[s + k] = vals_s[k];
+}
+
+template <int ND, int BS>
+__global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restrict__ x,
+                                                           const int32_t* __restrict__ cell_verts,
+                                                           const int32_t* __restrict__ cell_dofs,
+                                                           const int32_t* __restrict__ adj_off,
+                                                           const int32_t* __restrict__ adj_cells,
+                                                           const uint8_t* __restrict__ bc,
+                                                           const uint8_t* __restrict__ facet_mask,
+                                                           const double* __restrict__ f, const double* __restrict__ gc,
+                                                           double* __restrict__ b, int64_t nrows,
+                                                           const double* __restrict__ tab)
+{
+  constexpr int NN = ND * ND;
+  __shared__ double M_s[NN];
+  __shared__ double F_s[BS == 1 ? 4 * NN : 1];
+  for (int k = threadIdx.x; k < NN; k += ASM_BLOCK)
+    M_s[k] = tab[9 * NN + k];
+  if (BS == 1)
+    for (int k = threadIdx.x; k < 4 * NN; k += ASM_BLOCK)
+      F_s[k] = tab[10 * NN + k];
+  __syncthreads();
+  const int64_t r = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x;
+  if (r >= nrows)
+    return;
+  const int i = (int)(r / BS), c = (int)(r % BS);
+  double sum = 0.0;
+  for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+  {
+    const int cell = adj_cells[a];
+    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
+    const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
+    double p[4][3];
+    Geom G;
+    load_cell(x, v, p);
+    geometry(p, G);
+    int li = 0;
+    for (int jj = 0; jj < ND; ++jj)
+      if (cd[jj] == i)
+        li = jj;
+    double acc = 0.0;
+    for (int j = 0; j < ND; ++j)
+      acc += M_s[li * ND + j] * f[(int64_t)cd[j] * BS + c];
+    sum += G.adet * acc;
+    if (BS == 1)
+    {
+      const unsigned m = facet_mask[cell];
+      if (m)
+      {
+#pragma unroll
+        for (int lf = 0; lf < 4; ++lf)
+          if ((m >> lf) & 1u)
+          {
+            const int q0 = lf == 0 ? 1 : 0, q1 = lf <= 1 ? 2 : 1, q2 = lf == 3 ? 2 : 3;
+            double e1[3], e2[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+            {
+              e1[k] = p[q1][k] - p[q0][k];
+              e2[k] = p[q2][k] - p[q0][k];
+            }
+            const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2],
+                         cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const double scale = sqrt(cx * cx + cy * cy + cz * cz);
+            double fa = 0.0;
+            for (int j = 0; j < ND; ++j)
+              fa += F_s[(lf * ND + li) * ND + j] * gc[cd[j]]; // rows of dofs off the facet are zero
+            sum += scale * fa;
+          }
+      }
+    }
+  }
+  b[r] = bc[r] ? 0.0 : sum;
+}
+
+static int ensure_tables(zzz_ctx* ctx)
+{
+  if (ctx->tables_order == ctx->order)
+    return ZZZ_OK;
+  const double* src = ctx->order == 1 ? ZZZ_TAB_P1 : (ctx->order == 2 ? ZZZ_TAB_P2 : ZZZ_TAB_P3);
+  const size_t n = (size_t)14 * ctx->nd * ctx->nd;
+  ZZZ_HIP(ctx, ctx->tables.alloc(n));
+  ZZZ_HIP(ctx, hipMemcpy(ctx->tables.p, src, n * sizeof(double), hipMemcpyHostToDevice));
+  ctx->tables_order = ctx->order;
+  return ZZZ_OK;
+}
+
+int asm_rows_per_tile(int order) { return order == 1 ? ASM_BLOCK : (order == 2 ? ASM_BLOCK / 4 : ASM_BLOCK / 8); }
+
+template <int ND, int BS, int LPR>
+static int launch_matrix_pk(zzz_ctx* ctx)
+{
+  constexpr int NT = (BS == 1) ? 6 : 9;
+  const size_t lds = (size_t)ASM_NNZ * 8 + (size_t)NT * ND * ND * 8 + (size_t)ASM_NNZ * 4;
+  auto kern = asm_matrix_pk<ND, BS, LPR>;
+  ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)ctx->n_asm_tiles), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
+                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p,
+                     ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->tables.p);
+  return ZZZ_OK;
+}
+
+template <int ND, int BS>
+static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
+{
+  const dim3 grid((unsigned)((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+  hipLaunchKernelGGL((asm_vector_pk<ND, BS>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+                     ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
+                     BS == 1 ? ctx->coeff[1].p : (const double*)nullptr, ctx->b.p, nrows, ctx->tables.p);
+}
+
 int build_asm_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr)
 {
+  const int rows_max = asm_rows_per_tile(ctx->order);
   const int bs = ctx->bs;
   const int64_t nb = ctx->n_owned;
   std::vector<int32_t> tiles;
@@ -270,7 +518,7 @@ int build_asm_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr)
   {
     int64_t q = d;
     const int64_t s = h_rowptr[d * bs];
-    while (q < nb && (q + 1 - d) * bs <= ASM_BLOCK && h_rowptr[(q + 1) * bs] - s <= ASM_NNZ)
+    while (q < nb && (q + 1 - d) * bs <= rows_max && h_rowptr[(q + 1) * bs] - s <= ASM_NNZ)
       ++q;
     if (q == d)
       return fail(ctx, ZZZ_ERR_LIMIT, "rows of block dof %lld exceed the assembly tile (%d nonzeros)", (long long)d,
@@ -304,7 +552,17 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
                          ctx->asm_tile.p);
   }
   else
-    return fail(ctx, ZZZ_ERR_ARG, "order %d matrix assembly is not built yet", ctx->order);
+  {
+    int rc = ensure_tables(ctx);
+    if (rc)
+      return rc;
+    if (ctx->order == 2)
+      rc = bs == 1 ? launch_matrix_pk<10, 1, 4>(ctx) : launch_matrix_pk<10, 3, 4>(ctx);
+    else
+      rc = bs == 1 ? launch_matrix_pk<20, 1, 8>(ctx) : launch_matrix_pk<20, 3, 8>(ctx);
+    if (rc)
+      return rc;
+  }
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
@@ -328,7 +586,15 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
                          (const double*)nullptr, ctx->b.p, nrows);
   }
   else
-    return fail(ctx, ZZZ_ERR_ARG, "order %d vector assembly is not built yet", ctx->order);
+  {
+    int rc = ensure_tables(ctx);
+    if (rc)
+      return rc;
+    if (ctx->order == 2)
+      bs == 1 ? launch_vector_pk<10, 1>(ctx, nrows) : launch_vector_pk<10, 3>(ctx, nrows);
+    else
+      bs == 1 ? launch_vector_pk<20, 1>(ctx, nrows) : launch_vector_pk<20, 3>(ctx, nrows);
+  }
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }

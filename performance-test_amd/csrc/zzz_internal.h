@@ -82,6 +82,10 @@ struct zzz_ctx
   zzz::DevBuf<uint8_t> facet_mask;
   int64_t nfacets = 0;
 
+  // reference tensors of the element (element_tables.inc), for orders 2 and 3
+  zzz::DevBuf<double> tables;
+  int tables_order = 0;
+
   // coefficients
   zzz::DevBuf<double> coeff[2];
   bool have_coeff[2] = {false, false};
