@@ -189,6 +189,11 @@ int zzz_vec_norm(zzz_ctx* ctx, int which, double* out);
  * communicator is attached).  MatMult; for parity checks of the SpMV kernel alone. */
 int zzz_spmv(zzz_ctx* ctx, const double* x, double* y);
 
+/* y = action(x): the matrix-free operator lambda of cgpoisson (src/cgpoisson_problem.cpp:193-230):
+ * assemble_vector of form M = action(a, un) with un = x, rows of constrained dofs zeroed, ghosts
+ * of x updated first.  Needs zzz_csr_pattern_build (for the dof->cell adjacency), not the matrix. */
+int zzz_action(zzz_ctx* ctx, const double* x, double* y);
+
 /* ---- solve ----------------------------------------------------------------------------- */
 
 /* solver_function(u, b) (src/poisson_problem.cpp:164-179; src/cgpoisson_problem.cpp:178-244;

@@ -509,6 +509,28 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
   return ZZZ_OK;
 }
 
+int zzz_action(zzz_ctx* ctx, const double* x, double* y)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_pattern || !x || !y)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_action: no pattern/adjacency or NULL vector");
+  const size_t n = (size_t)(ctx->n_owned * ctx->bs);
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, ctx->p.n * sizeof(double), ctx->stream));
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->p.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->comm)
+  {
+    int rc = comm_halo_forward(ctx, ctx->p.p);
+    if (rc)
+      return rc;
+  }
+  int rc = launch_matfree_action(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
+  if (rc)
+    return rc;
+  ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
 int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 {
   ZZZ_ENTER(ctx);

@@ -599,8 +599,140 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
   return ZZZ_OK;
 }
 
-int launch_matfree_action(zzz_ctx* ctx, const double*, double*, double*, int*)
+// ---- matrix-free operator of cgpoisson: y = action(a, un = x), then y[bc] = 0
+// (form M of src/Poisson.py:33, applied as in src/cgpoisson_problem.cpp:193-230: assemble_vector of M
+// with un = x, bc->set(y, 0)).  Same row-gather walk: no element matrix is stored, the row of Ae is
+// contracted with x on the fly; per-workgroup partials of <x, y> feed the CG dot product.
+template <int ND>
+__global__ __launch_bounds__(ASM_BLOCK) void matfree_poisson(const double* __restrict__ x,
+                                                             const int32_t* __restrict__ cell_verts,
+                                                             const int32_t* __restrict__ cell_dofs,
+                                                             const int32_t* __restrict__ adj_off,
+                                                             const int32_t* __restrict__ adj_cells,
+                                                             const uint8_t* __restrict__ bc,
+                                                             const double* __restrict__ u, double* __restrict__ y,
+                                                             int64_t nrows, const double* __restrict__ tab,
+                                                             double* __restrict__ partials,
+                                                             const int* __restrict__ stop_flag)
 {
-  return fail(ctx, ZZZ_ERR_ARG, "matrix-free operator is not built yet");
+  if (stop_flag && *stop_flag)
+    return;
+  constexpr int NN = ND * ND;
+  __shared__ double T_s[ND == 4 ? 1 : 6 * NN];
+  __shared__ double red[ASM_BLOCK / 64];
+  if (ND != 4)
+  {
+    for (int k = threadIdx.x; k < 6 * NN; k += ASM_BLOCK)
+    {
+      const int t = k / NN, ij = k % NN;
+      const int a = t < 3 ? t : (t == 3 ? 0 : (t == 4 ? 0 : 1)), b = t < 3 ? t : (t == 3 ? 1 : 2);
+      T_s[k] = (t < 3) ? tab[(a * 3 + a) * NN + ij] : tab[(a * 3 + b) * NN + ij] + tab[(b * 3 + a) * NN + ij];
+    }
+    __syncthreads();
+  }
+  double dot = 0.0;
+  for (int64_t r = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * ASM_BLOCK)
+  {
+    const int i = (int)r;
+    double sum = 0.0;
+    for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+    {
+      const int cell = adj_cells[a];
+      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
+      const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
+      double p[4][3];
+      Geom G;
+      load_cell(x, v, p);
+      geometry(p, G);
+      if (ND == 4)
+      {
+        double g[4][3];
+        p1_grads(G, g);
+        double gu[3] = {0, 0, 0}, gi[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          const int dj = cd[j];
+          const double uj = u[dj];
+          gu[0] += g[j][0] * uj;
+          gu[1] += g[j][1] * uj;
+          gu[2] += g[j][2] * uj;
+          if (dj == i)
+          {
+            gi[0] = g[j][0];
+            gi[1] = g[j][1];
+            gi[2] = g[j][2];
+          }
+        }
+        sum += (G.adet / 6.0) * (gi[0] * gu[0] + gi[1] * gu[1] + gi[2] * gu[2]);
+      }
+      else
+      {
+        int li = 0;
+        for (int jj = 0; jj < ND; ++jj)
+          if (cd[jj] == i)
+            li = jj;
+        double GG[6];
+        GG[0] = G.adet * (G.K[0][0] * G.K[0][0] + G.K[0][1] * G.K[0][1] + G.K[0][2] * G.K[0][2]);
+        GG[1] = G.adet * (G.K[1][0] * G.K[1][0] + G.K[1][1] * G.K[1][1] + G.K[1][2] * G.K[1][2]);
+        GG[2] = G.adet * (G.K[2][0] * G.K[2][0] + G.K[2][1] * G.K[2][1] + G.K[2][2] * G.K[2][2]);
+        GG[3] = G.adet * (G.K[0][0] * G.K[1][0] + G.K[0][1] * G.K[1][1] + G.K[0][2] * G.K[1][2]);
+        GG[4] = G.adet * (G.K[0][0] * G.K[2][0] + G.K[0][1] * G.K[2][1] + G.K[0][2] * G.K[2][2]);
+        GG[5] = G.adet * (G.K[1][0] * G.K[2][0] + G.K[1][1] * G.K[2][1] + G.K[1][2] * G.K[2][2]);
+        const double* Tl = T_s + li * ND;
+        double acc = 0.0;
+        for (int j = 0; j < ND; ++j)
+        {
+          double aij = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            aij += GG[t] * Tl[t * NN + j];
+          acc += aij * u[cd[j]];
+        }
+        sum += acc;
+      }
+    }
+    if (bc[r])
+      sum = 0.0; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
+    y[r] = sum;
+    dot += sum * u[r];
+  }
+  if (partials)
+  {
+    const double t = block_reduce_sum(dot, red);
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = t;
+  }
+}
+
+int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
+{
+  if (ctx->bs != 1)
+    return fail(ctx, ZZZ_ERR_ARG, "the matrix-free operator exists for the Poisson form M only (src/Poisson.py:33)");
+  if (!ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "matrix-free operator needs zzz_csr_pattern_build (dof->cell adjacency)");
+  int rc = ensure_tables(ctx);
+  if (rc)
+    return rc;
+  const int64_t nrows = ctx->n_owned;
+  int64_t g = (nrows + ASM_BLOCK - 1) / ASM_BLOCK;
+  if (g > 2048)
+    g = 2048;
+  const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
+#define ZZZ_MF(ND_)                                                                                                    \
+  hipLaunchKernelGGL(matfree_poisson<ND_>, dim3((unsigned)g), dim3(ASM_BLOCK), 0, ctx->stream, ctx->x.p,               \
+                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, u, y, nrows,     \
+                     ctx->tables.p, partials, stop)
+  if (ctx->order == 1)
+    ZZZ_MF(4);
+  else if (ctx->order == 2)
+    ZZZ_MF(10);
+  else
+    ZZZ_MF(20);
+#undef ZZZ_MF
+  if (npartials)
+    *npartials = (int)g;
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
 }
 } // namespace zzz

@@ -1,0 +1,535 @@
+// dolfinx-scaling-test -- MI355X-native drop-in for the hot path of FEniCS/performance-test.
+//
+// Keeps the reference driver's surface (src/main.cpp): the double-hyphen options (:57-74, unknown
+// options ignored as with allow_unregistered(), :79), PETSc-style single-hyphen solver options
+// (-ksp_type cg -pc_type jacobi -ksp_rtol ..., consumed by solver.set_from_options() at
+// src/poisson_problem.cpp:169), the ZZZ timers (README.md:148-161) and the stdout summary
+// (:186-205, :232-233).  Everything between the timers is this repository's own code: the host
+// feed (mesh_part.cpp, C++) and the device library (libzzz_hip.so) behind the C-ABI of
+// include/zzz_abi.h.  One host thread drives one GPU ("process" = GPU: `--ngpus N` plays the role
+// of `mpirun -np N`); RCCL carries the halo and the CG all-reduces.  There is no CPU compute path.
+#include "../../include/zzz_abi.h"
+#include "../../include/zzz_host.h"
+
+#include <algorithm>
+#include <barrier>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace
+{
+// ---- timers: dolfinx::common::Timer + list_timings (src/main.cpp:130,226) ------------------------
+struct TimerRegistry
+{
+  std::mutex m;
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<int, double>> t; // reps, total seconds
+  void add(const std::string& name, double s)
+  {
+    std::lock_guard<std::mutex> lk(m);
+    auto it = t.find(name);
+    if (it == t.end())
+    {
+      order.push_back(name);
+      t[name] = {1, s};
+    }
+    else
+    {
+      it->second.first++;
+      it->second.second += s;
+    }
+  }
+  void list() const
+  {
+    size_t w = 30;
+    for (auto& n : order)
+      w = std::max(w, n.size());
+    std::cout << "\n[MPI_MAX] Summary of timings" << std::string(w - 17, ' ') << " |  reps  wall avg  wall tot\n";
+    std::cout << std::string(w + 30, '-') << "\n";
+    for (auto& n : order)
+    {
+      auto& e = t.at(n);
+      std::cout << std::left << std::setw((int)w + 11) << n << " | " << std::right << std::setw(5) << e.first << "  "
+                << std::fixed << std::setprecision(6) << e.second / e.first << "  " << e.second << "\n";
+    }
+    std::cout.unsetf(std::ios::fixed);
+    std::cout << std::setprecision(6) << std::endl;
+  }
+};
+TimerRegistry g_timers;
+
+// Per-thread stopwatch; rank 0 registers the MAX over ranks (the driver passes it after a barrier).
+struct Timer
+{
+  std::string name;
+  std::chrono::steady_clock::time_point t0;
+  bool running = true;
+  explicit Timer(std::string n) : name(std::move(n)), t0(std::chrono::steady_clock::now()) {}
+  double stop()
+  {
+    running = false;
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+
+// src/main.cpp:31-50
+std::string int64_to_human(std::int64_t n)
+{
+  double r = static_cast<double>(n);
+  const std::string name[] = {"", "thousand", "million", "billion", "trillion"};
+  int i = 0;
+  while (r > 1000.0)
+  {
+    r /= 1000.0;
+    i++;
+  }
+  if (i > 4)
+    throw std::runtime_error("number too big");
+  std::stringstream s;
+  if (i == 0)
+    return s.str();
+  s << " (" << std::setprecision(3) << r << " " << name[i] << ")";
+  return s.str();
+}
+
+struct Options
+{
+  // src/main.cpp:57-74
+  std::string problem_type = "poisson", mesh_type = "cube", scaling_type = "weak", output, scatterer = "neighbor";
+  bool mem_profile = false, use_subcomm = false, help = false;
+  std::size_t ndofs = 50000, order = 1;
+  // this driver only: number of GPUs ("processes")
+  int ngpus = 1;
+  // PETSc options database (README.md:66-82)
+  std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
+  double ksp_rtol = 1e-5, ksp_atol = 1e-50; // PETSc defaults
+  int ksp_max_it = 10000;
+  bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false;
+  std::vector<std::string> unused;
+};
+
+void usage()
+{
+  // boost::program_options layout of the reference's help (src/main.cpp:84-89)
+  std::cout << "Allowed options:\n"
+               "  -h [ --help ]                   print usage message\n"
+               "  --problem_type arg (=poisson)   problem (poisson, cgpoisson, or elasticity)\n"
+               "  --mesh_type arg (=cube)         mesh (cube or unstructured)\n"
+               "  --memory_profiling              turn on memory logging\n"
+               "  --subcomm_partition             Use sub-communicator for partitioning\n"
+               "  --scaling_type arg (=weak)      scaling (weak or strong)\n"
+               "  --output arg                    output directory (no output unless this is set)\n"
+               "  --ndofs arg (=50000)            number of degrees of freedom\n"
+               "  --order arg (=1)                polynomial order\n"
+               "  --scatterer arg (=neighbor)     scatterer for CG (neighbor or p2p)\n"
+               "  --ngpus arg (=1)                number of GPUs (takes the place of mpirun -np)\n"
+               "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol\n"
+               "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
+               "  -log_view -options_left\n"
+            << std::endl;
+}
+
+Options parse(int argc, char** argv)
+{
+  Options o;
+  auto value = [&](int& i, const std::string& arg, const std::string& key) -> std::string {
+    const size_t eq = arg.find('=');
+    if (eq != std::string::npos)
+      return arg.substr(eq + 1);
+    if (i + 1 >= argc)
+      throw std::runtime_error("the required argument for option '--" + key + "' is missing");
+    return argv[++i];
+  };
+  for (int i = 1; i < argc; ++i)
+  {
+    const std::string arg = argv[i];
+    if (arg == "-h" || arg == "--help")
+      o.help = true;
+    else if (arg.rfind("--", 0) == 0)
+    {
+      const std::string key = arg.substr(2, arg.find('=') == std::string::npos ? std::string::npos : arg.find('=') - 2);
+      if (key == "problem_type")
+        o.problem_type = value(i, arg, key);
+      else if (key == "mesh_type")
+        o.mesh_type = value(i, arg, key);
+      else if (key == "scaling_type")
+        o.scaling_type = value(i, arg, key);
+      else if (key == "output")
+        o.output = value(i, arg, key);
+      else if (key == "scatterer")
+        o.scatterer = value(i, arg, key);
+      else if (key == "ndofs")
+        o.ndofs = std::stoull(value(i, arg, key));
+      else if (key == "order")
+        o.order = std::stoull(value(i, arg, key));
+      else if (key == "ngpus")
+        o.ngpus = std::stoi(value(i, arg, key));
+      else if (key == "memory_profiling")
+        o.mem_profile = true;
+      else if (key == "subcomm_partition")
+        o.use_subcomm = true;
+      else
+        o.unused.push_back(arg); // allow_unregistered(), src/main.cpp:79
+    }
+    else if (arg.size() > 1 && arg[0] == '-')
+    {
+      // PETSc options database: "-name [value]"
+      const std::string key = arg.substr(1);
+      auto next = [&]() -> std::string {
+        if (i + 1 < argc && !(argv[i + 1][0] == '-' && !std::isdigit((unsigned char)argv[i + 1][1]) && argv[i + 1][1] != '.'))
+          return argv[++i];
+        return "";
+      };
+      if (key == "ksp_type")
+        o.ksp_type = next();
+      else if (key == "pc_type")
+        o.pc_type = next();
+      else if (key == "ksp_rtol")
+        o.ksp_rtol = std::stod(next());
+      else if (key == "ksp_atol")
+        o.ksp_atol = std::stod(next());
+      else if (key == "ksp_max_it")
+        o.ksp_max_it = std::stoi(next());
+      else if (key == "ksp_norm_type")
+        o.ksp_norm_type = next();
+      else if (key == "ksp_view")
+        o.ksp_view = true;
+      else if (key == "ksp_monitor")
+        o.ksp_monitor = true;
+      else if (key == "log_view")
+        o.log_view = true;
+      else if (key == "options_left")
+        o.options_left = true;
+      else
+      {
+        std::string v = next();
+        o.unused.push_back(arg + (v.empty() ? "" : " " + v));
+      }
+    }
+    else
+      o.unused.push_back(arg);
+  }
+  return o;
+}
+
+#define ZCK(ctx, call)                                                                          \
+  do                                                                                            \
+  {                                                                                             \
+    int rc_ = (call);                                                                           \
+    if (rc_ != 0)                                                                               \
+      throw std::runtime_error(std::string(#call) + " failed: " + zzz_last_error(ctx));         \
+  } while (0)
+
+struct Shared
+{
+  Options opt;
+  int nranks = 1;
+  std::int64_t dims[4] = {0, 0, 0, 0};
+  unsigned char uid[ZZZ_UNIQUE_ID_BYTES] = {0};
+  std::vector<double> tmax;   // scratch for max-over-ranks timing
+  std::vector<int> iters;
+  std::vector<double> norm, rnorm0, rnorm;
+  std::vector<std::string> error;
+  std::int64_t num_dofs = 0, num_cells = 0;
+};
+
+// problem() + the ZZZ Solve block of solve(): one rank (GPU)
+void run_rank(Shared& S, std::barrier<>& bar, int rank)
+{
+  const Options& o = S.opt;
+  const bool root = rank == 0;
+  zzz_ctx* ctx = nullptr;
+  zzzh_part* P = nullptr;
+  // a rank that fails must keep arriving at the barriers, or the others hang: catch, record, drain
+  bool failed = false;
+  auto phase = [&](const char* tname, auto&& body) {
+    Timer t(tname ? tname : "");
+    if (!failed)
+    {
+      try
+      {
+        body();
+        if (ctx)
+          ZCK(ctx, zzz_sync(ctx)); // GPU work is asynchronous: a timer brackets a device sync
+      }
+      catch (const std::exception& e)
+      {
+        failed = true;
+        S.error[rank] = e.what();
+      }
+    }
+    const double s = t.stop();
+    S.tmax[rank] = s;
+    bar.arrive_and_wait();
+    if (root && tname)
+      g_timers.add(tname, *std::max_element(S.tmax.begin(), S.tmax.end()));
+    bar.arrive_and_wait();
+  };
+
+  const int problem = o.problem_type == "elasticity" ? ZZZH_ELASTICITY : ZZZH_POISSON;
+  const int form = problem == ZZZH_ELASTICITY ? ZZZ_FORM_ELASTICITY : ZZZ_FORM_POISSON;
+  const bool cgpoisson = o.problem_type == "cgpoisson";
+  std::int64_t sz[ZZZH_NSIZES] = {0};
+
+  phase("ZZZ Create Mesh", [&] {
+    ZCK(nullptr, zzz_ctx_create(rank, &ctx));
+    if (S.nranks > 1)
+      ZCK(ctx, zzz_comm_init(ctx, S.nranks, rank, S.uid));
+    const int r = (int)S.dims[3];
+    P = zzzh_part_create(problem, (int)o.order, S.dims[0] << r, S.dims[1] << r, S.dims[2] << r, S.nranks, rank);
+    if (!P)
+      throw std::runtime_error(zzzh_last_error());
+    zzzh_part_sizes(P, sz);
+    ZCK(ctx, zzz_mesh_upload(ctx, sz[ZZZH_NVERTS], zzzh_part_x(P), sz[ZZZH_NCELLS], zzzh_part_cells(P)));
+  });
+  if (root && !failed)
+  {
+    S.num_dofs = sz[ZZZH_GLOBAL_DOFS];
+    S.num_cells = sz[ZZZH_GLOBAL_CELLS];
+  }
+  phase("ZZZ FunctionSpace", [&] {
+    ZCK(ctx, zzz_dofmap_upload(ctx, (int)o.order, (int)sz[ZZZH_BS], zzzh_part_cell_dofs(P), sz[ZZZH_NOWNED], sz[ZZZH_NGHOST]));
+    if (S.nranks > 1)
+      ZCK(ctx, zzz_halo_upload(ctx, (int)sz[ZZZH_NNEIGH], zzzh_part_neigh(P), zzzh_part_send_off(P), zzzh_part_send_idx(P),
+                               zzzh_part_recv_cnt(P)));
+  });
+  phase("ZZZ Create facets and facet->cell connectivity",
+        [&] { ZCK(ctx, zzz_facets_upload(ctx, sz[ZZZH_NFACETS], zzzh_part_facets(P))); });
+
+  Timer umbrella("ZZZ Assemble"); // poisson/cgpoisson only in the reference (src/poisson_problem.cpp:49)
+  phase("ZZZ Create boundary conditions", [&] { ZCK(ctx, zzz_bc_upload(ctx, sz[ZZZH_NBC], zzzh_part_bc_dofs(P))); });
+  phase("ZZZ Create RHS function", [&] {
+    ZCK(ctx, zzz_coeff_upload(ctx, ZZZ_COEFF_F, zzzh_part_coeff(P, 0)));
+    if (problem == ZZZH_POISSON)
+      ZCK(ctx, zzz_coeff_upload(ctx, ZZZ_COEFF_G, zzzh_part_coeff(P, 1)));
+  });
+  if (problem == ZZZH_ELASTICITY)
+    phase("ZZZ Create forms", [&] {});
+  // fem::petsc::create_matrix: untimed in the reference, inside the ZZZ Assemble umbrella
+  phase(nullptr, [&] { ZCK(ctx, zzz_csr_pattern_build(ctx)); });
+  if (!cgpoisson)
+    phase("ZZZ Assemble matrix", [&] { ZCK(ctx, zzz_assemble_matrix(ctx, form)); });
+  phase("ZZZ Assemble vector", [&] { ZCK(ctx, zzz_assemble_vector(ctx, form)); });
+  if (problem == ZZZH_ELASTICITY)
+    phase("ZZZ Create near-nullspace", [&] {}); // consumed by GAMG only; out of scope for Jacobi-CG
+  {
+    S.tmax[rank] = umbrella.stop();
+    bar.arrive_and_wait();
+    if (root && problem == ZZZH_POISSON)
+      g_timers.add("ZZZ Assemble", *std::max_element(S.tmax.begin(), S.tmax.end()));
+    bar.arrive_and_wait();
+  }
+
+  if (root)
+  {
+    // src/main.cpp:173-206
+    std::cout << "----------------------------------------------------------------" << std::endl;
+    std::cout << "Test problem summary" << std::endl;
+    std::cout << "  dolfinx version: n/a (libzzz_hip 0.1.0, MI355X/gfx950-native hot path)" << std::endl;
+    std::cout << "  dolfinx hash:    n/a" << std::endl;
+    std::cout << "  ufl hash:        n/a (hand-written HIP element kernels)" << std::endl;
+    std::cout << "  petsc version:   n/a (own CSR + CG on HIP/RCCL)" << std::endl;
+    std::cout << "  Problem type:    " << o.problem_type << std::endl;
+    std::cout << "  Scaling type:    " << o.scaling_type << std::endl;
+    std::cout << "  Num processes:   " << S.nranks << std::endl;
+    std::cout << "  Num cells:       " << S.num_cells << int64_to_human(S.num_cells) << std::endl;
+    std::cout << "  Total degrees of freedom:               " << S.num_dofs << int64_to_human(S.num_dofs) << std::endl;
+    std::cout << "  Average degrees of freedom per process: " << S.num_dofs / S.nranks << std::endl;
+    std::cout << "----------------------------------------------------------------" << std::endl;
+  }
+
+  zzz_solver_opts so;
+  std::memset(&so, 0, sizeof(so));
+  if (cgpoisson)
+  {
+    // linalg::cg(*u.x(), b, action, 100, 1e-6), src/cgpoisson_problem.cpp:233
+    so.variant = ZZZ_CG_CGH;
+    so.pc = ZZZ_PC_NONE;
+    so.op = ZZZ_OP_MATFREE;
+    so.max_it = 100;
+    so.rtol = 1e-6;
+  }
+  else
+  {
+    so.variant = ZZZ_CG_PETSC;
+    so.pc = o.pc_type == "none" ? ZZZ_PC_NONE : ZZZ_PC_JACOBI;
+    so.norm = o.ksp_norm_type == "unpreconditioned" ? ZZZ_NORM_UNPRECONDITIONED
+              : o.ksp_norm_type == "natural"        ? ZZZ_NORM_NATURAL
+                                                    : ZZZ_NORM_PRECONDITIONED;
+    so.op = ZZZ_OP_CSR;
+    so.max_it = o.ksp_max_it;
+    so.rtol = o.ksp_rtol;
+    so.atol = o.ksp_atol;
+  }
+  double solve_s = 0;
+  {
+    Timer ts("ZZZ Solve");
+    if (!failed)
+    {
+      try
+      {
+        double rn[2] = {0, 0};
+        ZCK(ctx, zzz_cg_solve(ctx, &so, &S.iters[rank], rn));
+        ZCK(ctx, zzz_sync(ctx));
+        S.rnorm[rank] = rn[0];
+        S.rnorm0[rank] = rn[1];
+      }
+      catch (const std::exception& e)
+      {
+        failed = true;
+        S.error[rank] = e.what();
+      }
+    }
+    S.tmax[rank] = ts.stop();
+    bar.arrive_and_wait();
+    solve_s = *std::max_element(S.tmax.begin(), S.tmax.end());
+    if (root)
+      g_timers.add("ZZZ Solve", solve_s);
+    bar.arrive_and_wait();
+  }
+  if (root && cgpoisson && !failed)
+  {
+    // src/cgpoisson_problem.cpp:236-241
+    const double gdofs = (S.iters[0] * (double)S.num_dofs) / solve_s / 1e9;
+    std::cout << "CG matrix-free action processed: " << gdofs << " Gdof/s\n";
+  }
+  if (!failed)
+  {
+    try
+    {
+      ZCK(ctx, zzz_vec_norm(ctx, ZZZ_VEC_U, &S.norm[rank])); // la::norm(*u->x()), src/main.cpp:229 (collective)
+    }
+    catch (const std::exception& e)
+    {
+      failed = true;
+      S.error[rank] = e.what();
+    }
+  }
+  bar.arrive_and_wait();
+  if (root && o.ksp_monitor && !failed)
+  {
+    std::vector<double> h((size_t)S.iters[0] + 1);
+    zzz_cg_history(ctx, (int)h.size(), h.data());
+    for (size_t k = 0; k < h.size(); ++k)
+      std::cout << std::setw(3) << k << " KSP Residual norm " << std::scientific << std::setprecision(12) << h[k] << "\n";
+    std::cout.unsetf(std::ios::scientific);
+  }
+  if (P)
+    zzzh_part_destroy(P);
+  if (ctx)
+    zzz_ctx_destroy(ctx);
+}
+
+void solve(int argc, char** argv)
+{
+  Options o = parse(argc, argv);
+  if (o.help)
+  {
+    usage();
+    return;
+  }
+  bool strong;
+  if (o.scaling_type == "strong")
+    strong = true;
+  else if (o.scaling_type == "weak")
+    strong = false;
+  else
+    throw std::runtime_error("Scaling type '" + o.scaling_type + "` unknown"); // src/main.cpp:115
+  if (o.problem_type != "poisson" && o.problem_type != "cgpoisson" && o.problem_type != "elasticity")
+    throw std::runtime_error("Unknown problem type: " + o.problem_type); // src/main.cpp:170
+  if (o.mesh_type != "cube")
+    throw std::runtime_error("mesh_type '" + o.mesh_type + "': only the cube mesh is built (the unstructured spoke mesh of "
+                                                             "src/mesh.cpp:209-453 is outside the hot-path scope)");
+  if (!o.output.empty())
+    std::cerr << "warning: --output (XDMF, src/main.cpp:213-223) is outside the hot-path scope; ignored\n";
+  if (o.ksp_type != "cg")
+    throw std::runtime_error("-ksp_type " + o.ksp_type + ": only cg is built");
+  if (o.pc_type != "jacobi" && o.pc_type != "none")
+    throw std::runtime_error("-pc_type " + o.pc_type + ": only jacobi and none are built (hypre/gamg are out of scope)");
+  if (o.order < 1 || o.order > 3)
+    throw std::out_of_range("vector::_M_range_check: order must be 1..3"); // form_*.at(order - 1)
+  const int ndev = zzz_device_count();
+  if (ndev < 1)
+    throw std::runtime_error("no GPU visible: this build has no CPU path");
+  if (o.ngpus < 1 || o.ngpus > ndev)
+    throw std::runtime_error("--ngpus " + std::to_string(o.ngpus) + " but " + std::to_string(ndev) + " GPU(s) visible");
+
+  Shared S;
+  S.opt = o;
+  S.nranks = o.ngpus;
+  const int ndofs_per_node = (o.problem_type == "elasticity") ? 3 : 1; // src/main.cpp:128
+  zzzh_mesh_size((std::int64_t)o.ndofs, strong ? 1 : 0, S.nranks, ndofs_per_node, (int)o.order, S.dims);
+  if (S.dims[0] < 1 || S.dims[1] < 1 || S.dims[2] < 1)
+    throw std::runtime_error("mesh size search returned a non-positive dimension (ndofs too small)");
+  // src/mesh.cpp:190-194
+  std::cout << "UnitCube (" << S.dims[0] << "x" << S.dims[1] << "x" << S.dims[2] << ") to be refined " << S.dims[3]
+            << " times" << std::endl;
+  if (S.nranks > 1)
+    if (zzz_comm_unique_id(S.uid) != 0)
+      throw std::runtime_error(zzz_last_error(nullptr));
+  S.tmax.assign(S.nranks, 0.0);
+  S.iters.assign(S.nranks, 0);
+  S.norm.assign(S.nranks, 0.0);
+  S.rnorm.assign(S.nranks, 0.0);
+  S.rnorm0.assign(S.nranks, 0.0);
+  S.error.assign(S.nranks, "");
+
+  std::barrier<> bar(S.nranks);
+  std::vector<std::thread> th;
+  for (int r = 1; r < S.nranks; ++r)
+    th.emplace_back(run_rank, std::ref(S), std::ref(bar), r);
+  run_rank(S, bar, 0);
+  for (auto& t : th)
+    t.join();
+  for (int r = 0; r < S.nranks; ++r)
+    if (!S.error[r].empty())
+      throw std::runtime_error("rank " + std::to_string(r) + ": " + S.error[r]);
+
+  if (o.ksp_view)
+    std::cout << "KSP Object: type: cg\n  maximum iterations=" << o.ksp_max_it << ", initial guess is zero\n  tolerances:  relative="
+              << o.ksp_rtol << ", absolute=" << o.ksp_atol << "\n  using " << o.ksp_norm_type
+              << " norm type for convergence test\nPC Object: type: " << o.pc_type
+              << "\n  linear system matrix: type=csr (fp64 values, int32 indices) on " << S.nranks << " MI355X\n";
+  g_timers.list(); // dolfinx::list_timings, src/main.cpp:226
+  // src/main.cpp:229-234
+  std::cout << "*** Number of Krylov iterations: " << S.iters[0] << std::endl;
+  std::cout << "*** Solution norm:  " << S.norm[0] << std::endl;
+  if (o.options_left && !o.unused.empty())
+  {
+    std::cout << "#PETSc Option Table entries:\n";
+    for (auto& u : o.unused)
+      std::cout << "option left (not used by this build): " << u << "\n";
+  }
+}
+} // namespace
+
+int main(int argc, char* argv[])
+{
+  // Init MPI / Init logging / Init PETSc of the reference (src/main.cpp:245-258) have no counterpart
+  // here; the rows are kept so that tools reading the timing table find them.
+  for (const char* n : {"Init MPI", "Init logging", "Init PETSc"})
+    g_timers.add(n, 0.0);
+  try
+  {
+    solve(argc, argv);
+  }
+  catch (const std::exception& e)
+  {
+    // the reference lets exceptions terminate the process (non-zero exit)
+    std::cerr << "terminate called after throwing an instance of 'std::runtime_error'\n  what():  " << e.what() << std::endl;
+    return 134;
+  }
+  return 0;
+}

@@ -185,3 +185,90 @@ def test_large_properties(ctx):
     ctx.assemble_matrix(zzz.FORM_POISSON)
     _, _, v2 = ctx.csr_download()
     np.testing.assert_array_equal(v1, v2)
+
+
+@pytest.mark.parametrize("order,dims", [(1, (7, 6, 5)), (2, (4, 3, 4)), (3, (3, 2, 3))])
+def test_matrix_free_operator_and_cg(ctx, order, dims):
+    """cgpoisson: the matrix-free action (src/cgpoisson_problem.cpp:193-230) and linalg::cg on it
+    with the reference's arguments kmax=100, rtol=1e-6 (:233)."""
+    P = zzz.Part("poisson", order, *dims)
+    ctx.upload_part(P)
+    ctx.pattern_build()
+    ctx.assemble_vector(zzz.FORM_POISSON)
+    bc = P.bc_marker()
+    rng = np.random.default_rng(order)
+    v = rng.standard_normal(P.n_owned)
+    y = ctx.action(v)
+    oy = zo.action_poisson(order, P.x, P.cells, P.cell_dofs, bc, v)
+    assert np.abs(y - oy).max() <= 1e-12 * np.abs(oy).max()
+    assert np.all(y[bc.astype(bool)] == 0)
+    b = ctx.vec_download(zzz.VEC_B)
+    ctx.vec_upload(zzz.VEC_U, np.zeros_like(b))
+    k, rr, rr0 = ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_NONE, op=zzz.OP_MATFREE, rtol=1e-6, max_it=100)
+    u = ctx.vec_download(zzz.VEC_U)
+    ok, ou = zo.cg_matfree_poisson(order, P.x, P.cells, P.cell_dofs, bc, b, kmax=100, rtol=1e-6)
+    assert abs(k - ok) <= 2 and k <= 100
+    assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+
+
+def test_rccl_path_single_rank(ctx):
+    """The multi-GPU code path (reduce -> ncclAllReduce -> scalar kernels, halo with no neighbour)
+    on a 1-rank communicator must reproduce the single-GPU solve exactly."""
+    P = zzz.Part("poisson", 1, 8, 8, 8)
+    ctx.upload_part(P)
+    ctx.pattern_build()
+    ctx.assemble_matrix(zzz.FORM_POISSON)
+    ctx.assemble_vector(zzz.FORM_POISSON)
+    it0, rn0, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+    u0 = ctx.vec_download(zzz.VEC_U)
+    n0 = ctx.vec_norm(zzz.VEC_U)
+    with zzz.Context(0) as c2:
+        c2.comm_init(1, 0, zzz.comm_unique_id())
+        c2.upload_part(P)
+        c2.upload_halo(P)
+        c2.pattern_build()
+        c2.assemble_matrix(zzz.FORM_POISSON)
+        c2.assemble_vector(zzz.FORM_POISSON)
+        it1, rn1, _ = c2.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        u1 = c2.vec_download(zzz.VEC_U)
+        assert it1 == it0 and rn1 == rn0
+        np.testing.assert_array_equal(u1, u0)
+        assert c2.vec_norm(zzz.VEC_U) == n0
+
+
+def test_driver_binary_surface():
+    """dolfinx-scaling-test keeps the reference's CLI, timer names and stdout lines
+    (src/main.cpp:57-74,186-205,232-233; src/mesh.cpp:192-193; README.md:148-161)."""
+    import subprocess
+
+    exe = os.path.join(zzz.PKG, "dolfinx-scaling-test")
+    assert os.path.exists(exe)
+    # the reference's CI configuration: weak, 50 000 dofs, P1 (ccpp.yml:56-70) with CG + Jacobi
+    cmd = [exe, "--problem_type", "poisson", "--scaling_type", "weak", "--ndofs", "50000", "-ksp_type", "cg",
+           "-pc_type", "jacobi", "-ksp_rtol", "1.0e-8", "-log_view", "-options_left", "--some_unknown_flag", "7"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    s = out.stdout
+    assert "UnitCube (36x32x40) to be refined 0 times" in s
+    for line in ("Test problem summary", "  Problem type:    poisson", "  Scaling type:    weak", "  Num processes:   1",
+                 "  Num cells:       276480 (276 thousand)", "  Total degrees of freedom:               50061 (50.1 thousand)",
+                 "  Average degrees of freedom per process: 50061", "Summary of timings", "ZZZ Create Mesh",
+                 "ZZZ FunctionSpace", "ZZZ Assemble ", "ZZZ Create boundary conditions", "ZZZ Create RHS function",
+                 "ZZZ Assemble matrix", "ZZZ Assemble vector", "ZZZ Solve", "*** Number of Krylov iterations: ",
+                 "*** Solution norm:  "):
+        assert line in s, line
+    its = int(s.split("*** Number of Krylov iterations: ")[1].split()[0])
+    nrm = float(s.split("*** Solution norm:  ")[1].split()[0])
+    # SURVEY.md 8c provisional sanity values for this config: 194 iterations, |u| = 47.56358
+    assert abs(its - 194) <= 2 and abs(nrm - 47.56358) < 1e-3
+    # elasticity + P2, cgpoisson, bad options
+    out = subprocess.run([exe, "--problem_type", "elasticity", "--order", "2", "--ndofs", "20000", "-pc_type", "jacobi",
+                          "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ZZZ Create near-nullspace" in out.stdout and "ZZZ Create forms" in out.stdout
+    out = subprocess.run([exe, "--problem_type", "cgpoisson", "--ndofs", "30000"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "CG matrix-free action processed: " in out.stdout and "Gdof/s" in out.stdout
+    assert "ZZZ Assemble matrix" not in out.stdout
+    for bad in (["--scaling_type", "sideways"], ["--problem_type", "stokes"], ["--order", "4"]):
+        out = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
+        assert out.returncode != 0
