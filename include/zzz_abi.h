@@ -189,6 +189,11 @@ int zzz_vec_norm(zzz_ctx* ctx, int which, double* out);
  * communicator is attached).  MatMult; for parity checks of the SpMV kernel alone. */
 int zzz_spmv(zzz_ctx* ctx, const double* x, double* y);
 
+/* Measurement aid: HIP-event time of `reps` back-to-back launches of the CG SpMV kernel
+ * (w = A p with the <p,w> partials) on the context's stream; variant < 0 keeps the configured
+ * kernel variant, 0..3 selects one for A/B runs (bit 0 non-temporal loads, bit 1 pipelined). */
+int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms);
+
 /* y = action(x): the matrix-free operator lambda of cgpoisson (src/cgpoisson_problem.cpp:193-230):
  * assemble_vector of form M = action(a, un) with un = x, rows of constrained dofs zeroed, ghosts
  * of x updated first.  Needs zzz_csr_pattern_build (for the dof->cell adjacency), not the matrix. */

@@ -3,6 +3,7 @@
 #include "zzz_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -89,6 +90,11 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     return fail(nullptr, ZZZ_ERR_HIP, "context allocation failed");
   }
   memset(ctx->h_state, 0, 8 * sizeof(zzz::CgState));
+  // tuning knobs for A/B measurements (defaults are the measured best)
+  if (const char* e = getenv("ZZZ_SPMV_TILE"))
+    ctx->spmv_tile = atoi(e) == 4096 ? 4096 : 2048;
+  if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
+    ctx->spmv_variant = atoi(e) & 3;
   *out = ctx;
   return ZZZ_OK;
 }
@@ -507,6 +513,34 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
+}
+
+int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_matrix || reps < 1 || !avg_ms)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_time: no matrix or bad arguments");
+  const int saved = ctx->spmv_variant;
+  if (variant >= 0)
+    ctx->spmv_variant = variant & 3;
+  hipEvent_t e0, e1;
+  ZZZ_HIP(ctx, hipEventCreate(&e0));
+  ZZZ_HIP(ctx, hipEventCreate(&e1));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(zzz::CgState), ctx->stream));
+  int np = 0;
+  int rc = launch_spmv(ctx, ctx->p.p, ctx->w.p, ctx->part_a.p, &np); // warm-up
+  ZZZ_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps && !rc; ++i)
+    rc = launch_spmv(ctx, ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+  ZZZ_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  ZZZ_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  ZZZ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  ctx->spmv_variant = saved;
+  *avg_ms = ms / reps;
+  return rc;
 }
 
 int zzz_action(zzz_ctx* ctx, const double* x, double* y)

@@ -104,11 +104,14 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
                                                            const uint8_t* __restrict__ bc,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
-                                                           const int32_t* __restrict__ tiles)
+                                                           const int32_t* __restrict__ tiles, int64_t ntiles)
 {
   __shared__ double vals_s[ASM_NNZ];
   __shared__ int32_t cols_s[ASM_NNZ];
-  const int d0 = tiles[blockIdx.x], d1 = tiles[blockIdx.x + 1];
+  const int64_t tile = xcd_item(ntiles);
+  if (tile < 0)
+    return;
+  const int d0 = tiles[tile], d1 = tiles[tile + 1];
   const int row0 = d0 * BS, row1 = d1 * BS;
   const int s = rowptr[row0], e = rowptr[row1];
   for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
@@ -195,8 +198,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
                                                            const double* __restrict__ f, const double* __restrict__ gc,
                                                            double* __restrict__ b, int64_t nrows)
 {
-  const int64_t r = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x;
-  if (r >= nrows)
+  const int64_t blk = xcd_item((nrows + ASM_BLOCK - 1) / ASM_BLOCK);
+  const int64_t r = blk * (int64_t)ASM_BLOCK + threadIdx.x;
+  if (blk < 0 || r >= nrows)
     return;
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
                                                            const uint8_t* __restrict__ bc,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
-                                                           const int32_t* __restrict__ tiles,
+                                                           const int32_t* __restrict__ tiles, int64_t ntiles,
                                                            const double* __restrict__ tab)
 {
   constexpr int NT = (BS == 1) ? 6 : 9;
@@ -297,7 +301,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
     else
       T_s[k] = tab[k];
   }
-  const int d0 = tiles[blockIdx.x], d1 = tiles[blockIdx.x + 1];
+  const int64_t tile = xcd_item(ntiles);
+  if (tile < 0)
+    return;
+  const int d0 = tiles[tile], d1 = tiles[tile + 1];
   const int row0 = d0 * BS, row1 = d1 * BS;
   const int s = rowptr[row0], e = rowptr[row1];
   for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
@@ -417,8 +424,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restr
     for (int k = threadIdx.x; k < 4 * NN; k += ASM_BLOCK)
       F_s[k] = tab[10 * NN + k];
   __syncthreads();
-  const int64_t r = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x;
-  if (r >= nrows)
+  const int64_t blk = xcd_item((nrows + ASM_BLOCK - 1) / ASM_BLOCK);
+  const int64_t r = blk * (int64_t)ASM_BLOCK + threadIdx.x;
+  if (blk < 0 || r >= nrows)
     return;
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
@@ -491,16 +499,16 @@ static int launch_matrix_pk(zzz_ctx* ctx)
   const size_t lds = (size_t)ASM_NNZ * 8 + (size_t)NT * ND * ND * 8 + (size_t)ASM_NNZ * 4;
   auto kern = asm_matrix_pk<ND, BS, LPR>;
   ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)ctx->n_asm_tiles), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
+  hipLaunchKernelGGL(kern, dim3((unsigned)xcd_grid(ctx->n_asm_tiles)), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
                      ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p,
-                     ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->tables.p);
+                     ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p);
   return ZZZ_OK;
 }
 
 template <int ND, int BS>
 static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
 {
-  const dim3 grid((unsigned)((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+  const dim3 grid((unsigned)xcd_grid((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
   hipLaunchKernelGGL((asm_vector_pk<ND, BS>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                      ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                      BS == 1 ? ctx->coeff[1].p : (const double*)nullptr, ctx->b.p, nrows, ctx->tables.p);
@@ -539,17 +547,17 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
   const int bs = form == ZZZ_FORM_ELASTICITY ? 3 : 1;
   if (bs != ctx->bs)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
-  const dim3 grid((unsigned)ctx->n_asm_tiles), block(ASM_BLOCK);
+  const dim3 grid((unsigned)xcd_grid(ctx->n_asm_tiles)), block(ASM_BLOCK);
   if (ctx->order == 1)
   {
     if (bs == 1)
       hipLaunchKernelGGL(asm_matrix_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                          ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                         ctx->asm_tile.p);
+                         ctx->asm_tile.p, ctx->n_asm_tiles);
     else
       hipLaunchKernelGGL(asm_matrix_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                          ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                         ctx->asm_tile.p);
+                         ctx->asm_tile.p, ctx->n_asm_tiles);
   }
   else
   {
@@ -573,7 +581,7 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
   if (bs != ctx->bs)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
   const int64_t nrows = ctx->n_owned * bs;
-  const dim3 grid((unsigned)((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+  const dim3 grid((unsigned)xcd_grid((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
   if (ctx->order == 1)
   {
     if (bs == 1)

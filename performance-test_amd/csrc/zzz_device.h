@@ -22,4 +22,17 @@ __device__ inline double block_reduce_sum(double v, double* sh /* >= blockDim.x/
       s += sh[i];
   return s;
 }
+
+// XCD-aware work mapping for one-shot grids: workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 shares an XCD, MI355X_MICROARCH.md "Workgroup dispatch"), so give XCD x the x-th
+// contiguous eighth of the `n` work items: neighbouring items then share that XCD's L2.  Launch
+// with xcd_grid(n) workgroups; returns -1 for the few surplus ones.  Placement only changes speed.
+__host__ __device__ inline int64_t xcd_grid(int64_t n) { return (n + 7) / 8 * 8; }
+__device__ inline int64_t xcd_item(int64_t n)
+{
+  const int xcd = blockIdx.x & 7;
+  const int64_t lo = n * xcd / 8, hi = n * (xcd + 1) / 8;
+  const int64_t t = lo + (blockIdx.x >> 3);
+  return t < hi ? t : -1;
+}
 } // namespace zzz

@@ -99,6 +99,8 @@ struct zzz_ctx
   // SpMV tiling (row-aligned tiles of the nonzero stream)
   zzz::DevBuf<int32_t> tile_row;
   int64_t ntiles = 0;
+  int spmv_tile = 2048;  // nonzeros per tile (2048 | 4096), fixed at pattern build
+  int spmv_variant = 1;  // bit 0: non-temporal matrix loads, bit 1: pipelined tiles
   // assembly tiling: contiguous owned block-dof ranges whose CSR segment fits LDS
   zzz::DevBuf<int32_t> asm_tile;
   int64_t n_asm_tiles = 0;

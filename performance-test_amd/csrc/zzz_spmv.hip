@@ -17,7 +17,6 @@
 namespace zzz
 {
 constexpr int SPMV_BLOCK = 256;
-constexpr int SPMV_TILE_NNZ = 2048;
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 
@@ -31,8 +30,24 @@ __device__ inline int64_t xcd_tile(int64_t ntiles, int b, int nb, int i)
   return t < hi ? t : -1;
 }
 
+// LDS-only workgroup barrier: orders the LDS writes/reads of the tile without draining the
+// global loads already issued for the NEXT tile (a plain __syncthreads() waits for vmcnt(0)).
+__device__ inline void lds_barrier()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <bool NT, typename T>
+__device__ inline T stream_load(const T* p)
+{
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
 // One tile descriptor = {first row, end row, first nonzero, end nonzero}: one 16-B load per tile.
-template <bool DOT>
+// TILE = nonzeros per tile; PIPE = issue the next tile's matrix loads before reducing this one.
+template <bool DOT, bool NT, bool PIPE, int TILE>
 __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ cols,
                                                                const double* __restrict__ vals,
@@ -43,31 +58,35 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
 {
   if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
     return;
-  __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE_NNZ + 16];
+  __shared__ __attribute__((aligned(16))) double prod[TILE + 16];
   __shared__ double red[SPMV_BLOCK / 64];
-  constexpr int NPASS = SPMV_TILE_NNZ / (2 * SPMV_BLOCK);
+  constexpr int NPASS = TILE / (2 * SPMV_BLOCK);
   double dot = 0.0;
-  for (int i = 0;; ++i)
-  {
-    const int64_t t = xcd_tile(ntiles, blockIdx.x, gridDim.x, i);
-    if (t < 0)
-      break;
-    const int4 td = tiles[t];
-    const int r0 = td.x, r1 = td.y, s = td.z, e = td.w;
-    const int s_al = s & ~1;
-    // stream the tile: every load below is unconditional (indices clamped into the padded arrays),
-    // so all 2*NPASS matrix loads, then all 2*NPASS gathers, are in flight together
-    dbl2 v[NPASS];
-    int2v c[NPASS];
-    int kk[NPASS];
+  dbl2 v[NPASS];
+  int2v c[NPASS];
+  int4 td = make_int4(0, 0, 0, 0);
+  int64_t t = xcd_tile(ntiles, blockIdx.x, gridDim.x, 0);
+  // every matrix load is unconditional (indices clamped into the padded arrays), so all 2*NPASS
+  // loads of a tile are in flight together, ahead of the 2*NPASS gathers that depend on them
+  auto issue = [&](const int4 d) {
+    const int s_al = d.z & ~1;
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
     {
-      kk[j] = s_al + 2 * (int)threadIdx.x + j * 2 * SPMV_BLOCK;
-      const int kc = min(kk[j], nnz_even);
-      v[j] = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(vals + kc));
-      c[j] = __builtin_nontemporal_load(reinterpret_cast<const int2v*>(cols + kc));
+      const int kc = min(s_al + 2 * (int)threadIdx.x + j * 2 * SPMV_BLOCK, nnz_even);
+      v[j] = stream_load<NT>(reinterpret_cast<const dbl2*>(vals + kc));
+      c[j] = stream_load<NT>(reinterpret_cast<const int2v*>(cols + kc));
     }
+  };
+  if (t >= 0)
+  {
+    td = tiles[t];
+    issue(td);
+  }
+  for (int i = 0; t >= 0; ++i)
+  {
+    const int r0 = td.x, r1 = td.y, s = td.z, e = td.w;
+    const int s_al = s & ~1;
     double xa[NPASS], xb[NPASS];
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
@@ -82,14 +101,26 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     const double xr = DOT ? x[rc] : 0.0;
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
-      if (kk[j] < e)
+    {
+      const int kk = s_al + 2 * (int)threadIdx.x + j * 2 * SPMV_BLOCK;
+      if (kk < e)
       {
         dbl2 pr;
-        pr.x = (kk[j] >= s) ? v[j].x * xa[j] : 0.0;
-        pr.y = (kk[j] + 1 < e) ? v[j].y * xb[j] : 0.0;
-        *reinterpret_cast<dbl2*>(prod + (kk[j] - s_al)) = pr;
+        pr.x = (kk >= s) ? v[j].x * xa[j] : 0.0;
+        pr.y = (kk + 1 < e) ? v[j].y * xb[j] : 0.0;
+        *reinterpret_cast<dbl2*>(prod + (kk - s_al)) = pr;
       }
-    __syncthreads();
+    }
+    const int64_t tn = xcd_tile(ntiles, blockIdx.x, gridDim.x, i + 1);
+    if (PIPE && tn >= 0)
+    {
+      td = tiles[tn];
+      issue(td);
+    }
+    if (PIPE)
+      lds_barrier();
+    else
+      __syncthreads();
     if (r < r1)
     {
       // products are added in column order (the serial CPU order); 8 LDS reads in flight at a time
@@ -109,7 +140,16 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
       if (DOT)
         dot += sum * xr;
     }
-    __syncthreads();
+    if (PIPE)
+      lds_barrier();
+    else
+      __syncthreads();
+    t = tn;
+    if (!PIPE && t >= 0)
+    {
+      td = tiles[t];
+      issue(td);
+    }
   }
   if (DOT)
   {
@@ -128,10 +168,10 @@ int build_spmv_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr)
   {
     const int64_t s_al = h_rowptr[r] & ~1;
     int64_t q = r;
-    while (q < n && q - r < SPMV_BLOCK && h_rowptr[q + 1] - s_al <= SPMV_TILE_NNZ)
+    while (q < n && q - r < SPMV_BLOCK && h_rowptr[q + 1] - s_al <= ctx->spmv_tile)
       ++q;
     if (q == r)
-      return fail(ctx, ZZZ_ERR_LIMIT, "matrix row %lld has more than %d nonzeros", (long long)r, SPMV_TILE_NNZ - 1);
+      return fail(ctx, ZZZ_ERR_LIMIT, "matrix row %lld has more than %d nonzeros", (long long)r, ctx->spmv_tile - 1);
     tiles.push_back((int32_t)r);
     tiles.push_back((int32_t)q);
     tiles.push_back(h_rowptr[r]);
@@ -159,6 +199,38 @@ static int spmv_grid(const zzz_ctx* ctx)
   return (int)g;
 }
 
+template <bool DOT>
+static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
+                           int nnz_even)
+{
+  const int4* tiles = reinterpret_cast<const int4*>(ctx->tile_row.p);
+#define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
+  hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, ctx->ntiles, nnz_even, partials, stop)
+  const int var = ctx->spmv_variant; // bit 0: non-temporal matrix loads, bit 1: pipelined tiles
+  if (ctx->spmv_tile == 4096)
+  {
+    switch (var & 3)
+    {
+    case 0: ZZZ_SPMV_GO(false, false, 4096); break;
+    case 1: ZZZ_SPMV_GO(true, false, 4096); break;
+    case 2: ZZZ_SPMV_GO(false, true, 4096); break;
+    default: ZZZ_SPMV_GO(true, true, 4096); break;
+    }
+  }
+  else
+  {
+    switch (var & 3)
+    {
+    case 0: ZZZ_SPMV_GO(false, false, 2048); break;
+    case 1: ZZZ_SPMV_GO(true, false, 2048); break;
+    case 2: ZZZ_SPMV_GO(false, true, 2048); break;
+    default: ZZZ_SPMV_GO(true, true, 2048); break;
+    }
+  }
+#undef ZZZ_SPMV_GO
+}
+
 int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials)
 {
   const int grid = spmv_grid(ctx);
@@ -168,14 +240,12 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
   {
     if ((size_t)grid > ctx->part_a.n)
       return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
-    hipLaunchKernelGGL(spmv_tile_kernel<true>, dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream, ctx->rowptr.p,
-                       ctx->cols.p, ctx->vals.p, x, y, reinterpret_cast<const int4*>(ctx->tile_row.p), ctx->ntiles, nnz_even, partials, stop);
+    launch_variant<true>(ctx, grid, x, y, partials, stop, nnz_even);
     if (npartials)
       *npartials = grid;
   }
   else
-    hipLaunchKernelGGL(spmv_tile_kernel<false>, dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream, ctx->rowptr.p,
-                       ctx->cols.p, ctx->vals.p, x, y, reinterpret_cast<const int4*>(ctx->tile_row.p), ctx->ntiles, nnz_even, (double*)nullptr, stop);
+    launch_variant<false>(ctx, grid, x, y, nullptr, stop, nnz_even);
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }

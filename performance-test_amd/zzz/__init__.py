@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "zzz_device_count", "zzz_ctx_create", "zzz_ctx_destroy", "zzz_last_error", "zzz_sync", "zzz_mesh_upload",
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
-    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
+    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload",
 ]
 HOST_SYMBOLS = [
@@ -102,6 +102,7 @@ def hip():
         L.zzz_vec_upload.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_vec_norm.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.zzz_spmv.argtypes = [C.c_void_p, _f64p, _f64p]
+        L.zzz_spmv_time.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.zzz_action.argtypes = [C.c_void_p, _f64p, _f64p]
         L.zzz_cg_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
@@ -319,6 +320,11 @@ class Context:
         y = np.zeros_like(x)
         self._ck(self.L.zzz_spmv(self.h, x, y))
         return y
+
+    def spmv_time(self, reps=20, variant=-1):
+        ms = C.c_double()
+        self._ck(self.L.zzz_spmv_time(self.h, reps, variant, C.byref(ms)))
+        return ms.value
 
     def action(self, x):
         x = np.ascontiguousarray(x, np.float64)
