@@ -269,11 +269,35 @@ int zzz_coeff_upload(zzz_ctx* ctx, int which, const double* values)
   return ZZZ_OK;
 }
 
+static int pattern_build_host(zzz_ctx* ctx);
+
 int zzz_csr_pattern_build(zzz_ctx* ctx)
 {
   ZZZ_ENTER(ctx);
   if (ctx->order == 0)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_pattern_build before zzz_dofmap_upload");
+  ctx->have_pattern = ctx->have_matrix = false;
+  const char* mode = getenv("ZZZ_PATTERN"); // "host": the C++ host builder (kept for meshes whose
+                                            // vertex valence exceeds the device kernel's LDS budget)
+  int rc;
+  if (mode && strcmp(mode, "host") == 0)
+    rc = pattern_build_host(ctx);
+  else
+  {
+    bool fallback = false;
+    rc = pattern_build_device(ctx, &fallback);
+    if (rc && fallback)
+      rc = pattern_build_host(ctx);
+  }
+  if (rc)
+    return rc;
+  ctx->have_pattern = true;
+  return ZZZ_OK;
+}
+
+// Host (C++/OpenMP) pattern builder: index bookkeeping only, no floating-point work.
+static int pattern_build_host(zzz_ctx* ctx)
+{
   const int nd = ctx->nd, bs = ctx->bs;
   const int64_t nb = ctx->n_owned, nc = ctx->ncells;
   const int32_t* cd = ctx->h_cell_dofs.data();
@@ -380,13 +404,10 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->vals.alloc((size_t)nnz + 8));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->vals.p, 0, ((size_t)nnz + 8) * sizeof(double), ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  rc = build_spmv_tiles(ctx, rowptr);
-  if (!rc)
-    rc = build_asm_tiles(ctx, rowptr);
+  rc = build_tiles_device(ctx, maxrow / bs);
   if (rc)
     return rc;
-  ctx->have_pattern = true;
-  ctx->have_matrix = false;
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
 }
 

@@ -120,8 +120,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
     vals_s[k] = 0.0;
   }
   __syncthreads();
-  const int r = row0 + (int)threadIdx.x;
-  if (r < row1)
+  for (int r = row0 + (int)threadIdx.x; r < row1; r += ASM_BLOCK)
   {
     const int i = r / BS, c = r % BS;
     const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
@@ -313,9 +312,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
     vals_s[k] = 0.0;
   }
   __syncthreads();
-  const int rl = (int)threadIdx.x / LPR, lane = (int)threadIdx.x % LPR;
-  const int r = row0 + rl;
-  if (r < row1)
+  const int lane = (int)threadIdx.x % LPR;
+  for (int r = row0 + (int)threadIdx.x / LPR; r < row1; r += ASM_BLOCK / LPR)
   {
     const int i = r / BS, c = r % BS;
     const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
@@ -490,7 +488,7 @@ static int ensure_tables(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-int asm_rows_per_tile(int order) { return order == 1 ? ASM_BLOCK : (order == 2 ? ASM_BLOCK / 4 : ASM_BLOCK / 8); }
+int asm_tile_nnz() { return ASM_NNZ; }
 
 template <int ND, int BS, int LPR>
 static int launch_matrix_pk(zzz_ctx* ctx)
@@ -512,34 +510,6 @@ static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
   hipLaunchKernelGGL((asm_vector_pk<ND, BS>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                      ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                      BS == 1 ? ctx->coeff[1].p : (const double*)nullptr, ctx->b.p, nrows, ctx->tables.p);
-}
-
-int build_asm_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr)
-{
-  const int rows_max = asm_rows_per_tile(ctx->order);
-  const int bs = ctx->bs;
-  const int64_t nb = ctx->n_owned;
-  std::vector<int32_t> tiles;
-  tiles.push_back(0);
-  int64_t d = 0;
-  while (d < nb)
-  {
-    int64_t q = d;
-    const int64_t s = h_rowptr[d * bs];
-    while (q < nb && (q + 1 - d) * bs <= rows_max && h_rowptr[(q + 1) * bs] - s <= ASM_NNZ)
-      ++q;
-    if (q == d)
-      return fail(ctx, ZZZ_ERR_LIMIT, "rows of block dof %lld exceed the assembly tile (%d nonzeros)", (long long)d,
-                  ASM_NNZ);
-    tiles.push_back((int32_t)q);
-    d = q;
-  }
-  ctx->n_asm_tiles = (int64_t)tiles.size() - 1;
-  ZZZ_HIP(ctx, ctx->asm_tile.alloc(tiles.size()));
-  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->asm_tile.p, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                              ctx->stream));
-  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZZZ_OK;
 }
 
 int launch_assemble_matrix(zzz_ctx* ctx, int form)

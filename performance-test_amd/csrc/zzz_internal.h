@@ -145,13 +145,15 @@ void set_global_error(const char* msg);
       return zzz::fail(ctx, ZZZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// pattern (zzz_pattern.hip)
+int pattern_build_device(zzz_ctx* ctx, bool* fallback);
+int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
+int asm_tile_nnz();
 // kernels_spmv
-int build_spmv_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr);
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
 int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
 
 // kernels_assemble
-int build_asm_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr);
 int launch_assemble_matrix(zzz_ctx* ctx, int form);
 int launch_assemble_vector(zzz_ctx* ctx, int form);
 int launch_matfree_action(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);

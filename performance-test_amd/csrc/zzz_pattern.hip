@@ -1,0 +1,292 @@
+// Sparsity pattern, dof->cell adjacency and kernel tile descriptors, built on the GPU.
+//
+// Replaces fem::petsc::create_matrix(*a) (src/poisson_problem.cpp:122-123, src/elasticity_problem.cpp:196-197),
+// which sits inside the reference's `ZZZ Assemble` umbrella timer: once assembly and solve are fast,
+// a host-side pattern build dominates that timer.
+//
+//   1. (dof, cell) pairs of all local cells, stable radix sort by dof  -> adjacency lists with
+//      ascending cell ids (the order the row-gather assembly sums in: reproducible);
+//   2. one wavefront per owned block row: gather the dofs of the row's cells into LDS, bitonic sort,
+//      count / emit the unique ones (two passes around an exclusive scan) -> CSR with ascending
+//      columns, block size expanded;
+//   3. tile descriptors for the SpMV and assembly kernels by binary search of fixed-width windows
+//      of the nonzero stream in rowptr (fully parallel, no host loop).
+// rocPRIM supplies the generic scan / radix-sort primitives; everything pattern-specific is below.
+#include <cstring>
+
+#include "zzz_device.h"
+#include "zzz_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <climits>
+
+namespace zzz
+{
+constexpr int PAT_CAP = 1024; // candidate columns per block row handled on the device
+
+__global__ void k_make_pairs(const int32_t* __restrict__ cell_dofs, int64_t n, int nd, int32_t nb,
+                             int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ cnt)
+{
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int32_t d = cell_dofs[k];
+    const bool owned = d < nb;
+    keys[k] = owned ? d : nb; // ghost rows are not assembled: park them behind the owned ones
+    vals[k] = (int32_t)(k / nd);
+    if (owned)
+      atomicAdd(&cnt[d], 1);
+  }
+}
+
+// One wavefront per block row: sorted unique dofs of the row's cells.
+// FILL = false: cnt[r] = number of unique columns (and the maximum over rows);
+// FILL = true : scalar CSR columns of the bs rows of block r.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__ cell_dofs, int nd, int bs,
+                                                     const int32_t* __restrict__ adj_off,
+                                                     const int32_t* __restrict__ adj_cells, int32_t nb,
+                                                     int32_t* __restrict__ cnt, int32_t* __restrict__ maxcnt,
+                                                     const int32_t* __restrict__ bptr, int32_t* __restrict__ cols,
+                                                     int32_t* __restrict__ overflow)
+{
+  __shared__ int32_t lds[4][PAT_CAP];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  volatile int32_t* c = lds[wv];
+  for (int64_t r = blockIdx.x * 4 + wv; r < nb; r += (int64_t)gridDim.x * 4)
+  {
+    const int a0 = adj_off[r], na = adj_off[r + 1] - a0;
+    const int n = na * nd;
+    if (n > PAT_CAP)
+    {
+      if (lane == 0)
+        atomicMax(overflow, n);
+      continue;
+    }
+    int P = 64;
+    while (P < n)
+      P <<= 1;
+    for (int idx = lane; idx < P; idx += 64)
+    {
+      int32_t v = INT_MAX;
+      if (idx < n)
+      {
+        const int a = idx / nd, j = idx - a * nd;
+        v = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+      }
+      c[idx] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // bitonic sort of P keys by one wavefront (LDS operations of a wave complete in order)
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1)
+      {
+        for (int t = lane; t < (P >> 1); t += 64)
+        {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)); // index with bit j clear
+          const int l = i | j;
+          const bool up = (i & k) == 0;
+          const int32_t x = c[i], y = c[l];
+          if ((x > y) == up)
+          {
+            c[i] = y;
+            c[l] = x;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    // unique
+    int base = 0;
+    const int32_t rp = FILL ? bptr[r] : 0, nu = FILL ? cnt[r] : 0;
+    for (int s = 0; s < n; s += 64)
+    {
+      const int idx = s + lane;
+      const bool flag = idx < n && (idx == 0 || c[idx] != c[idx - 1]);
+      const unsigned long long m = __ballot(flag);
+      if (FILL && flag)
+      {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        const int32_t col = c[idx];
+        // block (r, col) -> bs x bs scalar entries; scalar row (r, a) starts at bs*bs*rp + a*bs*nu
+        for (int a = 0; a < bs; ++a)
+          for (int d = 0; d < bs; ++d)
+            cols[(int64_t)bs * bs * rp + (int64_t)a * bs * nu + (int64_t)pos * bs + d] = col * bs + d;
+      }
+      base += __popcll(m);
+    }
+    if (!FILL && lane == 0)
+    {
+      cnt[r] = base;
+      atomicMax(maxcnt, base);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void k_scalar_rowptr(const int32_t* __restrict__ bptr, const int32_t* __restrict__ cnt, int32_t nb, int bs,
+                                int32_t* __restrict__ rowptr)
+{
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= nb; r += (int64_t)gridDim.x * blockDim.x)
+  {
+    if (r == nb)
+    {
+      rowptr[(int64_t)nb * bs] = bs * bs * bptr[nb];
+      continue;
+    }
+    for (int a = 0; a < bs; ++a)
+      rowptr[r * bs + a] = bs * bs * bptr[r] + a * bs * cnt[r];
+  }
+}
+
+__device__ inline int lower_bound_rows(const int32_t* __restrict__ rowptr, int stride, int n, int64_t target)
+{
+  // first i in [0, n] with rowptr[i*stride] >= target (rowptr[n*stride] = nnz closes the range)
+  int lo = 0, hi = n;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (rowptr[(int64_t)mid * stride] < target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// SpMV tiles: window t = rows whose first nonzero lies in [t*W, (t+1)*W); descriptor {r0, r1, s, e}
+__global__ void k_spmv_tiles(const int32_t* __restrict__ rowptr, int nrows, int64_t W, int64_t ntiles,
+                             int4* __restrict__ tiles)
+{
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int r0 = lower_bound_rows(rowptr, 1, nrows, t * W);
+    const int r1 = lower_bound_rows(rowptr, 1, nrows, (t + 1) * W);
+    tiles[t] = make_int4(r0, r1, rowptr[r0], rowptr[r1]);
+  }
+}
+
+// assembly tiles: boundaries in block dofs; tile t = block dofs whose first nonzero lies in window t
+__global__ void k_asm_tiles(const int32_t* __restrict__ rowptr, int nb, int bs, int64_t W, int64_t ntiles,
+                            int32_t* __restrict__ tiles)
+{
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= ntiles; t += (int64_t)gridDim.x * blockDim.x)
+    tiles[t] = (t == ntiles) ? nb : lower_bound_rows(rowptr, bs, nb, t * W);
+}
+
+static int grid_for(int64_t n, int block = 256, int cap = 4096)
+{
+  int64_t g = (n + block - 1) / block;
+  if (g > cap)
+    g = cap;
+  if (g < 1)
+    g = 1;
+  return (int)g;
+}
+
+// tile descriptors from a device rowptr (used by both the device and the host pattern builders)
+int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
+{
+  const int bs = ctx->bs;
+  hipStream_t s = ctx->stream;
+  const int maxrow = max_block_cols * bs;           // longest scalar row
+  const int maxblock = max_block_cols * bs * bs;    // nonzeros of the bs rows of one block dof
+  ctx->max_row_nnz = maxrow;
+  const int64_t Ws = (int64_t)ctx->spmv_tile - maxrow - 2;
+  const int64_t Wa = (int64_t)asm_tile_nnz() - maxblock;
+  if (Ws < maxrow || Wa < maxblock || Wa < 1)
+    return fail(ctx, ZZZ_ERR_LIMIT, "matrix rows too long for the kernel tiles (%d nonzeros per row)", maxrow);
+  ctx->ntiles = (ctx->nnz + Ws - 1) / Ws;
+  ctx->n_asm_tiles = (ctx->nnz + Wa - 1) / Wa;
+  ZZZ_HIP(ctx, ctx->tile_row.alloc((size_t)ctx->ntiles * 4 + 4));
+  ZZZ_HIP(ctx, ctx->asm_tile.alloc((size_t)ctx->n_asm_tiles + 1));
+  hipLaunchKernelGGL(k_spmv_tiles, dim3(grid_for(ctx->ntiles)), dim3(256), 0, s, ctx->rowptr.p, (int)ctx->nrows, Ws,
+                     ctx->ntiles, reinterpret_cast<int4*>(ctx->tile_row.p));
+  hipLaunchKernelGGL(k_asm_tiles, dim3(grid_for(ctx->n_asm_tiles + 1)), dim3(256), 0, s, ctx->rowptr.p,
+                     (int)ctx->n_owned, bs, Wa, ctx->n_asm_tiles, ctx->asm_tile.p);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+
+// returns ZZZ_OK, or ZZZ_ERR_LIMIT with *fallback = true when a row has more candidates than the
+// device kernel holds (the caller then uses the host builder)
+int pattern_build_device(zzz_ctx* ctx, bool* fallback)
+{
+  *fallback = false;
+  const int nd = ctx->nd, bs = ctx->bs;
+  const int32_t nb = (int32_t)ctx->n_owned;
+  const int64_t N = ctx->ncells * nd;
+  hipStream_t s = ctx->stream;
+  if (N > INT32_MAX - 8)
+    return fail(ctx, ZZZ_ERR_LIMIT, "dof->cell adjacency exceeds int32");
+
+  DevBuf<int32_t> keys_in, keys_out, vals_in, cnt, bptr, scal;
+  DevBuf<unsigned char> tmp;
+  ZZZ_HIP(ctx, keys_in.alloc((size_t)N));
+  ZZZ_HIP(ctx, keys_out.alloc((size_t)N));
+  ZZZ_HIP(ctx, vals_in.alloc((size_t)N));
+  ZZZ_HIP(ctx, ctx->adj_cells.alloc((size_t)N));
+  ZZZ_HIP(ctx, cnt.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, bptr.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, scal.alloc(4)); // [0] max unique cols, [1] overflow
+  ZZZ_HIP(ctx, hipMemsetAsync(cnt.p, 0, ((size_t)nb + 1) * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(scal.p, 0, 4 * sizeof(int32_t), s));
+
+  // 1. adjacency
+  hipLaunchKernelGGL(k_make_pairs, dim3(grid_for(N)), dim3(256), 0, s, ctx->cell_dofs.p, N, nd, nb, keys_in.p, vals_in.p,
+                     cnt.p);
+  int end_bit = 1;
+  while ((1ll << end_bit) <= (long long)nb)
+    ++end_bit;
+  size_t tb = 0, tb2 = 0;
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p, ctx->adj_cells.p, (size_t)N, 0,
+                                         (unsigned)end_bit, s));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, bptr.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
+  ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, keys_in.p, keys_out.p, vals_in.p, ctx->adj_cells.p, (size_t)N, 0,
+                                         (unsigned)end_bit, s));
+  ZZZ_HIP(ctx, ctx->adj_off.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb2, cnt.p, ctx->adj_off.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
+  keys_in.release();
+  keys_out.release();
+  vals_in.release();
+
+  // 2. pattern: count, scan, fill
+  const int rgrid = grid_for((int64_t)nb, 4, 256 * 16);
+  hipLaunchKernelGGL(k_row_pattern<false>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
+                     ctx->adj_cells.p, nb, cnt.p, scal.p, (const int32_t*)nullptr, (int32_t*)nullptr, scal.p + 1);
+  int32_t h[4] = {0, 0, 0, 0};
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (h[1] > 0)
+  {
+    *fallback = true;
+    return fail(ctx, ZZZ_ERR_LIMIT, "a row gathers %d candidate columns (device limit %d)", h[1], PAT_CAP);
+  }
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb2, cnt.p, bptr.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
+  int32_t nblk = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&nblk, bptr.p + nb, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  const int64_t nnz = (int64_t)nblk * bs * bs;
+  if (nnz > INT32_MAX - 8 || nblk < 0)
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range", (long long)nnz);
+  ctx->nrows = (int64_t)nb * bs;
+  ctx->ncols = ctx->nloc();
+  ctx->nnz = nnz;
+  ZZZ_HIP(ctx, ctx->rowptr.alloc((size_t)ctx->nrows + 1));
+  ZZZ_HIP(ctx, ctx->cols.alloc((size_t)nnz + 8));
+  ZZZ_HIP(ctx, ctx->vals.alloc((size_t)nnz + 8));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->cols.p + nnz, 0, 8 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->vals.p, 0, ((size_t)nnz + 8) * sizeof(double), s));
+  hipLaunchKernelGGL(k_scalar_rowptr, dim3(grid_for((int64_t)nb + 1)), dim3(256), 0, s, bptr.p, cnt.p, nb, bs,
+                     ctx->rowptr.p);
+  hipLaunchKernelGGL(k_row_pattern<true>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
+                     ctx->adj_cells.p, nb, cnt.p, scal.p, bptr.p, ctx->cols.p, scal.p + 1);
+  ZZZ_HIP(ctx, hipGetLastError());
+  // 3. tiles
+  int rc = build_tiles_device(ctx, h[0]);
+  if (rc)
+    return rc;
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  return ZZZ_OK;
+}
+} // namespace zzz

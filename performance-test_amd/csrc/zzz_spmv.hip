@@ -121,11 +121,13 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
       lds_barrier();
     else
       __syncthreads();
-    if (r < r1)
+    for (int rr = r; rr < r1; rr += SPMV_BLOCK) // one row per thread unless the rows are very short
     {
+      const int ra_ = (rr == r) ? ra : rowptr[rr] - s_al, rb_ = (rr == r) ? rb : rowptr[rr + 1] - s_al;
+      const double xr_ = (rr == r) ? xr : (DOT ? x[rr] : 0.0);
       // products are added in column order (the serial CPU order); 8 LDS reads in flight at a time
       double sum = 0.0;
-      for (int k = ra; k < rb; k += 8)
+      for (int k = ra_; k < rb_; k += 8)
       {
         double q[8];
 #pragma unroll
@@ -133,12 +135,12 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
           q[u] = prod[k + u]; // may run past the row: within the padded LDS array, masked below
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (k + u < rb)
+          if (k + u < rb_)
             sum += q[u];
       }
-      y[r] = sum;
+      y[rr] = sum;
       if (DOT)
-        dot += sum * xr;
+        dot += sum * xr_;
     }
     if (PIPE)
       lds_barrier();
@@ -157,33 +159,6 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     if (threadIdx.x == 0)
       partials[blockIdx.x] = sres;
   }
-}
-
-int build_spmv_tiles(zzz_ctx* ctx, const std::vector<int32_t>& h_rowptr)
-{
-  const int64_t n = (int64_t)h_rowptr.size() - 1;
-  std::vector<int32_t> tiles; // 4 ints per tile: r0, r1, s, e
-  int64_t r = 0;
-  while (r < n)
-  {
-    const int64_t s_al = h_rowptr[r] & ~1;
-    int64_t q = r;
-    while (q < n && q - r < SPMV_BLOCK && h_rowptr[q + 1] - s_al <= ctx->spmv_tile)
-      ++q;
-    if (q == r)
-      return fail(ctx, ZZZ_ERR_LIMIT, "matrix row %lld has more than %d nonzeros", (long long)r, ctx->spmv_tile - 1);
-    tiles.push_back((int32_t)r);
-    tiles.push_back((int32_t)q);
-    tiles.push_back(h_rowptr[r]);
-    tiles.push_back(h_rowptr[q]);
-    r = q;
-  }
-  ctx->ntiles = (int64_t)tiles.size() / 4;
-  ZZZ_HIP(ctx, ctx->tile_row.alloc(tiles.size()));
-  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->tile_row.p, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                              ctx->stream));
-  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZZZ_OK;
 }
 
 static int spmv_grid(const zzz_ctx* ctx)
