@@ -114,9 +114,15 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
+    # Load libzzz_hip (and with it /opt/rocm's HIP runtime) and, for N > 1, librccl BEFORE torch is
+    # imported: torch bundles its own HIP/RCCL copies, and the two sets must never resolve into each
+    # other.  torch is used for gloo plumbing only and never touches the GPU in this process.
+    zzz.hip()
+    uid_bytes = None
+    if world > 1 and rank == 0:
+        uid_bytes = zzz.comm_unique_id()  # ncclGetUniqueId (dlopens librccl.so.1)
     dist = None
     if world > 1:
-        # libzzz_hip (and its HIP runtime, /opt/rocm) is already loaded; torch is used for gloo only
         import torch
         import torch.distributed as dist
 
@@ -137,7 +143,7 @@ def main():
 
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
-            uid = torch.frombuffer(bytearray(zzz.comm_unique_id()), dtype=torch.uint8).clone()
+            uid = torch.frombuffer(bytearray(uid_bytes), dtype=torch.uint8).clone()
         dist.broadcast(uid, src=0)
         ctx.comm_init(world, rank, bytes(uid.numpy().tobytes()))
     ctx.upload_part(P)

@@ -1,17 +1,21 @@
 // Conjugate gradients on the GPU: linalg::cg of src/cg.h:38-86 (variant CGH) and PETSc's KSPCG with
 // PCJACOBI / PCNONE as the reference selects it at src/poisson_problem.cpp:168-177 (variant PETSC).
 //
-// All Krylov scalars live in device memory; the host only enqueues.  One iteration is
-//   k_update_p : p = z + (beta_k / beta_{k-1}) p                       (axpy, src/cg.h:82)
+// All Krylov scalars live in device memory; the host only enqueues.  One iteration is three kernels:
+//   k_update_p : sums the partials of <r,z> and of the test norm left by the previous kernel (every
+//                workgroup redundantly, in the same fixed order => identical scalars), does the
+//                convergence test (squared_norm + test, src/cg.h:74-79), then
+//                p = z + (beta_k / beta_{k-1}) p                        (axpy, src/cg.h:82)
 //   [halo]     : ghost values of p from their owners                   (scatter_fwd)
 //   spmv       : w = A p, per-workgroup partials of <p, w>             (action, src/cg.h:62)
-//   k_reduce   : <p,w> -> alpha = beta_k / <p,w>   [+ RCCL all-reduce]  (inner_product, src/cg.h:65)
-//   k_update_xr: x += alpha p; r -= alpha w; z = D^-1 r; partials of <r,z> and the test norm
+//   k_update_xr: sums the <p,w> partials -> alpha = beta_k / <p,w>     (inner_product, src/cg.h:65);
+//                x += alpha p; r -= alpha w; z = D^-1 r; partials of <r,z> and the test norm
 //                                                                      (axpy x2, src/cg.h:68,71)
-//   k_reduce   : beta_{k+1}, norm, convergence test  [+ all-reduce]     (squared_norm, src/cg.h:74-79)
+// With a communicator attached a one-workgroup reduce + ncclAllReduce sits between producer and
+// consumer, and the consumer reads the single all-reduced value instead of the partials.
 // Every kernel returns at once when the device-side `converged` flag is set; the host polls that
 // flag a few iterations behind the queue, so the returned iteration count is exact.
-// Reductions use fixed trees (per-workgroup partials, then one workgroup) => reproducible runs.
+// Reductions use fixed trees => reproducible runs.
 // HBM traffic per iteration beyond the SpMV: 24 B/row (p update) + 56 B/row (x, r, z update).
 #include "zzz_device.h"
 #include "zzz_internal.h"
@@ -74,26 +78,116 @@ __global__ __launch_bounds__(VB) void k_init_residual(const double* __restrict__
   }
 }
 
-__global__ __launch_bounds__(VB) void k_update_p(const CgState* __restrict__ st, const double* __restrict__ beta_hist,
-                                                 int it, const double* __restrict__ z, double* __restrict__ p, int64_t n)
+// The convergence flag can be set by workgroup 0 of the SAME launch while other workgroups start:
+// read it once per workgroup and broadcast, so all threads of a workgroup take the same branch.
+__device__ inline int block_converged(const CgState* st)
 {
-  if (st->converged)
+  __shared__ int flag;
+  if (threadIdx.x == 0)
+    flag = st->converged;
+  __syncthreads();
+  return flag;
+}
+
+// one workgroup-wide sum of parts[0..np) (fixed order); result in every thread
+__device__ inline double reduce_parts_bcast(const double* __restrict__ parts, int np, double* sh)
+{
+  double s = 0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x)
+    s += parts[i];
+  const double t = block_reduce_sum(s, sh);
+  __shared__ double bc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    bc = t;
+  __syncthreads();
+  return bc;
+}
+
+// `it` = number of completed iterations.  pa/pb: partials of <r,z> and of the test norm (np each).
+__global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, double* __restrict__ beta_hist,
+                                                 double* __restrict__ dp_hist, int it, CgParams P,
+                                                 const double* __restrict__ pa, const double* __restrict__ pb, int np,
+                                                 const double* __restrict__ z, double* __restrict__ p, int64_t n)
+{
+  if (block_converged(st))
     return;
-  const double bcoef = (it == 0) ? 0.0 : beta_hist[it] / beta_hist[it - 1];
+  __shared__ double sh[VB / 64];
+  const double rz = reduce_parts_bcast(pa, np, sh);
+  const double nn = reduce_parts_bcast(pb, np, sh);
+  // scalar logic, identical in every workgroup; workgroup 0 records it
+  double dp, dp0 = st->dp0, ttol = st->ttol;
+  int conv = 0;
+  if (P.variant == ZZZ_CG_CGH)
+  {
+    // src/cg.h:53-55,74-79: rnorm = <r,r>; break when rnorm/rnorm0 < rtol^2 (strict), no test at k = 0
+    dp = rz;
+    if (it == 0)
+    {
+      dp0 = rz;
+      ttol = P.rtol * P.rtol;
+    }
+    else if (rz / dp0 < P.rtol * P.rtol)
+      conv = 1;
+  }
+  else
+  {
+    dp = (P.norm == ZZZ_NORM_NATURAL) ? sqrt(fabs(rz)) : sqrt(nn);
+    if (it == 0)
+    {
+      dp0 = dp;
+      ttol = fmax(P.rtol * dp, P.atol);
+    }
+    if (!isfinite(dp))
+      conv = 2;
+    else if (dp <= ttol) // KSPConvergedDefault
+      conv = 1;
+  }
+  const double bprev = (it == 0) ? 1.0 : beta_hist[it - 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    beta_hist[it] = rz;
+    dp_hist[it] = dp;
+    st->dp = dp;
+    if (it == 0)
+    {
+      st->dp0 = dp0;
+      st->ttol = ttol;
+    }
+    if (conv)
+    {
+      st->iters = it;
+      st->converged = conv; // the other workgroups reach the same verdict from the same partials
+    }
+  }
+  if (conv || p == nullptr)
+    return;
+  const double bcoef = (it == 0) ? 0.0 : rz / bprev;
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
     p[i] = (it == 0) ? z[i] : bcoef * p[i] + z[i];
 }
 
-__global__ __launch_bounds__(VB) void k_update_xr(const CgState* __restrict__ st, const double* __restrict__ alpha_p,
+__global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, const double* __restrict__ beta_hist, int it,
+                                                  const double* __restrict__ pw_parts, int npw,
                                                   const double* __restrict__ p, const double* __restrict__ w,
                                                   const double* __restrict__ dinv, double* __restrict__ x,
                                                   double* __restrict__ r, double* __restrict__ z, int64_t n, int norm,
                                                   double* __restrict__ pa, double* __restrict__ pb)
 {
-  if (st->converged)
+  if (block_converged(st))
     return;
   __shared__ double sh[VB / 64];
-  const double alpha = *alpha_p;
+  const double pw = reduce_parts_bcast(pw_parts, npw, sh);
+  const double alpha = beta_hist[it] / pw; // src/cg.h:65
+  if (!isfinite(alpha))
+  {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      st->iters = it;
+      st->converged = 2;
+    }
+    return; // every workgroup sees the same non-finite alpha
+  }
   double sa = 0, sb = 0;
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
   {
@@ -114,7 +208,6 @@ __global__ __launch_bounds__(VB) void k_update_xr(const CgState* __restrict__ st
   }
 }
 
-// one workgroup: out[j] = sum(parts_j[0..np)), j < nvec
 __device__ inline double reduce_parts(const double* __restrict__ parts, int np, double* sh)
 {
   double s = 0;
@@ -123,111 +216,21 @@ __device__ inline double reduce_parts(const double* __restrict__ parts, int np, 
   return block_reduce_sum(s, sh);
 }
 
-// scalar logic after <p,w>: alpha = beta_it / <p,w>
-__device__ inline void scalar_alpha(CgState* st, const double* beta_hist, int it, double pw, double* alpha)
-{
-  const double a = beta_hist[it] / pw;
-  *alpha = a;
-  if (!isfinite(a) && st->converged == 0)
-  {
-    st->converged = 2;
-    st->iters = it;
-  }
-}
-
-// scalar logic after <r,z> and the norm partial: `it` = number of completed iterations
-__device__ inline void scalar_beta(CgState* st, double* beta_hist, double* dp_hist, int it, double rz, double nn,
-                                   CgParams P)
-{
-  beta_hist[it] = rz;
-  if (P.variant == ZZZ_CG_CGH)
-  {
-    // src/cg.h:53-55,74-79: rnorm = <r,r>; break when rnorm/rnorm0 < rtol^2 (strict), no test at k = 0
-    dp_hist[it] = rz;
-    st->dp = rz;
-    if (it == 0)
-    {
-      st->dp0 = rz;
-      st->ttol = P.rtol * P.rtol;
-    }
-    else if (rz / st->dp0 < P.rtol * P.rtol)
-    {
-      st->converged = 1;
-      st->iters = it;
-    }
-    return;
-  }
-  const double dp = (P.norm == ZZZ_NORM_NATURAL) ? sqrt(fabs(rz)) : sqrt(nn);
-  dp_hist[it] = dp;
-  st->dp = dp;
-  if (it == 0)
-  {
-    st->dp0 = dp;
-    st->ttol = fmax(P.rtol * dp, P.atol);
-  }
-  if (!isfinite(dp))
-  {
-    st->converged = 2;
-    st->iters = it;
-  }
-  else if (dp <= st->ttol) // KSPConvergedDefault
-  {
-    st->converged = 1;
-    st->iters = it;
-  }
-}
-
-// mode 0: reduce + scalar logic (single rank); mode 1: reduce only, sums to out[] (multi rank)
-__global__ __launch_bounds__(1024) void k_reduce_alpha(CgState* st, const double* __restrict__ parts, int np,
-                                                       const double* beta_hist, int it, double* alpha, double* out,
-                                                       int mode)
+// multi-rank: out[j] = sum of partial array j (one workgroup), then ncclAllReduce(out)
+__global__ __launch_bounds__(1024) void k_reduce_multi(const CgState* st, const double* __restrict__ pa,
+                                                       const double* __restrict__ pb, int np, double* out)
 {
   if (st->converged)
     return;
   __shared__ double sh[16];
-  const double pw = reduce_parts(parts, np, sh);
+  const double a = reduce_parts(pa, np, sh);
+  const double b = pb ? reduce_parts(pb, np, sh) : 0.0;
   if (threadIdx.x == 0)
   {
-    if (mode == 0)
-      scalar_alpha(st, beta_hist, it, pw, alpha);
-    else
-      out[0] = pw;
+    out[0] = a;
+    if (pb)
+      out[1] = b;
   }
-}
-
-__global__ __launch_bounds__(1024) void k_reduce_beta(CgState* st, const double* __restrict__ pa,
-                                                      const double* __restrict__ pb, int np, double* beta_hist,
-                                                      double* dp_hist, int it, CgParams P, double* out, int mode)
-{
-  if (st->converged)
-    return;
-  __shared__ double sh[16];
-  const double rz = reduce_parts(pa, np, sh);
-  const double nn = reduce_parts(pb, np, sh);
-  if (threadIdx.x == 0)
-  {
-    if (mode == 0)
-      scalar_beta(st, beta_hist, dp_hist, it, rz, nn, P);
-    else
-    {
-      out[0] = rz;
-      out[1] = nn;
-    }
-  }
-}
-
-// multi-rank: scalar logic on the all-reduced sums
-__global__ void k_scalar_alpha(CgState* st, const double* red, const double* beta_hist, int it, double* alpha)
-{
-  if (st->converged)
-    return;
-  scalar_alpha(st, beta_hist, it, red[0], alpha);
-}
-__global__ void k_scalar_beta(CgState* st, const double* red, double* beta_hist, double* dp_hist, int it, CgParams P)
-{
-  if (st->converged)
-    return;
-  scalar_beta(st, beta_hist, dp_hist, it, red[0], red[1], P);
 }
 
 __global__ __launch_bounds__(VB) void k_sqnorm(const double* __restrict__ v, int64_t n, double* __restrict__ parts)
@@ -284,7 +287,6 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   const int max_it = o->max_it;
   CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol};
   const bool multi = ctx->comm != nullptr;
-  const int mode = multi ? 1 : 0;
   const int g = vgrid(n);
   hipStream_t s = ctx->stream;
 
@@ -292,7 +294,6 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
-  double* alpha = ctx->red.p + 4;
 
   // PCSetUp(PCJACOBI): inverse diagonal (inside `ZZZ Solve`, as KSPSetUp is in the reference)
   if (o->op == ZZZ_OP_CSR)
@@ -325,23 +326,29 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   }
   else
     ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
+  double* pa = ctx->part_b.p;
+  double* pb = ctx->part_b.p + VGRID_MAX;
   hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(VB), 0, s, ctx->b.p, w0, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm,
-                     ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
-  auto reduce_beta = [&](int it) -> int {
-    hipLaunchKernelGGL(k_reduce_beta, dim3(1), dim3(1024), 0, s, ctx->state.p, ctx->part_b.p,
-                       ctx->part_b.p + VGRID_MAX, g, ctx->beta_hist.p, ctx->dp_hist.p, it, P, ctx->red.p, mode);
-    if (multi)
-    {
-      int rc = comm_allreduce_sum(ctx, ctx->red.p, 2);
-      if (rc)
-        return rc;
-      hipLaunchKernelGGL(k_scalar_beta, dim3(1), dim3(1), 0, s, ctx->state.p, ctx->red.p, ctx->beta_hist.p,
-                         ctx->dp_hist.p, it, P);
-    }
-    return ZZZ_OK;
+                     pa, pb);
+  // where the consumer kernels find <r,z>, the test norm and <p,w>: the producers' partials, or the
+  // single all-reduced value when a communicator is attached
+  const double *rz_src = pa, *nn_src = pb, *pw_src = ctx->part_a.p;
+  int n_rz = g;
+  if (multi)
+  {
+    rz_src = ctx->red.p;
+    nn_src = ctx->red.p + 1;
+    pw_src = ctx->red.p + 2;
+    n_rz = 1;
+  }
+  auto allreduce_beta = [&]() -> int {
+    if (!multi)
+      return ZZZ_OK;
+    hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(1024), 0, s, ctx->state.p, pa, pb, g, ctx->red.p);
+    return comm_allreduce_sum(ctx, ctx->red.p, 2);
   };
   {
-    int rc = reduce_beta(0);
+    int rc = allreduce_beta();
     if (rc)
       return rc;
   }
@@ -357,7 +364,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   }
   int nprof = 0;
 
-  // host polling: copy the state every CHECK iterations, look at it two batches later
+  // host polling: copy the state every CHECK iterations, look at it NSLOT-1 batches later
   constexpr int CHECK = 8, NSLOT = 4;
   hipEvent_t chk_ev[NSLOT];
   for (int i = 0; i < NSLOT; ++i)
@@ -368,7 +375,9 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   int it = 0;
   for (; it < max_it && !stop; ++it)
   {
-    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, it, ctx->z.p, ctx->p.p, n);
+    // convergence test of iteration `it` and the new search direction
+    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p, it, P, rz_src,
+                       nn_src, n_rz, ctx->z.p, ctx->p.p, n);
     int np = 0;
     if (nprof < max_prof)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
@@ -382,19 +391,19 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
       ++nprof;
     }
-    hipLaunchKernelGGL(k_reduce_alpha, dim3(1), dim3(1024), 0, s, ctx->state.p, ctx->part_a.p, np, ctx->beta_hist.p, it,
-                       alpha, ctx->red.p, mode);
     if (multi)
     {
-      int rc = comm_allreduce_sum(ctx, ctx->red.p, 1);
+      hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(1024), 0, s, ctx->state.p, ctx->part_a.p, (const double*)nullptr,
+                         np, ctx->red.p + 2);
+      int rc = comm_allreduce_sum(ctx, ctx->red.p + 2, 1);
       if (rc)
         return rc;
-      hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, s, ctx->state.p, ctx->red.p, ctx->beta_hist.p, it, alpha);
+      np = 1;
     }
-    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, alpha, ctx->p.p, ctx->w.p, ctx->dinv.p,
-                       ctx->u.p, ctx->r.p, ctx->z.p, n, P.norm, ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
+    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, it, pw_src, np, ctx->p.p,
+                       ctx->w.p, ctx->dinv.p, ctx->u.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
     {
-      int rc = reduce_beta(it + 1);
+      int rc = allreduce_beta();
       if (rc)
         return rc;
     }
@@ -403,7 +412,6 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       const int slot = nchk % NSLOT;
       if (nchk >= NSLOT - 1)
       {
-        // wait for the check issued NSLOT-1 batches ago
         const int old = (nchk - (NSLOT - 1)) % NSLOT;
         ZZZ_HIP(ctx, hipEventSynchronize(chk_ev[old]));
         if (ctx->h_state[old].converged)
@@ -414,6 +422,9 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       ++nchk;
     }
   }
+  // the test of the last completed iteration (it == max_it when the loop ran out): scalars only
+  hipLaunchKernelGGL(k_update_p, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p, it, P, rz_src,
+                     nn_src, n_rz, ctx->z.p, (double*)nullptr, n);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
