@@ -94,7 +94,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   if (const char* e = getenv("ZZZ_SPMV_TILE"))
     ctx->spmv_tile = atoi(e) == 4096 ? 4096 : 2048;
   if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
-    ctx->spmv_variant = atoi(e) & 3;
+    ctx->spmv_variant = atoi(e) & 15;
+  ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
   *out = ctx;
   return ZZZ_OK;
 }
@@ -291,6 +292,10 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
   }
   if (rc)
     return rc;
+  ctx->sell_current = false;
+  rc = sell_update(ctx, true);
+  if (rc)
+    return rc;
   ctx->have_pattern = true;
   return ZZZ_OK;
 }
@@ -447,8 +452,12 @@ int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals)
   if (!ctx->have_pattern || !vals)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_upload_values: no pattern or NULL values");
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->vals.p, vals, (size_t)ctx->nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = sell_update(ctx, false);
+  if (rc)
+    return rc;
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_matrix = true;
+  ctx->sell_current = ctx->have_sell;
   return ZZZ_OK;
 }
 
@@ -461,7 +470,12 @@ int zzz_assemble_matrix(zzz_ctx* ctx, int form)
     return fail(ctx, ZZZ_ERR_ARG, "unknown form %d", form);
   int rc = launch_assemble_matrix(ctx, form);
   if (!rc)
+    rc = sell_update(ctx, false); // MatAssemblyEnd-like finalisation: refresh the SpMV copy
+  if (!rc)
+  {
     ctx->have_matrix = true;
+    ctx->sell_current = ctx->have_sell;
+  }
   return rc;
 }
 
@@ -543,7 +557,7 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_time: no matrix or bad arguments");
   const int saved = ctx->spmv_variant;
   if (variant >= 0)
-    ctx->spmv_variant = variant & 3;
+    ctx->spmv_variant = variant & 15; // bit 2: gather-free timing diagnostic (wrong results); bit 3: SELL
   hipEvent_t e0, e1;
   ZZZ_HIP(ctx, hipEventCreate(&e0));
   ZZZ_HIP(ctx, hipEventCreate(&e1));

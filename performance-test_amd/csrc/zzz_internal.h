@@ -100,7 +100,16 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> tile_row;
   int64_t ntiles = 0;
   int spmv_tile = 2048;  // nonzeros per tile (2048 | 4096), fixed at pattern build
-  int spmv_variant = 1;  // bit 0: non-temporal matrix loads, bit 1: pipelined tiles
+  int spmv_variant = 1;  // bit 0: non-temporal matrix loads, bit 1: pipelined CSR tiles,
+                         // bit 3: build and use the SELL-64 copy (measured 13 % slower than the CSR
+                         // tile kernel on the 10 M-dof P1 matrix; kept as an A/B variant only)
+  // SELL-64 copy of the matrix for the CG SpMV (zzz_spmv.hip)
+  zzz::DevBuf<int32_t> slice_off, sell_cols;
+  zzz::DevBuf<double> sell_vals;
+  int64_t nslices = 0, sell_entries = 0;
+  bool have_sell = false;    // structure built
+  bool sell_current = false; // values match the CSR values
+  bool sell_requested = false;
   // assembly tiling: contiguous owned block-dof ranges whose CSR segment fits LDS
   zzz::DevBuf<int32_t> asm_tile;
   int64_t n_asm_tiles = 0;
@@ -152,6 +161,7 @@ int asm_tile_nnz();
 // kernels_spmv
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
 int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+int sell_update(zzz_ctx* ctx, bool structure);
 
 // kernels_assemble
 int launch_assemble_matrix(zzz_ctx* ctx, int form);
