@@ -272,3 +272,78 @@ def test_driver_binary_surface():
     for bad in (["--scaling_type", "sideways"], ["--problem_type", "stokes"], ["--order", "4"]):
         out = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
         assert out.returncode != 0
+
+
+@pytest.mark.parametrize("problem,order", [("poisson", 1), ("poisson", 2), ("poisson", 3), ("elasticity", 1),
+                                           ("elasticity", 3)])
+def test_unsorted_cells_and_foreign_numbering(ctx, problem, order):
+    """A mesh the structured feed never produces: the oracle's create_box-style cells (vertices NOT
+    sorted, both orientations of det J, edge sub-dofs permuted by the dofmap) with its entity-blocked
+    dof numbering, cells shuffled, on a stretched and sheared geometry."""
+    O = zo.Problem(problem, order, 3, 2, 3)
+    rng = np.random.default_rng(11 + order)
+    perm = rng.permutation(O.cells.shape[0])
+    cells = np.ascontiguousarray(O.cells[perm])
+    cell_dofs = np.ascontiguousarray(O.cell_dofs[perm])
+    # affine map of the geometry (kernels must not assume a unit cube); BC/facets/coefficients stay
+    # those of the original problem (they are inputs at the boundary)
+    M = np.array([[1.3, 0.2, 0.0], [0.1, 0.9, 0.3], [0.0, -0.2, 1.1]])
+    x = np.ascontiguousarray(O.x @ M.T + np.array([0.3, -0.1, 0.2]))
+    facets = zo.exterior_facets(cells) if problem == "poisson" else None
+    bs = O.bs
+    ctx.upload_mesh(x, cells)
+    ctx.upload_dofmap(order, bs, cell_dofs, O.nblock, 0)
+    ctx.upload_bc(np.nonzero(O.bc)[0].astype(np.int32))
+    ctx.upload_coeff(zzz.COEFF_F, O.f)
+    if problem == "poisson":
+        ctx.upload_facets(facets)
+        ctx.upload_coeff(zzz.COEFF_G, O.g)
+    ctx.pattern_build()
+    ctx.assemble_matrix(O.form)
+    ctx.assemble_vector(O.form)
+    rowptr, cols, vals = ctx.csr_download()
+    orp, ocl = zo.pattern(O.nblock, cell_dofs, bs)
+    np.testing.assert_array_equal(rowptr, orp)
+    np.testing.assert_array_equal(cols, ocl)
+    ov = zo.assemble_matrix(O.form, order, x, cells, cell_dofs, O.bc, orp, ocl)
+    ob = zo.assemble_vector(O.form, order, x, cells, cell_dofs, O.f, O.g, facets, O.bc)
+    assert np.abs(vals - ov).max() <= 1e-12 * np.abs(ov).max()
+    assert np.abs(ctx.vec_download(zzz.VEC_B) - ob).max() <= 1e-12 * np.abs(ob).max()
+    if problem == "poisson":
+        v = rng.standard_normal(O.n)
+        assert np.abs(ctx.action(v) - zo.action_poisson(order, x, cells, cell_dofs, O.bc, v)).max() <= 1e-11 * np.abs(ov).max()
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+    oit, ou, _, _ = zo.pcg(orp, ocl, ov, ob, rtol=1e-8)
+    assert abs(it - oit) <= 2
+    assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+
+
+def test_empty_and_ragged_inputs(ctx):
+    """Edge cases at the boundary: no constrained dofs, no exterior facets uploaded, a single cell,
+    bad arrays rejected with an error code (never a crash)."""
+    x = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]])
+    cells = np.array([[0, 1, 2, 3]], np.int32)
+    ctx.upload_mesh(x, cells)
+    ctx.upload_dofmap(1, 1, cells, 4, 0)
+    ctx.upload_bc(np.zeros(0, np.int32))          # empty BC set
+    ctx.upload_facets(np.zeros((0, 2), np.int32))  # no ds term
+    ctx.upload_coeff(zzz.COEFF_F, np.ones(4))
+    ctx.upload_coeff(zzz.COEFF_G, np.ones(4))
+    ctx.pattern_build()
+    ctx.assemble_matrix(zzz.FORM_POISSON)
+    ctx.assemble_vector(zzz.FORM_POISSON)
+    rowptr, cols, vals = ctx.csr_download()
+    np.testing.assert_array_equal(rowptr, [0, 4, 8, 12, 16])
+    A = vals.reshape(4, 4)
+    np.testing.assert_allclose(6 * A, [[3, -1, -1, -1], [-1, 1, 0, 0], [-1, 0, 1, 0], [-1, 0, 0, 1]], atol=1e-15)
+    np.testing.assert_allclose(ctx.vec_download(zzz.VEC_B), np.full(4, 1 / 24), rtol=1e-14)
+    with pytest.raises(zzz.ZzzError):
+        ctx.upload_mesh(x, np.array([[0, 1, 2, 4]], np.int32))  # vertex index out of range
+    with pytest.raises(zzz.ZzzError):
+        ctx.upload_dofmap(1, 1, np.array([[0, 1, 2, 7]], np.int32), 4, 0)
+    with pytest.raises(zzz.ZzzError):
+        ctx.upload_bc(np.array([99], np.int32))
+    with pytest.raises(zzz.ZzzError):
+        ctx.upload_facets(np.array([[0, 5]], np.int32))
+    with pytest.raises(zzz.ZzzError):
+        ctx.upload_dofmap(1, 2, cells, 4, 0)  # block size 2 unsupported
