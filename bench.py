@@ -40,6 +40,23 @@ def spmv_algorithmic_bytes(n, nnz):
     return 12 * nnz + 4 * (n + 1) + 16 * n
 
 
+def pmc_traffic(nrows, nnz):
+    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command (they cannot share a pass and PMC
+    collection cannot run inside a timed benchmark), corrected as MI355X_MICROARCH.md prescribes for
+    gfx950 (FETCH_SIZE counts half of a coalesced stream: x2; KiB units).  Only reported when the
+    profile was taken on the same matrix."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench10m.json")
+    try:
+        d = json.load(open(path))
+        if d["rows"] != nrows or d["nnz"] != nnz:
+            return None, None
+        k = d["kernels"]["spmv"]
+        return 2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024, os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(P, ctx, iters_gpu, sample_iters=20):
     """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample
     of the same workload: full matrix + vector assembly, then `sample_iters` Jacobi-PCG iterations,
@@ -199,6 +216,7 @@ def main():
     out = None
     if rank == 0:
         alg_bytes = spmv_algorithmic_bytes(nrows, nnz)
+        traffic, traffic_src = pmc_traffic(nrows, nnz)
         achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
         out = {
@@ -224,7 +242,7 @@ def main():
                            "iterations x dofs / ZZZ Solve": iters * ndofs_global / avg("solve")},
             "roofline": {"bound": "hbm", "kernel": "spmv_tile_kernel (CG SpMV + <p,Ap> partials)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n},
         }
         if world == 1 and not a.no_cpu_baseline:
