@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none"])
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--force_comm", action="store_true",
+                    help="N=1 only: attach a 1-rank RCCL communicator to time the multi-GPU code path's fixed costs")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,8 +165,10 @@ def main():
             uid = torch.frombuffer(bytearray(uid_bytes), dtype=torch.uint8).clone()
         dist.broadcast(uid, src=0)
         ctx.comm_init(world, rank, bytes(uid.numpy().tobytes()))
+    if world == 1 and a.force_comm:
+        ctx.comm_init(1, 0, zzz.comm_unique_id())
     ctx.upload_part(P)
-    if world > 1:
+    if world > 1 or a.force_comm:
         ctx.upload_halo(P)
     ctx.pattern_build()  # fem::petsc::create_matrix: outside ZZZ Assemble matrix (src/poisson_problem.cpp:122-123)
     nrows, ncols, nnz = ctx.csr_sizes()

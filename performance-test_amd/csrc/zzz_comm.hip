@@ -10,6 +10,7 @@
 #include "zzz_internal.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstring>
 
@@ -72,6 +73,30 @@ static const char* load_rccl()
   g_rccl.h = h;
   return nullptr;
 }
+
+// RCCL (ROCm 7.2) prints a version banner with printf to STDOUT while a communicator is created.
+// Programs whose stdout is parsed (bench.py prints one JSON line) must not see it: send fd 1 to
+// stderr for the duration of the call.
+struct StdoutToStderr
+{
+  int saved = -1;
+  StdoutToStderr()
+  {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0)
+      dup2(2, 1);
+  }
+  ~StdoutToStderr()
+  {
+    fflush(stdout);
+    if (saved >= 0)
+    {
+      dup2(saved, 1);
+      close(saved);
+    }
+  }
+};
 
 struct Comm
 {
@@ -156,6 +181,7 @@ int zzz_comm_unique_id(void* id)
   if (const char* e = load_rccl())
     return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, dlerror() ? dlerror() : "");
   ncclUniqueId u;
+  StdoutToStderr quiet;
   ncclResult_t r = g_rccl.GetUniqueId(&u);
   if (r != 0)
     return fail(nullptr, ZZZ_ERR_RCCL, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
@@ -178,7 +204,11 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
   Comm* c = new Comm();
   c->nranks = nranks;
   c->rank = rank;
-  ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  ncclResult_t r;
+  {
+    StdoutToStderr quiet;
+    r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  }
   if (r != 0)
   {
     delete c;
