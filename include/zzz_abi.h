@@ -149,6 +149,17 @@ int zzz_facets_upload(zzz_ctx* ctx, int64_t nfacets, const int32_t* cell_facet_p
  * src/poisson_problem.cpp:83-106, src/elasticity_problem.cpp:153-176): (n_owned+n_ghost)*bs. */
 int zzz_coeff_upload(zzz_ctx* ctx, int which, const double* values);
 
+/* The whole feed above for the reference's structured cube problems, generated on the device in
+ * closed form instead of uploaded: create_cube_mesh's box of nx*ny*nz sub-cubes x 6 tetrahedra
+ * (src/mesh.cpp:184-186) cut into `nparts` z-slabs, the P_order function space, the Dirichlet set and
+ * the interpolated coefficients of problem() (src/poisson_problem.cpp:33-106,
+ * src/elasticity_problem.cpp:101-176) and the halo plan.  Equivalent to uploading the arrays of
+ * zzzh_part_create() (include/zzz_host.h); problem = ZZZ_FORM_POISSON | ZZZ_FORM_ELASTICITY.
+ * info (optional, 6 entries): global scalar dofs, global cells, owned block dofs, ghost block dofs,
+ * global block index of local dof 0, local cells. */
+int zzz_cube_generate(zzz_ctx* ctx, int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part,
+                      int64_t* info);
+
 /* ---- matrix ---------------------------------------------------------------------------- */
 
 /* fem::petsc::create_matrix(*a) (src/poisson_problem.cpp:122-123): sparsity pattern of the

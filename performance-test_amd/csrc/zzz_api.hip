@@ -46,6 +46,23 @@ static int upload(zzz_ctx* ctx, DevBuf<T>& d, const T* h, size_t n, size_t pad =
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
 }
+// bc marker (nothing constrained yet), coefficient and Krylov vectors, reduction buffers
+int alloc_problem_vectors(zzz_ctx* ctx)
+{
+  const size_t nv = (size_t)ctx->nloc();
+  ZZZ_HIP(ctx, ctx->bc.alloc(nv));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bc.p, 0, nv, ctx->stream));
+  DevBuf<double>* vecs[] = {&ctx->b, &ctx->u, &ctx->r, &ctx->z, &ctx->p, &ctx->w, &ctx->dinv, &ctx->coeff[0], &ctx->coeff[1]};
+  for (DevBuf<double>* v : vecs)
+  {
+    ZZZ_HIP(ctx, v->alloc(nv));
+    ZZZ_HIP(ctx, hipMemsetAsync(v->p, 0, nv * sizeof(double), ctx->stream));
+  }
+  ZZZ_HIP(ctx, ctx->part_a.alloc(4096));
+  ZZZ_HIP(ctx, ctx->part_b.alloc(4096));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
 } // namespace zzz
 
 using namespace zzz;
@@ -193,22 +210,13 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   int rc = upload(ctx, ctx->cell_dofs, cell_dofs, (size_t)(ctx->ncells * nd));
   if (rc)
     return rc;
-  const size_t nv = (size_t)ctx->nloc();
-  // bc marker: nothing constrained until zzz_bc_upload; facet mask: no exterior facets until uploaded
-  ZZZ_HIP(ctx, ctx->bc.alloc(nv));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bc.p, 0, nv, ctx->stream));
+  // facet mask: no exterior facets until uploaded
   ZZZ_HIP(ctx, ctx->facet_mask.alloc((size_t)ctx->ncells));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->facet_mask.p, 0, (size_t)ctx->ncells, ctx->stream));
   ctx->nfacets = 0;
-  DevBuf<double>* vecs[] = {&ctx->b, &ctx->u, &ctx->r, &ctx->z, &ctx->p, &ctx->w, &ctx->dinv, &ctx->coeff[0], &ctx->coeff[1]};
-  for (DevBuf<double>* v : vecs)
-  {
-    ZZZ_HIP(ctx, v->alloc(nv));
-    ZZZ_HIP(ctx, hipMemsetAsync(v->p, 0, nv * sizeof(double), ctx->stream));
-  }
-  ZZZ_HIP(ctx, ctx->part_a.alloc(4096));
-  ZZZ_HIP(ctx, ctx->part_b.alloc(4096));
-  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = alloc_problem_vectors(ctx);
+  if (rc)
+    return rc;
   ctx->have_bc = false;
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
@@ -303,6 +311,12 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
 // Host (C++/OpenMP) pattern builder: index bookkeeping only, no floating-point work.
 static int pattern_build_host(zzz_ctx* ctx)
 {
+  if (ctx->h_cell_dofs.empty()) // feed was generated on the device
+  {
+    ctx->h_cell_dofs.resize((size_t)(ctx->ncells * ctx->nd));
+    ZZZ_HIP(ctx, hipMemcpy(ctx->h_cell_dofs.data(), ctx->cell_dofs.p, ctx->h_cell_dofs.size() * sizeof(int32_t),
+                           hipMemcpyDeviceToHost));
+  }
   const int nd = ctx->nd, bs = ctx->bs;
   const int64_t nb = ctx->n_owned, nc = ctx->ncells;
   const int32_t* cd = ctx->h_cell_dofs.data();

@@ -154,6 +154,8 @@ void set_global_error(const char* msg);
       return zzz::fail(ctx, ZZZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// api
+int alloc_problem_vectors(zzz_ctx* ctx);
 // pattern (zzz_pattern.hip)
 int pattern_build_device(zzz_ctx* ctx, bool* fallback);
 int build_tiles_device(zzz_ctx* ctx, int max_block_cols);

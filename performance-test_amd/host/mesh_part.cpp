@@ -7,6 +7,7 @@
 // partition then owns one contiguous global range, ghost blocks arrive already in ghost order
 // (no unpack kernel), and rows that are neighbours in the mesh are neighbours in memory.
 #include "../../include/zzz_host.h"
+#include "cube_layout.h"
 
 #include <algorithm>
 #include <cmath>
@@ -63,80 +64,6 @@ int64_t num_pdofs(int64_t i, int64_t j, int64_t k, int nrefine, int order)
   }
 }
 
-// Basix local entity ordering of the tetrahedron (src/poisson_problem.cpp:35-38) [EXT]
-const int EDGE_V[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
-const int FACE_V[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
-// the six Kuhn simplices of a sub-cube: axis permutations (0 = x, 1 = y, 2 = z)
-const int PERM[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
-
-struct Layout
-{
-  int64_t nx, ny, nz, PX, PY;
-  int order, npe, nfd;
-  int64_t offP[5], NP, offL[7], NL;
-
-  Layout(int64_t nx_, int64_t ny_, int64_t nz_, int order_)
-      : nx(nx_), ny(ny_), nz(nz_), PX(nx_ + 1), PY(ny_ + 1), order(order_), npe(order_ - 1), nfd(order_ == 3 ? 1 : 0)
-  {
-    const int64_t cntP[5] = {PX * PY, nx * PY * npe, PX * ny * npe, nx * ny * npe, 2 * nx * ny * nfd};
-    NP = 0;
-    for (int t = 0; t < 5; ++t)
-    {
-      offP[t] = NP;
-      NP += cntP[t];
-    }
-    const int64_t cntL[7] = {PX * PY * npe, nx * PY * npe,      PX * ny * npe,     nx * ny * npe,
-                             2 * nx * PY * nfd, 2 * PX * ny * nfd, 6 * nx * ny * nfd};
-    NL = 0;
-    for (int t = 0; t < 7; ++t)
-    {
-      offL[t] = NL;
-      NL += cntL[t];
-    }
-  }
-  int64_t level_base(int64_t k) const { return k * (NP + NL); }
-  int64_t total() const { return (nz + 1) * NP + nz * NL; }
-
-  int64_t vertex(const int64_t a[3]) const { return level_base(a[2]) + offP[0] + a[1] * PX + a[0]; }
-  // edge anchored at lattice point a with axis mask m (x=1, y=2, z=4), sub-dof s
-  int64_t edge(const int64_t a[3], int m, int s) const
-  {
-    switch (m)
-    {
-    case 1:
-      return level_base(a[2]) + offP[1] + (a[1] * nx + a[0]) * npe + s;
-    case 2:
-      return level_base(a[2]) + offP[2] + (a[1] * PX + a[0]) * npe + s;
-    case 3:
-      return level_base(a[2]) + offP[3] + (a[1] * nx + a[0]) * npe + s;
-    case 4:
-      return level_base(a[2]) + NP + offL[0] + (a[1] * PX + a[0]) * npe + s;
-    case 5:
-      return level_base(a[2]) + NP + offL[1] + (a[1] * nx + a[0]) * npe + s;
-    case 6:
-      return level_base(a[2]) + NP + offL[2] + (a[1] * PX + a[0]) * npe + s;
-    default:
-      return level_base(a[2]) + NP + offL[3] + (a[1] * nx + a[0]) * npe + s;
-    }
-  }
-  // face with vertices a, a+S1, a+S1+S2 (axis masks)
-  int64_t face(const int64_t a[3], int S1, int S2) const
-  {
-    const int u = S1 | S2;
-    if (u == 3)
-      return level_base(a[2]) + offP[4] + (a[1] * nx + a[0]) * 2 + (S1 == 1 ? 0 : 1);
-    if (u == 5)
-      return level_base(a[2]) + NP + offL[4] + (a[1] * nx + a[0]) * 2 + (S1 == 1 ? 0 : 1);
-    if (u == 6)
-      return level_base(a[2]) + NP + offL[5] + (a[1] * PX + a[0]) * 2 + (S1 == 2 ? 0 : 1);
-    int t;
-    if (S1 == 1 || S1 == 2 || S1 == 4)
-      t = S1 == 1 ? 0 : (S1 == 2 ? 1 : 2);
-    else
-      t = 3 + (S2 == 1 ? 0 : (S2 == 2 ? 1 : 2));
-    return level_base(a[2]) + NP + offL[6] + (a[1] * nx + a[0]) * 6 + t;
-  }
-};
 } // namespace
 
 struct zzzh_part
@@ -228,32 +155,18 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
     set_err("z-slab partition needs nz >= number of parts (%lld < %d)", (long long)nz, nparts);
     return nullptr;
   }
-  const Layout L(nx, ny, nz, order);
   const int bs = problem == ZZZH_ELASTICITY ? 3 : 1;
-  const int nd = order == 1 ? 4 : order == 2 ? 10 : 20;
-  const int npe = order - 1;
-  const int64_t zs = nz * part / nparts, ze = nz * (part + 1) / nparts; // own layers [zs, ze)
-  const bool lower = part > 0, upper = part < nparts - 1;
-  const int64_t zl_end = upper ? ze + 1 : ze; // local layers [zs, zl_end)
-  const int64_t own_lo = L.level_base(zs) + (lower ? L.NP : 0);
-  const int64_t own_hi = L.level_base(ze) + L.NP;
-  const int64_t n_owned = own_hi - own_lo;
-  const int64_t n_lower = lower ? L.NP : 0;
-  const int64_t n_upper = upper ? L.NL + L.NP : 0;
-  const int64_t up_lo = L.level_base(ze) + L.NP; // first upper ghost (global)
-  const int64_t nloc = n_owned + n_lower + n_upper;
+  const zzzcube::Slab S(nx, ny, nz, order, bs, nparts, part);
+  const zzzcube::Layout& L = S.L;
+  const int nd = S.nd;
+  const int64_t zs = S.zs, ze = S.ze, zl_end = S.zl_end;
+  const bool lower = S.lower, upper = S.upper;
+  const int64_t n_owned = S.n_owned, n_lower = S.n_lower, n_upper = S.n_upper, nloc = S.nloc, own_lo = S.own_lo;
   if (nloc * bs > INT32_MAX - 8)
   {
     set_err("partition has %lld scalar dofs: exceeds int32 local indexing, use more parts", (long long)(nloc * bs));
     return nullptr;
   }
-  auto to_local = [&](int64_t g) -> int32_t {
-    if (g >= own_lo && g < own_hi)
-      return (int32_t)(g - own_lo);
-    if (lower && g >= L.level_base(zs) && g < own_lo)
-      return (int32_t)(n_owned + (g - L.level_base(zs)));
-    return (int32_t)(n_owned + n_lower + (g - up_lo)); // upper ghost
-  };
 
   zzzh_part* P = new zzzh_part();
   P->problem = problem;
@@ -267,109 +180,49 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
   P->nz = nz;
 
   // geometry: vertex planes zs .. zl_end
-  const int64_t nplanes = zl_end - zs + 1;
-  const int64_t nverts = nplanes * L.PX * L.PY;
+  const int64_t nverts = S.nverts;
   P->x.resize((size_t)(3 * nverts));
   for (int64_t iz = zs; iz <= zl_end; ++iz)
     for (int64_t iy = 0; iy <= ny; ++iy)
       for (int64_t ix = 0; ix <= nx; ++ix)
       {
-        const int64_t v = ((iz - zs) * L.PY + iy) * L.PX + ix;
+        const int64_t a[3] = {ix, iy, iz};
+        const int64_t v = S.local_vertex(a);
         P->x[3 * v + 0] = (double)ix / (double)nx;
         P->x[3 * v + 1] = (double)iy / (double)ny;
         P->x[3 * v + 2] = (double)iz / (double)nz;
       }
 
-  const int64_t ncells = 6 * nx * ny * (zl_end - zs);
+  const int64_t ncells = S.ncells;
   P->cells.resize((size_t)(4 * ncells));
   P->cell_dofs.resize((size_t)(nd * ncells));
   P->dof_x.assign((size_t)(3 * nloc), 0.0);
   P->global_dofs.assign((size_t)nloc, -1);
-  const double tt[2] = {order == 2 ? 0.5 : 0.5 * (1.0 - 1.0 / std::sqrt(5.0)), 0.5 * (1.0 + 1.0 / std::sqrt(5.0))};
-  const double nn[3] = {(double)nx, (double)ny, (double)nz};
-
-  // Cell numbering: simplex-type major (all type-0 simplices of the slab in lexicographic sub-cube
-  // order, then type 1, ...).  The row-gather kernels walk "the a-th cell of my dof" in lockstep over
-  // 64 neighbouring dofs; with this numbering those 64 cells are consecutive in memory (one dense
-  // 1-KiB read of the connectivity per wave instruction) instead of 96 B apart.
-  const int64_t ncubes = nx * ny * (zl_end - zs);
+  // cells: closed form per (sub-cube, simplex type), see cube_layout.h (shared with the device generator)
   for (int64_t iz = zs; iz < zl_end; ++iz)
     for (int64_t iy = 0; iy < ny; ++iy)
       for (int64_t ix = 0; ix < nx; ++ix)
         for (int q = 0; q < 6; ++q)
         {
-          const int64_t c = q * ncubes + ((iz - zs) * ny + iy) * nx + ix;
-          int64_t p[4][3] = {{ix, iy, iz}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-          int step[3];
-          for (int k = 0; k < 3; ++k)
-          {
-            step[k] = 1 << PERM[q][k];
-            for (int a = 0; a < 3; ++a)
-              p[k + 1][a] = p[k][a] + (a == PERM[q][k] ? 1 : 0);
-          }
-          // mask of the steps between path vertices a < b
-          auto mask = [&](int a, int b) {
-            int m = 0;
-            for (int k = a; k < b; ++k)
-              m |= step[k];
-            return m;
-          };
-          int32_t* cv = &P->cells[(size_t)(4 * c)];
-          int32_t* cd = &P->cell_dofs[(size_t)(nd * c)];
-          int n = 0;
+          const int64_t c = q * S.ncubes + ((iz - zs) * ny + iy) * nx + ix;
+          zzzcube::Cell C;
+          zzzcube::make_cell(S, ix, iy, iz, q, C);
           for (int v = 0; v < 4; ++v)
+            P->cells[(size_t)(4 * c + v)] = C.verts[v];
+          for (int i = 0; i < nd; ++i)
           {
-            cv[v] = (int32_t)(((p[v][2] - zs) * L.PY + p[v][1]) * L.PX + p[v][0]);
-            const int64_t g = L.vertex(p[v]);
-            const int32_t l = to_local(g);
-            cd[n++] = l;
-            P->global_dofs[l] = g;
+            const int32_t l = C.dofs[i];
+            P->cell_dofs[(size_t)(nd * c + i)] = l;
+            P->global_dofs[l] = C.gdofs[i];
             for (int a = 0; a < 3; ++a)
-              P->dof_x[3 * (size_t)l + a] = (double)p[v][a] / nn[a];
+              P->dof_x[3 * (size_t)l + a] = C.dof_x[i][a];
           }
-          if (order >= 2)
-            for (int e = 0; e < 6; ++e)
-            {
-              const int a = EDGE_V[e][0], b = EDGE_V[e][1];
-              const int m = mask(a, b);
-              for (int s = 0; s < npe; ++s)
-              {
-                const int64_t g = L.edge(p[a], m, s);
-                const int32_t l = to_local(g);
-                cd[n++] = l;
-                P->global_dofs[l] = g;
-                for (int d = 0; d < 3; ++d)
-                  P->dof_x[3 * (size_t)l + d] = ((double)p[a][d] + tt[s] * (double)(p[b][d] - p[a][d])) / nn[d];
-              }
-            }
-          if (order == 3)
-            for (int f = 0; f < 4; ++f)
-            {
-              const int a = FACE_V[f][0], b = FACE_V[f][1], cc = FACE_V[f][2];
-              const int64_t g = L.face(p[a], mask(a, b), mask(b, cc));
-              const int32_t l = to_local(g);
-              cd[n++] = l;
-              P->global_dofs[l] = g;
-              for (int d = 0; d < 3; ++d)
-                P->dof_x[3 * (size_t)l + d] = ((double)(p[a][d] + p[b][d] + p[cc][d]) / 3.0) / nn[d];
-            }
-          // exterior facets: all three vertices on one face of the cube
           for (int f = 0; f < 4; ++f)
-          {
-            bool ext = false;
-            for (int d = 0; d < 3 && !ext; ++d)
-            {
-              const int64_t lim = d == 0 ? nx : (d == 1 ? ny : nz);
-              const int64_t v0 = p[FACE_V[f][0]][d];
-              if ((v0 == 0 || v0 == lim) && p[FACE_V[f][1]][d] == v0 && p[FACE_V[f][2]][d] == v0)
-                ext = true;
-            }
-            if (ext)
+            if ((C.facet_mask >> f) & 1u)
             {
               P->facets.push_back((int32_t)c);
               P->facets.push_back(f);
             }
-          }
         }
   {
     // exterior facets ordered by (cell, local facet)
@@ -391,17 +244,12 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
       return nullptr;
     }
 
-  // Dirichlet dofs (marker lambdas of src/poisson_problem.cpp:60-71, src/elasticity_problem.cpp:127-138
-  // evaluated on the dof coordinates; on this mesh the closure of the marked facets is exactly that set)
-  const double eps = 1.0e-8;
+  // Dirichlet dofs: the marker lambdas of src/poisson_problem.cpp:60-71, src/elasticity_problem.cpp:127-138
+  // evaluated on the dof coordinates (on this mesh the closure of the marked facets is exactly that set)
   for (int64_t l = 0; l < nloc; ++l)
-  {
-    const double* X = &P->dof_x[3 * (size_t)l];
-    const bool m = problem == ZZZH_POISSON ? (std::abs(X[0]) < eps || std::abs(X[0] - 1) < eps) : (std::abs(X[1]) < eps);
-    if (m)
+    if (zzzcube::is_dirichlet(problem, &P->dof_x[3 * (size_t)l]))
       for (int k = 0; k < bs; ++k)
         P->bc_dofs.push_back((int32_t)(l * bs + k));
-  }
 
   // coefficients (src/poisson_problem.cpp:85-106, src/elasticity_problem.cpp:154-176)
   P->coeff[0].resize((size_t)(nloc * bs));
@@ -410,23 +258,13 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
     P->coeff[1].resize((size_t)nloc);
     for (int64_t l = 0; l < nloc; ++l)
     {
-      const double* X = &P->dof_x[3 * (size_t)l];
-      const double dx = X[0] - 0.5, dy = X[1] - 0.5;
-      const double dr = dx * dx + dy * dy;
-      P->coeff[0][(size_t)l] = 10 * std::exp(-dr / 0.02);
-      P->coeff[1][(size_t)l] = std::sin(5 * X[0]);
+      P->coeff[0][(size_t)l] = zzzcube::poisson_f(&P->dof_x[3 * (size_t)l]);
+      P->coeff[1][(size_t)l] = zzzcube::poisson_g(&P->dof_x[3 * (size_t)l]);
     }
   }
   else
     for (int64_t l = 0; l < nloc; ++l)
-    {
-      const double* X = &P->dof_x[3 * (size_t)l];
-      const double dx = X[0] - 0.5, dz = X[2] - 0.5;
-      const double r = std::sqrt(dx * dx + dz * dz);
-      P->coeff[0][3 * (size_t)l + 0] = -dz * r * X[1];
-      P->coeff[0][3 * (size_t)l + 1] = 1.0;
-      P->coeff[0][3 * (size_t)l + 2] = dx * r * X[1];
-    }
+      zzzcube::elasticity_f(&P->dof_x[3 * (size_t)l], &P->coeff[0][3 * (size_t)l]);
 
   // forward-scatter plan: neighbours in ghost order (lower, then upper)
   P->send_off.push_back(0);
@@ -449,21 +287,21 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
     P->recv_cnt.push_back(n_upper);
   }
 
-  int64_t* S = P->sizes;
-  S[ZZZH_NVERTS] = nverts;
-  S[ZZZH_NCELLS] = ncells;
-  S[ZZZH_NOWNED] = n_owned;
-  S[ZZZH_NGHOST] = n_lower + n_upper;
-  S[ZZZH_ND] = nd;
-  S[ZZZH_BS] = bs;
-  S[ZZZH_NFACETS] = (int64_t)P->facets.size() / 2;
-  S[ZZZH_NBC] = (int64_t)P->bc_dofs.size();
-  S[ZZZH_NNEIGH] = (int64_t)P->neigh.size();
-  S[ZZZH_NSEND] = (int64_t)P->send_idx.size();
-  S[ZZZH_GLOBAL_DOFS] = L.total() * bs;
-  S[ZZZH_GLOBAL_CELLS] = 6 * nx * ny * nz;
-  S[ZZZH_OWNED_CELLS] = 6 * nx * ny * (ze - zs);
-  S[ZZZH_OWN_OFFSET] = own_lo;
+  int64_t* Sz = P->sizes;
+  Sz[ZZZH_NVERTS] = nverts;
+  Sz[ZZZH_NCELLS] = ncells;
+  Sz[ZZZH_NOWNED] = n_owned;
+  Sz[ZZZH_NGHOST] = n_lower + n_upper;
+  Sz[ZZZH_ND] = nd;
+  Sz[ZZZH_BS] = bs;
+  Sz[ZZZH_NFACETS] = (int64_t)P->facets.size() / 2;
+  Sz[ZZZH_NBC] = (int64_t)P->bc_dofs.size();
+  Sz[ZZZH_NNEIGH] = (int64_t)P->neigh.size();
+  Sz[ZZZH_NSEND] = (int64_t)P->send_idx.size();
+  Sz[ZZZH_GLOBAL_DOFS] = L.total() * bs;
+  Sz[ZZZH_GLOBAL_CELLS] = 6 * nx * ny * nz;
+  Sz[ZZZH_OWNED_CELLS] = 6 * nx * ny * (ze - zs);
+  Sz[ZZZH_OWN_OFFSET] = own_lo;
   return P;
 }
 

@@ -25,7 +25,8 @@ ERR_NO_GPU = 4
 
 ABI_SYMBOLS = [
     "zzz_device_count", "zzz_ctx_create", "zzz_ctx_destroy", "zzz_last_error", "zzz_sync", "zzz_mesh_upload",
-    "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_csr_pattern_build",
+    "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
+    "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload",
@@ -92,6 +93,8 @@ def hip():
         L.zzz_bc_upload.argtypes = [C.c_void_p, C.c_int64, _i32p]
         L.zzz_facets_upload.argtypes = [C.c_void_p, C.c_int64, _i32p]
         L.zzz_coeff_upload.argtypes = [C.c_void_p, C.c_int, _f64p]
+        L.zzz_cube_generate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                        _i64p]
         L.zzz_csr_pattern_build.argtypes = [C.c_void_p]
         L.zzz_csr_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
         L.zzz_csr_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -273,6 +276,15 @@ class Context:
         self.upload_coeff(COEFF_F, P.f)
         if P.g is not None:
             self.upload_coeff(COEFF_G, P.g)
+
+    def cube_generate(self, problem, order, nx, ny, nz, nparts=1, part=0):
+        """device-side feed (zzz_cube_generate); returns the info array"""
+        info = np.zeros(6, np.int64)
+        pid = FORM_ELASTICITY if problem == "elasticity" else FORM_POISSON
+        self._ck(self.L.zzz_cube_generate(self.h, pid, order, nx, ny, nz, nparts, part, info))
+        self.bs = 3 if pid == FORM_ELASTICITY else 1
+        self.n_owned, self.n_ghost = int(info[2]), int(info[3])
+        return info
 
     def pattern_build(self):
         self._ck(self.L.zzz_csr_pattern_build(self.h))

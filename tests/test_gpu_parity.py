@@ -347,3 +347,35 @@ def test_empty_and_ragged_inputs(ctx):
         ctx.upload_facets(np.array([[0, 5]], np.int32))
     with pytest.raises(zzz.ZzzError):
         ctx.upload_dofmap(1, 2, cells, 4, 0)  # block size 2 unsupported
+
+
+@pytest.mark.parametrize("problem,order,dims,nparts", [
+    ("poisson", 1, (7, 5, 6), 1), ("poisson", 2, (4, 3, 5), 1), ("poisson", 3, (3, 3, 4), 1),
+    ("elasticity", 1, (5, 4, 6), 1), ("elasticity", 3, (2, 3, 3), 1),
+    ("poisson", 1, (5, 4, 9), 3), ("poisson", 3, (3, 2, 6), 2), ("elasticity", 2, (3, 3, 4), 2),
+])
+def test_device_generated_feed_equals_host_feed(ctx, problem, order, dims, nparts):
+    """zzz_cube_generate (closed-form kernels) against uploading host/mesh_part.cpp's arrays: same CSR
+    indices and matrix values bit for bit (identical integers and coordinates); b to 1e-13 (device
+    exp()/sin() may differ from glibc in the last ulp)."""
+    for part in range(nparts):
+        P = zzz.Part(problem, order, *dims, nparts, part)
+        ctx.upload_part(P)
+        ctx.pattern_build()
+        ctx.assemble_matrix(P.form)
+        ctx.assemble_vector(P.form)
+        rp0, cl0, v0 = ctx.csr_download()
+        b0 = ctx.vec_download(zzz.VEC_B)
+        with zzz.Context(0) as c2:
+            info = c2.cube_generate(problem, order, *dims, nparts, part)
+            assert int(info[0]) == P.global_dofs_total and int(info[1]) == P.global_cells
+            assert (int(info[2]), int(info[3]), int(info[4]), int(info[5])) == (P.n_owned, P.n_ghost, P.own_offset, P.ncells)
+            c2.pattern_build()
+            c2.assemble_matrix(P.form)
+            c2.assemble_vector(P.form)
+            rp1, cl1, v1 = c2.csr_download()
+            b1 = c2.vec_download(zzz.VEC_B)
+        np.testing.assert_array_equal(rp1, rp0)
+        np.testing.assert_array_equal(cl1, cl0)
+        np.testing.assert_array_equal(v1, v0)
+        assert np.abs(b1 - b0).max() <= 1e-13 * np.abs(b0).max()
