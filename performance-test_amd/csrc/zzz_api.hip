@@ -166,7 +166,7 @@ int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncell
   ZZZ_ENTER(ctx);
   if (nverts <= 0 || ncells <= 0 || !x || !cell_verts)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_mesh_upload: empty mesh or NULL array");
-  if (nverts > INT32_MAX / 4 || ncells > INT32_MAX / 32)
+  if (nverts > INT32_MAX / 4 || ncells > (INT32_MAX - 8) / 20)
     return fail(ctx, ZZZ_ERR_LIMIT, "mesh too large for int32 indexing (%lld vertices, %lld cells)", (long long)nverts,
                 (long long)ncells);
   for (int64_t i = 0; i < 4 * ncells; ++i)

@@ -107,7 +107,7 @@ extern "C" int zzz_cube_generate(zzz_ctx* ctx, int problem, int order, int64_t n
     return fail(ctx, ZZZ_ERR_ARG, "z-slab partition needs nz >= number of parts (%lld < %d)", (long long)nz, nparts);
   const int bs = problem == ZZZ_FORM_ELASTICITY ? 3 : 1;
   const Slab S(nx, ny, nz, order, bs, nparts, part);
-  if (S.nloc * bs > INT32_MAX - 8 || S.ncells > INT32_MAX / 32 || S.nverts > INT32_MAX / 4)
+  if (S.nloc * bs > INT32_MAX - 8 || S.ncells * S.nd > INT32_MAX - 8 || S.nverts > INT32_MAX / 4)
     return fail(ctx, ZZZ_ERR_LIMIT, "partition too large for int32 local indexing (%lld scalar dofs, %lld cells): use more parts",
                 (long long)(S.nloc * bs), (long long)S.ncells);
   hipStream_t s = ctx->stream;

@@ -20,6 +20,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <climits>
+#include <cstdlib>
 
 namespace zzz
 {
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
   __shared__ int32_t lds[4][PAT_CAP];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   volatile int32_t* c = lds[wv];
+  int wmax = 0;
   for (int64_t r = blockIdx.x * 4 + wv; r < nb; r += (int64_t)gridDim.x * 4)
   {
     const int a0 = adj_off[r], na = adj_off[r + 1] - a0;
@@ -115,12 +117,14 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
       base += __popcll(m);
     }
     if (!FILL && lane == 0)
-    {
       cnt[r] = base;
-      atomicMax(maxcnt, base);
-    }
+    wmax = max(wmax, base);
     __builtin_amdgcn_wave_barrier();
   }
+  // one atomic per wavefront, not per row: ~10^7 same-address atomics (or sc1 loads) serialise at
+  // one L2 channel and cost ~100 ms
+  if (!FILL && lane == 0 && wmax > 0)
+    atomicMax(maxcnt, wmax);
 }
 
 __global__ void k_scalar_rowptr(const int32_t* __restrict__ bptr, const int32_t* __restrict__ cnt, int32_t nb, int bs,
