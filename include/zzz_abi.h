@@ -237,6 +237,14 @@ int zzz_comm_unique_id(void* id /* ZZZ_UNIQUE_ID_BYTES */);
 /* ncclCommInitRank: attaches this context as `rank` of `nranks`. */
 int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id);
 
+/* Host-mediated communicator for single-process runs: the `nranks` contexts are driven by `nranks`
+ * threads of one process (they may share a GPU); collectives meet at a barrier and exchange through
+ * host memory.  Functionally identical to the RCCL path, far slower: meant for validating
+ * partitioned runs on a single-GPU machine.  Every rank must make the same sequence of calls. */
+int zzz_local_group_create(int nranks, void** group);
+void zzz_local_group_destroy(void* group);
+int zzz_comm_init_local(zzz_ctx* ctx, void* group, int rank);
+
 /* The forward scatter of common::Scatterer / IndexMap (src/cgpoisson_problem.cpp:187-190,
  * 225-229): for neighbour k, this rank sends x[send_idx[send_off[k]..send_off[k+1])] (owned
  * block dofs) and receives recv_cnt[k] block values into the next ghost slots; the ghost block

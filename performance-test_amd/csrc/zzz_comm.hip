@@ -10,9 +10,11 @@
 #include "zzz_internal.h"
 
 #include <dlfcn.h>
+#include <pthread.h>
 #include <unistd.h>
 
 #include <cstring>
+#include <vector>
 
 namespace zzz
 {
@@ -98,9 +100,26 @@ struct StdoutToStderr
   }
 };
 
+// A second, host-mediated backend: the ranks are contexts driven by threads of ONE process (they may
+// even share a GPU).  Every collective synchronises the rank's stream, meets the others at a barrier
+// and exchanges through host mailboxes.  Slow by design -- it exists so that the partitioned
+// assemble + CG logic (ghost layout, halo plan, multi-rank scalar logic, lock-step convergence
+// polling) can be run with the real kernels on a single-GPU box; production runs use RCCL.
+struct LocalGroup
+{
+  int n = 0;
+  pthread_barrier_t bar;
+  std::vector<std::vector<double>> red;  // per rank: values to reduce
+  std::vector<std::vector<double>> mail; // per rank: packed send buffer (all neighbours)
+  std::vector<std::vector<int32_t>> neigh;
+  std::vector<std::vector<int64_t>> send_off;
+  std::vector<int> bs;
+};
+
 struct Comm
 {
   ncclComm_t comm = nullptr;
+  LocalGroup* local = nullptr;
   int nranks = 1, rank = 0;
 };
 
@@ -119,17 +138,37 @@ __global__ void k_pack(const double* __restrict__ v, const int32_t* __restrict__
     out[i] = v[(int64_t)idx[i / bs] * bs + i % bs]; // pack_fn, src/cgpoisson_problem.cpp:32-37
 }
 
+static int local_allreduce(zzz_ctx* ctx, double* dev, int n)
+{
+  LocalGroup* G = ctx->comm->local;
+  const int me = ctx->comm->rank;
+  G->red[me].resize((size_t)n);
+  ZZZ_HIP(ctx, hipMemcpyAsync(G->red[me].data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pthread_barrier_wait(&G->bar);
+  std::vector<double> sum((size_t)n, 0.0);
+  for (int r = 0; r < G->n; ++r) // rank order: every rank forms the same sum
+    for (int i = 0; i < n; ++i)
+      sum[i] += G->red[r][i];
+  pthread_barrier_wait(&G->bar);
+  ZZZ_HIP(ctx, hipMemcpyAsync(dev, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
 int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n)
 {
   if (!ctx->comm)
     return ZZZ_OK;
+  if (ctx->comm->local)
+    return local_allreduce(ctx, dev, n);
   ZZZ_NCCL(ctx, g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, ctx->comm->comm, ctx->stream));
   return ZZZ_OK;
 }
 
 int comm_halo_forward(zzz_ctx* ctx, double* vec)
 {
-  if (!ctx->comm || ctx->nneigh == 0)
+  if (!ctx->comm || (ctx->nneigh == 0 && !ctx->comm->local))
     return ZZZ_OK;
   const int bs = ctx->bs;
   const int64_t nsend = ctx->send_off[ctx->nneigh];
@@ -140,6 +179,37 @@ int comm_halo_forward(zzz_ctx* ctx, double* vec)
       g = 1024;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)g), dim3(256), 0, ctx->stream, vec, ctx->send_idx.p, ctx->send_buf.p, nsend,
                        bs);
+  }
+  if (ctx->comm->local)
+  {
+    LocalGroup* G = ctx->comm->local;
+    const int me = ctx->comm->rank;
+    G->mail[me].resize((size_t)(nsend * bs));
+    if (nsend > 0)
+      ZZZ_HIP(ctx, hipMemcpyAsync(G->mail[me].data(), ctx->send_buf.p, sizeof(double) * nsend * bs, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pthread_barrier_wait(&G->bar);
+    int64_t gh = ctx->n_owned;
+    for (int k = 0; k < ctx->nneigh; ++k)
+    {
+      const int src = ctx->neigh_rank[k];
+      const int64_t nr = ctx->recv_cnt[k];
+      // where, in the sender's packed buffer, is the block meant for me?
+      int kk = -1;
+      for (size_t q = 0; q < G->neigh[src].size(); ++q)
+        if (G->neigh[src][q] == me)
+          kk = (int)q;
+      if (kk < 0 || G->send_off[src][kk + 1] - G->send_off[src][kk] != nr)
+        return fail(ctx, ZZZ_ERR_ARG, "local halo: rank %d does not send %lld block dofs to rank %d", src, (long long)nr, me);
+      if (nr > 0)
+        ZZZ_HIP(ctx, hipMemcpyAsync(vec + gh * bs, G->mail[src].data() + G->send_off[src][kk] * bs, sizeof(double) * nr * bs,
+                                    hipMemcpyHostToDevice, ctx->stream));
+      gh += nr;
+    }
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pthread_barrier_wait(&G->bar);
+    return ZZZ_OK;
   }
   ZZZ_NCCL(ctx, g_rccl.GroupStart());
   int64_t ghost = ctx->n_owned;
@@ -162,7 +232,7 @@ void comm_destroy(zzz_ctx* ctx)
 {
   if (ctx->comm)
   {
-    if (ctx->comm->comm && g_rccl.CommDestroy)
+    if (ctx->comm->comm && !ctx->comm->local && g_rccl.CommDestroy)
       (void)g_rccl.CommDestroy(ctx->comm->comm);
     delete ctx->comm;
     ctx->comm = nullptr;
@@ -218,6 +288,47 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
   return ZZZ_OK;
 }
 
+int zzz_local_group_create(int nranks, void** group)
+{
+  if (nranks < 1 || !group)
+    return fail(nullptr, ZZZ_ERR_ARG, "zzz_local_group_create: bad arguments");
+  LocalGroup* G = new LocalGroup();
+  G->n = nranks;
+  pthread_barrier_init(&G->bar, nullptr, (unsigned)nranks);
+  G->red.resize((size_t)nranks);
+  G->mail.resize((size_t)nranks);
+  G->neigh.resize((size_t)nranks);
+  G->send_off.resize((size_t)nranks);
+  G->bs.assign((size_t)nranks, 1);
+  *group = G;
+  return ZZZ_OK;
+}
+
+void zzz_local_group_destroy(void* group)
+{
+  LocalGroup* G = static_cast<LocalGroup*>(group);
+  if (!G)
+    return;
+  pthread_barrier_destroy(&G->bar);
+  delete G;
+}
+
+int zzz_comm_init_local(zzz_ctx* ctx, void* group, int rank)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  LocalGroup* G = static_cast<LocalGroup*>(group);
+  if (!G || rank < 0 || rank >= G->n)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_init_local: bad group or rank %d", rank);
+  comm_destroy(ctx);
+  Comm* c = new Comm();
+  c->local = G;
+  c->nranks = G->n;
+  c->rank = rank;
+  ctx->comm = c;
+  return ZZZ_OK;
+}
+
 int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const int64_t* send_off,
                     const int32_t* send_idx, const int64_t* recv_cnt)
 {
@@ -252,6 +363,14 @@ int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const i
   ZZZ_HIP(ctx, ctx->send_buf.alloc((size_t)(nsend * ctx->bs)));
   if (nsend)
     ZZZ_HIP(ctx, hipMemcpy(ctx->send_idx.p, send_idx, (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (ctx->comm && ctx->comm->local)
+  {
+    LocalGroup* G = ctx->comm->local;
+    const int me = ctx->comm->rank;
+    G->neigh[me] = ctx->neigh_rank;
+    G->send_off[me] = ctx->send_off;
+    G->bs[me] = ctx->bs;
+  }
   return ZZZ_OK;
 }
 

@@ -319,7 +319,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     bar.arrive_and_wait();
   }
 
-  if (root)
+  if (root && !failed)
   {
     // src/main.cpp:173-206
     std::cout << "----------------------------------------------------------------" << std::endl;

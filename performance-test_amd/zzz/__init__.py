@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload",
+    "zzz_profile_get", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_local_group_destroy", "zzz_comm_init_local",
 ]
 HOST_SYMBOLS = [
     "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_part_create", "zzzh_part_destroy",
@@ -112,6 +113,10 @@ def hip():
         L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.zzz_comm_unique_id.argtypes = [C.c_void_p]
         L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.zzz_local_group_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.zzz_local_group_destroy.argtypes = [C.c_void_p]
+        L.zzz_local_group_destroy.restype = None
+        L.zzz_comm_init_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.zzz_halo_upload.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, _i32p, _i64p]
         _HIP = L
     return _HIP
@@ -366,6 +371,9 @@ class Context:
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         self._ck(self.L.zzz_comm_init(self.h, nranks, rank, buf))
 
+    def comm_init_local(self, group, rank):
+        self._ck(self.L.zzz_comm_init_local(self.h, group, rank))
+
     def upload_halo(self, P):
         nn = len(P.neigh)
         z32, z64 = np.zeros(1, np.int32), np.zeros(1, np.int64)
@@ -379,3 +387,19 @@ def comm_unique_id():
     if rc:
         raise ZzzError(rc, hip().zzz_last_error(None).decode())
     return buf.raw
+
+
+class LocalGroup:
+    """zzz_local_group_create: host-mediated communicator for N contexts driven by N threads."""
+
+    def __init__(self, nranks):
+        self.h = C.c_void_p()
+        rc = hip().zzz_local_group_create(int(nranks), C.byref(self.h))
+        if rc:
+            raise ZzzError(rc, hip().zzz_last_error(None).decode())
+        self.n = nranks
+
+    def close(self):
+        if self.h:
+            hip().zzz_local_group_destroy(self.h)
+            self.h = None

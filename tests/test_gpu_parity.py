@@ -379,3 +379,79 @@ def test_device_generated_feed_equals_host_feed(ctx, problem, order, dims, npart
         np.testing.assert_array_equal(cl1, cl0)
         np.testing.assert_array_equal(v1, v0)
         assert np.abs(b1 - b0).max() <= 1e-13 * np.abs(b0).max()
+
+
+@pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (10, 9, 12), 2), ("poisson", 1, (8, 8, 13), 4),
+                                                       ("poisson", 3, (3, 3, 6), 3), ("elasticity", 1, (5, 5, 8), 2),
+                                                       ("elasticity", 2, (3, 3, 5), 2)])
+def test_partitioned_solve_on_one_gpu(problem, order, dims, nparts):
+    """The whole multi-rank path with the real kernels on ONE GPU: nparts contexts (one thread each)
+    joined by the host-mediated local communicator -- z-slab feed with ghost-cell layer, owned-row
+    assembly, forward halo per the plan, all-reduced CG scalars, lock-step convergence polling.
+    Only the transport differs from production (host mailboxes instead of RCCL).  The partitioned
+    solve must reproduce the single-rank solve: same iteration count (+-1: the dot products are
+    summed per rank first) and the same solution to 1e-9."""
+    import threading
+
+    zo.set_num_threads(1)
+    G = zzz.Part(problem, order, *dims)
+    with zzz.Context(0) as c0:
+        c0.upload_part(G)
+        c0.pattern_build()
+        c0.assemble_matrix(G.form)
+        c0.assemble_vector(G.form)
+        it0, rn0, r00 = c0.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        u0 = c0.vec_download(zzz.VEC_U)
+        b0 = c0.vec_download(zzz.VEC_B)
+        n0 = c0.vec_norm(zzz.VEC_U)
+        # matrix-free action of a fixed vector, for the Poisson cases
+        rng = np.random.default_rng(5)
+        xg = rng.standard_normal(G.n_owned * G.bs)
+        y0 = c0.spmv(xg)
+    grp = zzz.LocalGroup(nparts)
+    out = [None] * nparts
+    err = []
+
+    def run(rank):
+        try:
+            P = zzz.Part(problem, order, *dims, nparts, rank)
+            with zzz.Context(0) as c:
+                c.comm_init_local(grp.h, rank)
+                if rank % 2 == 0:
+                    c.upload_part(P)       # host feed ...
+                    c.upload_halo(P)
+                else:
+                    c.cube_generate(problem, order, *dims, nparts, rank)  # ... and device feed, mixed
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                lo, hi = P.own_offset * P.bs, (P.own_offset + P.n_owned) * P.bs
+                y = c.spmv(xg[lo:hi])      # halo exchange + SpMV on a known global vector
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                out[rank] = (it, rn, r0, P.own_offset, c.vec_download(zzz.VEC_U), c.vec_download(zzz.VEC_B),
+                             c.vec_norm(zzz.VEC_U), y)
+        except Exception as e:  # noqa: BLE001
+            err.append((rank, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    grp.close()
+    assert not err, err
+    assert all(o is not None for o in out)
+    its = {o[0] for o in out}
+    assert len(its) == 1 and abs(its.pop() - it0) <= 1
+    u = np.concatenate([o[4] for o in out])
+    b = np.concatenate([o[5] for o in out])
+    y = np.concatenate([o[7] for o in out])
+    assert [o[3] for o in out] == sorted(o[3] for o in out) and u.shape == u0.shape
+    # owned rows are complete locally; only the column ORDER differs (ghost columns sort last locally),
+    # so the row sums differ by round-off only
+    assert np.abs(y - y0).max() <= 1e-13 * np.abs(y0).max()
+    assert np.abs(b - b0).max() <= 1e-13 * np.abs(b0).max()
+    assert np.linalg.norm(u - u0) <= 1e-9 * np.linalg.norm(u0)
+    for o in out:
+        assert abs(o[6] - n0) <= 1e-9 * n0  # la::norm is global on every rank
+        assert o[1] == out[0][1] and o[2] == out[0][2]
