@@ -113,6 +113,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
     ctx->spmv_variant = atoi(e) & 15;
   ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
+  if (const char* e = getenv("ZZZ_OVERLAP"))
+    ctx->overlap = atoi(e) != 0;
   *out = ctx;
   return ZZZ_OK;
 }
@@ -550,13 +552,19 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
   const size_t n = (size_t)(ctx->n_owned * ctx->bs);
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, ctx->p.n * sizeof(double), ctx->stream));
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->p.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->comm)
+  int rc;
+  if (ctx->comm && ctx->overlap && ctx->have_tile_split && !(ctx->spmv_variant & 8))
+    rc = launch_spmv_overlapped(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
+  else
   {
-    int rc = comm_halo_forward(ctx, ctx->p.p);
-    if (rc)
-      return rc;
+    if (ctx->comm)
+    {
+      rc = comm_halo_forward(ctx, ctx->p.p);
+      if (rc)
+        return rc;
+    }
+    rc = launch_spmv(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
   }
-  int rc = launch_spmv(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
   if (rc)
     return rc;
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

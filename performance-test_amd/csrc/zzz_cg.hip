@@ -304,6 +304,9 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
                        (const double*)nullptr, ctx->dinv.p, n, 0);
 
   auto apply = [&](double* x, double* y, double* parts, int* np) -> int {
+    // partitioned CSR operator: halo of x overlapped with the interior tiles
+    if (multi && o->op == ZZZ_OP_CSR && ctx->overlap && ctx->have_tile_split && !(ctx->spmv_variant & 8))
+      return launch_spmv_overlapped(ctx, x, y, parts, np);
     if (multi)
     {
       int rc = comm_halo_forward(ctx, x);

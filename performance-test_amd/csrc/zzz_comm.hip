@@ -166,19 +166,58 @@ int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n)
   return ZZZ_OK;
 }
 
-int comm_halo_forward(zzz_ctx* ctx, double* vec)
+static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st);
+
+int comm_halo_forward(zzz_ctx* ctx, double* vec) { return halo_on_stream(ctx, vec, ctx->stream); }
+
+// overlap form: the exchange runs on the comm stream behind everything enqueued on the main stream
+// so far (vec is final), the main stream goes on with work that needs no ghost value
+int comm_halo_begin(zzz_ctx* ctx, double* vec)
+{
+  if (!ctx->comm || (ctx->nneigh == 0 && !ctx->comm->local))
+    return ZZZ_OK;
+  if (ctx->comm->local) // host-synchronous backend: nothing to overlap, same results
+    return halo_on_stream(ctx, vec, ctx->stream);
+  if (!ctx->comm_stream)
+  {
+    ZZZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_x_ready, hipEventDisableTiming));
+    ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_halo_done, hipEventDisableTiming));
+  }
+  ZZZ_HIP(ctx, hipEventRecord(ctx->ev_x_ready, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_x_ready, 0));
+  int rc = halo_on_stream(ctx, vec, ctx->comm_stream);
+  if (rc)
+    return rc;
+  ZZZ_HIP(ctx, hipEventRecord(ctx->ev_halo_done, ctx->comm_stream));
+  return ZZZ_OK;
+}
+
+int comm_halo_end(zzz_ctx* ctx)
+{
+  if (!ctx->comm || ctx->comm->local || ctx->nneigh == 0 || !ctx->comm_stream)
+    return ZZZ_OK;
+  ZZZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done, 0));
+  return ZZZ_OK;
+}
+
+static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
 {
   if (!ctx->comm || (ctx->nneigh == 0 && !ctx->comm->local))
     return ZZZ_OK;
   const int bs = ctx->bs;
   const int64_t nsend = ctx->send_off[ctx->nneigh];
-  if (nsend > 0)
+  // pack only what is not already contiguous in the vector (z-slab partitions send contiguous ranges)
+  bool need_pack = ctx->comm->local != nullptr;
+  for (int k = 0; k < ctx->nneigh; ++k)
+    if (ctx->send_contig[k] < 0)
+      need_pack = true;
+  if (nsend > 0 && need_pack)
   {
     int64_t g = (nsend * bs + 255) / 256;
     if (g > 1024)
       g = 1024;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)g), dim3(256), 0, ctx->stream, vec, ctx->send_idx.p, ctx->send_buf.p, nsend,
-                       bs);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)g), dim3(256), 0, st, vec, ctx->send_idx.p, ctx->send_buf.p, nsend, bs);
   }
   if (ctx->comm->local)
   {
@@ -216,12 +255,11 @@ int comm_halo_forward(zzz_ctx* ctx, double* vec)
   for (int k = 0; k < ctx->nneigh; ++k)
   {
     const int64_t ns = ctx->send_off[k + 1] - ctx->send_off[k], nr = ctx->recv_cnt[k];
+    const double* src = ctx->send_contig[k] >= 0 ? vec + ctx->send_contig[k] * bs : ctx->send_buf.p + ctx->send_off[k] * bs;
     if (ns > 0)
-      ZZZ_NCCL(ctx, g_rccl.Send(ctx->send_buf.p + ctx->send_off[k] * bs, (size_t)(ns * bs), ncclFloat64,
-                                ctx->neigh_rank[k], ctx->comm->comm, ctx->stream));
+      ZZZ_NCCL(ctx, g_rccl.Send(src, (size_t)(ns * bs), ncclFloat64, ctx->neigh_rank[k], ctx->comm->comm, st));
     if (nr > 0)
-      ZZZ_NCCL(ctx, g_rccl.Recv(vec + ghost * bs, (size_t)(nr * bs), ncclFloat64, ctx->neigh_rank[k], ctx->comm->comm,
-                                ctx->stream));
+      ZZZ_NCCL(ctx, g_rccl.Recv(vec + ghost * bs, (size_t)(nr * bs), ncclFloat64, ctx->neigh_rank[k], ctx->comm->comm, st));
     ghost += nr;
   }
   ZZZ_NCCL(ctx, g_rccl.GroupEnd());
@@ -230,6 +268,14 @@ int comm_halo_forward(zzz_ctx* ctx, double* vec)
 
 void comm_destroy(zzz_ctx* ctx)
 {
+  if (ctx->comm_stream)
+  {
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    (void)hipEventDestroy(ctx->ev_x_ready);
+    (void)hipEventDestroy(ctx->ev_halo_done);
+    (void)hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr;
+  }
   if (ctx->comm)
   {
     if (ctx->comm->comm && !ctx->comm->local && g_rccl.CommDestroy)
@@ -359,6 +405,15 @@ int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const i
   ctx->recv_cnt.assign(recv_cnt, recv_cnt + nneigh);
   if (nneigh == 0)
     ctx->send_off.assign(1, 0);
+  ctx->send_contig.assign((size_t)nneigh, -1);
+  for (int k = 0; k < nneigh; ++k)
+  {
+    bool contig = send_off[k + 1] > send_off[k];
+    for (int64_t i = send_off[k] + 1; i < send_off[k + 1] && contig; ++i)
+      contig = send_idx[i] == send_idx[i - 1] + 1;
+    if (contig)
+      ctx->send_contig[(size_t)k] = send_idx[send_off[k]];
+  }
   ZZZ_HIP(ctx, ctx->send_idx.alloc((size_t)nsend));
   ZZZ_HIP(ctx, ctx->send_buf.alloc((size_t)(nsend * ctx->bs)));
   if (nsend)

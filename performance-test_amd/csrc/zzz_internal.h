@@ -99,6 +99,10 @@ struct zzz_ctx
   // SpMV tiling (row-aligned tiles of the nonzero stream)
   zzz::DevBuf<int32_t> tile_row;
   int64_t ntiles = 0;
+  // tiles of a partitioned matrix split by "references a ghost column" (halo/compute overlap)
+  zzz::DevBuf<int32_t> tiles_interior, tiles_boundary;
+  int64_t n_tiles_interior = 0, n_tiles_boundary = 0;
+  bool have_tile_split = false;
   int spmv_tile = 2048;  // nonzeros per tile (2048 | 4096), fixed at pattern build
   int spmv_variant = 1;  // bit 0: non-temporal matrix loads, bit 1: pipelined CSR tiles,
                          // bit 3: build and use the SELL-64 copy (measured 13 % slower than the CSR
@@ -137,6 +141,10 @@ struct zzz_ctx
   std::vector<int64_t> send_off, recv_cnt;
   zzz::DevBuf<int32_t> send_idx;
   zzz::DevBuf<double> send_buf;
+  std::vector<int64_t> send_contig; // per neighbour: first owned block dof when its list is a contiguous range, else -1
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;
+  bool overlap = true; // ZZZ_OVERLAP=0 disables the halo/compute overlap
 
   int64_t nloc() const { return (n_owned + n_ghost) * bs; }
 };
@@ -177,5 +185,9 @@ int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out);
 // comm
 int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n);
 int comm_halo_forward(zzz_ctx* ctx, double* vec);
+int comm_halo_begin(zzz_ctx* ctx, double* vec); // on the comm stream, after the work enqueued so far
+int comm_halo_end(zzz_ctx* ctx);                // main stream waits for the halo
+int build_tile_split(zzz_ctx* ctx);
+int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials);
 void comm_destroy(zzz_ctx* ctx);
 } // namespace zzz

@@ -208,7 +208,7 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   hipLaunchKernelGGL(k_asm_tiles, dim3(grid_for(ctx->n_asm_tiles + 1)), dim3(256), 0, s, ctx->rowptr.p,
                      (int)ctx->n_owned, bs, Wa, ctx->n_asm_tiles, ctx->asm_tile.p);
   ZZZ_HIP(ctx, hipGetLastError());
-  return ZZZ_OK;
+  return build_tile_split(ctx);
 }
 
 // returns ZZZ_OK, or ZZZ_ERR_LIMIT with *fallback = true when a row has more candidates than the
@@ -291,6 +291,52 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   if (rc)
     return rc;
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  return ZZZ_OK;
+}
+// Which SpMV tiles reference a ghost column (>= nrows)?  One wavefront per tile scans its columns.
+__global__ __launch_bounds__(256) void k_tile_ghost_flag(const int4* __restrict__ tiles, int64_t ntiles,
+                                                         const int32_t* __restrict__ cols, int32_t nrows,
+                                                         uint8_t* __restrict__ flag)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4)
+  {
+    const int4 d = tiles[t];
+    bool g = false;
+    for (int k = d.z + lane; k < d.w; k += 64)
+      g |= cols[k] >= nrows;
+    const unsigned long long m = __ballot(g);
+    if (lane == 0)
+      flag[t] = m != 0ull;
+  }
+}
+
+// interior / boundary tile lists for the halo-compute overlap of a partitioned matrix
+int build_tile_split(zzz_ctx* ctx)
+{
+  ctx->have_tile_split = false;
+  ctx->n_tiles_interior = ctx->n_tiles_boundary = 0;
+  if (ctx->n_ghost == 0 || ctx->ntiles == 0)
+    return ZZZ_OK;
+  DevBuf<uint8_t> flag;
+  ZZZ_HIP(ctx, flag.alloc((size_t)ctx->ntiles));
+  hipLaunchKernelGGL(k_tile_ghost_flag, dim3(grid_for(ctx->ntiles, 4, 4096)), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const int4*>(ctx->tile_row.p), ctx->ntiles, ctx->cols.p, (int32_t)ctx->nrows, flag.p);
+  std::vector<uint8_t> h((size_t)ctx->ntiles);
+  ZZZ_HIP(ctx, hipMemcpyAsync(h.data(), flag.p, h.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> in, bd;
+  for (int64_t t = 0; t < ctx->ntiles; ++t)
+    (h[(size_t)t] ? bd : in).push_back((int32_t)t);
+  ZZZ_HIP(ctx, ctx->tiles_interior.alloc(in.size()));
+  ZZZ_HIP(ctx, ctx->tiles_boundary.alloc(bd.size()));
+  if (!in.empty())
+    ZZZ_HIP(ctx, hipMemcpy(ctx->tiles_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!bd.empty())
+    ZZZ_HIP(ctx, hipMemcpy(ctx->tiles_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  ctx->n_tiles_interior = (int64_t)in.size();
+  ctx->n_tiles_boundary = (int64_t)bd.size();
+  ctx->have_tile_split = true;
   return ZZZ_OK;
 }
 } // namespace zzz

@@ -58,8 +58,11 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
                                                                const double* __restrict__ x, double* __restrict__ y,
                                                                const int4* __restrict__ tiles, int64_t ntiles,
                                                                int nnz_even, double* __restrict__ partials,
-                                                               const int* __restrict__ stop_flag)
+                                                               const int* __restrict__ stop_flag,
+                                                               const int32_t* __restrict__ tile_list)
 {
+  // tile_list != nullptr: this launch covers only the listed tiles (interior or boundary subset of a
+  // partitioned matrix); ntiles is then the length of the list
   if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
     return;
   __shared__ __attribute__((aligned(16))) double prod[TILE + 16];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
   };
   if (t >= 0)
   {
-    td = tiles[t];
+    td = tiles[tile_list ? tile_list[t] : t];
     issue(td);
   }
   for (int i = 0; t >= 0; ++i)
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     const int64_t tn = xcd_tile(ntiles, blockIdx.x, gridDim.x, i + 1);
     if (PIPE && tn >= 0)
     {
-      td = tiles[tn];
+      td = tiles[tile_list ? tile_list[tn] : tn];
       issue(td);
     }
     if (PIPE)
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     t = tn;
     if (!PIPE && t >= 0)
     {
-      td = tiles[t];
+      td = tiles[tile_list ? tile_list[t] : t];
       issue(td);
     }
   }
@@ -369,17 +372,18 @@ static int spmv_grid(const zzz_ctx* ctx)
 
 template <bool DOT>
 static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
-                           int nnz_even)
+                           int nnz_even, const int32_t* tile_list = nullptr, int64_t nlist = 0)
 {
   const int4* tiles = reinterpret_cast<const int4*>(ctx->tile_row.p);
+  const int64_t nt = tile_list ? nlist : ctx->ntiles;
 #define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
   hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
-                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, ctx->ntiles, nnz_even, partials, stop)
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list)
   const int var = ctx->spmv_variant; // bit 0: non-temporal matrix loads, bit 1: pipelined tiles
   if (var & 4) // diagnostic only (zzz_spmv_time): no gather
   {
     hipLaunchKernelGGL((spmv_tile_kernel<DOT, true, false, 2048, true>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,
-                       ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, ctx->ntiles, nnz_even, partials, stop);
+                       ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list);
     return;
   }
   if (ctx->spmv_tile == 4096)
@@ -439,6 +443,55 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
   }
   else
     launch_variant<false>(ctx, grid, x, y, nullptr, stop, nnz_even);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+static int grid_for_tiles(int64_t nt)
+{
+  int64_t g = 256 * 8;
+  const int64_t need = (nt + 7) / 8 * 8;
+  if (g > need)
+    g = need;
+  if (g < 8)
+    g = 8;
+  return (int)g;
+}
+
+// Partitioned matrix: y = A x with the forward halo of x overlapped with the interior tiles.
+//   comm stream : (waits for x) pack + send/recv of the ghost entries        -- issued FIRST so that
+//   main stream : SpMV over the tiles that reference no ghost column            its kernels get CUs
+//   main stream : (waits for the halo) SpMV over the boundary tiles
+// Partials of <x,y>: interior workgroups first, then the boundary ones.
+int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials)
+{
+  const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1);
+  const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
+  const int64_t n_in = ctx->n_tiles_interior, n_bd = ctx->n_tiles_boundary;
+  const int g_in = n_in ? grid_for_tiles(n_in) : 0, g_bd = n_bd ? grid_for_tiles(n_bd) : 0;
+  if (partials && (size_t)(g_in + g_bd) > ctx->part_a.n)
+    return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
+  int rc = comm_halo_begin(ctx, x);
+  if (rc)
+    return rc;
+  if (n_in)
+  {
+    if (partials)
+      launch_variant<true>(ctx, g_in, x, y, partials, stop, nnz_even, ctx->tiles_interior.p, n_in);
+    else
+      launch_variant<false>(ctx, g_in, x, y, nullptr, stop, nnz_even, ctx->tiles_interior.p, n_in);
+  }
+  rc = comm_halo_end(ctx);
+  if (rc)
+    return rc;
+  if (n_bd)
+  {
+    if (partials)
+      launch_variant<true>(ctx, g_bd, x, y, partials + g_in, stop, nnz_even, ctx->tiles_boundary.p, n_bd);
+    else
+      launch_variant<false>(ctx, g_bd, x, y, nullptr, stop, nnz_even, ctx->tiles_boundary.p, n_bd);
+  }
+  if (npartials)
+    *npartials = g_in + g_bd;
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
