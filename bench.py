@@ -155,7 +155,11 @@ def main():
     strong = a.scaling_type == "strong"
     nx, ny, nz, r = zzz.mesh_size(a.ndofs, strong, world, bs, a.order)
     nx, ny, nz = nx << r, ny << r, nz << r
-    P = zzz.Part(a.problem_type, a.order, nx, ny, nz, world, rank)
+    form = zzz.FORM_ELASTICITY if a.problem_type == "elasticity" else zzz.FORM_POISSON
+    # host feed (C++ generator + upload) only when the CPU baseline needs the host arrays; otherwise the
+    # feed is generated on the device (zzz_cube_generate) -- identical problem, no PCIe traffic
+    need_host_arrays = world == 1 and not a.no_cpu_baseline
+    P = zzz.Part(a.problem_type, a.order, nx, ny, nz, world, rank) if need_host_arrays else None
     ctx = zzz.Context(local_rank)
     if world > 1:
         import torch
@@ -167,9 +171,14 @@ def main():
         ctx.comm_init(world, rank, bytes(uid.numpy().tobytes()))
     if world == 1 and a.force_comm:
         ctx.comm_init(1, 0, zzz.comm_unique_id())
-    ctx.upload_part(P)
-    if world > 1 or a.force_comm:
-        ctx.upload_halo(P)
+    if P is not None:
+        ctx.upload_part(P)
+        if a.force_comm:
+            ctx.upload_halo(P)
+        ndofs_global, ncells_global = P.global_dofs_total, P.global_cells
+    else:
+        info = ctx.cube_generate(a.problem_type, a.order, nx, ny, nz, world, rank)  # includes the halo plan
+        ndofs_global, ncells_global = int(info[0]), int(info[1])
     ctx.pattern_build()  # fem::petsc::create_matrix: outside ZZZ Assemble matrix (src/poisson_problem.cpp:122-123)
     nrows, ncols, nnz = ctx.csr_sizes()
     pc = zzz.PC_JACOBI if a.pc == "jacobi" else zzz.PC_NONE
@@ -178,11 +187,11 @@ def main():
         t = {}
         ctx.sync()
         t0 = time.perf_counter()
-        ctx.assemble_matrix(P.form)
+        ctx.assemble_matrix(form)
         ctx.sync()
         t["assemble_matrix"] = time.perf_counter() - t0
         t1 = time.perf_counter()
-        ctx.assemble_vector(P.form)
+        ctx.assemble_vector(form)
         ctx.sync()
         t["assemble_vector"] = time.perf_counter() - t1
         t2 = time.perf_counter()
@@ -213,7 +222,6 @@ def main():
 
     spmv_ms, spmv_n = ctx.profile()
     unorm = ctx.vec_norm(zzz.VEC_U)
-    ndofs_global = P.global_dofs_total
     ms_per_step = elapsed / a.steps * 1e3
     iters = phases[-1]["iters"]
 
@@ -234,7 +242,7 @@ def main():
                 "workload": (f"--problem_type {a.problem_type} --order {a.order} --scaling_type {a.scaling_type} "
                              f"--ndofs {a.ndofs} -ksp_type cg -pc_type {a.pc} -ksp_rtol {a.rtol:g}"),
                 "mesh": f"{nx}x{ny}x{nz} sub-cubes x 6 tetrahedra", "dofs": ndofs_global,
-                "cells": P.global_cells, "nnz_rank0": nnz, "rows_rank0": nrows,
+                "cells": ncells_global, "nnz_rank0": nnz, "rows_rank0": nrows,
                 "partition": f"{world} z-slab(s)", "krylov_iterations": iters,
                 "relative_residual": phases[-1]["rel"], "solution_norm": unorm,
             },
@@ -249,6 +257,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n},
         }
+        out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, ctx, iters)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
