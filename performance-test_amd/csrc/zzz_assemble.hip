@@ -13,8 +13,12 @@
 //     the path is bound by the 8 B/nonzero it must write, not by arithmetic).
 // Constrained rows and columns are zeroed as the element tensor is produced, and the diagonal of a
 // constrained row is set to 1.0 (fem::set_diagonal) by the thread that owns the row.
+#include <cstring>
+
 #include "zzz_device.h"
 #include "zzz_internal.h"
+
+#include <rocprim/rocprim.hpp>
 
 namespace zzz
 {
@@ -579,25 +583,29 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
 
 // ---- matrix-free operator of cgpoisson: y = action(a, un = x), then y[bc] = 0
 // (form M of src/Poisson.py:33, applied as in src/cgpoisson_problem.cpp:193-230: assemble_vector of M
-// with un = x, bc->set(y, 0)).  Same row-gather walk: no element matrix is stored, the row of Ae is
-// contracted with x on the fly; per-workgroup partials of <x, y> feed the CG dot product.
+// with un = x, bc->set(y, 0)).  No element matrix is stored.  Two dense passes:
+//   1. matfree_cell  : one thread per cell computes w_c = Ae_c u_c once (geometry once per cell, not
+//                      once per row as in a row-gather walk) and stores it component-major
+//                      (w[i][cell]); with the feed's simplex-type-major cell numbering neighbouring
+//                      lanes hold neighbouring sub-cubes, so connectivity, coordinates and u are read
+//                      as dense streams;
+//   2. matfree_gather: one thread per owned row adds the w entries of its cells in ascending cell
+//                      order (fixed order => reproducible), zeroes constrained rows, leaves the
+//                      <x, y> partials for the CG dot product.
+// Traffic: ~(16 + 4 nd) B connectivity + 8 nd B of w written per cell, 13 B per (row, cell) incidence
+// read back -- ~6 GB at 10 M P1 dofs against 40 GB through L2 for the single-pass walk.
 template <int ND>
-__global__ __launch_bounds__(ASM_BLOCK) void matfree_poisson(const double* __restrict__ x,
-                                                             const int32_t* __restrict__ cell_verts,
-                                                             const int32_t* __restrict__ cell_dofs,
-                                                             const int32_t* __restrict__ adj_off,
-                                                             const int32_t* __restrict__ adj_cells,
-                                                             const uint8_t* __restrict__ bc,
-                                                             const double* __restrict__ u, double* __restrict__ y,
-                                                             int64_t nrows, const double* __restrict__ tab,
-                                                             double* __restrict__ partials,
-                                                             const int* __restrict__ stop_flag)
+__global__ __launch_bounds__(ASM_BLOCK) void matfree_cell(const double* __restrict__ x,
+                                                          const int32_t* __restrict__ cell_verts,
+                                                          const int32_t* __restrict__ cell_dofs, int64_t ncells,
+                                                          const double* __restrict__ u, double* __restrict__ w,
+                                                          const double* __restrict__ tab,
+                                                          const int* __restrict__ stop_flag)
 {
   if (stop_flag && *stop_flag)
     return;
   constexpr int NN = ND * ND;
   __shared__ double T_s[ND == 4 ? 1 : 6 * NN];
-  __shared__ double red[ASM_BLOCK / 64];
   if (ND != 4)
   {
     for (int k = threadIdx.x; k < 6 * NN; k += ASM_BLOCK)
@@ -608,72 +616,156 @@ __global__ __launch_bounds__(ASM_BLOCK) void matfree_poisson(const double* __res
     }
     __syncthreads();
   }
-  double dot = 0.0;
-  for (int64_t r = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * ASM_BLOCK)
+  for (int64_t c = blockIdx.x * (int64_t)ASM_BLOCK + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * ASM_BLOCK)
   {
-    const int i = (int)r;
-    double sum = 0.0;
-    for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * c);
+    const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * c;
+    double p[4][3];
+    Geom G;
+    load_cell(x, v, p);
+    geometry(p, G);
+    if (ND == 4)
     {
-      const int cell = adj_cells[a];
-      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
-      const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
-      double p[4][3];
-      Geom G;
-      load_cell(x, v, p);
-      geometry(p, G);
-      if (ND == 4)
-      {
-        double g[4][3];
-        p1_grads(G, g);
-        double gu[3] = {0, 0, 0}, gi[3] = {0, 0, 0};
+      double g[4][3];
+      p1_grads(G, g);
+      const int4 dd = *reinterpret_cast<const int4*>(cd);
+      const double ul[4] = {u[dd.x], u[dd.y], u[dd.z], u[dd.w]};
+      double gu[3] = {0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-          const int dj = cd[j];
-          const double uj = u[dj];
-          gu[0] += g[j][0] * uj;
-          gu[1] += g[j][1] * uj;
-          gu[2] += g[j][2] * uj;
-          if (dj == i)
-          {
-            gi[0] = g[j][0];
-            gi[1] = g[j][1];
-            gi[2] = g[j][2];
-          }
-        }
-        sum += (G.adet / 6.0) * (gi[0] * gu[0] + gi[1] * gu[1] + gi[2] * gu[2]);
-      }
-      else
+      for (int j = 0; j < 4; ++j)
       {
-        int li = 0;
-        for (int jj = 0; jj < ND; ++jj)
-          if (cd[jj] == i)
-            li = jj;
-        double GG[6];
-        GG[0] = G.adet * (G.K[0][0] * G.K[0][0] + G.K[0][1] * G.K[0][1] + G.K[0][2] * G.K[0][2]);
-        GG[1] = G.adet * (G.K[1][0] * G.K[1][0] + G.K[1][1] * G.K[1][1] + G.K[1][2] * G.K[1][2]);
-        GG[2] = G.adet * (G.K[2][0] * G.K[2][0] + G.K[2][1] * G.K[2][1] + G.K[2][2] * G.K[2][2]);
-        GG[3] = G.adet * (G.K[0][0] * G.K[1][0] + G.K[0][1] * G.K[1][1] + G.K[0][2] * G.K[1][2]);
-        GG[4] = G.adet * (G.K[0][0] * G.K[2][0] + G.K[0][1] * G.K[2][1] + G.K[0][2] * G.K[2][2]);
-        GG[5] = G.adet * (G.K[1][0] * G.K[2][0] + G.K[1][1] * G.K[2][1] + G.K[1][2] * G.K[2][2]);
-        const double* Tl = T_s + li * ND;
+        gu[0] += g[j][0] * ul[j];
+        gu[1] += g[j][1] * ul[j];
+        gu[2] += g[j][2] * ul[j];
+      }
+      const double s = G.adet / 6.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        w[(int64_t)i * ncells + c] = s * (g[i][0] * gu[0] + g[i][1] * gu[1] + g[i][2] * gu[2]);
+    }
+    else
+    {
+      double GG[6];
+      GG[0] = G.adet * (G.K[0][0] * G.K[0][0] + G.K[0][1] * G.K[0][1] + G.K[0][2] * G.K[0][2]);
+      GG[1] = G.adet * (G.K[1][0] * G.K[1][0] + G.K[1][1] * G.K[1][1] + G.K[1][2] * G.K[1][2]);
+      GG[2] = G.adet * (G.K[2][0] * G.K[2][0] + G.K[2][1] * G.K[2][1] + G.K[2][2] * G.K[2][2]);
+      GG[3] = G.adet * (G.K[0][0] * G.K[1][0] + G.K[0][1] * G.K[1][1] + G.K[0][2] * G.K[1][2]);
+      GG[4] = G.adet * (G.K[0][0] * G.K[2][0] + G.K[0][1] * G.K[2][1] + G.K[0][2] * G.K[2][2]);
+      GG[5] = G.adet * (G.K[1][0] * G.K[2][0] + G.K[1][1] * G.K[2][1] + G.K[1][2] * G.K[2][2]);
+      double ul[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        ul[j] = u[cd[j]];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        // (sum_t GG[t] T[t][i][:]) . u ; the table reads are wave-uniform (LDS broadcast)
         double acc = 0.0;
+#pragma unroll
         for (int j = 0; j < ND; ++j)
         {
           double aij = 0.0;
 #pragma unroll
           for (int t = 0; t < 6; ++t)
-            aij += GG[t] * Tl[t * NN + j];
-          acc += aij * u[cd[j]];
+            aij += GG[t] * T_s[t * NN + i * ND + j];
+          acc += aij * ul[j];
         }
-        sum += acc;
+        w[(int64_t)i * ncells + c] = acc;
       }
     }
-    if (bc[r])
-      sum = 0.0; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
-    y[r] = sum;
-    dot += sum * u[r];
+  }
+}
+
+// Adjacency transposed in slices of 64 rows: entry a of row (64 s + lane) sits at off[s] + 64 a + lane
+// (cell index, -1 = padding) with the dof's local index in that cell beside it.  A wavefront owns a
+// slice, so "the a-th cell of my row" is one dense 256-B read instead of 64 reads 96 B apart.
+__global__ void k_adjT_slice_len(const int32_t* __restrict__ adj_off, int64_t nb, int64_t nslices, int32_t* __restrict__ slen)
+{
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s <= nslices; s += (int64_t)gridDim.x * blockDim.x)
+  {
+    int m = 0;
+    if (s < nslices)
+      for (int64_t r = s * 64; r < min(nb, s * 64 + 64); ++r)
+        m = max(m, adj_off[r + 1] - adj_off[r]);
+    slen[s] = m * 64;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_adjT_fill(const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj_cells,
+                                                   const int32_t* __restrict__ cell_dofs, int nd, int64_t nb, int64_t nslices,
+                                                   const int32_t* __restrict__ off, int32_t* __restrict__ cellT,
+                                                   uint8_t* __restrict__ liT)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    const int o = off[s], len = (off[s + 1] - o) >> 6;
+    const int64_t r = s * 64 + lane;
+    const int a0 = r < nb ? adj_off[r] : 0, n = r < nb ? adj_off[r + 1] - a0 : 0;
+    for (int a = 0; a < len; ++a)
+    {
+      int32_t c = -1;
+      int li = 0;
+      if (a < n)
+      {
+        c = adj_cells[a0 + a];
+        const int32_t* cd = cell_dofs + (int64_t)nd * c;
+        for (int j = 0; j < nd; ++j)
+          if (cd[j] == (int32_t)r)
+            li = j;
+      }
+      cellT[o + a * 64 + lane] = c;
+      liT[o + a * 64 + lane] = (uint8_t)li;
+    }
+  }
+}
+
+__global__ __launch_bounds__(ASM_BLOCK) void matfree_gather(const int32_t* __restrict__ off, const int32_t* __restrict__ cellT,
+                                                            const uint8_t* __restrict__ liT, const uint8_t* __restrict__ bc,
+                                                            const double* __restrict__ w, int64_t ncells,
+                                                            const double* __restrict__ u, double* __restrict__ y,
+                                                            int64_t nrows, int64_t nslices, double* __restrict__ partials,
+                                                            const int* __restrict__ stop_flag)
+{
+  if (stop_flag && *stop_flag)
+    return;
+  __shared__ double red[ASM_BLOCK / 64];
+  const int lane = threadIdx.x & 63;
+  double dot = 0.0;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    const int o = off[s], len = (off[s + 1] - o) >> 6;
+    const int64_t r = s * 64 + lane;
+    const int32_t* __restrict__ cp = cellT + o + lane;
+    const uint8_t* __restrict__ lp = liT + o + lane;
+    double sum = 0.0;
+    for (int a = 0; a < len; a += 8)
+    {
+      int32_t c[8];
+      int li[8];
+      double wv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+      {
+        const int aa = min(a + k, len - 1) * 64;
+        c[k] = cp[aa];
+        li[k] = lp[aa];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        wv[k] = c[k] >= 0 ? w[(int64_t)li[k] * ncells + c[k]] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (a + k < len && c[k] >= 0)
+          sum += wv[k]; // ascending cell order, like the serial assembly loop
+    }
+    if (r < nrows)
+    {
+      if (bc[r])
+        sum = 0.0; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
+      y[r] = sum;
+      dot += sum * u[r];
+    }
   }
   if (partials)
   {
@@ -692,22 +784,60 @@ int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* part
   int rc = ensure_tables(ctx);
   if (rc)
     return rc;
-  const int64_t nrows = ctx->n_owned;
-  int64_t g = (nrows + ASM_BLOCK - 1) / ASM_BLOCK;
+  const int64_t nrows = ctx->n_owned, nc = ctx->ncells;
+  const int64_t nsl = (nrows + 63) / 64;
+  if (!ctx->have_adj_li)
+  {
+    // one-time: slice-transposed adjacency with local indices, and the per-cell result buffer
+    DevBuf<int32_t> slen;
+    DevBuf<unsigned char> tmp;
+    ZZZ_HIP(ctx, slen.alloc((size_t)nsl + 1));
+    ZZZ_HIP(ctx, ctx->adjT_off.alloc((size_t)nsl + 1));
+    int g0 = (int)((nsl + 256) / 256);
+    if (g0 > 4096)
+      g0 = 4096;
+    hipLaunchKernelGGL(k_adjT_slice_len, dim3(g0), dim3(256), 0, ctx->stream, ctx->adj_off.p, nrows, nsl, slen.p);
+    size_t tb = 0;
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, slen.p, ctx->adjT_off.p, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(),
+                                         ctx->stream));
+    ZZZ_HIP(ctx, tmp.alloc(tb));
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, slen.p, ctx->adjT_off.p, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(),
+                                         ctx->stream));
+    int32_t total = 0;
+    ZZZ_HIP(ctx, hipMemcpyAsync(&total, ctx->adjT_off.p + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (total < 0)
+      return fail(ctx, ZZZ_ERR_LIMIT, "transposed adjacency exceeds int32");
+    ZZZ_HIP(ctx, ctx->adjT_cells.alloc((size_t)total + 64));
+    ZZZ_HIP(ctx, ctx->adj_li.alloc((size_t)total + 64));
+    int g1 = (int)((nsl + 3) / 4);
+    if (g1 > 8192)
+      g1 = 8192;
+    hipLaunchKernelGGL(k_adjT_fill, dim3(g1), dim3(256), 0, ctx->stream, ctx->adj_off.p, ctx->adj_cells.p, ctx->cell_dofs.p,
+                       ctx->nd, nrows, nsl, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
+    ZZZ_HIP(ctx, ctx->cell_w.alloc((size_t)(nc * ctx->nd)));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_adj_li = true;
+  }
+  const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
+  int64_t gc = (nc + ASM_BLOCK - 1) / ASM_BLOCK;
+  if (gc > 4096)
+    gc = 4096;
+#define ZZZ_MFC(ND_)                                                                                                    \
+  hipLaunchKernelGGL(matfree_cell<ND_>, dim3((unsigned)gc), dim3(ASM_BLOCK), 0, ctx->stream, ctx->x.p, ctx->cell_verts.p,  \
+                     ctx->cell_dofs.p, nc, u, ctx->cell_w.p, ctx->tables.p, stop)
+  if (ctx->order == 1)
+    ZZZ_MFC(4);
+  else if (ctx->order == 2)
+    ZZZ_MFC(10);
+  else
+    ZZZ_MFC(20);
+#undef ZZZ_MFC
+  int64_t g = (nsl + 3) / 4;
   if (g > 2048)
     g = 2048;
-  const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
-#define ZZZ_MF(ND_)                                                                                                    \
-  hipLaunchKernelGGL(matfree_poisson<ND_>, dim3((unsigned)g), dim3(ASM_BLOCK), 0, ctx->stream, ctx->x.p,               \
-                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, u, y, nrows,     \
-                     ctx->tables.p, partials, stop)
-  if (ctx->order == 1)
-    ZZZ_MF(4);
-  else if (ctx->order == 2)
-    ZZZ_MF(10);
-  else
-    ZZZ_MF(20);
-#undef ZZZ_MF
+  hipLaunchKernelGGL(matfree_gather, dim3((unsigned)g), dim3(ASM_BLOCK), 0, ctx->stream, ctx->adjT_off.p, ctx->adjT_cells.p,
+                     ctx->adj_li.p, ctx->bc.p, ctx->cell_w.p, nc, u, y, nrows, nsl, partials, stop);
   if (npartials)
     *npartials = (int)g;
   ZZZ_HIP(ctx, hipGetLastError());

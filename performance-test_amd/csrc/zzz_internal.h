@@ -95,6 +95,10 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> rowptr, cols;
   zzz::DevBuf<double> vals;
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
+  zzz::DevBuf<int32_t> adjT_off, adjT_cells; // the same lists transposed in 64-row slices (dense wave reads)
+  zzz::DevBuf<uint8_t> adj_li;             // local index of the dof in each of those cells, same layout
+  zzz::DevBuf<double> cell_w;              // matrix-free: Ae_c u_c per cell, component-major
+  bool have_adj_li = false;
   int max_row_nnz = 0;
   // SpMV tiling (row-aligned tiles of the nonzero stream)
   zzz::DevBuf<int32_t> tile_row;
