@@ -303,6 +303,9 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
   }
   if (rc)
     return rc;
+  rc = build_adjT(ctx);
+  if (rc)
+    return rc;
   ctx->sell_current = false;
   rc = sell_update(ctx, true);
   if (rc)

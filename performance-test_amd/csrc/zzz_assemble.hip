@@ -98,13 +98,76 @@ __device__ inline int find_pos(const int32_t* __restrict__ c, int len, int32_t c
   return lo;
 }
 
+// Adjacency transposed in slices of 64 rows: entry a of row (64 s + lane) sits at off[s] + 64 a + lane
+// (cell index, -1 = padding) with the dof's local index in that cell beside it.  A wavefront owns a
+// slice, so "the a-th cell of my row" is one dense 256-B read instead of 64 reads 96 B apart.
+__global__ void k_adjT_slice_len(const int32_t* __restrict__ adj_off, int64_t nb, int64_t nslices, int32_t* __restrict__ slen)
+{
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s <= nslices; s += (int64_t)gridDim.x * blockDim.x)
+  {
+    int m = 0;
+    if (s < nslices)
+      for (int64_t r = s * 64; r < min(nb, s * 64 + 64); ++r)
+        m = max(m, adj_off[r + 1] - adj_off[r]);
+    slen[s] = m * 64;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_adjT_fill(const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj_cells,
+                                                   const int32_t* __restrict__ cell_dofs, int nd, int64_t nb, int64_t nslices,
+                                                   const int32_t* __restrict__ off, int32_t* __restrict__ cellT,
+                                                   uint8_t* __restrict__ liT)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    const int o = off[s], len = (off[s + 1] - o) >> 6;
+    const int64_t r = s * 64 + lane;
+    const int a0 = r < nb ? adj_off[r] : 0, n = r < nb ? adj_off[r + 1] - a0 : 0;
+    for (int a = 0; a < len; ++a)
+    {
+      int32_t c = -1;
+      int li = 0;
+      if (a < n)
+      {
+        c = adj_cells[a0 + a];
+        const int32_t* cd = cell_dofs + (int64_t)nd * c;
+        for (int j = 0; j < nd; ++j)
+          if (cd[j] == (int32_t)r)
+            li = j;
+      }
+      cellT[o + a * 64 + lane] = c;
+      liT[o + a * 64 + lane] = (uint8_t)li;
+    }
+  }
+}
+
+// iteration over the cells of block dof i through the transposed adjacency
+struct AdjIter
+{
+  const int32_t* cp;
+  const uint8_t* lp;
+  int len;
+  __device__ AdjIter(const int32_t* __restrict__ off, const int32_t* __restrict__ cellT, const uint8_t* __restrict__ liT, int i)
+  {
+    const int sl = i >> 6, ln = i & 63;
+    const int o = off[sl];
+    len = (off[sl + 1] - o) >> 6;
+    cp = cellT + o + ln;
+    lp = liT + o + ln;
+  }
+  __device__ int cell(int a) const { return cp[a * 64]; } // -1 once the list of this row is exhausted
+  __device__ int li(int a) const { return lp[a * 64]; }
+};
+
 // ---- matrix, P1, BS = 1 (Poisson a1, src/Poisson.py:31) or 3 (Elasticity a1, src/Elasticity.py:39)
 template <int BS>
 __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restrict__ x,
                                                            const int32_t* __restrict__ cell_verts,
                                                            const int32_t* __restrict__ cell_dofs,
-                                                           const int32_t* __restrict__ adj_off,
-                                                           const int32_t* __restrict__ adj_cells,
+                                                           const int32_t* __restrict__ adjT_off,
+                                                           const int32_t* __restrict__ adjT_cells,
+                                                           const uint8_t* __restrict__ adj_li,
                                                            const uint8_t* __restrict__ bc,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
@@ -132,9 +195,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
     constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
     constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
-    for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+    const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+    for (int a = 0; a < adj.len; ++a)
     {
-      const int cell = adj_cells[a];
+      const int cell = adj.cell(a);
+      if (cell < 0)
+        break;
+      const int li = adj.li(a);
       const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
       const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
       const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
@@ -143,7 +210,6 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
       load_cell(x, v, p);
       geometry(p, G);
       p1_grads(G, g);
-      const int li = (dofs[0] == i) ? 0 : (dofs[1] == i) ? 1 : (dofs[2] == i) ? 2 : 3;
       const double w = G.adet / 6.0; // reference volume
       double gi[3] = {0, 0, 0};
 #pragma unroll
@@ -194,8 +260,9 @@ template <int BS>
 __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restrict__ x,
                                                            const int32_t* __restrict__ cell_verts,
                                                            const int32_t* __restrict__ cell_dofs,
-                                                           const int32_t* __restrict__ adj_off,
-                                                           const int32_t* __restrict__ adj_cells,
+                                                           const int32_t* __restrict__ adjT_off,
+                                                           const int32_t* __restrict__ adjT_cells,
+                                                           const uint8_t* __restrict__ adj_li,
                                                            const uint8_t* __restrict__ bc,
                                                            const uint8_t* __restrict__ facet_mask,
                                                            const double* __restrict__ f, const double* __restrict__ gc,
@@ -207,9 +274,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
     return;
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
-  for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+  const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+  for (int a = 0; a < adj.len; ++a)
   {
-    const int cell = adj_cells[a];
+    const int cell = adj.cell(a);
+    if (cell < 0)
+      break;
+    const int li = adj.li(a);
     const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
     const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
     const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
@@ -217,7 +288,6 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
     Geom G;
     load_cell(x, v, p);
     geometry(p, G);
-    const int li = (dofs[0] == i) ? 0 : (dofs[1] == i) ? 1 : (dofs[2] == i) ? 2 : 3;
     double fl[4], fs = 0.0, fi = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -278,8 +348,9 @@ template <int ND, int BS, int LPR>
 __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restrict__ x,
                                                            const int32_t* __restrict__ cell_verts,
                                                            const int32_t* __restrict__ cell_dofs,
-                                                           const int32_t* __restrict__ adj_off,
-                                                           const int32_t* __restrict__ adj_cells,
+                                                           const int32_t* __restrict__ adjT_off,
+                                                           const int32_t* __restrict__ adjT_cells,
+                                                           const uint8_t* __restrict__ adj_li,
                                                            const uint8_t* __restrict__ bc,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
@@ -325,19 +396,19 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
     constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
     constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
-    for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+    const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+    for (int a = 0; a < adj.len; ++a)
     {
-      const int cell = adj_cells[a];
+      const int cell = adj.cell(a);
+      if (cell < 0)
+        break;
+      const int li = adj.li(a);
       const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
       const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
       double p[4][3];
       Geom G;
       load_cell(x, v, p);
       geometry(p, G);
-      int li = 0;
-      for (int jj = 0; jj < ND; ++jj)
-        if (cd[jj] == i)
-          li = jj;
       const double* Tl = T_s + li * ND;
       if (BS == 1)
       {
@@ -409,8 +480,9 @@ template <int ND, int BS>
 __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restrict__ x,
                                                            const int32_t* __restrict__ cell_verts,
                                                            const int32_t* __restrict__ cell_dofs,
-                                                           const int32_t* __restrict__ adj_off,
-                                                           const int32_t* __restrict__ adj_cells,
+                                                           const int32_t* __restrict__ adjT_off,
+                                                           const int32_t* __restrict__ adjT_cells,
+                                                           const uint8_t* __restrict__ adj_li,
                                                            const uint8_t* __restrict__ bc,
                                                            const uint8_t* __restrict__ facet_mask,
                                                            const double* __restrict__ f, const double* __restrict__ gc,
@@ -432,19 +504,19 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restr
     return;
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
-  for (int a = adj_off[i]; a < adj_off[i + 1]; ++a)
+  const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+  for (int a = 0; a < adj.len; ++a)
   {
-    const int cell = adj_cells[a];
+    const int cell = adj.cell(a);
+    if (cell < 0)
+      break;
+    const int li = adj.li(a);
     const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
     const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
     double p[4][3];
     Geom G;
     load_cell(x, v, p);
     geometry(p, G);
-    int li = 0;
-    for (int jj = 0; jj < ND; ++jj)
-      if (cd[jj] == i)
-        li = jj;
     double acc = 0.0;
     for (int j = 0; j < ND; ++j)
       acc += M_s[li * ND + j] * f[(int64_t)cd[j] * BS + c];
@@ -502,7 +574,7 @@ static int launch_matrix_pk(zzz_ctx* ctx)
   auto kern = asm_matrix_pk<ND, BS, LPR>;
   ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)xcd_grid(ctx->n_asm_tiles)), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
-                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p,
+                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p,
                      ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p);
   return ZZZ_OK;
 }
@@ -512,7 +584,7 @@ static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
 {
   const dim3 grid((unsigned)xcd_grid((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
   hipLaunchKernelGGL((asm_vector_pk<ND, BS>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
-                     ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
+                     ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                      BS == 1 ? ctx->coeff[1].p : (const double*)nullptr, ctx->b.p, nrows, ctx->tables.p);
 }
 
@@ -526,11 +598,11 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
   {
     if (bs == 1)
       hipLaunchKernelGGL(asm_matrix_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
-                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
     else
       hipLaunchKernelGGL(asm_matrix_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
-                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
   }
   else
@@ -560,11 +632,11 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
   {
     if (bs == 1)
       hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
-                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
+                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                          ctx->coeff[1].p, ctx->b.p, nrows);
     else
       hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
-                         ctx->adj_off.p, ctx->adj_cells.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
+                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                          (const double*)nullptr, ctx->b.p, nrows);
   }
   else
@@ -676,50 +748,6 @@ __global__ __launch_bounds__(ASM_BLOCK) void matfree_cell(const double* __restri
   }
 }
 
-// Adjacency transposed in slices of 64 rows: entry a of row (64 s + lane) sits at off[s] + 64 a + lane
-// (cell index, -1 = padding) with the dof's local index in that cell beside it.  A wavefront owns a
-// slice, so "the a-th cell of my row" is one dense 256-B read instead of 64 reads 96 B apart.
-__global__ void k_adjT_slice_len(const int32_t* __restrict__ adj_off, int64_t nb, int64_t nslices, int32_t* __restrict__ slen)
-{
-  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s <= nslices; s += (int64_t)gridDim.x * blockDim.x)
-  {
-    int m = 0;
-    if (s < nslices)
-      for (int64_t r = s * 64; r < min(nb, s * 64 + 64); ++r)
-        m = max(m, adj_off[r + 1] - adj_off[r]);
-    slen[s] = m * 64;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_adjT_fill(const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj_cells,
-                                                   const int32_t* __restrict__ cell_dofs, int nd, int64_t nb, int64_t nslices,
-                                                   const int32_t* __restrict__ off, int32_t* __restrict__ cellT,
-                                                   uint8_t* __restrict__ liT)
-{
-  const int lane = threadIdx.x & 63;
-  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
-  {
-    const int o = off[s], len = (off[s + 1] - o) >> 6;
-    const int64_t r = s * 64 + lane;
-    const int a0 = r < nb ? adj_off[r] : 0, n = r < nb ? adj_off[r + 1] - a0 : 0;
-    for (int a = 0; a < len; ++a)
-    {
-      int32_t c = -1;
-      int li = 0;
-      if (a < n)
-      {
-        c = adj_cells[a0 + a];
-        const int32_t* cd = cell_dofs + (int64_t)nd * c;
-        for (int j = 0; j < nd; ++j)
-          if (cd[j] == (int32_t)r)
-            li = j;
-      }
-      cellT[o + a * 64 + lane] = c;
-      liT[o + a * 64 + lane] = (uint8_t)li;
-    }
-  }
-}
-
 __global__ __launch_bounds__(ASM_BLOCK) void matfree_gather(const int32_t* __restrict__ off, const int32_t* __restrict__ cellT,
                                                             const uint8_t* __restrict__ liT, const uint8_t* __restrict__ bc,
                                                             const double* __restrict__ w, int64_t ncells,
@@ -775,20 +803,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void matfree_gather(const int32_t* __res
   }
 }
 
-int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
+// slice-transposed adjacency with local indices: built once per pattern, read by every row-gather kernel
+int build_adjT(zzz_ctx* ctx)
 {
-  if (ctx->bs != 1)
-    return fail(ctx, ZZZ_ERR_ARG, "the matrix-free operator exists for the Poisson form M only (src/Poisson.py:33)");
-  if (!ctx->have_pattern)
-    return fail(ctx, ZZZ_ERR_ARG, "matrix-free operator needs zzz_csr_pattern_build (dof->cell adjacency)");
-  int rc = ensure_tables(ctx);
-  if (rc)
-    return rc;
-  const int64_t nrows = ctx->n_owned, nc = ctx->ncells;
+  const int64_t nrows = ctx->n_owned;
   const int64_t nsl = (nrows + 63) / 64;
-  if (!ctx->have_adj_li)
+  ctx->have_adj_li = false;
   {
-    // one-time: slice-transposed adjacency with local indices, and the per-cell result buffer
     DevBuf<int32_t> slen;
     DevBuf<unsigned char> tmp;
     ZZZ_HIP(ctx, slen.alloc((size_t)nsl + 1));
@@ -815,10 +836,28 @@ int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* part
       g1 = 8192;
     hipLaunchKernelGGL(k_adjT_fill, dim3(g1), dim3(256), 0, ctx->stream, ctx->adj_off.p, ctx->adj_cells.p, ctx->cell_dofs.p,
                        ctx->nd, nrows, nsl, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
-    ZZZ_HIP(ctx, ctx->cell_w.alloc((size_t)(nc * ctx->nd)));
+    ZZZ_HIP(ctx, hipGetLastError());
     ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_adj_li = true;
   }
+  return ZZZ_OK;
+}
+
+int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
+{
+  if (ctx->bs != 1)
+    return fail(ctx, ZZZ_ERR_ARG, "the matrix-free operator exists for the Poisson form M only (src/Poisson.py:33)");
+  if (!ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "matrix-free operator needs zzz_csr_pattern_build (dof->cell adjacency)");
+  int rc = ensure_tables(ctx);
+  if (rc)
+    return rc;
+  const int64_t nrows = ctx->n_owned, nc = ctx->ncells;
+  const int64_t nsl = (nrows + 63) / 64;
+  if (!ctx->have_adj_li)
+    return fail(ctx, ZZZ_ERR_ARG, "transposed adjacency missing (zzz_csr_pattern_build not run)");
+  if (ctx->cell_w.n < (size_t)(nc * ctx->nd))
+    ZZZ_HIP(ctx, ctx->cell_w.alloc((size_t)(nc * ctx->nd)));
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   int64_t gc = (nc + ASM_BLOCK - 1) / ASM_BLOCK;
   if (gc > 4096)
