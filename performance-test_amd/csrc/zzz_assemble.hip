@@ -196,21 +196,45 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
     constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
     const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
-    for (int a = 0; a < adj.len; ++a)
+    // Two-stage software pipeline over the row's cells: the loads of cell a+1 (adjacency ->
+    // connectivity -> coordinates and BC flags: a three-deep dependent chain) are in flight while
+    // cell a is evaluated; with the workgroup's CSR segment taking 48 KiB of LDS only three
+    // wavefronts per SIMD are resident, so the chain is not hidden by occupancy alone.
+    struct Stage
     {
-      const int cell = adj.cell(a);
-      if (cell < 0)
-        break;
-      const int li = adj.li(a);
-      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
-      const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
-      const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
-      double p[4][3], g[4][3];
+      int cell, li;
+      int4 dd;
+      double p[4][3];
+      uint8_t bcj[4 * BS];
+    };
+    auto fetch = [&](int a, Stage& S) {
+      S.cell = a < adj.len ? adj.cell(a) : -1;
+      if (S.cell < 0)
+        return;
+      S.li = adj.li(a);
+      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)S.cell);
+      S.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)S.cell);
+      load_cell(x, v, S.p);
+      const int dj[4] = {S.dd.x, S.dd.y, S.dd.z, S.dd.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < BS; ++d)
+          S.bcj[j * BS + d] = bc[dj[j] * BS + d];
+    };
+    Stage cur, nxt;
+    fetch(0, cur);
+    for (int a = 0; cur.cell >= 0; ++a)
+    {
+      fetch(a + 1, nxt);
+      const int li = cur.li;
+      const int dofs[4] = {cur.dd.x, cur.dd.y, cur.dd.z, cur.dd.w};
+      double g[4][3];
       Geom G;
-      load_cell(x, v, p);
-      geometry(p, G);
+      geometry(cur.p, G);
       p1_grads(G, g);
       const double w = G.adet / 6.0; // reference volume
+
       double gi[3] = {0, 0, 0};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
         if (BS == 1)
         {
           double val = w * gg;
-          if (bcr || bc[dofs[j]])
+          if (bcr || cur.bcj[j])
             val = 0.0;
           vals_s[a0 + pos] += val;
         }
@@ -240,12 +264,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
           {
             // mu (delta_cd g_i.g_j + d_d phi_i d_c phi_j) + lambda d_c phi_i d_d phi_j
             double val = w * (mu * ((c == d ? gg : 0.0) + gi[d] * gjc) + lmbda * gic * g[j][d]);
-            if (bcr || bc[dofs[j] * 3 + d])
+            if (bcr || cur.bcj[j * BS + d])
               val = 0.0;
             vals_s[a0 + pos + d] += val;
           }
         }
       }
+      cur = nxt;
     }
     if (bcr) // fem::set_diagonal: 1.0 on constrained rows
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
