@@ -18,7 +18,8 @@ template <typename T>
 struct DevBuf
 {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0;   // elements in use
+  size_t cap = 0; // elements allocated
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -28,16 +29,24 @@ struct DevBuf
     if (p)
       (void)hipFree(p);
     p = nullptr;
-    n = 0;
+    n = cap = 0;
   }
+  // Contents are NOT preserved.  An existing allocation is reused when it is large enough (and not
+  // more than twice too large): hipFree/hipMalloc of GB-sized buffers cost milliseconds each and a
+  // re-assembly of the same problem asks for the same sizes again.
   hipError_t alloc(size_t count)
   {
-    release();
     if (count == 0)
       count = 1;
+    if (p && cap >= count && cap <= 2 * count + 1024)
+    {
+      n = count;
+      return hipSuccess;
+    }
+    release();
     hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
     if (e == hipSuccess)
-      n = count;
+      n = cap = count;
     return e;
   }
 };
@@ -94,6 +103,9 @@ struct zzz_ctx
   int64_t nrows = 0, ncols = 0, nnz = 0;
   zzz::DevBuf<int32_t> rowptr, cols;
   zzz::DevBuf<double> vals;
+  // scratch of the pattern build (kept: a rebuild of the same problem reuses it)
+  zzz::DevBuf<int32_t> scr_keys_in, scr_keys_out, scr_vals_in, scr_cnt, scr_bptr;
+  zzz::DevBuf<unsigned char> scr_tmp;
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
   zzz::DevBuf<int32_t> adjT_off, adjT_cells; // the same lists transposed in 64-row slices (dense wave reads)
   zzz::DevBuf<uint8_t> adj_li;             // local index of the dof in each of those cells, same layout

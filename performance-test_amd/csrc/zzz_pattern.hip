@@ -223,8 +223,10 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   if (N > INT32_MAX - 8)
     return fail(ctx, ZZZ_ERR_LIMIT, "dof->cell adjacency exceeds int32");
 
-  DevBuf<int32_t> keys_in, keys_out, vals_in, cnt, bptr, scal;
-  DevBuf<unsigned char> tmp;
+  DevBuf<int32_t>&keys_in = ctx->scr_keys_in, &keys_out = ctx->scr_keys_out, &vals_in = ctx->scr_vals_in,
+  &cnt = ctx->scr_cnt, &bptr = ctx->scr_bptr;
+  DevBuf<unsigned char>& tmp = ctx->scr_tmp;
+  DevBuf<int32_t> scal;
   ZZZ_HIP(ctx, keys_in.alloc((size_t)N));
   ZZZ_HIP(ctx, keys_out.alloc((size_t)N));
   ZZZ_HIP(ctx, vals_in.alloc((size_t)N));
@@ -250,9 +252,6 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
                                          (unsigned)end_bit, s));
   ZZZ_HIP(ctx, ctx->adj_off.alloc((size_t)nb + 1));
   ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb2, cnt.p, ctx->adj_off.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
-  keys_in.release();
-  keys_out.release();
-  vals_in.release();
 
   // 2. pattern: count, scan, fill
   const int rgrid = grid_for((int64_t)nb, 4, 256 * 16);
