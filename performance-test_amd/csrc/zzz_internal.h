@@ -104,7 +104,7 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> rowptr, cols;
   zzz::DevBuf<double> vals;
   // scratch of the pattern build (kept: a rebuild of the same problem reuses it)
-  zzz::DevBuf<int32_t> scr_keys_in, scr_keys_out, scr_vals_in, scr_cnt, scr_bptr;
+  zzz::DevBuf<int32_t> scr_keys_in, scr_keys_out, scr_vals_in, scr_cnt, scr_bptr, scr_stage;
   zzz::DevBuf<unsigned char> scr_tmp;
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
   zzz::DevBuf<int32_t> adjT_off, adjT_cells; // the same lists transposed in 64-row slices (dense wave reads)

@@ -41,15 +41,17 @@ __global__ void k_make_pairs(const int32_t* __restrict__ cell_dofs, int64_t n, i
 }
 
 // One wavefront per block row: sorted unique dofs of the row's cells.
-// FILL = false: cnt[r] = number of unique columns (and the maximum over rows);
-// FILL = true : scalar CSR columns of the bs rows of block r.
+// FILL = false: cnt[r] = number of unique columns (and the maximum over rows); when `stage` is given
+//               the sorted unique columns are also parked at stage[adj_off[r]*nd ...] so that the
+//               fill pass (k_row_copy) need not sort again;
+// FILL = true : scalar CSR columns of the bs rows of block r (used when no staging area is available).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__ cell_dofs, int nd, int bs,
                                                      const int32_t* __restrict__ adj_off,
                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
                                                      int32_t* __restrict__ cnt, int32_t* __restrict__ maxcnt,
                                                      const int32_t* __restrict__ bptr, int32_t* __restrict__ cols,
-                                                     int32_t* __restrict__ overflow)
+                                                     int32_t* __restrict__ overflow, int32_t* __restrict__ stage)
 {
   __shared__ int32_t lds[4][PAT_CAP];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
       const int idx = s + lane;
       const bool flag = idx < n && (idx == 0 || c[idx] != c[idx - 1]);
       const unsigned long long m = __ballot(flag);
+      if (!FILL && stage && flag)
+        stage[(int64_t)a0 * nd + base + __popcll(m & ((1ull << lane) - 1ull))] = c[idx];
       if (FILL && flag)
       {
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -125,6 +129,28 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
   // one L2 channel and cost ~100 ms
   if (!FILL && lane == 0 && wmax > 0)
     atomicMax(maxcnt, wmax);
+}
+
+// fill pass when the count pass staged the sorted unique columns: expand block (r, col) to bs x bs
+__global__ __launch_bounds__(256) void k_row_copy(const int32_t* __restrict__ stage, const int32_t* __restrict__ adj_off,
+                                                  int nd, int bs, int32_t nb, const int32_t* __restrict__ cnt,
+                                                  const int32_t* __restrict__ bptr, int32_t* __restrict__ cols)
+{
+  // 16 lanes per row: FE rows have tens of columns, not hundreds
+  const int sub = threadIdx.x & 15;
+  for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; r < nb; r += ((int64_t)gridDim.x * blockDim.x) >> 4)
+  {
+    const int nu = cnt[r];
+    const int32_t rp = bptr[r];
+    const int32_t* src = stage + (int64_t)adj_off[r] * nd;
+    for (int k = sub; k < nu; k += 16)
+    {
+      const int32_t col = src[k];
+      for (int a = 0; a < bs; ++a)
+        for (int d = 0; d < bs; ++d)
+          cols[(int64_t)bs * bs * rp + (int64_t)a * bs * nu + (int64_t)k * bs + d] = col * bs + d;
+    }
+  }
 }
 
 __global__ void k_scalar_rowptr(const int32_t* __restrict__ bptr, const int32_t* __restrict__ cnt, int32_t nb, int bs,
@@ -255,8 +281,14 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
 
   // 2. pattern: count, scan, fill
   const int rgrid = grid_for((int64_t)nb, 4, 256 * 16);
+  // staging area for the sorted unique columns (upper bound: every candidate distinct); skipped when
+  // it would not fit comfortably -- then the fill pass sorts again
+  const int64_t nstage = N * nd;
+  int32_t* stage = nullptr;
+  if (nstage < ((int64_t)3 << 30) && ctx->scr_stage.alloc((size_t)nstage) == hipSuccess)
+    stage = ctx->scr_stage.p;
   hipLaunchKernelGGL(k_row_pattern<false>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
-                     ctx->adj_cells.p, nb, cnt.p, scal.p, (const int32_t*)nullptr, (int32_t*)nullptr, scal.p + 1);
+                     ctx->adj_cells.p, nb, cnt.p, scal.p, (const int32_t*)nullptr, (int32_t*)nullptr, scal.p + 1, stage);
   int32_t h[4] = {0, 0, 0, 0};
   ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
@@ -282,8 +314,12 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->vals.p, 0, ((size_t)nnz + 8) * sizeof(double), s));
   hipLaunchKernelGGL(k_scalar_rowptr, dim3(grid_for((int64_t)nb + 1)), dim3(256), 0, s, bptr.p, cnt.p, nb, bs,
                      ctx->rowptr.p);
-  hipLaunchKernelGGL(k_row_pattern<true>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
-                     ctx->adj_cells.p, nb, cnt.p, scal.p, bptr.p, ctx->cols.p, scal.p + 1);
+  if (stage)
+    hipLaunchKernelGGL(k_row_copy, dim3(grid_for((int64_t)nb * 16, 256, 8192)), dim3(256), 0, s, stage, ctx->adj_off.p, nd, bs,
+                       nb, cnt.p, bptr.p, ctx->cols.p);
+  else
+    hipLaunchKernelGGL(k_row_pattern<true>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
+                       ctx->adj_cells.p, nb, cnt.p, scal.p, bptr.p, ctx->cols.p, scal.p + 1, (int32_t*)nullptr);
   ZZZ_HIP(ctx, hipGetLastError());
   // 3. tiles
   int rc = build_tiles_device(ctx, h[0]);
