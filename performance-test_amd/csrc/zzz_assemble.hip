@@ -577,7 +577,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restr
   b[r] = bc[r] ? 0.0 : sum;
 }
 
-static int ensure_tables(zzz_ctx* ctx)
+int ensure_tables(zzz_ctx* ctx)
 {
   if (ctx->tables_order == ctx->order)
     return ZZZ_OK;
@@ -597,7 +597,12 @@ static int launch_matrix_pk(zzz_ctx* ctx)
   constexpr int NT = (BS == 1) ? 6 : 9;
   const size_t lds = (size_t)ASM_NNZ * 8 + (size_t)NT * ND * ND * 8 + (size_t)ASM_NNZ * 4;
   auto kern = asm_matrix_pk<ND, BS, LPR>;
-  ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static bool attr_set = false; // per instantiation; the attribute is a property of the kernel, set once
+  if (!attr_set)
+  {
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)xcd_grid(ctx->n_asm_tiles)), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
                      ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p,
                      ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p);

@@ -41,10 +41,23 @@ __global__ void k_extract_dinv(const int32_t* __restrict__ rowptr, const int32_t
     double d = 1.0;
     if (jacobi)
     {
+      // columns are ascending: binary search for the diagonal (MatGetDiagonal)
+      int lo = rowptr[r], hi = rowptr[r + 1] - 1;
       d = 0.0;
-      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
-        if (cols[k] == (int32_t)r)
-          d = vals[k];
+      while (lo <= hi)
+      {
+        const int mid = (lo + hi) >> 1;
+        const int32_t cm = cols[mid];
+        if (cm == (int32_t)r)
+        {
+          d = vals[mid];
+          break;
+        }
+        if (cm < (int32_t)r)
+          lo = mid + 1;
+        else
+          hi = mid - 1;
+      }
       if (d == 0.0)
         d = 1.0; // PCJACOBI replaces zero diagonal entries by one
     }
