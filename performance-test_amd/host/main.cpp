@@ -110,8 +110,9 @@ struct Options
   std::string problem_type = "poisson", mesh_type = "cube", scaling_type = "weak", output, scatterer = "neighbor";
   bool mem_profile = false, use_subcomm = false, help = false;
   std::size_t ndofs = 50000, order = 1;
-  // this driver only: number of GPUs ("processes")
+  // this driver only: number of GPUs ("processes") and the communicator between them
   int ngpus = 1;
+  std::string comm = "rccl"; // "local": host-mediated exchange, all ranks on GPU 0 (validation on one GPU)
   // PETSc options database (README.md:66-82)
   std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50; // PETSc defaults
@@ -135,6 +136,7 @@ void usage()
                "  --order arg (=1)                polynomial order\n"
                "  --scatterer arg (=neighbor)     scatterer for CG (neighbor or p2p)\n"
                "  --ngpus arg (=1)                number of GPUs (takes the place of mpirun -np)\n"
+               "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
                "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
                "  -log_view -options_left\n"
@@ -176,6 +178,8 @@ Options parse(int argc, char** argv)
         o.order = std::stoull(value(i, arg, key));
       else if (key == "ngpus")
         o.ngpus = std::stoi(value(i, arg, key));
+      else if (key == "comm")
+        o.comm = value(i, arg, key);
       else if (key == "memory_profiling")
         o.mem_profile = true;
       else if (key == "subcomm_partition")
@@ -238,6 +242,7 @@ struct Shared
   int nranks = 1;
   std::int64_t dims[4] = {0, 0, 0, 0};
   unsigned char uid[ZZZ_UNIQUE_ID_BYTES] = {0};
+  void* local_group = nullptr; // --comm local
   std::vector<double> tmax;   // scratch for max-over-ranks timing
   std::vector<int> iters;
   std::vector<double> norm, rnorm0, rnorm;
@@ -285,8 +290,10 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   // on the GPU in closed form (zzz_cube_generate); the reference's setup timers are kept as rows.
   std::int64_t info[6] = {0, 0, 0, 0, 0, 0};
   phase("ZZZ Create Mesh", [&] {
-    ZCK(nullptr, zzz_ctx_create(rank, &ctx));
-    if (S.nranks > 1)
+    ZCK(nullptr, zzz_ctx_create(S.local_group ? 0 : rank, &ctx));
+    if (S.local_group)
+      ZCK(ctx, zzz_comm_init_local(ctx, S.local_group, rank));
+    else if (S.nranks > 1)
       ZCK(ctx, zzz_comm_init(ctx, S.nranks, rank, S.uid));
     const int r = (int)S.dims[3];
     ZCK(ctx, zzz_cube_generate(ctx, form, (int)o.order, S.dims[0] << r, S.dims[1] << r, S.dims[2] << r, S.nranks, rank, info));
@@ -448,7 +455,9 @@ void solve(int argc, char** argv)
   const int ndev = zzz_device_count();
   if (ndev < 1)
     throw std::runtime_error("no GPU visible: this build has no CPU path");
-  if (o.ngpus < 1 || o.ngpus > ndev)
+  if (o.comm != "rccl" && o.comm != "local")
+    throw std::runtime_error("--comm " + o.comm + ": rccl or local");
+  if (o.ngpus < 1 || (o.comm == "rccl" && o.ngpus > ndev))
     throw std::runtime_error("--ngpus " + std::to_string(o.ngpus) + " but " + std::to_string(ndev) + " GPU(s) visible");
 
   Shared S;
@@ -461,7 +470,12 @@ void solve(int argc, char** argv)
   // src/mesh.cpp:190-194
   std::cout << "UnitCube (" << S.dims[0] << "x" << S.dims[1] << "x" << S.dims[2] << ") to be refined " << S.dims[3]
             << " times" << std::endl;
-  if (S.nranks > 1)
+  if (o.comm == "local")
+  {
+    if (zzz_local_group_create(S.nranks, &S.local_group) != 0)
+      throw std::runtime_error(zzz_last_error(nullptr));
+  }
+  else if (S.nranks > 1)
     if (zzz_comm_unique_id(S.uid) != 0)
       throw std::runtime_error(zzz_last_error(nullptr));
   S.tmax.assign(S.nranks, 0.0);
@@ -478,6 +492,8 @@ void solve(int argc, char** argv)
   run_rank(S, bar, 0);
   for (auto& t : th)
     t.join();
+  if (S.local_group)
+    zzz_local_group_destroy(S.local_group);
   for (int r = 0; r < S.nranks; ++r)
     if (!S.error[r].empty())
       throw std::runtime_error("rank " + std::to_string(r) + ": " + S.error[r]);

@@ -288,7 +288,8 @@ def test_unsorted_cells_and_foreign_numbering(ctx, problem, order):
     # affine map of the geometry (kernels must not assume a unit cube); BC/facets/coefficients stay
     # those of the original problem (they are inputs at the boundary)
     M = np.array([[1.3, 0.2, 0.0], [0.1, 0.9, 0.3], [0.0, -0.2, 1.1]])
-    x = np.ascontiguousarray(O.x @ M.T + np.array([0.3, -0.1, 0.2]))
+    jitter = 0.06 * (rng.random(O.x.shape) - 0.5)  # < 1/5 of the mesh size: cells stay valid, none alike
+    x = np.ascontiguousarray((O.x + jitter) @ M.T + np.array([0.3, -0.1, 0.2]))
     facets = zo.exterior_facets(cells) if problem == "poisson" else None
     bs = O.bs
     ctx.upload_mesh(x, cells)
@@ -455,3 +456,32 @@ def test_partitioned_solve_on_one_gpu(problem, order, dims, nparts):
     for o in out:
         assert abs(o[6] - n0) <= 1e-9 * n0  # la::norm is global on every rank
         assert o[1] == out[0][1] and o[2] == out[0][2]
+
+
+def test_driver_multi_rank_threads_on_one_gpu():
+    """The driver's multi-rank machinery (one thread per rank, barriers, max-over-ranks timers, summary)
+    with the host-mediated communicator: 3 ranks on GPU 0 must print the single-rank iteration count
+    and solution norm."""
+    import subprocess
+
+    exe = os.path.join(zzz.PKG, "dolfinx-scaling-test")
+    base = [exe, "--problem_type", "poisson", "--scaling_type", "strong", "--ndofs", "60000", "-ksp_type", "cg",
+            "-pc_type", "jacobi", "-ksp_rtol", "1e-8"]
+    one = subprocess.run(base, capture_output=True, text=True, timeout=300)
+    three = subprocess.run(base + ["--ngpus", "3", "--comm", "local"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and three.returncode == 0, three.stderr
+
+    def parse(s):
+        return (int(s.split("*** Number of Krylov iterations: ")[1].split()[0]),
+                float(s.split("*** Solution norm:  ")[1].split()[0]))
+
+    i1, n1 = parse(one.stdout)
+    i3, n3 = parse(three.stdout)
+    assert "Num processes:   3" in three.stdout
+    assert abs(i3 - i1) <= 1 and abs(n3 - n1) <= 1e-6 * n1
+    # weak scaling: ndofs is per process (src/mesh.cpp:87-90)
+    w = subprocess.run([exe, "--problem_type", "elasticity", "--scaling_type", "weak", "--ndofs", "9000", "--ngpus", "2",
+                        "--comm", "local", "-pc_type", "jacobi", "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=300)
+    assert w.returncode == 0 and "Num processes:   2" in w.stdout, w.stderr
+    tot = int(w.stdout.split("Total degrees of freedom:")[1].split()[0])
+    assert 15000 < tot < 21000
