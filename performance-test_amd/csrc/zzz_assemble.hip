@@ -597,11 +597,12 @@ static int launch_matrix_pk(zzz_ctx* ctx)
   constexpr int NT = (BS == 1) ? 6 : 9;
   const size_t lds = (size_t)ASM_NNZ * 8 + (size_t)NT * ND * ND * 8 + (size_t)ASM_NNZ * 4;
   auto kern = asm_matrix_pk<ND, BS, LPR>;
-  static bool attr_set = false; // per instantiation; the attribute is a property of the kernel, set once
-  if (!attr_set)
+  // the attribute belongs to (kernel, device): set it once per context, outside the hot path
+  const unsigned bit = 1u << ((ND == 10 ? 0 : 2) + (BS == 1 ? 0 : 1));
+  if (!(ctx->lds_attr_set & bit))
   {
     ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->lds_attr_set |= bit;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)xcd_grid(ctx->n_asm_tiles)), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
                      ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p,

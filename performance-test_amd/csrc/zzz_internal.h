@@ -94,6 +94,7 @@ struct zzz_ctx
   // reference tensors of the element (element_tables.inc), for orders 2 and 3
   zzz::DevBuf<double> tables;
   int tables_order = 0;
+  unsigned lds_attr_set = 0; // which P2/P3 matrix kernels had their dynamic-LDS limit raised on this device
 
   // coefficients
   zzz::DevBuf<double> coeff[2];

@@ -319,6 +319,20 @@ def test_unsorted_cells_and_foreign_numbering(ctx, problem, order):
     assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
 
 
+def test_size_limits_are_errors_not_crashes():
+    """Maximum sizes: local indices are int32; a partition beyond that range is refused up front
+    (before anything is allocated) with ZZZ_ERR_LIMIT and a message that says what to do."""
+    with zzz.Context(0) as c:
+        with pytest.raises(zzz.ZzzError) as e:
+            c.cube_generate("poisson", 1, 1000, 1000, 1000)  # 1.0e9 dofs, 6e9 cells on one GPU
+        assert e.value.code == 5 and "use more parts" in str(e.value)
+        with pytest.raises(zzz.ZzzError):
+            c.cube_generate("poisson", 1, 8, 8, 2, 3, 0)  # fewer layers than parts
+        c.cube_generate("poisson", 1, 4, 4, 4)  # the context is still usable afterwards
+        c.pattern_build()
+        assert c.csr_sizes()[0] == 125
+
+
 def test_empty_and_ragged_inputs(ctx):
     """Edge cases at the boundary: no constrained dofs, no exterior facets uploaded, a single cell,
     bad arrays rejected with an error code (never a crash)."""
