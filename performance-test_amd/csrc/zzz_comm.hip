@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace zzz
@@ -47,7 +48,17 @@ struct Rccl
 
 static Rccl g_rccl;
 
+static const char* load_rccl_once();
+
 static const char* load_rccl()
+{
+  // several driver threads may attach communicators at the same time
+  static std::mutex m;
+  std::lock_guard<std::mutex> lk(m);
+  return load_rccl_once();
+}
+
+static const char* load_rccl_once()
 {
   if (g_rccl.h)
     return nullptr;
