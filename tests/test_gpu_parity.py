@@ -499,3 +499,20 @@ def test_driver_multi_rank_threads_on_one_gpu():
     assert w.returncode == 0 and "Num processes:   2" in w.stdout, w.stderr
     tot = int(w.stdout.split("Total degrees of freedom:")[1].split()[0])
     assert 15000 < tot < 21000
+
+
+def test_run_to_run_reproducibility(ctx):
+    """No atomics on the data path and fixed reduction trees: two runs of assemble + solve give the
+    same bits (matrix, right-hand side, iteration count, residual history, solution)."""
+    P = zzz.Part("elasticity", 1, 9, 8, 10)
+    res = []
+    for _ in range(2):
+        ctx.upload_part(P)
+        ctx.pattern_build()
+        ctx.assemble_matrix(P.form)
+        ctx.assemble_vector(P.form)
+        it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        res.append((ctx.csr_download()[2], ctx.vec_download(zzz.VEC_B), it, ctx.cg_history(it + 1),
+                    ctx.vec_download(zzz.VEC_U)))
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
