@@ -111,7 +111,10 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   if (const char* e = getenv("ZZZ_SPMV_TILE"))
     ctx->spmv_tile = atoi(e) == 4096 ? 4096 : 2048;
   if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
+  {
     ctx->spmv_variant = atoi(e) & 15;
+    ctx->spmv_auto = false;
+  }
   ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
   if (const char* e = getenv("ZZZ_OVERLAP"))
     ctx->overlap = atoi(e) != 0;
@@ -584,8 +587,12 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
   if (!ctx->have_matrix || reps < 1 || !avg_ms)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_time: no matrix or bad arguments");
   const int saved = ctx->spmv_variant;
+  const bool saved_auto = ctx->spmv_auto;
   if (variant >= 0)
+  {
     ctx->spmv_variant = variant & 15; // bit 2: gather-free timing diagnostic (wrong results); bit 3: SELL
+    ctx->spmv_auto = false;
+  }
   hipEvent_t e0, e1;
   ZZZ_HIP(ctx, hipEventCreate(&e0));
   ZZZ_HIP(ctx, hipEventCreate(&e1));
@@ -602,6 +609,7 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   ctx->spmv_variant = saved;
+  ctx->spmv_auto = saved_auto;
   *avg_ms = ms / reps;
   return rc;
 }

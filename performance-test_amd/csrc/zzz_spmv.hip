@@ -379,7 +379,13 @@ static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, d
 #define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
   hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
                      ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list)
-  const int var = ctx->spmv_variant; // bit 0: non-temporal matrix loads, bit 1: pipelined tiles
+  // bit 0: non-temporal matrix loads, bit 1: pipelined tiles.  Unless a variant was forced, the load
+  // policy follows the matrix size: a matrix that fits the 256 MiB Infinity Cache is re-read from it
+  // every CG iteration, and non-temporal loads would throw that away (measured, 1.25 M-dof P1 matrix,
+  // 221 MB: 44 us plain vs 55 us nt; 2.5 M dofs and up: nt 2-8 % faster).
+  int var = ctx->spmv_variant;
+  if (ctx->spmv_auto)
+    var = (var & ~1) | (12.0 * (double)ctx->nnz > 300.0e6 ? 1 : 0);
   if (var & 4) // diagnostic only (zzz_spmv_time): no gather
   {
     hipLaunchKernelGGL((spmv_tile_kernel<DOT, true, false, 2048, true>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,

@@ -516,3 +516,35 @@ def test_run_to_run_reproducibility(ctx):
                     ctx.vec_download(zzz.VEC_U)))
     for a, b in zip(res[0], res[1]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 8, 9])
+@pytest.mark.parametrize("tile", [2048, 4096])
+def test_spmv_kernel_variants_are_bit_exact(variant, tile):
+    """Every SpMV kernel variant (plain / non-temporal loads, pipelined tiles, 4096-nonzero tiles, the
+    sliced-ELL copy) adds a row's products in the same column order: bit-identical y, identical solve."""
+    old = {k: os.environ.get(k) for k in ("ZZZ_SPMV_VARIANT", "ZZZ_SPMV_TILE")}
+    os.environ["ZZZ_SPMV_VARIANT"], os.environ["ZZZ_SPMV_TILE"] = str(variant), str(tile)
+    try:
+        zo.set_num_threads(1)
+        for problem, order, dims in (("poisson", 1, (11, 9, 10)), ("elasticity", 2, (3, 3, 4)), ("poisson", 3, (3, 4, 3))):
+            P = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                rp, cl, v = c.csr_download()
+                rng = np.random.default_rng(variant)
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                oit, ou, _, _ = zo.pcg(rp.astype(np.int64), cl, v, c.vec_download(zzz.VEC_B), rtol=1e-8)
+                assert abs(it - oit) <= 2
+                assert np.linalg.norm(c.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
