@@ -385,7 +385,7 @@ static int pattern_build_host(zzz_ctx* ctx)
   for (int64_t r = 0; r < nb; ++r)
     nblk += bptr[r + 1];
   const int64_t nnz = nblk * bs * bs;
-  if (nnz > INT32_MAX - 8)
+  if (nnz > INT32_MAX - 16384)
     overflow = true;
   if (overflow)
     return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range", (long long)nnz);

@@ -13,6 +13,7 @@
 //     the path is bound by the 8 B/nonzero it must write, not by arithmetic).
 // Constrained rows and columns are zeroed as the element tensor is produced, and the diagonal of a
 // constrained row is set to 1.0 (fem::set_diagonal) by the thread that owns the row.
+#include <climits>
 #include <cstring>
 
 #include "zzz_device.h"
@@ -101,8 +102,10 @@ __device__ inline int find_pos(const int32_t* __restrict__ c, int len, int32_t c
 // Adjacency transposed in slices of 64 rows: entry a of row (64 s + lane) sits at off[s] + 64 a + lane
 // (cell index, -1 = padding) with the dof's local index in that cell beside it.  A wavefront owns a
 // slice, so "the a-th cell of my row" is one dense 256-B read instead of 64 reads 96 B apart.
-__global__ void k_adjT_slice_len(const int32_t* __restrict__ adj_off, int64_t nb, int64_t nslices, int32_t* __restrict__ slen)
+__global__ void k_adjT_slice_len(const int32_t* __restrict__ adj_off, int64_t nb, int64_t nslices, int32_t* __restrict__ slen,
+                                 unsigned long long* __restrict__ total)
 {
+  unsigned long long mine = 0;
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s <= nslices; s += (int64_t)gridDim.x * blockDim.x)
   {
     int m = 0;
@@ -110,7 +113,10 @@ __global__ void k_adjT_slice_len(const int32_t* __restrict__ adj_off, int64_t nb
       for (int64_t r = s * 64; r < min(nb, s * 64 + 64); ++r)
         m = max(m, adj_off[r + 1] - adj_off[r]);
     slen[s] = m * 64;
+    mine += (unsigned long long)m * 64ull;
   }
+  if (mine)
+    atomicAdd(total, mine); // 64-bit size check before the 32-bit scan (one atomic per thread that has slices)
 }
 
 __global__ __launch_bounds__(256) void k_adjT_fill(const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj_cells,
@@ -848,7 +854,15 @@ int build_adjT(zzz_ctx* ctx)
     int g0 = (int)((nsl + 256) / 256);
     if (g0 > 4096)
       g0 = 4096;
-    hipLaunchKernelGGL(k_adjT_slice_len, dim3(g0), dim3(256), 0, ctx->stream, ctx->adj_off.p, nrows, nsl, slen.p);
+    DevBuf<unsigned long long> tot64;
+    ZZZ_HIP(ctx, tot64.alloc(1));
+    ZZZ_HIP(ctx, hipMemsetAsync(tot64.p, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_adjT_slice_len, dim3(g0), dim3(256), 0, ctx->stream, ctx->adj_off.p, nrows, nsl, slen.p, tot64.p);
+    unsigned long long h64 = 0;
+    ZZZ_HIP(ctx, hipMemcpyAsync(&h64, tot64.p, sizeof(h64), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h64 > (unsigned long long)(INT32_MAX - 4096))
+      return fail(ctx, ZZZ_ERR_LIMIT, "transposed adjacency (%llu entries) exceeds int32: use more parts", h64);
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, slen.p, ctx->adjT_off.p, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(),
                                          ctx->stream));

@@ -302,8 +302,9 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   ZZZ_HIP(ctx, hipMemcpyAsync(&nblk, bptr.p + nb, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   const int64_t nnz = (int64_t)nblk * bs * bs;
-  if (nnz > INT32_MAX - 8 || nblk < 0)
-    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range", (long long)nnz);
+  // head-room of one SpMV/assembly tile: the kernels form indices up to (tile start + tile size)
+  if (nnz > INT32_MAX - 16384 || nblk < 0)
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range: use more parts", (long long)nnz);
   ctx->nrows = (int64_t)nb * bs;
   ctx->ncols = ctx->nloc();
   ctx->nnz = nnz;
