@@ -548,3 +548,30 @@ def test_spmv_kernel_variants_are_bit_exact(variant, tile):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line (last line of stdout) with the contract's keys, also when the RCCL
+    code path is attached (RCCL's init banner must not reach stdout)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(zzz.PKG)
+    for extra in ([], ["--no_cpu_baseline", "--force_comm"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ndofs", "40000", "--steps", "1",
+                              "--warmup", "0"] + extra, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        d = json.loads(lines[-1])
+        assert len([ln for ln in lines if ln.lstrip().startswith("{")]) == 1
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["unit"] == "DoF/s" and d["dtype"] == "f64" and d["n_gpus"] == 1 and d["vs_baseline"] is None
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        if not extra:
+            c = d["cpu_baseline"]
+            assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
