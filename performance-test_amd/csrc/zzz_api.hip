@@ -112,7 +112,7 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->spmv_tile = atoi(e) == 4096 ? 4096 : 2048;
   if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
   {
-    ctx->spmv_variant = atoi(e) & 15;
+    ctx->spmv_variant = atoi(e) & 11;
     ctx->spmv_auto = false;
   }
   ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
@@ -590,7 +590,7 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
   const bool saved_auto = ctx->spmv_auto;
   if (variant >= 0)
   {
-    ctx->spmv_variant = variant & 15; // bit 2: gather-free timing diagnostic (wrong results); bit 3: SELL
+    ctx->spmv_variant = variant & 11; // bit 0 nt, bit 1 pipelined tiles, bit 3 SELL
     ctx->spmv_auto = false;
   }
   hipEvent_t e0, e1;

@@ -51,7 +51,7 @@ __device__ inline T stream_load(const T* p)
 
 // One tile descriptor = {first row, end row, first nonzero, end nonzero}: one 16-B load per tile.
 // TILE = nonzeros per tile; PIPE = issue the next tile's matrix loads before reducing this one.
-template <bool DOT, bool NT, bool PIPE, int TILE, bool FAKE = false>
+template <bool DOT, bool NT, bool PIPE, int TILE>
 __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ cols,
                                                                const double* __restrict__ vals,
@@ -98,11 +98,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
     {
-      // FAKE: timing-only diagnostic (wrong results): a cached coalesced read instead of the gather
-      if (FAKE)
-        asm volatile("" ::"v"(c[j].x), "v"(c[j].y)); // keep the column stream alive
-      xa[j] = FAKE ? x[threadIdx.x & 1023] : x[c[j].x];
-      xb[j] = FAKE ? x[(threadIdx.x + 1) & 1023] : x[c[j].y];
+      xa[j] = x[c[j].x];
+      xb[j] = x[c[j].y];
     }
     // this thread's row bounds (used after the barrier): issue the loads now
     const int r = r0 + (int)threadIdx.x;
@@ -386,12 +383,6 @@ static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, d
   int var = ctx->spmv_variant;
   if (ctx->spmv_auto)
     var = (var & ~1) | (12.0 * (double)ctx->nnz > 300.0e6 ? 1 : 0);
-  if (var & 4) // diagnostic only (zzz_spmv_time): no gather
-  {
-    hipLaunchKernelGGL((spmv_tile_kernel<DOT, true, false, 2048, true>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,
-                       ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list);
-    return;
-  }
   if (ctx->spmv_tile == 4096)
   {
     switch (var & 3)
