@@ -62,6 +62,8 @@ def cpu_baseline(P, ctx, iters_gpu, sample_iters=60):
     of the same workload: full matrix + vector assembly, then `sample_iters` Jacobi-PCG iterations,
     extrapolated to the iteration count the GPU solve needed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.setdefault("OMP_PROC_BIND", "spread")  # before libgomp starts: spread threads over the sockets
+    os.environ.setdefault("OMP_PLACES", "cores")
     import zzz_oracle as zo
 
     rowptr32, cols, _ = ctx.csr_download(values=False)
@@ -77,10 +79,8 @@ def cpu_baseline(P, ctx, iters_gpu, sample_iters=60):
         if c > avail:
             continue
         zo.set_num_threads(c)
-        zo.pcg(rowptr, cols, ones, xs, rtol=1e-30, max_it=2)  # whole iterations (SpMV, dots, axpys), not SpMV alone
-        t = time.perf_counter()
-        zo.pcg(rowptr, cols, ones, xs, rtol=1e-30, max_it=4)
-        dt = time.perf_counter() - t
+        zo.pcg(rowptr, cols, ones, xs, rtol=1e-30, max_it=6)  # whole iterations (SpMV, dots, axpys), not SpMV alone
+        dt = zo.last_pcg_loop_seconds
         if best[0] is None or dt < best[0]:
             best = (dt, c)
     cores = best[1]
@@ -92,16 +92,12 @@ def cpu_baseline(P, ctx, iters_gpu, sample_iters=60):
     b = zo.assemble_vector(P.form, P.order, P.x, P.cells, P.cell_dofs, P.f, P.g,
                            P.facets if P.form == 0 else None, bc)
     t2 = time.perf_counter()
-    zo.pcg(rowptr, cols, vals, b, rtol=1e-8, max_it=2)  # touch pages
-    t3 = time.perf_counter()
     zo.pcg(rowptr, cols, vals, b, rtol=1e-8, max_it=sample_iters)
-    t4 = time.perf_counter()
-    t_iter = (t4 - t3) / sample_iters
+    t_iter = zo.last_pcg_loop_seconds / sample_iters  # iteration loop alone; NUMA-aware working copies inside
     # "1 MPI rank" (BASELINE configs[0] is the reference's 1-rank case): Krylov iteration time on one thread
     zo.set_num_threads(1)
-    t5 = time.perf_counter()
     zo.pcg(rowptr, cols, vals, b, rtol=1e-8, max_it=4)
-    t_iter1 = (time.perf_counter() - t5) / 4
+    t_iter1 = zo.last_pcg_loop_seconds / 4
     zo.set_num_threads(cores)
     t_total = (t2 - t0) + t_iter * iters_gpu
     n = P.n_owned * P.bs

@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+last_pcg_loop_seconds = 0.0
 
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -245,8 +246,10 @@ def cg_matfree_poisson(order, x, cells, cell_dofs, bc, b, kmax=100, rtol=1e-6):
 def pcg(rowptr, cols, vals, b, pc=PC_JACOBI, norm_type=NORM_PRECONDITIONED, rtol=1e-8, atol=1e-50, max_it=10000):
     """PETSc KSPCG restatement; returns (iterations, x, final_norm, initial_norm)"""
     x = np.zeros_like(b)
-    rn = np.zeros(2)
+    rn = np.zeros(3)
     it = lib().zo_pcg(b.shape[0], rowptr, cols, vals, b, x, pc, norm_type, rtol, atol, max_it, rn)
+    global last_pcg_loop_seconds
+    last_pcg_loop_seconds = float(rn[2])  # the iteration loop alone (setup copies excluded)
     return int(it), x, float(rn[0]), float(rn[1])
 
 
