@@ -13,6 +13,7 @@
 #include <pthread.h>
 #include <unistd.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -41,6 +42,7 @@ struct Rccl
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr; // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -83,6 +85,7 @@ static const char* load_rccl_once()
   ZZZ_SYM(GroupEnd, "ncclGroupEnd")
   ZZZ_SYM(GetErrorString, "ncclGetErrorString")
 #undef ZZZ_SYM
+  *(void**)(&g_rccl.CommSplit) = dlsym(h, "ncclCommSplit"); // absent in old RCCL: then no halo overlap
   g_rccl.h = h;
   return nullptr;
 }
@@ -129,7 +132,9 @@ struct LocalGroup
 
 struct Comm
 {
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;      // all-reduces, on the context's main stream
+  ncclComm_t comm_halo = nullptr; // send/recv of the halo, on the comm stream: one communicator per
+                                  // stream, so no communicator is ever alternated between two streams
   LocalGroup* local = nullptr;
   int nranks = 1, rank = 0;
 };
@@ -187,8 +192,8 @@ int comm_halo_begin(zzz_ctx* ctx, double* vec)
 {
   if (!ctx->comm || (ctx->nneigh == 0 && !ctx->comm->local))
     return ZZZ_OK;
-  if (ctx->comm->local) // host-synchronous backend: nothing to overlap, same results
-    return halo_on_stream(ctx, vec, ctx->stream);
+  if (ctx->comm->local || !ctx->comm->comm_halo) // host-synchronous backend / no second communicator:
+    return halo_on_stream(ctx, vec, ctx->stream); // nothing to overlap, same results
   if (!ctx->comm_stream)
   {
     ZZZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
@@ -206,7 +211,7 @@ int comm_halo_begin(zzz_ctx* ctx, double* vec)
 
 int comm_halo_end(zzz_ctx* ctx)
 {
-  if (!ctx->comm || ctx->comm->local || ctx->nneigh == 0 || !ctx->comm_stream)
+  if (!ctx->comm || ctx->comm->local || !ctx->comm->comm_halo || ctx->nneigh == 0 || !ctx->comm_stream)
     return ZZZ_OK;
   ZZZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done, 0));
   return ZZZ_OK;
@@ -261,6 +266,7 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
     pthread_barrier_wait(&G->bar);
     return ZZZ_OK;
   }
+  ncclComm_t hc = (st != ctx->stream && ctx->comm->comm_halo) ? ctx->comm->comm_halo : ctx->comm->comm;
   ZZZ_NCCL(ctx, g_rccl.GroupStart());
   int64_t ghost = ctx->n_owned;
   for (int k = 0; k < ctx->nneigh; ++k)
@@ -268,9 +274,9 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
     const int64_t ns = ctx->send_off[k + 1] - ctx->send_off[k], nr = ctx->recv_cnt[k];
     const double* src = ctx->send_contig[k] >= 0 ? vec + ctx->send_contig[k] * bs : ctx->send_buf.p + ctx->send_off[k] * bs;
     if (ns > 0)
-      ZZZ_NCCL(ctx, g_rccl.Send(src, (size_t)(ns * bs), ncclFloat64, ctx->neigh_rank[k], ctx->comm->comm, st));
+      ZZZ_NCCL(ctx, g_rccl.Send(src, (size_t)(ns * bs), ncclFloat64, ctx->neigh_rank[k], hc, st));
     if (nr > 0)
-      ZZZ_NCCL(ctx, g_rccl.Recv(vec + ghost * bs, (size_t)(nr * bs), ncclFloat64, ctx->neigh_rank[k], ctx->comm->comm, st));
+      ZZZ_NCCL(ctx, g_rccl.Recv(vec + ghost * bs, (size_t)(nr * bs), ncclFloat64, ctx->neigh_rank[k], hc, st));
     ghost += nr;
   }
   ZZZ_NCCL(ctx, g_rccl.GroupEnd());
@@ -289,6 +295,8 @@ void comm_destroy(zzz_ctx* ctx)
   }
   if (ctx->comm)
   {
+    if (ctx->comm->comm_halo && !ctx->comm->local && g_rccl.CommDestroy)
+      (void)g_rccl.CommDestroy(ctx->comm->comm_halo);
     if (ctx->comm->comm && !ctx->comm->local && g_rccl.CommDestroy)
       (void)g_rccl.CommDestroy(ctx->comm->comm);
     delete ctx->comm;
@@ -335,6 +343,11 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
   {
     StdoutToStderr quiet;
     r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+    // second communicator over the same ranks for the halo stream (collective: every rank calls it);
+    // without it the halo stays on the main stream and is simply not overlapped
+    if (r == 0 && g_rccl.CommSplit && !getenv("ZZZ_NO_COMM_SPLIT"))
+      if (g_rccl.CommSplit(c->comm, 0, rank, &c->comm_halo, nullptr) != 0)
+        c->comm_halo = nullptr;
   }
   if (r != 0)
   {
