@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--force_comm", action="store_true",
                     help="N=1 only: attach a 1-rank RCCL communicator to time the multi-GPU code path's fixed costs")
+    ap.add_argument("--cg", default="auto", choices=["auto", "classical", "single_reduction"],
+                    help="KSPCG form: classical (PETSc default, two reductions per iteration) or "
+                         "-ksp_cg_single_reduction (one); auto = classical on one GPU, single_reduction on N > 1")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +187,7 @@ def main():
     ctx.pattern_build()  # once up front so that sizes are known; rebuilt inside every timed step
     nrows, ncols, nnz = ctx.csr_sizes()
     pc = zzz.PC_JACOBI if a.pc == "jacobi" else zzz.PC_NONE
+    single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and world > 1)
 
     def step(profile=False):
         t = {}
@@ -201,7 +205,8 @@ def main():
         ctx.sync()
         t["assemble_vector"] = time.perf_counter() - t1
         t2 = time.perf_counter()
-        it, rn, r0 = ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, profile=profile)
+        it, rn, r0 = ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, profile=profile,
+                                  single_reduction=single_reduction)
         ctx.sync()
         t["solve"] = time.perf_counter() - t2
         t["iters"] = it
@@ -233,7 +238,7 @@ def main():
 
     out = None
     if rank == 0:
-        alg_bytes = spmv_algorithmic_bytes(nrows, nnz)
+        alg_bytes = spmv_algorithmic_bytes(nrows, nnz) + (8 * nrows if single_reduction else 0)  # + read of r
         traffic, traffic_src = pmc_traffic(nrows, nnz)
         achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
@@ -246,7 +251,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": (f"--problem_type {a.problem_type} --order {a.order} --scaling_type {a.scaling_type} "
-                             f"--ndofs {a.ndofs} -ksp_type cg -pc_type {a.pc} -ksp_rtol {a.rtol:g}"),
+                             f"--ndofs {a.ndofs} -ksp_type cg -pc_type {a.pc} -ksp_rtol {a.rtol:g}"
+                             + (" -ksp_cg_single_reduction" if single_reduction else "")),
                 "mesh": f"{nx}x{ny}x{nz} sub-cubes x 6 tetrahedra", "dofs": ndofs_global,
                 "cells": ncells_global, "nnz_rank0": nnz, "rows_rank0": nrows,
                 "partition": f"{world} z-slab(s)", "krylov_iterations": iters,

@@ -103,6 +103,11 @@ typedef struct
   int32_t op;       /* ZZZ_OP_* */
   int32_t max_it;   /* -ksp_max_it (PETSc default 10000) / kmax */
   int32_t profile;  /* != 0: record HIP events around the SpMV launches (see zzz_profile_get) */
+  int32_t single_reduction; /* != 0: PETSc's -ksp_cg_single_reduction (KSPCGUseSingleReduction): the same CG
+                             * with the recurrences s = A z, w = s + b w, <p,w> by recurrence, so that one
+                             * iteration needs ONE fused reduction of (<r,z>, <z,s>, norm) instead of two.
+                             * ZZZ_CG_PETSC + ZZZ_OP_CSR only. */
+  int32_t reserved; /* keep 0 */
   double rtol;      /* -ksp_rtol / rtol */
   double atol;      /* -ksp_atol (PETSc default 1e-50); unused by ZZZ_CG_CGH */
 } zzz_solver_opts;

@@ -1350,6 +1350,89 @@ int zo_pcg(i64 n, const i64* rowptr_in, const i32* cols_in, const double* vals_i
   return it;
 }
 
+/* KSPCG with -ksp_cg_single_reduction (KSPCGUseSingleReduction; PETSc cg.c, the branches guarded by
+ * cg->singlereduction) [EXT, restated from the published algorithm]: the same iteration with
+ *   s = A z kept beside z,  w = s + b w (= A p by recurrence),  delta = (z,s),
+ *   (p,w) = delta - beta^2 (p,w)_old / betaold^2,
+ * so that beta, delta and the norm are reduced together once per iteration.  Same arguments and
+ * return values as zo_pcg.  In exact arithmetic the iterates equal zo_pcg's. */
+int zo_pcg_sr(i64 n, const i64* rowptr, const i32* cols, const double* vals, const double* b, double* x, int pc,
+              int norm_type, double rtol, double atol, int max_it, double* rnorm_out)
+{
+  double* r = malloc(sizeof(double) * (size_t)n);
+  double* z = malloc(sizeof(double) * (size_t)n);
+  double* s = malloc(sizeof(double) * (size_t)n);
+  double* p = calloc((size_t)n, sizeof(double));
+  double* w = calloc((size_t)n, sizeof(double));
+  double* dinv = malloc(sizeof(double) * (size_t)n);
+  for (i64 i = 0; i < n; ++i)
+  {
+    double d = 1.0;
+    if (pc == 1)
+    {
+      i64 q = find_col(rowptr, cols, i, (i32)i);
+      d = q >= 0 ? vals[q] : 0.0;
+      if (d == 0.0)
+        d = 1.0;
+    }
+    dinv[i] = 1.0 / d;
+    x[i] = 0.0;
+    r[i] = b[i];
+    z[i] = dinv[i] * r[i];
+  }
+  zo_spmv(n, rowptr, cols, vals, z, s);
+  double delta = dot(n, z, s);
+  double beta = dot(n, r, z), betaold = 1.0, dpi = 0.0, dpiold;
+  double dp = norm_type == 0 ? sqrt(dot(n, z, z)) : norm_type == 1 ? sqrt(dot(n, r, r)) : sqrt(fabs(beta));
+  const double dp0 = dp;
+  const double ttol = fmax(rtol * dp0, atol);
+  int it = 0;
+  if (!(dp <= ttol))
+  {
+    while (it < max_it)
+    {
+      const double bb = it == 0 ? 0.0 : beta / betaold;
+      if (it == 0)
+      {
+        memcpy(p, z, sizeof(double) * (size_t)n);
+        memcpy(w, s, sizeof(double) * (size_t)n);
+      }
+      else
+      {
+        axpy(n, p, bb, p, z);
+        axpy(n, w, bb, w, s);
+      }
+      dpiold = dpi;
+      dpi = it == 0 ? delta : delta - beta * beta * dpiold / (betaold * betaold);
+      betaold = beta;
+      const double a = beta / dpi;
+      axpy(n, x, a, p, x);
+      axpy(n, r, -a, w, r);
+      for (i64 i = 0; i < n; ++i)
+        z[i] = dinv[i] * r[i];
+      zo_spmv(n, rowptr, cols, vals, z, s);
+      delta = dot(n, z, s);
+      beta = dot(n, r, z);
+      dp = norm_type == 0 ? sqrt(dot(n, z, z)) : norm_type == 1 ? sqrt(dot(n, r, r)) : sqrt(fabs(beta));
+      ++it;
+      if (dp <= ttol)
+        break;
+    }
+  }
+  if (rnorm_out)
+  {
+    rnorm_out[0] = dp;
+    rnorm_out[1] = dp0;
+  }
+  free(r);
+  free(z);
+  free(s);
+  free(p);
+  free(w);
+  free(dinv);
+  return it;
+}
+
 double zo_norm2(i64 n, const double* x) { return sqrt(dot(n, x, x)); } /* la::norm, src/main.cpp:229 */
 
 int zo_num_threads(void)

@@ -63,6 +63,7 @@ def lib():
                                             C.c_int, C.c_double]
         L.zo_pcg.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_double,
                              C.c_int, f64p]
+        L.zo_pcg_sr.argtypes = L.zo_pcg.argtypes
         L.zo_norm2.restype = C.c_double
         L.zo_norm2.argtypes = [C.c_int64, f64p]
         L.zo_set_num_threads.argtypes = [C.c_int]
@@ -250,6 +251,15 @@ def pcg(rowptr, cols, vals, b, pc=PC_JACOBI, norm_type=NORM_PRECONDITIONED, rtol
     it = lib().zo_pcg(b.shape[0], rowptr, cols, vals, b, x, pc, norm_type, rtol, atol, max_it, rn)
     global last_pcg_loop_seconds
     last_pcg_loop_seconds = float(rn[2])  # the iteration loop alone (setup copies excluded)
+    return int(it), x, float(rn[0]), float(rn[1])
+
+
+def pcg_single_reduction(rowptr, cols, vals, b, pc=PC_JACOBI, norm_type=NORM_PRECONDITIONED, rtol=1e-8, atol=1e-50,
+                         max_it=10000):
+    """KSPCG with -ksp_cg_single_reduction restated; returns (iterations, x, final_norm, initial_norm)"""
+    x = np.zeros_like(b)
+    rn = np.zeros(3)
+    it = lib().zo_pcg_sr(b.shape[0], rowptr, cols, vals, b, x, pc, norm_type, rtol, atol, max_it, rn)
     return int(it), x, float(rn[0]), float(rn[1])
 
 

@@ -58,7 +58,7 @@ int alloc_problem_vectors(zzz_ctx* ctx)
     ZZZ_HIP(ctx, v->alloc(nv));
     ZZZ_HIP(ctx, hipMemsetAsync(v->p, 0, nv * sizeof(double), ctx->stream));
   }
-  ZZZ_HIP(ctx, ctx->part_a.alloc(4096));
+  ZZZ_HIP(ctx, ctx->part_a.alloc(3 * 4096));
   ZZZ_HIP(ctx, ctx->part_b.alloc(4096));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
@@ -655,6 +655,8 @@ int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rno
     return fail(ctx, ZZZ_ERR_ARG, "Jacobi needs the assembled operator");
   if (o->norm < 0 || o->norm > 2)
     return fail(ctx, ZZZ_ERR_ARG, "unknown norm type %d", o->norm);
+  if (o->single_reduction && (o->variant != ZZZ_CG_PETSC || o->op != ZZZ_OP_CSR))
+    return fail(ctx, ZZZ_ERR_ARG, "-ksp_cg_single_reduction applies to KSPCG on the assembled operator only");
   if (o->max_it < 0 || o->max_it > (1 << 24))
     return fail(ctx, ZZZ_ERR_ARG, "max_it %d out of range", o->max_it);
   return cg_solve(ctx, o, iters, rnorm);

@@ -221,6 +221,77 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   }
 }
 
+// ---- PETSc's -ksp_cg_single_reduction (KSPCGUseSingleReduction; Chronopoulos/Gear form) ----------
+// One iteration = this kernel + one SpMV (s = A z with the partials of <z,s>, <r,z> and the norm):
+//   b = beta_k/beta_{k-1};  <p,w>_k = <z,s> - beta_k^2 <p,w>_{k-1} / beta_{k-1}^2;  a = beta_k / <p,w>_k
+//   p = z + b p;  w = s + b w  (= A p by recurrence);  x += a p;  r -= a w;  z = D^-1 r
+// so a whole iteration has ONE reduction point (after the SpMV) instead of two.
+// pa/pb/pc: partials (or the single all-reduced values) of <r,z>, the test norm^2 and <z,s>.
+__global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, double* __restrict__ beta_hist,
+                                                  double* __restrict__ dpi_hist, double* __restrict__ dp_hist, int it,
+                                                  CgParams P, const double* __restrict__ pa, const double* __restrict__ pb,
+                                                  const double* __restrict__ pc, int np, const double* __restrict__ dinv,
+                                                  const double* __restrict__ s, double* __restrict__ z, double* __restrict__ p,
+                                                  double* __restrict__ w, double* __restrict__ x, double* __restrict__ r,
+                                                  int64_t n, int scalars_only)
+{
+  if (block_converged(st))
+    return;
+  __shared__ double sh[VB / 64];
+  const double rz = reduce_parts_bcast(pa, np, sh);
+  const double nn = reduce_parts_bcast(pb, np, sh);
+  const double zs = reduce_parts_bcast(pc, np, sh);
+  const double dp = (P.norm == ZZZ_NORM_NATURAL) ? sqrt(fabs(rz)) : sqrt(nn);
+  double ttol = st->ttol;
+  if (it == 0)
+    ttol = fmax(P.rtol * dp, P.atol);
+  int conv = 0;
+  if (!isfinite(dp))
+    conv = 2;
+  else if (dp <= ttol) // KSPConvergedDefault
+    conv = 1;
+  double b = 0.0, dpi = zs;
+  if (it > 0)
+  {
+    const double bo = beta_hist[it - 1];
+    b = rz / bo;
+    dpi = zs - rz * rz * dpi_hist[it - 1] / (bo * bo);
+  }
+  const double a = rz / dpi;
+  if (!conv && !scalars_only && !isfinite(a))
+    conv = 2;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    beta_hist[it] = rz;
+    dpi_hist[it] = dpi;
+    dp_hist[it] = dp;
+    st->dp = dp;
+    if (it == 0)
+    {
+      st->dp0 = dp;
+      st->ttol = ttol;
+    }
+    if (conv)
+    {
+      st->iters = it;
+      st->converged = conv;
+    }
+  }
+  if (conv || scalars_only)
+    return;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    const double pn = (it == 0) ? z[i] : b * p[i] + z[i];
+    const double wn = (it == 0) ? s[i] : b * w[i] + s[i];
+    p[i] = pn;
+    w[i] = wn;
+    x[i] = a * pn + x[i];
+    const double ri = -a * wn + r[i];
+    r[i] = ri;
+    z[i] = dinv[i] * ri;
+  }
+}
+
 __device__ inline double reduce_parts(const double* __restrict__ parts, int np, double* sh)
 {
   double s = 0;
@@ -231,18 +302,22 @@ __device__ inline double reduce_parts(const double* __restrict__ parts, int np, 
 
 // multi-rank: out[j] = sum of partial array j (one workgroup), then ncclAllReduce(out)
 __global__ __launch_bounds__(1024) void k_reduce_multi(const CgState* st, const double* __restrict__ pa,
-                                                       const double* __restrict__ pb, int np, double* out)
+                                                       const double* __restrict__ pb, int np, double* out,
+                                                       const double* __restrict__ pc = nullptr)
 {
   if (st->converged)
     return;
   __shared__ double sh[16];
   const double a = reduce_parts(pa, np, sh);
   const double b = pb ? reduce_parts(pb, np, sh) : 0.0;
+  const double c = pc ? reduce_parts(pc, np, sh) : 0.0;
   if (threadIdx.x == 0)
   {
     out[0] = a;
     if (pb)
       out[1] = b;
+    if (pc)
+      out[2] = c;
   }
 }
 
@@ -294,8 +369,12 @@ int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out)
   return ZZZ_OK;
 }
 
+static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);
+
 int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 {
+  if (o->single_reduction)
+    return cg_solve_single_reduction(ctx, o, iters, rnorm);
   const int64_t n = ctx->n_owned * ctx->bs; // owned scalar rows
   const int max_it = o->max_it;
   CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol};
@@ -463,6 +542,163 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   ctx->prof_spmv_ms = 0.0;
   ctx->prof_spmv_n = 0;
   const int used = nprof < its ? nprof : its; // launches past convergence return at once: not counted
+  for (int i = 0; i < used; ++i)
+  {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess)
+    {
+      ctx->prof_spmv_ms += ms;
+      ctx->prof_spmv_n++;
+    }
+  }
+  if (ctx->prof_spmv_n)
+    ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
+  if (fin.converged == 2)
+    return fail(ctx, ZZZ_ERR_DIVERGED, "CG broke down: non-finite scalar at iteration %d", fin.iters);
+  return ZZZ_OK;
+}
+
+// -ksp_cg_single_reduction: see k_sr_update.  Two kernels and one reduction point per iteration.
+static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
+{
+  const int64_t n = ctx->n_owned * ctx->bs;
+  const int max_it = o->max_it;
+  CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol};
+  const bool multi = ctx->comm != nullptr;
+  const int g = vgrid(n);
+  hipStream_t s = ctx->stream;
+  const int nn_is_rr = o->norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
+
+  ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dpi_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->sr_s.alloc((size_t)ctx->nloc()));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->w.p, 0, sizeof(double) * ctx->w.n, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->z.p, 0, sizeof(double) * ctx->z.n, s)); // ghost entries of z are exchanged
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
+  hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n,
+                     o->pc == ZZZ_PC_JACOBI ? 1 : 0);
+  // r = b, z = D^-1 r (the partials of this kernel are not used: the SpMV below leaves all three)
+  hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(VB), 0, s, ctx->b.p, (const double*)nullptr, ctx->dinv.p, ctx->r.p,
+                     ctx->z.p, n, P.norm, ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
+
+  double* parts = ctx->part_a.p; // <z,s> | <r,z> | norm, SPMV_PSTRIDE apart
+  const double *zs_src = parts, *rz_src = parts + SPMV_PSTRIDE, *nn_src = parts + 2 * SPMV_PSTRIDE;
+  if (multi)
+  {
+    rz_src = ctx->red.p;
+    nn_src = ctx->red.p + 1;
+    zs_src = ctx->red.p + 2;
+  }
+  int np = 0;
+  // s = A z with the three partial dot products; then (multi) one all-reduce of three doubles
+  auto apply = [&]() -> int {
+    int rc;
+    if (multi && ctx->overlap && ctx->have_tile_split)
+      rc = launch_spmv_overlapped(ctx, ctx->z.p, ctx->sr_s.p, parts, &np, ctx->r.p, nn_is_rr);
+    else
+    {
+      if (multi)
+      {
+        rc = comm_halo_forward(ctx, ctx->z.p);
+        if (rc)
+          return rc;
+      }
+      rc = launch_spmv(ctx, ctx->z.p, ctx->sr_s.p, parts, &np, ctx->r.p, nn_is_rr);
+    }
+    if (rc)
+      return rc;
+    if (multi)
+    {
+      hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(1024), 0, s, ctx->state.p, parts + SPMV_PSTRIDE,
+                         parts + 2 * SPMV_PSTRIDE, np, ctx->red.p, parts);
+      rc = comm_allreduce_sum(ctx, ctx->red.p, 3);
+      if (rc)
+        return rc;
+      np = 1;
+    }
+    return ZZZ_OK;
+  };
+
+  const int max_prof = o->profile ? 512 : 0;
+  if ((int)ctx->ev.size() < 2 * max_prof)
+  {
+    size_t old = ctx->ev.size();
+    ctx->ev.resize(2 * max_prof);
+    for (size_t i = old; i < ctx->ev.size(); ++i)
+      ZZZ_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+  }
+  int nprof = 0;
+  {
+    int rc = apply();
+    if (rc)
+      return rc;
+  }
+  constexpr int CHECK = 8, NSLOT = 4;
+  hipEvent_t chk_ev[NSLOT];
+  for (int i = 0; i < NSLOT; ++i)
+    ZZZ_HIP(ctx, hipEventCreateWithFlags(&chk_ev[i], hipEventDisableTiming));
+  int nchk = 0;
+  bool stop = false;
+  int it = 0;
+  for (; it < max_it && !stop; ++it)
+  {
+    hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p,
+                       it, P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p,
+                       ctx->r.p, n, 0);
+    if (nprof < max_prof)
+      (void)hipEventRecord(ctx->ev[2 * nprof], s);
+    {
+      int rc = apply();
+      if (rc)
+        return rc;
+    }
+    if (nprof < max_prof)
+    {
+      (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
+      ++nprof;
+    }
+    if ((it + 1) % CHECK == 0)
+    {
+      const int slot = nchk % NSLOT;
+      if (nchk >= NSLOT - 1)
+      {
+        const int old = (nchk - (NSLOT - 1)) % NSLOT;
+        ZZZ_HIP(ctx, hipEventSynchronize(chk_ev[old]));
+        if (ctx->h_state[old].converged)
+          stop = true;
+      }
+      ZZZ_HIP(ctx, hipMemcpyAsync(&ctx->h_state[slot], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+      ZZZ_HIP(ctx, hipEventRecord(chk_ev[slot], s));
+      ++nchk;
+    }
+  }
+  // convergence test of the last completed iteration: scalars only
+  hipLaunchKernelGGL(k_sr_update, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p, it,
+                     P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p, ctx->r.p,
+                     n, 1);
+  ZZZ_HIP(ctx, hipGetLastError());
+  CgState fin;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  for (int i = 0; i < NSLOT; ++i)
+    (void)hipEventDestroy(chk_ev[i]);
+  const int its = fin.converged ? fin.iters : max_it;
+  ctx->last_iters = its;
+  if (iters)
+    *iters = its;
+  if (rnorm)
+  {
+    rnorm[0] = fin.dp;
+    rnorm[1] = fin.dp0;
+  }
+  ctx->history.resize((size_t)its + 1);
+  ZZZ_HIP(ctx, hipMemcpy(ctx->history.data(), ctx->dp_hist.p, sizeof(double) * ((size_t)its + 1), hipMemcpyDeviceToHost));
+  ctx->prof_spmv_ms = 0.0;
+  ctx->prof_spmv_n = 0;
+  const int used = nprof < its ? nprof : its;
   for (int i = 0; i < used; ++i)
   {
     float ms = 0;

@@ -53,6 +53,8 @@ struct DevBuf
 
 struct Comm; // zzz_comm.cpp
 
+constexpr int SPMV_PSTRIDE = 4096; // distance between the three partial arrays of the single-reduction SpMV
+
 // CG scalars kept on the device so the iteration loop never waits for the host.
 struct CgState
 {
@@ -141,7 +143,8 @@ struct zzz_ctx
   zzz::DevBuf<double> b, u, r, z, p, w, dinv;
   // reductions
   zzz::DevBuf<double> part_a, part_b, red; // block partials; reduced scalars
-  zzz::DevBuf<double> beta_hist, dp_hist;
+  zzz::DevBuf<double> beta_hist, dp_hist, dpi_hist;
+  zzz::DevBuf<double> sr_s; // single-reduction CG: s = A z
   zzz::DevBuf<zzz::CgState> state;
   zzz::CgState* h_state = nullptr; // pinned
   std::vector<double> history;
@@ -190,7 +193,8 @@ int build_adjT(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);
 // kernels_spmv
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
-int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec = nullptr,
+                int nn_is_rr = 0);
 int sell_update(zzz_ctx* ctx, bool structure);
 
 // kernels_assemble
@@ -208,6 +212,7 @@ int comm_halo_forward(zzz_ctx* ctx, double* vec);
 int comm_halo_begin(zzz_ctx* ctx, double* vec); // on the comm stream, after the work enqueued so far
 int comm_halo_end(zzz_ctx* ctx);                // main stream waits for the halo
 int build_tile_split(zzz_ctx* ctx);
-int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials);
+int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials,
+                           const double* rvec = nullptr, int nn_is_rr = 0);
 void comm_destroy(zzz_ctx* ctx);
 } // namespace zzz

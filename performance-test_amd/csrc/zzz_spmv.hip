@@ -59,8 +59,12 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
                                                                const int4* __restrict__ tiles, int64_t ntiles,
                                                                int nnz_even, double* __restrict__ partials,
                                                                const int* __restrict__ stop_flag,
-                                                               const int32_t* __restrict__ tile_list)
+                                                               const int32_t* __restrict__ tile_list,
+                                                               const double* __restrict__ rvec, int pstride,
+                                                               int nn_is_rr)
 {
+  // rvec != nullptr (single-reduction CG, x = z): besides <x,y> also leave the partials of <r,x> at
+  // partials[pstride + b] and of the test norm (<x,x>, or <r,r> when nn_is_rr) at partials[2 pstride + b]
   // tile_list != nullptr: this launch covers only the listed tiles (interior or boundary subset of a
   // partitioned matrix); ntiles is then the length of the list
   if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
   __shared__ __attribute__((aligned(16))) double prod[TILE + 16];
   __shared__ double red[SPMV_BLOCK / 64];
   constexpr int NPASS = TILE / (2 * SPMV_BLOCK);
-  double dot = 0.0;
+  double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
   dbl2 v[NPASS];
   int2v c[NPASS];
   int4 td = make_int4(0, 0, 0, 0);
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     const int rc = min(r, r1 - 1);
     const int ra = rowptr[rc] - s_al, rb = rowptr[rc + 1] - s_al;
     const double xr = DOT ? x[rc] : 0.0;
+    const double rv = (DOT && rvec) ? rvec[rc] : 0.0;
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
     {
@@ -147,7 +152,15 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
       }
       y[rr] = sum;
       if (DOT)
+      {
         dot += sum * xr_;
+        if (rvec)
+        {
+          const double rr_ = (rr == r) ? rv : rvec[rr];
+          dot_rx += rr_ * xr_;
+          dot_nn += nn_is_rr ? rr_ * rr_ : xr_ * xr_;
+        }
+      }
     }
     if (PIPE)
       lds_barrier();
@@ -165,6 +178,16 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     const double sres = block_reduce_sum(dot, red);
     if (threadIdx.x == 0)
       partials[blockIdx.x] = sres;
+    if (rvec)
+    {
+      const double s1 = block_reduce_sum(dot_rx, red);
+      const double s2 = block_reduce_sum(dot_nn, red);
+      if (threadIdx.x == 0)
+      {
+        partials[pstride + blockIdx.x] = s1;
+        partials[2 * pstride + blockIdx.x] = s2;
+      }
+    }
   }
 }
 
@@ -369,13 +392,15 @@ static int spmv_grid(const zzz_ctx* ctx)
 
 template <bool DOT>
 static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
-                           int nnz_even, const int32_t* tile_list = nullptr, int64_t nlist = 0)
+                           int nnz_even, const int32_t* tile_list = nullptr, int64_t nlist = 0, const double* rvec = nullptr,
+                           int nn_is_rr = 0)
 {
   const int4* tiles = reinterpret_cast<const int4*>(ctx->tile_row.p);
   const int64_t nt = tile_list ? nlist : ctx->ntiles;
 #define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
   hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
-                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list)
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list,    \
+                     rvec, SPMV_PSTRIDE, nn_is_rr)
   // bit 0: non-temporal matrix loads, bit 1: pipelined tiles.  Unless a variant was forced, the load
   // policy follows the matrix size: a matrix that fits the 256 MiB Infinity Cache is re-read from it
   // every CG iteration, and non-temporal loads would throw that away (measured, 1.25 M-dof P1 matrix,
@@ -406,12 +431,13 @@ static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, d
 #undef ZZZ_SPMV_GO
 }
 
-int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials)
+int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec,
+                int nn_is_rr)
 {
   const int grid = spmv_grid(ctx);
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1); // last valid clamped index (arrays are padded by 8)
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
-  if ((ctx->spmv_variant & 8) && ctx->have_sell && ctx->sell_current)
+  if ((ctx->spmv_variant & 8) && ctx->have_sell && ctx->sell_current && !rvec)
   {
     int64_t gs = 256 * 8;
     const int64_t need = ((ctx->nslices + 3) / 4 + 7) / 8 * 8;
@@ -434,7 +460,7 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
   {
     if ((size_t)grid > ctx->part_a.n)
       return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
-    launch_variant<true>(ctx, grid, x, y, partials, stop, nnz_even);
+    launch_variant<true>(ctx, grid, x, y, partials, stop, nnz_even, nullptr, 0, rvec, nn_is_rr);
     if (npartials)
       *npartials = grid;
   }
@@ -459,7 +485,8 @@ static int grid_for_tiles(int64_t nt)
 //   main stream : SpMV over the tiles that reference no ghost column            its kernels get CUs
 //   main stream : (waits for the halo) SpMV over the boundary tiles
 // Partials of <x,y>: interior workgroups first, then the boundary ones.
-int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials)
+int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,
+                           int nn_is_rr)
 {
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1);
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
@@ -473,7 +500,7 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
   if (n_in)
   {
     if (partials)
-      launch_variant<true>(ctx, g_in, x, y, partials, stop, nnz_even, ctx->tiles_interior.p, n_in);
+      launch_variant<true>(ctx, g_in, x, y, partials, stop, nnz_even, ctx->tiles_interior.p, n_in, rvec, nn_is_rr);
     else
       launch_variant<false>(ctx, g_in, x, y, nullptr, stop, nnz_even, ctx->tiles_interior.p, n_in);
   }
@@ -483,7 +510,7 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
   if (n_bd)
   {
     if (partials)
-      launch_variant<true>(ctx, g_bd, x, y, partials + g_in, stop, nnz_even, ctx->tiles_boundary.p, n_bd);
+      launch_variant<true>(ctx, g_bd, x, y, partials + g_in, stop, nnz_even, ctx->tiles_boundary.p, n_bd, rvec, nn_is_rr);
     else
       launch_variant<false>(ctx, g_bd, x, y, nullptr, stop, nnz_even, ctx->tiles_boundary.p, n_bd);
   }

@@ -117,7 +117,7 @@ struct Options
   std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50; // PETSc defaults
   int ksp_max_it = 10000;
-  bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false;
+  bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false, ksp_cg_single_reduction = false;
   std::vector<std::string> unused;
 };
 
@@ -139,6 +139,7 @@ void usage()
                "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
                "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
+               "  -ksp_cg_single_reduction\n"
                "  -log_view -options_left\n"
             << std::endl;
 }
@@ -212,6 +213,22 @@ Options parse(int argc, char** argv)
         o.ksp_view = true;
       else if (key == "ksp_monitor")
         o.ksp_monitor = true;
+      else if (key == "ksp_cg_single_reduction")
+      {
+        // PETSc bool option: bare flag, or followed by true/false/1/0
+        o.ksp_cg_single_reduction = true;
+        if (i + 1 < argc)
+        {
+          std::string v = argv[i + 1];
+          if (v == "true" || v == "1" || v == "yes")
+            ++i;
+          else if (v == "false" || v == "0" || v == "no")
+          {
+            o.ksp_cg_single_reduction = false;
+            ++i;
+          }
+        }
+      }
       else if (key == "log_view")
         o.log_view = true;
       else if (key == "options_left")
@@ -366,6 +383,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     so.max_it = o.ksp_max_it;
     so.rtol = o.ksp_rtol;
     so.atol = o.ksp_atol;
+    so.single_reduction = o.ksp_cg_single_reduction ? 1 : 0;
   }
   double solve_s = 0;
   {
@@ -501,7 +519,8 @@ void solve(int argc, char** argv)
   if (o.ksp_view)
     std::cout << "KSP Object: type: cg\n  maximum iterations=" << o.ksp_max_it << ", initial guess is zero\n  tolerances:  relative="
               << o.ksp_rtol << ", absolute=" << o.ksp_atol << "\n  using " << o.ksp_norm_type
-              << " norm type for convergence test\nPC Object: type: " << o.pc_type
+              << " norm type for convergence test\n"
+              << (o.ksp_cg_single_reduction ? "  using single-reduction variant\n" : "") << "PC Object: type: " << o.pc_type
               << "\n  linear system matrix: type=csr (fp64 values, int32 indices) on " << S.nranks << " MI355X\n";
   g_timers.list(); // dolfinx::list_timings, src/main.cpp:226
   // src/main.cpp:229-234

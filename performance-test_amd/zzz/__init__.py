@@ -45,7 +45,8 @@ HOST_SYMBOLS = [
 
 class SolverOpts(C.Structure):
     _fields_ = [("variant", C.c_int32), ("pc", C.c_int32), ("norm", C.c_int32), ("op", C.c_int32),
-                ("max_it", C.c_int32), ("profile", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double)]
+                ("max_it", C.c_int32), ("profile", C.c_int32), ("single_reduction", C.c_int32), ("reserved", C.c_int32),
+                ("rtol", C.c_double), ("atol", C.c_double)]
 
 
 class ZzzError(RuntimeError):
@@ -350,8 +351,8 @@ class Context:
         return y
 
     def cg_solve(self, variant=CG_PETSC, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, op=OP_CSR, rtol=1e-8, atol=1e-50,
-                 max_it=10000, profile=False):
-        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, rtol, atol)
+                 max_it=10000, profile=False, single_reduction=False):
+        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0, 0, rtol, atol)
         it = C.c_int()
         rn = (C.c_double * 2)()
         self._ck(self.L.zzz_cg_solve(self.h, C.byref(o), C.byref(it), rn))

@@ -419,6 +419,9 @@ def test_partitioned_solve_on_one_gpu(problem, order, dims, nparts):
         u0 = c0.vec_download(zzz.VEC_U)
         b0 = c0.vec_download(zzz.VEC_B)
         n0 = c0.vec_norm(zzz.VEC_U)
+        it0s, _, _ = c0.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=True)
+        u0s = c0.vec_download(zzz.VEC_U)
+        c0.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
         # matrix-free action of a fixed vector, for the Poisson cases
         rng = np.random.default_rng(5)
         xg = rng.standard_normal(G.n_owned * G.bs)
@@ -443,8 +446,11 @@ def test_partitioned_solve_on_one_gpu(problem, order, dims, nparts):
                 lo, hi = P.own_offset * P.bs, (P.own_offset + P.n_owned) * P.bs
                 y = c.spmv(xg[lo:hi])      # halo exchange + SpMV on a known global vector
                 it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
-                out[rank] = (it, rn, r0, P.own_offset, c.vec_download(zzz.VEC_U), c.vec_download(zzz.VEC_B),
-                             c.vec_norm(zzz.VEC_U), y)
+                res = (it, rn, r0, P.own_offset, c.vec_download(zzz.VEC_U), c.vec_download(zzz.VEC_B),
+                       c.vec_norm(zzz.VEC_U), y)
+                # -ksp_cg_single_reduction: one fused all-reduce per iteration
+                its, rns, r0s = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=True)
+                out[rank] = res + (its, rns, r0s, c.vec_download(zzz.VEC_U))
         except Exception as e:  # noqa: BLE001
             err.append((rank, repr(e)))
 
@@ -467,6 +473,12 @@ def test_partitioned_solve_on_one_gpu(problem, order, dims, nparts):
     assert np.abs(y - y0).max() <= 1e-13 * np.abs(y0).max()
     assert np.abs(b - b0).max() <= 1e-13 * np.abs(b0).max()
     assert np.linalg.norm(u - u0) <= 1e-9 * np.linalg.norm(u0)
+    its_s = {o[8] for o in out}
+    assert len(its_s) == 1 and abs(its_s.pop() - it0s) <= 1
+    us = np.concatenate([o[11] for o in out])
+    assert np.linalg.norm(us - u0s) <= 1e-9 * np.linalg.norm(u0s)
+    assert np.linalg.norm(us - u0) <= 1e-7 * np.linalg.norm(u0)
+    assert all(o[9] <= 1e-8 * o[10] for o in out)
     for o in out:
         assert abs(o[6] - n0) <= 1e-9 * n0  # la::norm is global on every rank
         assert o[1] == out[0][1] and o[2] == out[0][2]
@@ -575,3 +587,57 @@ def test_bench_contract_line():
         if not extra:
             c = d["cpu_baseline"]
             assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (12, 10, 14)), ("poisson", 2, (6, 5, 7)),
+                                                ("poisson", 3, (4, 3, 5)), ("elasticity", 1, (6, 6, 6)),
+                                                ("elasticity", 2, (3, 3, 4))])
+@pytest.mark.parametrize("norm", [zzz.NORM_PRECONDITIONED, zzz.NORM_UNPRECONDITIONED, zzz.NORM_NATURAL])
+def test_single_reduction_cg(ctx, problem, order, dims, norm):
+    """-ksp_cg_single_reduction (KSPCGUseSingleReduction) against its oracle restatement and against the
+    classical iteration: same iteration count (+-2), same solution, same norm history."""
+    P = zo.Problem(problem, order, *dims)
+    P.assemble()
+    G = zzz.Part(problem, order, *dims)
+    ctx.upload_part(G)
+    ctx.pattern_build()
+    ctx.assemble_matrix(G.form)
+    ctx.assemble_vector(G.form)
+    rowptr, cols, vals = ctx.csr_download()
+    b = ctx.vec_download(zzz.VEC_B)
+    ito, uo, rno, r0o = zo.pcg_single_reduction(rowptr.astype(np.int64), cols, vals, b, norm_type=norm, rtol=1e-9)
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, norm=norm, rtol=1e-9, single_reduction=True)
+    u = ctx.vec_download(zzz.VEC_U)
+    hist = ctx.cg_history(it + 1)
+    assert abs(it - ito) <= 2
+    assert abs(r0 - r0o) <= 1e-12 * r0o and rn <= 1e-9 * r0
+    assert hist.shape[0] == it + 1 and hist[0] == r0 and hist[-1] == rn
+    assert np.linalg.norm(u - uo) <= 1e-7 * np.linalg.norm(uo)
+    itc, rnc, r0c = ctx.cg_solve(pc=zzz.PC_JACOBI, norm=norm, rtol=1e-9)
+    uc = ctx.vec_download(zzz.VEC_U)
+    assert abs(it - itc) <= 2 and r0 == pytest.approx(r0c, rel=1e-13)
+    assert np.linalg.norm(u - uc) <= 1e-7 * np.linalg.norm(uc)
+    # true residual of the single-reduction solution
+    r = b - zo.spmv(rowptr.astype(np.int64), cols, vals, u)
+    if norm == zzz.NORM_UNPRECONDITIONED:
+        assert np.linalg.norm(r) <= 1.1e-9 * np.linalg.norm(b)
+    # the option is KSPCG/assembled-operator only
+    with pytest.raises(zzz.ZzzError):
+        ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_NONE, single_reduction=True)
+    with pytest.raises(zzz.ZzzError):
+        ctx.cg_solve(op=zzz.OP_MATFREE, pc=zzz.PC_NONE, single_reduction=True)
+
+
+def test_single_reduction_cg_breakdown_and_limits(ctx):
+    """max_it reached, zero right-hand side and immediate convergence behave as in the classical path"""
+    G = zzz.Part("poisson", 1, 6, 6, 6)
+    ctx.upload_part(G)
+    ctx.pattern_build()
+    ctx.assemble_matrix(G.form)
+    ctx.assemble_vector(G.form)
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-14, max_it=5, single_reduction=True)
+    itc, rnc, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-14, max_it=5)
+    assert it == 5 and itc == 5 and rn == pytest.approx(rnc, rel=1e-9)
+    ctx.vec_upload(zzz.VEC_B, np.zeros(G.n_owned))
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, single_reduction=True)
+    assert it == 0 and rn == 0.0 and np.all(ctx.vec_download(zzz.VEC_U) == 0.0)

@@ -206,3 +206,23 @@ def test_cg_h_semantics():
     # partly converged x needs further iterations for the same rtol and stays a solution
     k4, u4, _ = zo.cg(P.rowptr, P.cols, P.vals, P.b, x0=u3, kmax=1000, rtol=1e-8)
     assert 1 < k4 <= k and np.linalg.norm(u4 - u) < 1e-6 * np.linalg.norm(u)
+
+
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (8, 7, 9)), ("poisson", 2, (4, 4, 5)),
+                                                ("elasticity", 1, (5, 4, 6))])
+@pytest.mark.parametrize("norm", [zo.NORM_PRECONDITIONED, zo.NORM_UNPRECONDITIONED, zo.NORM_NATURAL])
+def test_single_reduction_pcg_equals_classical(problem, order, dims, norm):
+    """KSPCG with -ksp_cg_single_reduction is the same iteration in exact arithmetic: the restatement
+    must reproduce the classical iteration count and iterate to round-off."""
+    P = zo.Problem(problem, order, *dims)
+    P.assemble()
+    it0, u0, rn0, r00 = zo.pcg(P.rowptr, P.cols, P.vals, P.b, norm_type=norm, rtol=1e-10)
+    it1, u1, rn1, r01 = zo.pcg_single_reduction(P.rowptr, P.cols, P.vals, P.b, norm_type=norm, rtol=1e-10)
+    assert it0 == it1 and r00 == r01
+    assert np.linalg.norm(u1 - u0) <= 1e-11 * np.linalg.norm(u0)
+    assert abs(rn1 - rn0) <= 0.05 * rn0  # the recurrences drift apart by round-off (elasticity: 5e-3)
+    # max_it and trivial right-hand side
+    it2, _, _, _ = zo.pcg_single_reduction(P.rowptr, P.cols, P.vals, P.b, rtol=1e-30, max_it=3)
+    assert it2 == 3
+    it3, u3, rn3, _ = zo.pcg_single_reduction(P.rowptr, P.cols, P.vals, np.zeros_like(P.b))
+    assert it3 == 0 and rn3 == 0.0 and not u3.any()
