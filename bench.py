@@ -272,6 +272,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n},
         }
+        c16 = ctx.spmv_info()
+        out["config"]["spmv_column_stream"] = (f"16-bit band codes ({c16[1]} offset bits), {c16[2]} of {c16[3]} tiles on int32 columns"
+                                               if c16[0] else "int32")
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, ctx, iters)

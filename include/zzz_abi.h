@@ -231,6 +231,12 @@ int zzz_cg_history(zzz_ctx* ctx, int n, double* out);
  * zzz_cg_solve with opts.profile != 0. */
 int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);
 
+/* Storage the CG SpMV streams for the current matrix (no reference counterpart: MatMult on AIJ reads
+ * 12 B per nonzero, src/poisson_problem.cpp:168-177 [EXT]).  info[0] = 1 when the column stream is the
+ * 16-bit band code (10 B per nonzero), 0 for int32 columns; info[1] = offset bits of the code;
+ * info[2] = tiles left on int32 columns; info[3] = number of tiles. */
+int zzz_spmv_info(zzz_ctx* ctx, int64_t info[4]);
+
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */
 
 #define ZZZ_UNIQUE_ID_BYTES 128

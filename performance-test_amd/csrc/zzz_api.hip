@@ -112,10 +112,17 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->spmv_tile = atoi(e) == 4096 ? 4096 : 2048;
   if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
   {
-    ctx->spmv_variant = atoi(e) & 11;
+    ctx->spmv_variant = atoi(e) & 27;
     ctx->spmv_auto = false;
   }
   ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
+  if (const char* e = getenv("ZZZ_COLS16")) // 0: keep the SpMV on the int32 columns; 10..13: force the offset width
+  {
+    const int v = atoi(e);
+    ctx->cols16_enabled = v != 0;
+    if (v >= 10 && v <= 13)
+      ctx->cols16_offb_forced = v;
+  }
   if (const char* e = getenv("ZZZ_OVERLAP"))
     ctx->overlap = atoi(e) != 0;
   *out = ctx;
@@ -590,7 +597,7 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
   const bool saved_auto = ctx->spmv_auto;
   if (variant >= 0)
   {
-    ctx->spmv_variant = variant & 11; // bit 0 nt, bit 1 pipelined tiles, bit 3 SELL
+    ctx->spmv_variant = variant & 27; // bit 0 nt, bit 1 pipelined tiles, bit 3 SELL, bit 4 int32 columns
     ctx->spmv_auto = false;
   }
   hipEvent_t e0, e1;
@@ -668,6 +675,18 @@ int zzz_cg_history(zzz_ctx* ctx, int n, double* out)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_history: bad arguments");
   const size_t m = std::min((size_t)n, ctx->history.size());
   std::copy(ctx->history.begin(), ctx->history.begin() + (long)m, out);
+  return ZZZ_OK;
+}
+
+int zzz_spmv_info(zzz_ctx* ctx, int64_t info[4])
+{
+  ZZZ_ENTER(ctx);
+  if (!info || !ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_info: no pattern");
+  info[0] = ctx->have_cols16 ? 1 : 0;
+  info[1] = ctx->cols16_offb;
+  info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
+  info[3] = ctx->ntiles;
   return ZZZ_OK;
 }
 

@@ -117,6 +117,12 @@ struct zzz_ctx
   int max_row_nnz = 0;
   // SpMV tiling (row-aligned tiles of the nonzero stream)
   zzz::DevBuf<int32_t> tile_row;
+  zzz::DevBuf<uint16_t> cols16;   // 16-bit column codes for the SpMV (k_tile_encode_cols); cols stays the matrix of record
+  zzz::DevBuf<int32_t> tile_base; // band bases: 2^(16-cols16_offb) per tile
+  zzz::DevBuf<int32_t> scr_c16;   // fallback-tile counter
+  bool have_cols16 = false, cols16_enabled = true;
+  int cols16_offb = 12, cols16_offb_forced = 0;
+  int64_t cols16_fallback_tiles = 0;
   int64_t ntiles = 0;
   // tiles of a partitioned matrix split by "references a ghost column" (halo/compute overlap)
   zzz::DevBuf<int32_t> tiles_interior, tiles_boundary;

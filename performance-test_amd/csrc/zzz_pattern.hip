@@ -195,6 +195,93 @@ __global__ void k_spmv_tiles(const int32_t* __restrict__ rowptr, int nrows, int6
   }
 }
 
+// 16-bit column stream for the SpMV.  Per tile the columns are covered greedily by up to NB = 2^(16-offb)
+// bands of width 2^offb (band 0 starts at the smallest column, band k+1 at the smallest column beyond
+// band k); a column is stored as (band << offb) | (column - base[band]).  FE matrices with any locality in
+// their numbering need a handful of narrow bands per 2048-nonzero tile, so the column stream shrinks from
+// 4 to 2 bytes per nonzero (12 -> 10 B per nonzero of SpMV traffic).  A tile that does not fit keeps its
+// int32 columns: its descriptor gets .y = ~r1 and `nfallback` counts it.  One workgroup per tile.
+template <int TILE>
+__global__ __launch_bounds__(256) void k_tile_encode_cols(int4* __restrict__ tiles, int64_t ntiles,
+                                                          const int32_t* __restrict__ cols, int offb,
+                                                          uint16_t* __restrict__ cols16, int32_t* __restrict__ tile_base,
+                                                          int32_t* __restrict__ nfallback)
+{
+  constexpr int PER = TILE / 256;
+  const int NB = 1 << (16 - offb), W = 1 << offb;
+  __shared__ int sbase[64];
+  __shared__ int red[4];
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+  {
+    int4 d = tiles[t];
+    if (d.y < 0)
+      d.y = ~d.y; // re-encoding with another width
+    int c[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+    {
+      const int k = d.z + (int)threadIdx.x + j * 256;
+      c[j] = k < d.w ? cols[k] : INT32_MAX;
+    }
+    int thr = 0, nb = 0;
+    bool more = true;
+    while (more && nb < NB)
+    {
+      int m = INT32_MAX;
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        m = min(m, c[j] >= thr ? c[j] : INT32_MAX);
+      for (int o = 32; o; o >>= 1)
+        m = min(m, __shfl_xor(m, o));
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = m;
+      __syncthreads();
+      m = min(min(red[0], red[1]), min(red[2], red[3]));
+      if (m == INT32_MAX)
+        more = false;
+      else
+      {
+        if (threadIdx.x == 0)
+          sbase[nb] = m;
+        ++nb;
+        thr = (m > INT32_MAX - W) ? INT32_MAX : m + W;
+      }
+    }
+    // anything left beyond the last band?
+    int left = 0;
+    if (more)
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        left |= (c[j] != INT32_MAX && c[j] >= thr) ? 1 : 0;
+    const int fb = __syncthreads_or(left);
+    if (threadIdx.x < NB)
+      tile_base[t * NB + threadIdx.x] = fb ? 0 : sbase[min((int)threadIdx.x, max(nb - 1, 0))] * (nb > 0 ? 1 : 0);
+    if (threadIdx.x == 0)
+    {
+      tiles[t] = make_int4(d.x, fb ? ~d.y : d.y, d.z, d.w);
+      if (fb)
+        atomicAdd(nfallback, 1);
+    }
+    if (!fb)
+    {
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+      {
+        const int k = d.z + (int)threadIdx.x + j * 256;
+        if (k < d.w)
+        {
+          int b = 0;
+          while (b + 1 < nb && sbase[b + 1] <= c[j])
+            ++b;
+          cols16[k] = (uint16_t)((b << offb) | (c[j] - sbase[b]));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // assembly tiles: boundaries in block dofs; tile t = block dofs whose first nonzero lies in window t
 __global__ void k_asm_tiles(const int32_t* __restrict__ rowptr, int nb, int bs, int64_t W, int64_t ntiles,
                             int32_t* __restrict__ tiles)
@@ -211,6 +298,70 @@ static int grid_for(int64_t n, int block = 256, int cap = 4096)
   if (g < 1)
     g = 1;
   return (int)g;
+}
+
+// packed column stream of the SpMV tiles; the offset width is the first of four candidates (10..13 bits)
+// that leaves no tile on int32 columns, else the one that leaves the fewest
+static int encode_cols16(zzz_ctx* ctx)
+{
+  ctx->have_cols16 = false;
+  ctx->cols16_fallback_tiles = 0;
+  if (!ctx->cols16_enabled || ctx->ntiles == 0)
+    return ZZZ_OK;
+  hipStream_t s = ctx->stream;
+  ZZZ_HIP(ctx, ctx->cols16.alloc((size_t)ctx->nnz + 16));
+  ZZZ_HIP(ctx, ctx->tile_base.alloc((size_t)ctx->ntiles * 64));
+  ZZZ_HIP(ctx, ctx->scr_c16.alloc(4));
+  // the padding is read by the clamped tail loads of the last tile
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->cols16.p + ctx->nnz, 0, 16 * sizeof(uint16_t), s));
+  // long rows (high order, vector-valued) spread a tile over more, narrower clusters: start narrower
+  const bool long_rows = ctx->max_row_nnz > 64;
+  const int order[4] = {long_rows ? 11 : 12, long_rows ? 12 : 11, long_rows ? 10 : 13, long_rows ? 13 : 10};
+  const int ntry = ctx->cols16_offb_forced ? 1 : 4;
+  int best = -1;
+  int32_t best_fb = INT32_MAX;
+  auto run = [&](int offb, int32_t* nfb) -> int {
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->scr_c16.p, 0, sizeof(int32_t), s));
+    const int g = grid_for(ctx->ntiles, 1, 256 * 8);
+    if (ctx->spmv_tile == 4096)
+      hipLaunchKernelGGL(k_tile_encode_cols<4096>, dim3(g), dim3(256), 0, s, reinterpret_cast<int4*>(ctx->tile_row.p),
+                         ctx->ntiles, ctx->cols.p, offb, ctx->cols16.p, ctx->tile_base.p, ctx->scr_c16.p);
+    else
+      hipLaunchKernelGGL(k_tile_encode_cols<2048>, dim3(g), dim3(256), 0, s, reinterpret_cast<int4*>(ctx->tile_row.p),
+                         ctx->ntiles, ctx->cols.p, offb, ctx->cols16.p, ctx->tile_base.p, ctx->scr_c16.p);
+    ZZZ_HIP(ctx, hipGetLastError());
+    ZZZ_HIP(ctx, hipMemcpyAsync(nfb, ctx->scr_c16.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    return ZZZ_OK;
+  };
+  int last = -1;
+  for (int i = 0; i < ntry; ++i)
+  {
+    const int offb = ctx->cols16_offb_forced ? ctx->cols16_offb_forced : order[i];
+    int32_t nfb = 0;
+    int rc = run(offb, &nfb);
+    if (rc)
+      return rc;
+    last = offb;
+    if (nfb < best_fb)
+    {
+      best_fb = nfb;
+      best = offb;
+    }
+    if (nfb == 0)
+      break;
+  }
+  if (best != last)
+  {
+    int32_t nfb = 0;
+    int rc = run(best, &nfb);
+    if (rc)
+      return rc;
+  }
+  ctx->cols16_offb = best;
+  ctx->cols16_fallback_tiles = best_fb;
+  ctx->have_cols16 = true;
+  return ZZZ_OK;
 }
 
 // tile descriptors from a device rowptr (used by both the device and the host pattern builders)
@@ -234,7 +385,10 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   hipLaunchKernelGGL(k_asm_tiles, dim3(grid_for(ctx->n_asm_tiles + 1)), dim3(256), 0, s, ctx->rowptr.p,
                      (int)ctx->n_owned, bs, Wa, ctx->n_asm_tiles, ctx->asm_tile.p);
   ZZZ_HIP(ctx, hipGetLastError());
-  return build_tile_split(ctx);
+  int rc = build_tile_split(ctx);
+  if (rc)
+    return rc;
+  return encode_cols16(ctx);
 }
 
 // returns ZZZ_OK, or ZZZ_ERR_LIMIT with *fallback = true when a row has more candidates than the

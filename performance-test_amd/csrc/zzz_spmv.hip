@@ -61,8 +61,14 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
                                                                const int* __restrict__ stop_flag,
                                                                const int32_t* __restrict__ tile_list,
                                                                const double* __restrict__ rvec, int pstride,
-                                                               int nn_is_rr)
+                                                               int nn_is_rr, const uint16_t* __restrict__ cols16,
+                                                               const int32_t* __restrict__ tile_base, int offb,
+                                                               int col_max)
 {
+  // cols16 != nullptr: 16-bit column codes (zzz_pattern.hip, k_tile_encode_cols): column = band base
+  // of the tile [code >> offb] + (code & mask); the 2^(16-offb) band bases of a tile sit one per lane
+  // in a register and are looked up with ds_bpermute.  Tiles whose columns do not fit (descriptor
+  // .y < 0, holding ~r1) read the int32 columns.  Same columns, same arithmetic: results identical.
   // rvec != nullptr (single-reduction CG, x = z): besides <x,y> also leave the partials of <r,x> at
   // partials[pstride + b] and of the test norm (<x,x>, or <r,r> when nn_is_rr) at partials[2 pstride + b]
   // tile_list != nullptr: this launch covers only the listed tiles (interior or boundary subset of a
@@ -76,29 +82,49 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
   dbl2 v[NPASS];
   int2v c[NPASS];
   int4 td = make_int4(0, 0, 0, 0);
+  int bands = 0;
+  const int nbands = 1 << (16 - offb);
   int64_t t = xcd_tile(ntiles, blockIdx.x, gridDim.x, 0);
   // every matrix load is unconditional (indices clamped into the padded arrays), so all 2*NPASS
   // loads of a tile are in flight together, ahead of the 2*NPASS gathers that depend on them
-  auto issue = [&](const int4 d) {
+  auto issue = [&](const int4 d, const int64_t tt) {
     const int s_al = d.z & ~1;
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
     {
       const int kc = min(s_al + 2 * (int)threadIdx.x + j * 2 * SPMV_BLOCK, nnz_even);
       v[j] = stream_load<NT>(reinterpret_cast<const dbl2*>(vals + kc));
-      c[j] = stream_load<NT>(reinterpret_cast<const int2v*>(cols + kc));
+      if (cols16 && d.y >= 0) // packed columns: 4 B per pair instead of 8
+        c[j].x = (int)stream_load<NT>(reinterpret_cast<const unsigned*>(cols16 + kc));
+      else
+        c[j] = stream_load<NT>(reinterpret_cast<const int2v*>(cols + kc));
     }
+    if (cols16 && d.y >= 0)
+      bands = tile_base[tt * nbands + (threadIdx.x & (nbands - 1))];
   };
   if (t >= 0)
   {
-    td = tiles[tile_list ? tile_list[t] : t];
-    issue(td);
+    const int64_t ti = tile_list ? tile_list[t] : t;
+    td = tiles[ti];
+    issue(td, ti);
   }
   for (int i = 0; t >= 0; ++i)
   {
-    const int r0 = td.x, r1 = td.y, s = td.z, e = td.w;
+    const int r0 = td.x, r1 = td.y < 0 ? ~td.y : td.y, s = td.z, e = td.w;
     const int s_al = s & ~1;
     double xa[NPASS], xb[NPASS];
+    if (cols16 && td.y >= 0)
+    {
+      const unsigned mask = (1u << offb) - 1u;
+#pragma unroll
+      for (int j = 0; j < NPASS; ++j)
+      {
+        const unsigned u = (unsigned)c[j].x, lo = u & 0xffffu, hi = u >> 16;
+        // window entries outside [s, e) carry another tile's codes: clamp, they are masked below
+        c[j].x = min(__builtin_amdgcn_ds_bpermute((int)((lo >> offb) << 2), bands) + (int)(lo & mask), col_max);
+        c[j].y = min(__builtin_amdgcn_ds_bpermute((int)((hi >> offb) << 2), bands) + (int)(hi & mask), col_max);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NPASS; ++j)
     {
@@ -126,8 +152,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     const int64_t tn = xcd_tile(ntiles, blockIdx.x, gridDim.x, i + 1);
     if (PIPE && tn >= 0)
     {
-      td = tiles[tile_list ? tile_list[tn] : tn];
-      issue(td);
+      const int64_t ti = tile_list ? tile_list[tn] : tn;
+      td = tiles[ti];
+      issue(td, ti);
     }
     if (PIPE)
       lds_barrier();
@@ -169,8 +196,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     t = tn;
     if (!PIPE && t >= 0)
     {
-      td = tiles[tile_list ? tile_list[t] : t];
-      issue(td);
+      const int64_t ti = tile_list ? tile_list[t] : t;
+      td = tiles[ti];
+      issue(td, ti);
     }
   }
   if (DOT)
@@ -397,10 +425,13 @@ static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, d
 {
   const int4* tiles = reinterpret_cast<const int4*>(ctx->tile_row.p);
   const int64_t nt = tile_list ? nlist : ctx->ntiles;
+  // bit 4 of the variant: ignore the packed columns (A/B and parity of the two index streams)
+  const uint16_t* c16 = (ctx->have_cols16 && !(ctx->spmv_variant & 16)) ? ctx->cols16.p : nullptr;
+  const int col_max = (int)(ctx->nloc() * ctx->bs) - 1;
 #define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
   hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
                      ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list,    \
-                     rvec, SPMV_PSTRIDE, nn_is_rr)
+                     rvec, SPMV_PSTRIDE, nn_is_rr, c16, ctx->tile_base.p, ctx->cols16_offb, col_max)
   // bit 0: non-temporal matrix loads, bit 1: pipelined tiles.  Unless a variant was forced, the load
   // policy follows the matrix size: a matrix that fits the 256 MiB Infinity Cache is re-read from it
   // every CG iteration, and non-temporal loads would throw that away (measured, 1.25 M-dof P1 matrix,

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_profile_get", "zzz_spmv_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_comm_init_local",
 ]
 HOST_SYMBOLS = [
@@ -112,6 +112,7 @@ def hip():
         L.zzz_cg_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.zzz_spmv_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.zzz_comm_unique_id.argtypes = [C.c_void_p]
         L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.zzz_local_group_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -362,6 +363,12 @@ class Context:
         out = np.zeros(n)
         self._ck(self.L.zzz_cg_history(self.h, n, out))
         return out
+
+    def spmv_info(self):
+        """(packed 16-bit columns in use, offset bits, tiles on int32 columns, tiles)"""
+        info = (C.c_int64 * 4)()
+        self._ck(self.L.zzz_spmv_info(self.h, info))
+        return tuple(int(v) for v in info)
 
     def profile(self):
         ms, n = C.c_double(), C.c_int64()

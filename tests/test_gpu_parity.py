@@ -530,11 +530,12 @@ def test_run_to_run_reproducibility(ctx):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 8, 9, 16, 17, 19])
 @pytest.mark.parametrize("tile", [2048, 4096])
 def test_spmv_kernel_variants_are_bit_exact(variant, tile):
     """Every SpMV kernel variant (plain / non-temporal loads, pipelined tiles, 4096-nonzero tiles, the
-    sliced-ELL copy) adds a row's products in the same column order: bit-identical y, identical solve."""
+    sliced-ELL copy, int32 instead of packed 16-bit columns) adds a row's products in the same column
+    order: bit-identical y, identical solve."""
     old = {k: os.environ.get(k) for k in ("ZZZ_SPMV_VARIANT", "ZZZ_SPMV_TILE")}
     os.environ["ZZZ_SPMV_VARIANT"], os.environ["ZZZ_SPMV_TILE"] = str(variant), str(tile)
     try:
@@ -641,3 +642,74 @@ def test_single_reduction_cg_breakdown_and_limits(ctx):
     ctx.vec_upload(zzz.VEC_B, np.zeros(G.n_owned))
     it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, single_reduction=True)
     assert it == 0 and rn == 0.0 and np.all(ctx.vec_download(zzz.VEC_U) == 0.0)
+
+
+@pytest.mark.parametrize("cols16", ["0", "10", "11", "12", "13", "auto"])
+def test_packed_column_stream(cols16):
+    """The SpMV's 16-bit band-coded column stream is lossless: for every code width, with and without
+    tiles that fall back to int32 columns, y = A x is bit-identical to the oracle's CSR loop.
+    Cases: the structured feed (a few narrow bands per tile: everything packs), high-order and
+    vector-valued rows, a partition-style far band, and a RANDOM dof numbering (columns of a tile
+    scattered over > 65536 dofs: tiles must fall back, not mis-decode)."""
+    old = os.environ.get("ZZZ_COLS16")
+    if cols16 == "auto":
+        os.environ.pop("ZZZ_COLS16", None)
+    else:
+        os.environ["ZZZ_COLS16"] = cols16
+    try:
+        zo.set_num_threads(4)
+        rng = np.random.default_rng(3)
+        with zzz.Context(0) as c:
+            for problem, order, dims in (("poisson", 1, (30, 28, 26)), ("poisson", 3, (7, 6, 8)),
+                                         ("elasticity", 2, (5, 6, 5))):
+                P = zzz.Part(problem, order, *dims)
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                packed, offb, nfb, ntiles = c.spmv_info()
+                assert packed == (cols16 != "0") and 0 <= nfb <= ntiles
+                if cols16 == "auto":
+                    assert nfb == 0, "structured feed: every tile must pack"
+                elif cols16 != "0":
+                    assert offb == int(cols16)
+                rp, cl, v = c.csr_download()
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+            # random global numbering of a 97 k-dof P1 problem
+            O = zo.Problem("poisson", 1, 45, 45, 45)
+            perm = rng.permutation(O.n).astype(np.int32)
+            cell_dofs = np.ascontiguousarray(perm[O.cell_dofs])
+            bc = np.zeros_like(O.bc)
+            bc[perm] = O.bc
+            f, g = np.zeros_like(O.f), np.zeros_like(O.g)
+            f[perm], g[perm] = O.f, O.g
+            c.upload_mesh(O.x, O.cells)
+            c.upload_dofmap(1, 1, cell_dofs, O.nblock, 0)
+            c.upload_bc(np.nonzero(bc)[0].astype(np.int32))
+            c.upload_facets(O.facets)
+            c.upload_coeff(zzz.COEFF_F, f)
+            c.upload_coeff(zzz.COEFF_G, g)
+            c.pattern_build()
+            c.assemble_matrix(zzz.FORM_POISSON)
+            c.assemble_vector(zzz.FORM_POISSON)
+            packed, offb, nfb, ntiles = c.spmv_info()
+            if cols16 != "0":
+                assert packed and nfb > ntiles // 2, (nfb, ntiles)
+            rp, cl, v = c.csr_download()
+            orp, ocl = zo.pattern(O.nblock, cell_dofs, 1)
+            np.testing.assert_array_equal(rp, orp)
+            np.testing.assert_array_equal(cl, ocl)
+            xv = rng.standard_normal(O.n)
+            np.testing.assert_array_equal(c.spmv(xv), zo.spmv(orp, ocl, v, xv))
+            it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+            u = c.vec_download(zzz.VEC_U)
+            # same problem in the natural numbering: same solution, permuted
+            O.assemble()
+            oit, ou, _, _ = zo.pcg(O.rowptr, O.cols, O.vals, O.b, rtol=1e-8)
+            assert abs(it - oit) <= 2
+            assert np.linalg.norm(u[perm] - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_COLS16", None)
+        else:
+            os.environ["ZZZ_COLS16"] = old
