@@ -5,18 +5,19 @@
 //   k_update_p : sums the partials of <r,z> and of the test norm left by the previous kernel (every
 //                workgroup redundantly, in the same fixed order => identical scalars), does the
 //                convergence test (squared_norm + test, src/cg.h:74-79), then
-//                p = z + (beta_k / beta_{k-1}) p                        (axpy, src/cg.h:82)
+//                x += alpha_{k-1} p  (the previous iteration's axpy, src/cg.h:68, applied here because p
+//                is read anyway) and p = z + (beta_k / beta_{k-1}) p    (axpy, src/cg.h:82)
 //   [halo]     : ghost values of p from their owners                   (scatter_fwd)
 //   spmv       : w = A p, per-workgroup partials of <p, w>             (action, src/cg.h:62)
 //   k_update_xr: sums the <p,w> partials -> alpha = beta_k / <p,w>     (inner_product, src/cg.h:65);
-//                x += alpha p; r -= alpha w; z = D^-1 r; partials of <r,z> and the test norm
-//                                                                      (axpy x2, src/cg.h:68,71)
+//                r -= alpha w; z = D^-1 r; partials of <r,z> and the test norm
+//                                                                      (axpy, src/cg.h:71)
 // With a communicator attached a one-workgroup reduce + ncclAllReduce sits between producer and
 // consumer, and the consumer reads the single all-reduced value instead of the partials.
 // Every kernel returns at once when the device-side `converged` flag is set; the host polls that
 // flag a few iterations behind the queue, so the returned iteration count is exact.
 // Reductions use fixed trees => reproducible runs.
-// HBM traffic per iteration beyond the SpMV: 24 B/row (p update) + 56 B/row (x, r, z update).
+// HBM traffic per iteration beyond the SpMV: 40 B/row (x and p update) + 40 B/row (r, z update).
 #include "zzz_device.h"
 #include "zzz_internal.h"
 
@@ -118,13 +119,28 @@ __device__ inline double reduce_parts_bcast(const double* __restrict__ parts, in
 }
 
 // `it` = number of completed iterations.  pa/pb: partials of <r,z> and of the test norm (np each).
+// The solution update of the PREVIOUS iteration, x += alpha_{it-1} p_{it-1}, is applied here (p is read
+// anyway) instead of in k_update_xr: one vector read less per iteration, same operations on the same
+// operands, so x is bit-identical.  It must be applied by the launch that detects convergence too; only
+// launches enqueued after that one skip it (conv_it1).  update_dir == 0: the final test after max_it.
 __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, double* __restrict__ beta_hist,
-                                                 double* __restrict__ dp_hist, int it, CgParams P,
-                                                 const double* __restrict__ pa, const double* __restrict__ pb, int np,
-                                                 const double* __restrict__ z, double* __restrict__ p, int64_t n)
+                                                 double* __restrict__ dp_hist, const double* __restrict__ alpha_hist,
+                                                 int it, CgParams P, const double* __restrict__ pa,
+                                                 const double* __restrict__ pb, int np, const double* __restrict__ z,
+                                                 double* __restrict__ p, double* __restrict__ x, int64_t n,
+                                                 int update_dir)
 {
-  if (block_converged(st))
-    return;
+  {
+    __shared__ int flag;
+    if (threadIdx.x == 0)
+    {
+      const int c = __atomic_load_n(&st->conv_it1, __ATOMIC_RELAXED);
+      flag = c != 0 && c - 1 < it;
+    }
+    __syncthreads();
+    if (flag)
+      return;
+  }
   __shared__ double sh[VB / 64];
   const double rz = reduce_parts_bcast(pa, np, sh);
   const double nn = reduce_parts_bcast(pb, np, sh);
@@ -171,19 +187,32 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
     {
       st->iters = it;
       st->converged = conv; // the other workgroups reach the same verdict from the same partials
+      __atomic_store_n(&st->conv_it1, it + 1, __ATOMIC_RELAXED);
     }
   }
-  if (conv || p == nullptr)
+  const bool dir = !conv && update_dir;
+  if (it == 0)
+  {
+    if (dir)
+      for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+        p[i] = z[i];
     return;
-  const double bcoef = (it == 0) ? 0.0 : rz / bprev;
+  }
+  const double alpha = alpha_hist[it - 1];
+  const double bcoef = rz / bprev;
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
-    p[i] = (it == 0) ? z[i] : bcoef * p[i] + z[i];
+  {
+    const double pi = p[i];
+    x[i] = alpha * pi + x[i]; // src/cg.h:68, one kernel late
+    if (dir)
+      p[i] = bcoef * pi + z[i];
+  }
 }
 
-__global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, const double* __restrict__ beta_hist, int it,
+__global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, const double* __restrict__ beta_hist,
+                                                  double* __restrict__ alpha_hist, int it,
                                                   const double* __restrict__ pw_parts, int npw,
-                                                  const double* __restrict__ p, const double* __restrict__ w,
-                                                  const double* __restrict__ dinv, double* __restrict__ x,
+                                                  const double* __restrict__ w, const double* __restrict__ dinv,
                                                   double* __restrict__ r, double* __restrict__ z, int64_t n, int norm,
                                                   double* __restrict__ pa, double* __restrict__ pb)
 {
@@ -198,13 +227,15 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
     {
       st->iters = it;
       st->converged = 2;
+      __atomic_store_n(&st->conv_it1, it + 1, __ATOMIC_RELAXED);
     }
     return; // every workgroup sees the same non-finite alpha
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    alpha_hist[it] = alpha; // x += alpha p: applied by k_update_p(it + 1)
   double sa = 0, sb = 0;
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
   {
-    x[i] = alpha * p[i] + x[i];           // src/cg.h:68
     const double ri = -alpha * w[i] + r[i]; // src/cg.h:71
     const double zi = dinv[i] * ri;
     r[i] = ri;
@@ -384,6 +415,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 
   ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->alpha_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
 
@@ -471,8 +503,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   for (; it < max_it && !stop; ++it)
   {
     // convergence test of iteration `it` and the new search direction
-    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p, it, P, rz_src,
-                       nn_src, n_rz, ctx->z.p, ctx->p.p, n);
+    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
+                       ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
     int np = 0;
     if (nprof < max_prof)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
@@ -495,8 +527,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
         return rc;
       np = 1;
     }
-    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, it, pw_src, np, ctx->p.p,
-                       ctx->w.p, ctx->dinv.p, ctx->u.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
+    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->alpha_hist.p, it, pw_src,
+                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
     {
       int rc = allreduce_beta();
       if (rc)
@@ -517,9 +549,10 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       ++nchk;
     }
   }
-  // the test of the last completed iteration (it == max_it when the loop ran out): scalars only
-  hipLaunchKernelGGL(k_update_p, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p, it, P, rz_src,
-                     nn_src, n_rz, ctx->z.p, (double*)nullptr, n);
+  // the test of the last completed iteration (it == max_it when the loop ran out) and its pending
+  // solution update; no new direction
+  hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
+                     ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 0);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));

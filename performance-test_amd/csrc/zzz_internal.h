@@ -63,6 +63,9 @@ struct CgState
   double dp0;    // initial norm (variant PETSC) or <r0,r0> (variant CGH)
   double ttol;   // max(rtol*dp0, atol)
   double dp;     // last norm
+  int conv_it1;  // 0 running, else (iteration of the launch that set `converged`) + 1: one word, so a
+                 // workgroup can tell "stopped by an EARLIER launch" from "being stopped by this one"
+  int pad;
 };
 
 } // namespace zzz
@@ -116,6 +119,7 @@ struct zzz_ctx
   bool have_adj_li = false;
   int max_row_nnz = 0;
   // SpMV tiling (row-aligned tiles of the nonzero stream)
+  zzz::DevBuf<double> alpha_hist; // step lengths: x += alpha_k p_k is applied by the NEXT direction update
   zzz::DevBuf<int32_t> tile_row;
   zzz::DevBuf<uint16_t> cols16;   // 16-bit column codes for the SpMV (k_tile_encode_cols); cols stays the matrix of record
   zzz::DevBuf<int32_t> tile_base; // band bases: 2^(16-cols16_offb) per tile
