@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Post-processing of tools/profile_bench.sh.
+
+reduce <dir> <COUNTER>   per-kernel mean of a rocprofv3 --pmc counter (KiB) -> JSON on stdout (GPU box)
+merge <profile_dir> <tag>  write profiles/<tag>_*.{json,csv} from gpurun_out/profile_<tag>/ (here)
+
+HBM bytes follow MI355X_MICROARCH.md's rocprofv3 section: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950
+FETCH_SIZE under-reports coalesced streams by 2x (corrected here), calibrated on the CG vector kernels
+whose traffic is known exactly."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+KEYS = [("spmv", r"spmv_tile_kernel"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
+        ("k_sr_update", r"k_sr_update"), ("asm_matrix", r"asm_matrix"), ("asm_vector", r"asm_vector"),
+        ("k_row_pattern", r"k_row_pattern"), ("k_row_copy", r"k_row_copy"), ("k_tile_encode_cols", r"k_tile_encode_cols"),
+        ("k_adjT_fill", r"k_adjT_fill"), ("k_make_pairs", r"k_make_pairs"), ("radix_sort", r"radix_sort_onesweep_iteration"),
+        ("k_cube_cells", r"k_cube_cells"), ("k_extract_dinv", r"k_extract_dinv")]
+
+
+def reduce_counter(d, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"]
+                for key, pat in KEYS:
+                    if re.search(pat, name):
+                        dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                        if key == "spmv" and dur < 50000:  # launches past convergence return at once
+                            break
+                        a = acc.setdefault(key, [0.0, 0])
+                        a[0] += float(row["Counter_Value"])
+                        a[1] += 1
+                        break
+    return {k: {counter + "_KiB": v[0] / v[1], "dispatches": v[1]} for k, v in acc.items()}
+
+
+def merge(pdir, tag):
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = os.path.join(root, "profiles")
+    bench = json.loads(open(os.path.join(pdir, "bench_plain.json")).read().strip().splitlines()[-1])
+    json.dump(bench, open(os.path.join(out, f"{tag}_bench_default.json"), "w"), indent=1)
+    under = json.loads(open(os.path.join(pdir, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    json.dump(under, open(os.path.join(out, f"{tag}_bench_default_under_rocprof.json"), "w"), indent=1)
+    stats = glob.glob(os.path.join(pdir, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.reader(open(stats, newline="")))
+    with open(os.path.join(out, f"{tag}_bench_default_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        for r in rows:
+            r[0] = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", r[0])[:160]  # keep names readable
+            w.writerow(r)
+    fetch = json.load(open(os.path.join(pdir, "pmc_FETCH_SIZE.reduced.json")))
+    write = json.load(open(os.path.join(pdir, "pmc_WRITE_SIZE.reduced.json")))
+    kern = {}
+    for k in fetch:
+        e = dict(fetch[k])
+        e.update({"WRITE_SIZE_KiB": write.get(k, {}).get("WRITE_SIZE_KiB", 0.0)})
+        e["hbm_bytes_corrected"] = (2.0 * e["FETCH_SIZE_KiB"] + e["WRITE_SIZE_KiB"]) * 1024.0
+        kern[k] = e
+    cfg = bench["config"]
+    doc = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py "
+                      "--steps 1 --warmup 0 --no_cpu_baseline (one pass per counter; performance-test_amd/tools/profile_bench.sh)",
+           "correction": "gfx950: FETCH_SIZE x2 for coalesced streams (MI355X_MICROARCH.md, HBM); check: the CG vector kernels "
+                         "move 40 B/row each (k_update_p: x, p, z in, x, p out; k_update_xr: w, r, dinv in, r, z out). "
+                         "Scattered-access kernels (assembly, pattern) are uncalibrated: read their numbers as relative.",
+           "rows": cfg["rows_rank0"], "nnz": cfg["nnz_rank0"], "spmv_column_stream": cfg.get("spmv_column_stream"),
+           "kernels": kern}
+    n = cfg["rows_rank0"]
+    for k in ("k_update_p", "k_update_xr"):
+        if k in kern:
+            kern[k]["algorithmic_bytes"] = 40 * n
+            kern[k]["corrected_over_algorithmic"] = kern[k]["hbm_bytes_corrected"] / (40 * n)
+    if "spmv" in kern:
+        alg = 12 * cfg["nnz_rank0"] + 4 * (n + 1) + 16 * n
+        kern["spmv"]["algorithmic_bytes"] = alg
+        kern["spmv"]["corrected_over_algorithmic"] = kern["spmv"]["hbm_bytes_corrected"] / alg
+    json.dump(doc, open(os.path.join(out, f"{tag}_pmc_bench10m.json"), "w"), indent=1)
+    print(json.dumps({k: {"GB": round(v["hbm_bytes_corrected"] / 1e9, 3),
+                          "ratio": round(v.get("corrected_over_algorithmic", 0), 3)} for k, v in kern.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "reduce":
+        print(json.dumps(reduce_counter(sys.argv[2], sys.argv[3])))
+    else:
+        merge(sys.argv[2], sys.argv[3])
