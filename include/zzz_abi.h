@@ -256,6 +256,22 @@ int zzz_local_group_create(int nranks, void** group);
 void zzz_local_group_destroy(void* group);
 int zzz_comm_init_local(zzz_ctx* ctx, void* group, int rank);
 
+/* Optional: carry the CG's scalar all-reduces (MPI_Allreduce inside la::inner_product /
+ * la::squared_norm, src/cg.h:53,65,74) through peer memory over xGMI instead of ncclAllReduce: each
+ * rank exports a small device mailbox, every rank attaches all of them (hipIpcOpenMemHandle between
+ * processes, peer access between contexts of one process).  Call after zzz_comm_init /
+ * zzz_comm_init_local, on every rank: export, exchange the handles out of band in rank order (as the
+ * unique id), attach.  Attach runs test rounds and makes the ranks agree; *enabled = 0 means the
+ * communicator's own all-reduce stays in use (never an error).  The mailbox sums in rank order on
+ * every rank (bit-identical everywhere); RCCL sums in its own order: the same iteration to round-off. */
+#define ZZZ_P2P_HANDLE_BYTES 128
+/* A communicator with no transport of its own: only the peer-memory all-reduce below works on it (no
+ * halo).  For replicated runs and for exercising the mailbox transport between processes. */
+int zzz_comm_init_peer_only(zzz_ctx* ctx, int nranks, int rank);
+int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle /* ZZZ_P2P_HANDLE_BYTES */);
+int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles /* nranks x ZZZ_P2P_HANDLE_BYTES */, int* enabled);
+int zzz_comm_p2p_disable(zzz_ctx* ctx);
+
 /* The forward scatter of common::Scatterer / IndexMap (src/cgpoisson_problem.cpp:187-190,
  * 225-229): for neighbour k, this rank sends x[send_idx[send_off[k]..send_off[k+1])] (owned
  * block dofs) and receives recv_cnt[k] block values into the next ghost slots; the ghost block

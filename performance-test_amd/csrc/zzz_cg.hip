@@ -331,27 +331,6 @@ __device__ inline double reduce_parts(const double* __restrict__ parts, int np, 
   return block_reduce_sum(s, sh);
 }
 
-// multi-rank: out[j] = sum of partial array j (one workgroup), then ncclAllReduce(out)
-__global__ __launch_bounds__(1024) void k_reduce_multi(const CgState* st, const double* __restrict__ pa,
-                                                       const double* __restrict__ pb, int np, double* out,
-                                                       const double* __restrict__ pc = nullptr)
-{
-  if (st->converged)
-    return;
-  __shared__ double sh[16];
-  const double a = reduce_parts(pa, np, sh);
-  const double b = pb ? reduce_parts(pb, np, sh) : 0.0;
-  const double c = pc ? reduce_parts(pc, np, sh) : 0.0;
-  if (threadIdx.x == 0)
-  {
-    out[0] = a;
-    if (pb)
-      out[1] = b;
-    if (pc)
-      out[2] = c;
-  }
-}
-
 __global__ __launch_bounds__(VB) void k_sqnorm(const double* __restrict__ v, int64_t n, double* __restrict__ parts)
 {
   __shared__ double sh[VB / 64];
@@ -385,19 +364,20 @@ int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out)
 {
   const int g = vgrid(n);
   hipLaunchKernelGGL(k_sqnorm, dim3(g), dim3(VB), 0, ctx->stream, v, n, ctx->part_b.p);
-  hipLaunchKernelGGL(k_reduce_plain, dim3(1), dim3(1024), 0, ctx->stream, ctx->part_b.p, g, ctx->red.p);
-  ZZZ_HIP(ctx, hipGetLastError());
   if (ctx->comm)
   {
-    int rc = comm_allreduce_sum(ctx, ctx->red.p, 1);
+    int rc = comm_reduce_allreduce(ctx, nullptr, ctx->part_b.p, nullptr, nullptr, g, 1, ctx->red.p);
     if (rc)
       return rc;
   }
+  else
+    hipLaunchKernelGGL(k_reduce_plain, dim3(1), dim3(1024), 0, ctx->stream, ctx->part_b.p, g, ctx->red.p);
+  ZZZ_HIP(ctx, hipGetLastError());
   double s = 0;
   ZZZ_HIP(ctx, hipMemcpyAsync(&s, ctx->red.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = std::sqrt(s);
-  return ZZZ_OK;
+  return comm_p2p_check(ctx);
 }
 
 static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);
@@ -468,11 +448,11 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     pw_src = ctx->red.p + 2;
     n_rz = 1;
   }
+  const int* stop_flag = reinterpret_cast<const int*>(ctx->state.p); // CgState::converged
   auto allreduce_beta = [&]() -> int {
     if (!multi)
       return ZZZ_OK;
-    hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(1024), 0, s, ctx->state.p, pa, pb, g, ctx->red.p);
-    return comm_allreduce_sum(ctx, ctx->red.p, 2);
+    return comm_reduce_allreduce(ctx, stop_flag, pa, pb, nullptr, g, 2, ctx->red.p);
   };
   {
     int rc = allreduce_beta();
@@ -520,9 +500,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     }
     if (multi)
     {
-      hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(1024), 0, s, ctx->state.p, ctx->part_a.p, (const double*)nullptr,
-                         np, ctx->red.p + 2);
-      int rc = comm_allreduce_sum(ctx, ctx->red.p + 2, 1);
+      int rc = comm_reduce_allreduce(ctx, stop_flag, ctx->part_a.p, nullptr, nullptr, np, 1, ctx->red.p + 2);
       if (rc)
         return rc;
       np = 1;
@@ -559,6 +537,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   for (int i = 0; i < NSLOT; ++i)
     (void)hipEventDestroy(chk_ev[i]);
+  if (int rc = comm_p2p_check(ctx))
+    return rc;
 
   const int its = fin.converged ? fin.iters : max_it;
   ctx->last_iters = its;
@@ -645,9 +625,8 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
       return rc;
     if (multi)
     {
-      hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(1024), 0, s, ctx->state.p, parts + SPMV_PSTRIDE,
-                         parts + 2 * SPMV_PSTRIDE, np, ctx->red.p, parts);
-      rc = comm_allreduce_sum(ctx, ctx->red.p, 3);
+      rc = comm_reduce_allreduce(ctx, reinterpret_cast<const int*>(ctx->state.p), parts + SPMV_PSTRIDE,
+                                 parts + 2 * SPMV_PSTRIDE, parts, np, 3, ctx->red.p);
       if (rc)
         return rc;
       np = 1;
@@ -718,6 +697,8 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   for (int i = 0; i < NSLOT; ++i)
     (void)hipEventDestroy(chk_ev[i]);
+  if (int rc = comm_p2p_check(ctx))
+    return rc;
   const int its = fin.converged ? fin.iters : max_it;
   ctx->last_iters = its;
   if (iters)

@@ -7,6 +7,7 @@
 // host synchronisation.  The halo is a grouped ncclSend/ncclRecv per neighbour (<= 7 peers on one
 // node = one xGMI link each); owned values are packed by a gather kernel, received values land
 // directly in the ghost segment, which the partitioner orders by (neighbour, sender order).
+#include "zzz_device.h"
 #include "zzz_internal.h"
 
 #include <dlfcn.h>
@@ -130,8 +131,42 @@ struct LocalGroup
   std::vector<int> bs;
 };
 
+// Peer-memory all-reduce of the CG scalars (MPI_Allreduce of la::inner_product / la::squared_norm,
+// src/cg.h:53,65,74): every rank owns a small UNCACHED device mailbox, box[parity][source rank] =
+// {v0, v1, v2, tag}; a one-workgroup kernel reduces the producer's partials, stores the three sums and then
+// (system-scope release) the tag into its slot of every peer's mailbox over xGMI, polls its own mailbox
+// until all `nranks` tags of this round have arrived (system-scope acquire) and adds the contributions
+// in rank order, so every rank forms the bit-identical sum.  One kernel replaces reduce + ncclAllReduce.
+// Two parities suffice: a rank can only be one round ahead of the slowest peer.  The poll is bounded
+// (P2P_TIMEOUT_TICKS of the 100 MHz wall clock): on time-out the kernel raises a flag and the solve
+// returns an error instead of hanging.
+struct P2P
+{
+  int nranks = 0, rank = 0;
+  double* box = nullptr;                // own mailbox (uncached device memory)
+  std::vector<double*> peer;            // peer[r] = rank r's mailbox as mapped here
+  std::vector<bool> ipc_opened;         // peer[r] came from hipIpcOpenMemHandle
+  zzz::DevBuf<double*> peer_dev;        // the same pointers for the kernel
+  zzz::DevBuf<int32_t> fail;            // device flag: a poll timed out
+  int64_t seq = 0;                      // round counter = tag; identical call sequence on every rank
+  bool enabled = false;
+};
+constexpr long long P2P_TIMEOUT_TICKS = 300000000LL; // 3 s
+constexpr int P2P_SLOT = 4;                          // doubles per mailbox slot
+
+struct P2PHandle // ZZZ_P2P_HANDLE_BYTES
+{
+  hipIpcMemHandle_t ipc; // 64 bytes
+  int64_t pid;
+  double* raw;           // valid in the exporting process only
+  int32_t device, ok;
+  char pad[128 - 64 - 8 - 8 - 8];
+};
+static_assert(sizeof(P2PHandle) == ZZZ_P2P_HANDLE_BYTES, "p2p handle size");
+
 struct Comm
 {
+  P2P* p2p = nullptr;             // optional: all-reduces through peer memory instead of RCCL
   ncclComm_t comm = nullptr;      // all-reduces, on the context's main stream
   ncclComm_t comm_halo = nullptr; // send/recv of the halo, on the comm stream: one communicator per
                                   // stream, so no communicator is ever alternated between two streams
@@ -172,12 +207,151 @@ static int local_allreduce(zzz_ctx* ctx, double* dev, int n)
   return ZZZ_OK;
 }
 
+// one workgroup: out[j] = sum over ranks of (sum of partial array j), j < nv <= 3
+__global__ __launch_bounds__(1024) void k_allreduce_p2p(const int* __restrict__ stop, const double* __restrict__ pa,
+                                                        const double* __restrict__ pb, const double* __restrict__ pc,
+                                                        int np, int nv, double* __restrict__ out, double* const* peers,
+                                                        double* box, int nranks, int rank, long long seq,
+                                                        int* __restrict__ fail, long long timeout)
+{
+  if (stop && *stop) // CG already converged (the same on every rank: identical scalars everywhere)
+    return;
+  __shared__ double sh[16];
+  __shared__ double val[3];
+  __shared__ int timed_out;
+  const double* parts[3] = {pa, pb, pc};
+  if (threadIdx.x == 0)
+    timed_out = 0;
+  for (int j = 0; j < nv; ++j)
+  {
+    double s = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+      s += parts[j][i];
+    const double t = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0)
+      val[j] = t;
+    __syncthreads();
+  }
+  const int par = (int)(seq & 1);
+  if ((int)threadIdx.x < nranks)
+  {
+    // my contribution into slot [par][rank] of peer threadIdx.x (my own mailbox included)
+    double* slot = peers[threadIdx.x] + ((size_t)par * nranks + rank) * P2P_SLOT;
+    for (int j = 0; j < nv; ++j)
+      __hip_atomic_store(slot + j, val[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<long long*>(slot + 3), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // contribution of rank threadIdx.x in my mailbox
+    const double* mine = box + ((size_t)par * nranks + threadIdx.x) * P2P_SLOT;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(reinterpret_cast<const long long*>(mine + 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq)
+    {
+      if (wall_clock64() - t0 > timeout)
+      {
+        timed_out = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    if (timed_out)
+    {
+      *fail = 1;
+      for (int j = 0; j < nv; ++j)
+        out[j] = __builtin_nan("");
+    }
+    else
+      for (int j = 0; j < nv; ++j)
+      {
+        double s = 0;
+        for (int r = 0; r < nranks; ++r) // rank order: the same sum on every rank
+          s += __hip_atomic_load(box + ((size_t)par * nranks + r) * P2P_SLOT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        out[j] = s;
+      }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_partials(const int* __restrict__ stop, const double* __restrict__ pa,
+                                                          const double* __restrict__ pb, const double* __restrict__ pc,
+                                                          int np, int nv, double* __restrict__ out)
+{
+  if (stop && *stop)
+    return;
+  __shared__ double sh[16];
+  const double* parts[3] = {pa, pb, pc};
+  for (int j = 0; j < nv; ++j)
+  {
+    double s = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+      s += parts[j][i];
+    const double t = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0)
+      out[j] = t;
+    __syncthreads();
+  }
+}
+
+bool comm_p2p_enabled(const zzz_ctx* ctx) { return ctx->comm && ctx->comm->p2p && ctx->comm->p2p->enabled; }
+
+// out[0..nv) = all-reduced sums of up to three partial arrays of length np (pb/pc may be null for nv < 2/3).
+// stop: device flag that turns the call into a no-op (CgState::converged) or null.
+int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const double* pb, const double* pc, int np,
+                          int nv, double* out)
+{
+  hipStream_t s = ctx->stream;
+  if (comm_p2p_enabled(ctx))
+  {
+    P2P* P = ctx->comm->p2p;
+    const long long seq = ++P->seq;
+    hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(1024), 0, s, stop, pa, pb, pc, np, nv, out, P->peer_dev.p, P->box,
+                       P->nranks, P->rank, seq, P->fail.p, P2P_TIMEOUT_TICKS);
+    ZZZ_HIP(ctx, hipGetLastError());
+    return ZZZ_OK;
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, stop, pa, pb, pc, np, nv, out);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return comm_allreduce_sum(ctx, out, nv);
+}
+
+// did a peer all-reduce time out since the last call?  (checked at the end of a solve)
+int comm_p2p_check(zzz_ctx* ctx)
+{
+  if (!comm_p2p_enabled(ctx))
+    return ZZZ_OK;
+  int32_t f = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&f, ctx->comm->p2p->fail.p, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (f)
+  {
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->comm->p2p->fail.p, 0, sizeof(int32_t), ctx->stream));
+    return fail(ctx, ZZZ_ERR_RCCL, "peer-memory all-reduce timed out (rank %d of %d)", ctx->comm->p2p->rank,
+                ctx->comm->p2p->nranks);
+  }
+  return ZZZ_OK;
+}
+
+static void p2p_destroy(P2P* P)
+{
+  if (!P)
+    return;
+  for (size_t r = 0; r < P->peer.size(); ++r)
+    if (P->ipc_opened[r] && P->peer[r])
+      (void)hipIpcCloseMemHandle(P->peer[r]);
+  if (P->box)
+    (void)hipFree(P->box);
+  delete P;
+}
+
 int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n)
 {
   if (!ctx->comm)
     return ZZZ_OK;
   if (ctx->comm->local)
     return local_allreduce(ctx, dev, n);
+  if (!ctx->comm->comm)
+    return fail(ctx, ZZZ_ERR_RCCL, "all-reduce: this communicator has no transport (peer-only) and the peer-memory path is off");
   ZZZ_NCCL(ctx, g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, ctx->comm->comm, ctx->stream));
   return ZZZ_OK;
 }
@@ -267,6 +441,8 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
     return ZZZ_OK;
   }
   ncclComm_t hc = (st != ctx->stream && ctx->comm->comm_halo) ? ctx->comm->comm_halo : ctx->comm->comm;
+  if (!hc)
+    return fail(ctx, ZZZ_ERR_RCCL, "halo exchange: this communicator has no transport (peer-only)");
   ZZZ_NCCL(ctx, g_rccl.GroupStart());
   int64_t ghost = ctx->n_owned;
   for (int k = 0; k < ctx->nneigh; ++k)
@@ -295,6 +471,8 @@ void comm_destroy(zzz_ctx* ctx)
   }
   if (ctx->comm)
   {
+    p2p_destroy(ctx->comm->p2p);
+    ctx->comm->p2p = nullptr;
     if (ctx->comm->comm_halo && !ctx->comm->local && g_rccl.CommDestroy)
       (void)g_rccl.CommDestroy(ctx->comm->comm_halo);
     if (ctx->comm->comm && !ctx->comm->local && g_rccl.CommDestroy)
@@ -355,6 +533,186 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
     return fail(ctx, ZZZ_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
   }
   ctx->comm = c;
+  return ZZZ_OK;
+}
+
+int zzz_comm_init_peer_only(zzz_ctx* ctx, int nranks, int rank)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  if (nranks < 1 || rank < 0 || rank >= nranks)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_init_peer_only: bad rank %d of %d", rank, nranks);
+  comm_destroy(ctx);
+  Comm* c = new Comm();
+  c->nranks = nranks;
+  c->rank = rank;
+  ctx->comm = c;
+  return ZZZ_OK;
+}
+
+int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  ZZZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->comm || !handle)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_p2p_export: attach a communicator first");
+  P2PHandle h;
+  memset(&h, 0, sizeof(h));
+  p2p_destroy(ctx->comm->p2p);
+  ctx->comm->p2p = nullptr;
+  P2P* P = new P2P();
+  P->nranks = ctx->comm->nranks;
+  P->rank = ctx->comm->rank;
+  const size_t bytes = sizeof(double) * 2 * (size_t)P->nranks * P2P_SLOT;
+  // uncached: remote stores must be visible to the local poll without a kernel boundary
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes < 4096 ? 4096 : bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes < 4096 ? 4096 : bytes, hipDeviceMallocFinegrained);
+  }
+  if (e == hipSuccess)
+    e = hipMemset(P->box, 0xff, bytes < 4096 ? 4096 : bytes); // tags = -1: no round has that number
+  if (e == hipSuccess)
+  {
+    h.ok = 1;
+    h.pid = (int64_t)getpid();
+    h.raw = P->box;
+    h.device = ctx->device;
+    if (hipIpcGetMemHandle(&h.ipc, P->box) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      h.ok = 2; // usable by ranks of this process only
+    }
+  }
+  else
+  {
+    (void)hipGetLastError();
+    P->box = nullptr;
+  }
+  ctx->comm->p2p = P;
+  memcpy(handle, &h, sizeof(h));
+  return ZZZ_OK; // h.ok == 0 tells every rank (zzz_comm_p2p_attach) that this one has no mailbox
+}
+
+int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles, int* enabled)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  ZZZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (enabled)
+    *enabled = 0;
+  if (!ctx->comm || !ctx->comm->p2p || !handles)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_p2p_attach: call zzz_comm_p2p_export first");
+  P2P* P = ctx->comm->p2p;
+  const P2PHandle* H = static_cast<const P2PHandle*>(handles);
+  const int n = P->nranks;
+  P->enabled = false;
+  P->peer.assign((size_t)n, nullptr);
+  P->ipc_opened.assign((size_t)n, false);
+  bool ok = P->box != nullptr;
+  const int64_t me = (int64_t)getpid();
+  for (int r = 0; r < n && ok; ++r)
+  {
+    if (!H[r].ok)
+      ok = false;
+    else if (r == P->rank)
+      P->peer[r] = P->box;
+    else if (H[r].pid == me)
+    {
+      // another context of this process: the pointer itself, after enabling peer access between GPUs
+      if (H[r].device != ctx->device)
+      {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctx->device, H[r].device) != hipSuccess || !can)
+          ok = false;
+        else
+        {
+          hipError_t e = hipDeviceEnablePeerAccess(H[r].device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            ok = false;
+          (void)hipGetLastError();
+        }
+      }
+      P->peer[r] = H[r].raw;
+    }
+    else if (H[r].ok == 1)
+    {
+      void* q = nullptr;
+      if (hipIpcOpenMemHandle(&q, H[r].ipc, hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+      {
+        (void)hipGetLastError();
+        ok = false;
+      }
+      else
+      {
+        P->peer[r] = static_cast<double*>(q);
+        P->ipc_opened[r] = true;
+      }
+    }
+    else
+      ok = false;
+  }
+  ZZZ_HIP(ctx, P->peer_dev.alloc((size_t)n));
+  ZZZ_HIP(ctx, P->fail.alloc(4));
+  ZZZ_HIP(ctx, hipMemset(P->fail.p, 0, 4 * sizeof(int32_t)));
+  if (ok)
+    ZZZ_HIP(ctx, hipMemcpy(P->peer_dev.p, P->peer.data(), sizeof(double*) * (size_t)n, hipMemcpyHostToDevice));
+  // Every rank must take the same decision, and it must rest on evidence: all ranks run the same
+  // rounds of the kernel on known values (a rank that could not map a peer sits them out and the
+  // others time out), then agree through the communicator that is already attached.
+  double verdict = ok ? 1.0 : 0.0;
+  if (ok)
+  {
+    zzz::DevBuf<double> tv;
+    ZZZ_HIP(ctx, tv.alloc(8));
+    const int rounds = 8;
+    for (int k = 0; k < rounds && verdict == 1.0; ++k)
+    {
+      const double in[3] = {(double)(P->rank + 1) * (k + 1), 0.5 * (P->rank + 1), (double)k};
+      ZZZ_HIP(ctx, hipMemcpyAsync(tv.p, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream));
+      const long long seq = ++P->seq;
+      hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(1024), 0, ctx->stream, (const int*)nullptr, tv.p, tv.p + 1, tv.p + 2,
+                         1, 3, tv.p + 4, P->peer_dev.p, P->box, n, P->rank, seq, P->fail.p,
+                         k == 0 ? 10 * P2P_TIMEOUT_TICKS : P2P_TIMEOUT_TICKS); // ranks reach round 0 far apart
+      double outv[3];
+      ZZZ_HIP(ctx, hipMemcpyAsync(outv, tv.p + 4, sizeof(outv), hipMemcpyDeviceToHost, ctx->stream));
+      ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      const double tri = 0.5 * n * (n + 1);
+      if (!(outv[0] == tri * (k + 1) && outv[1] == 0.5 * tri && outv[2] == (double)k * n))
+        verdict = 0.0;
+    }
+    ZZZ_HIP(ctx, hipMemset(P->fail.p, 0, 4 * sizeof(int32_t)));
+  }
+  if (ctx->comm->comm || ctx->comm->local)
+  {
+    // product of the verdicts = 1 only if every rank passed (sum all-reduce of the failures)
+    zzz::DevBuf<double> v;
+    ZZZ_HIP(ctx, v.alloc(1));
+    const double bad = 1.0 - verdict;
+    ZZZ_HIP(ctx, hipMemcpyAsync(v.p, &bad, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = comm_allreduce_sum(ctx, v.p, 1);
+    if (rc)
+      return rc;
+    double nbad = 1.0;
+    ZZZ_HIP(ctx, hipMemcpyAsync(&nbad, v.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nbad != 0.0)
+      verdict = 0.0;
+  }
+  P->enabled = verdict == 1.0;
+  if (enabled)
+    *enabled = P->enabled ? 1 : 0;
+  return ZZZ_OK;
+}
+
+int zzz_comm_p2p_disable(zzz_ctx* ctx)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  if (ctx->comm && ctx->comm->p2p)
+    ctx->comm->p2p->enabled = false;
   return ZZZ_OK;
 }
 

@@ -218,6 +218,12 @@ int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out);
 
 // comm
 int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n);
+// out[0..nv) = all-reduced sums of up to three partial arrays (one kernel with the peer-memory backend,
+// reduce kernel + ncclAllReduce otherwise); stop: device flag that makes the call a no-op, or null
+int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const double* pb, const double* pc, int np, int nv,
+                          double* out);
+bool comm_p2p_enabled(const zzz_ctx* ctx);
+int comm_p2p_check(zzz_ctx* ctx);
 int comm_halo_forward(zzz_ctx* ctx, double* vec);
 int comm_halo_begin(zzz_ctx* ctx, double* vec); // on the comm stream, after the work enqueued so far
 int comm_halo_end(zzz_ctx* ctx);                // main stream waits for the halo

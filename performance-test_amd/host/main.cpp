@@ -113,6 +113,7 @@ struct Options
   // this driver only: number of GPUs ("processes") and the communicator between them
   int ngpus = 1;
   std::string comm = "rccl"; // "local": host-mediated exchange, all ranks on GPU 0 (validation on one GPU)
+  std::string allreduce = "peer"; // CG scalar all-reduces: "peer" memory mailboxes (falls back) | "comm" (RCCL / local)
   // PETSc options database (README.md:66-82)
   std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50; // PETSc defaults
@@ -137,6 +138,7 @@ void usage()
                "  --scatterer arg (=neighbor)     scatterer for CG (neighbor or p2p)\n"
                "  --ngpus arg (=1)                number of GPUs (takes the place of mpirun -np)\n"
                "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
+               "  --allreduce arg (=peer)         peer (xGMI peer-memory mailboxes, else falls back) | comm\n"
                "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
                "  -ksp_cg_single_reduction\n"
@@ -181,6 +183,8 @@ Options parse(int argc, char** argv)
         o.ngpus = std::stoi(value(i, arg, key));
       else if (key == "comm")
         o.comm = value(i, arg, key);
+      else if (key == "allreduce")
+        o.allreduce = value(i, arg, key);
       else if (key == "memory_profiling")
         o.mem_profile = true;
       else if (key == "subcomm_partition")
@@ -260,6 +264,8 @@ struct Shared
   std::int64_t dims[4] = {0, 0, 0, 0};
   unsigned char uid[ZZZ_UNIQUE_ID_BYTES] = {0};
   void* local_group = nullptr; // --comm local
+  std::vector<unsigned char> p2p_handles; // nranks x ZZZ_P2P_HANDLE_BYTES
+  std::vector<int> p2p_enabled;
   std::vector<double> tmax;   // scratch for max-over-ranks timing
   std::vector<int> iters;
   std::vector<double> norm, rnorm0, rnorm;
@@ -319,6 +325,13 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   {
     S.num_dofs = info[0];
     S.num_cells = info[1];
+  }
+  // CG scalar all-reduces through peer memory (xGMI stores into the peers' mailboxes) when every rank
+  // can map every peer; otherwise the communicator's all-reduce stays in use
+  if (S.nranks > 1 && o.allreduce == "peer")
+  {
+    phase(nullptr, [&] { ZCK(ctx, zzz_comm_p2p_export(ctx, S.p2p_handles.data() + (size_t)rank * ZZZ_P2P_HANDLE_BYTES)); });
+    phase(nullptr, [&] { ZCK(ctx, zzz_comm_p2p_attach(ctx, S.p2p_handles.data(), &S.p2p_enabled[rank])); });
   }
   phase("ZZZ FunctionSpace", [&] {});
   phase("ZZZ Create facets and facet->cell connectivity", [&] {});
@@ -475,6 +488,8 @@ void solve(int argc, char** argv)
     throw std::runtime_error("no GPU visible: this build has no CPU path");
   if (o.comm != "rccl" && o.comm != "local")
     throw std::runtime_error("--comm " + o.comm + ": rccl or local");
+  if (o.allreduce != "peer" && o.allreduce != "comm")
+    throw std::runtime_error("--allreduce " + o.allreduce + ": peer or comm");
   if (o.ngpus < 1 || (o.comm == "rccl" && o.ngpus > ndev))
     throw std::runtime_error("--ngpus " + std::to_string(o.ngpus) + " but " + std::to_string(ndev) + " GPU(s) visible");
 
@@ -502,6 +517,8 @@ void solve(int argc, char** argv)
   S.rnorm.assign(S.nranks, 0.0);
   S.rnorm0.assign(S.nranks, 0.0);
   S.error.assign(S.nranks, "");
+  S.p2p_handles.assign((size_t)S.nranks * ZZZ_P2P_HANDLE_BYTES, 0);
+  S.p2p_enabled.assign(S.nranks, 0);
 
   std::barrier<> bar(S.nranks);
   std::vector<std::thread> th;
@@ -521,7 +538,9 @@ void solve(int argc, char** argv)
               << o.ksp_rtol << ", absolute=" << o.ksp_atol << "\n  using " << o.ksp_norm_type
               << " norm type for convergence test\n"
               << (o.ksp_cg_single_reduction ? "  using single-reduction variant\n" : "") << "PC Object: type: " << o.pc_type
-              << "\n  linear system matrix: type=csr (fp64 values, int32 indices) on " << S.nranks << " MI355X\n";
+              << "\n  linear system matrix: type=csr (fp64 values, int32 indices) on " << S.nranks << " MI355X\n"
+              << (S.nranks > 1 ? (S.p2p_enabled[0] ? "  scalar all-reduces: peer-memory mailboxes\n" : "  scalar all-reduces: communicator\n")
+                               : "");
   g_timers.list(); // dolfinx::list_timings, src/main.cpp:226
   // src/main.cpp:229-234
   std::cout << "*** Number of Krylov iterations: " << S.iters[0] << std::endl;

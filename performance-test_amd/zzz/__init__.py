@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_spmv_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
-    "zzz_local_group_destroy", "zzz_comm_init_local",
+    "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable",
 ]
 HOST_SYMBOLS = [
     "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_part_create", "zzzh_part_destroy",
@@ -119,6 +119,10 @@ def hip():
         L.zzz_local_group_destroy.argtypes = [C.c_void_p]
         L.zzz_local_group_destroy.restype = None
         L.zzz_comm_init_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.zzz_comm_init_peer_only.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.zzz_comm_p2p_export.argtypes = [C.c_void_p, C.c_void_p]
+        L.zzz_comm_p2p_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.zzz_comm_p2p_disable.argtypes = [C.c_void_p]
         L.zzz_halo_upload.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, _i32p, _i64p]
         _HIP = L
     return _HIP
@@ -382,11 +386,34 @@ class Context:
     def comm_init_local(self, group, rank):
         self._ck(self.L.zzz_comm_init_local(self.h, group, rank))
 
+    def comm_init_peer_only(self, nranks, rank):
+        self._ck(self.L.zzz_comm_init_peer_only(self.h, nranks, rank))
+
+    def comm_p2p_export(self):
+        """this rank's mailbox handle (P2P_HANDLE_BYTES) for the peer-memory all-reduce"""
+        buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+        self._ck(self.L.zzz_comm_p2p_export(self.h, buf))
+        return bytes(buf.raw)
+
+    def comm_p2p_attach(self, handles):
+        """handles: the nranks exported handles concatenated in rank order; True if the peer-memory
+        all-reduce is now in use on every rank"""
+        buf = C.create_string_buffer(bytes(handles), len(handles))
+        en = C.c_int(0)
+        self._ck(self.L.zzz_comm_p2p_attach(self.h, buf, C.byref(en)))
+        return bool(en.value)
+
+    def comm_p2p_disable(self):
+        self._ck(self.L.zzz_comm_p2p_disable(self.h))
+
     def upload_halo(self, P):
         nn = len(P.neigh)
         z32, z64 = np.zeros(1, np.int32), np.zeros(1, np.int64)
         self._ck(self.L.zzz_halo_upload(self.h, nn, P.neigh if nn else z32, P.send_off if nn else z64,
                                         P.send_idx if P.send_idx.size else z32, P.recv_cnt if nn else z64))
+
+
+P2P_HANDLE_BYTES = 128
 
 
 def comm_unique_id():

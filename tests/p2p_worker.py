@@ -1,0 +1,35 @@
+"""Worker of test_peer_memory_allreduce_between_processes: one rank = one PROCESS, both on GPU 0.
+Each rank solves the same complete problem; the 2-rank peer-only communicator doubles every dot
+product (exactly, in fp64), so the iteration must reproduce the un-communicated solve bit for bit
+-- if and only if the mailbox transport (hipIpcOpenMemHandle mapping, system-scope stores, tags)
+delivers every value of every round."""
+import numpy as np
+
+
+def run(rank, nranks, conn, single_reduction):
+    try:
+        import zzz
+
+        P = zzz.Part("poisson", 1, 14, 12, 13)
+        with zzz.Context(0) as c:
+            c.upload_part(P)
+            c.pattern_build()
+            c.assemble_matrix(P.form)
+            c.assemble_vector(P.form)
+            it0, rn0, r00 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9, single_reduction=single_reduction)
+            u0 = c.vec_download(zzz.VEC_U)
+            nrm0 = c.vec_norm(zzz.VEC_U)
+            c.comm_init_peer_only(nranks, rank)
+            conn.send(c.comm_p2p_export())
+            enabled = c.comm_p2p_attach(conn.recv())
+            if not enabled:
+                conn.send(("disabled",))
+                return
+            res = []
+            for _ in range(3):
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9, single_reduction=single_reduction)
+                res.append((it, rn / r0, bool(np.array_equal(c.vec_download(zzz.VEC_U), u0))))
+            nrm = c.vec_norm(zzz.VEC_U)  # la::norm over both (replicated) ranks: sqrt(2) x the single-rank norm
+            conn.send(("ok", it0, rn0 / r00, res, nrm, nrm0))
+    except Exception as e:  # noqa: BLE001
+        conn.send(("error", repr(e)))
