@@ -130,3 +130,19 @@ def test_two_rank_pcg_matches_serial_oracle(problem, order, dims):
     assert res[0][2] == 0 and res[1][2] * G.bs == res[0][3].size
     assert abs(res[0][1] - it) <= 2 and res[0][1] == res[1][1]
     assert np.linalg.norm(ug - u) <= 1e-7 * np.linalg.norm(u)
+
+
+def test_bench_launch_plumbing_under_torchrun():
+    """bench.py's N > 1 plumbing exactly as the driver launches it (torch.distributed.run, env://
+    rendezvous on 127.0.0.1, gloo): unique-id broadcast, peer-memory handle all_gather, warm-up verdict
+    (all-reduce MIN), barrier, max-over-ranks timing.  No GPU work: tools/gloo_probe.py."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = os.path.join(root, "performance-test_amd", "tools", "gloo_probe.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), probe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gloo probe ok 2" in r.stdout
