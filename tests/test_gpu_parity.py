@@ -782,3 +782,58 @@ def test_peer_memory_allreduce_between_processes(single_reduction):
             assert it == it0 and same, (it, it0, same)
             assert rel == pytest.approx(rel0, rel=1e-12)
         assert nrm == pytest.approx(np.sqrt(2.0) * nrm0, rel=1e-14)
+
+
+def test_full_size_baseline_config_properties():
+    """BASELINE configs[1] at its FULL size (216x206x222 sub-cubes, 10 016 937 dofs, 59 268 672 cells,
+    149 140 873 nonzeros), fed by the device generator: size-independent properties only -- sizes of
+    SURVEY.md Appendix B/C, symmetry, Dirichlet rows = identity, constants in the kernel of the
+    un-constrained rows, linearity, idempotent assembly, matrix-free action == assembled action, the
+    classical and the single-reduction CG agree, and the solution's TRUE residual meets 1e-8."""
+    nx, ny, nz, r = zzz.mesh_size(10000000, True, 1, 1, 1)
+    assert (nx << r, ny << r, nz << r) == (216, 206, 222)
+    rng = np.random.default_rng(17)
+    with zzz.Context(0) as c:
+        info = c.cube_generate("poisson", 1, nx << r, ny << r, nz << r, 1, 0)
+        assert int(info[0]) == 10016937 and int(info[1]) == 59268672
+        c.pattern_build()
+        nrows, ncols, nnz = c.csr_sizes()
+        assert (nrows, ncols, nnz) == (10016937, 10016937, 149140873)
+        packed, offb, nfb, ntiles = c.spmv_info()
+        assert packed and nfb == 0
+        c.assemble_matrix(zzz.FORM_POISSON)
+        c.assemble_vector(zzz.FORM_POISSON)
+        b = c.vec_download(zzz.VEC_B)
+        xv, yv = rng.standard_normal(nrows), rng.standard_normal(nrows)
+        Ax, Ay = c.spmv(xv), c.spmv(yv)
+        assert abs(yv @ Ax - xv @ Ay) <= 1e-10 * abs(yv @ Ax)                     # symmetry
+        A1 = c.spmv(np.ones(nrows))
+        bc = A1 == 1.0                                                            # identity rows map 1 -> 1 exactly
+        X = np.linspace(0.0, 1.0, 217)
+        assert bc.sum() == 2 * 207 * 223                                          # the x = 0 and x = 1 planes
+        np.testing.assert_array_equal(Ax[bc], xv[bc])
+        assert np.all(b[bc] == 0.0)
+        # rows not coupled to a Dirichlet dof annihilate constants: |A 1| tiny there, O(h) next to the planes
+        assert np.sum(np.abs(A1) < 1e-12) >= nrows - 4 * 207 * 223
+        np.testing.assert_allclose(c.spmv(2.0 * xv - 3.0 * yv), 2.0 * Ax - 3.0 * Ay, rtol=0, atol=1e-11 * np.abs(Ax).max())
+        # matrix-free action of form M == assembled operator on vectors that vanish on the Dirichlet dofs (the
+        # action keeps the Dirichlet COLUMNS and zeroes the rows, src/cgpoisson_problem.cpp:193-230)
+        x0 = np.where(bc, 0.0, xv)
+        assert np.abs(c.action(x0) - c.spmv(x0)).max() <= 1e-11 * np.abs(Ax).max()
+        _, _, v1 = c.csr_download()
+        c.assemble_matrix(zzz.FORM_POISSON)
+        _, _, v2 = c.csr_download()
+        np.testing.assert_array_equal(v1, v2)
+        del v1, v2
+        it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, norm=zzz.NORM_UNPRECONDITIONED, rtol=1e-8)
+        u = c.vec_download(zzz.VEC_U)
+        res = b - c.spmv(u)
+        assert np.linalg.norm(res) <= 1.01e-8 * np.linalg.norm(b) and rn <= 1e-8 * r0
+        it_p, rn_p, r0_p = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)                # the bench's solve
+        up = c.vec_download(zzz.VEC_U)
+        assert abs(it_p - 975) <= 3 and abs(np.linalg.norm(up) - 673.43434) < 1e-3  # recorded in profiles/r01_bench_default.json
+        it_s, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=True)
+        us = c.vec_download(zzz.VEC_U)
+        assert abs(it_s - it_p) <= 2 and np.linalg.norm(us - up) <= 1e-7 * np.linalg.norm(up)
+        assert np.linalg.norm(u - up) <= 1e-6 * np.linalg.norm(up)
+        del X
