@@ -166,14 +166,15 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
       const double xr_ = (rr == r) ? xr : (DOT ? x[rr] : 0.0);
       // products are added in column order (the serial CPU order); 8 LDS reads in flight at a time
       double sum = 0.0;
-      for (int k = ra_; k < rb_; k += 8)
+      constexpr int QB = PIPE ? 4 : 8; // the pipelined form holds the next tile's loads in registers meanwhile
+      for (int k = ra_; k < rb_; k += QB)
       {
-        double q[8];
+        double q[QB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < QB; ++u)
           q[u] = prod[k + u]; // may run past the row: within the padded LDS array, masked below
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < QB; ++u)
           if (k + u < rb_)
             sum += q[u];
       }

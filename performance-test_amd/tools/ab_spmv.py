@@ -25,7 +25,7 @@ for tile in (2048,):
         nrows, _, nnz = ctx.csr_sizes()
         alg = 12 * nnz + 4 * (nrows + 1) + 16 * nrows
         for rnd in range(6):
-            for var in (1, 17):  # 17 = int32 columns, 1 = packed 16-bit columns (default)
+            for var in (0, 1, 2, 3, 17):  # bit 0 nt, bit 1 pipelined, 16 = int32 columns
                 ms = ctx.spmv_time(reps=30, variant=var)
                 res.setdefault((tile, var), []).append(ms)
 for (tile, var), v in sorted(res.items()):
