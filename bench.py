@@ -197,7 +197,7 @@ def main():
     ctx.pattern_build()  # once up front so that sizes are known; rebuilt inside every timed step
     nrows, ncols, nnz = ctx.csr_sizes()
     pc = zzz.PC_JACOBI if a.pc == "jacobi" else zzz.PC_NONE
-    single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and world > 1)
+    single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and (world > 1 or a.force_comm))
 
     def step(profile=False):
         t = {}
@@ -223,7 +223,8 @@ def main():
         t["rel"] = rn / r0 if r0 else 0.0
         return t
 
-    for _ in range(a.warmup):
+    tuning = None
+    for w in range(a.warmup):
         ok = 1
         try:
             step()
@@ -240,6 +241,34 @@ def main():
                 ctx.comm_p2p_disable()
                 p2p = False
                 step()
+        if w == 0 and a.cg == "auto" and (dist is not None or a.force_comm):
+            # N > 1: which CG form and which all-reduce transport are faster depends on the all-reduce latency
+            # of this node, which only a run on it can tell: time one solve of each combination on the
+            # assembled warm-up system (untimed region), MAX over ranks, and keep the fastest for the timed steps.
+            combos = [(sr, pm) for pm in ((True, False) if p2p else (False,)) for sr in (True, False)]
+            tuning = {}
+            for sr, pm in combos:
+                if p2p:
+                    (ctx.comm_p2p_enable if pm else ctx.comm_p2p_disable)()
+                barrier()
+                ctx.sync()
+                t0 = time.perf_counter()
+                try:
+                    ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, single_reduction=sr)
+                    ctx.sync()
+                    dt = time.perf_counter() - t0
+                except zzz.ZzzError:
+                    dt = float("inf")
+                if dist is not None:
+                    tt = torch.tensor([dt], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt[0])
+                tuning[(sr, pm)] = dt
+            best = min(tuning, key=lambda k: (tuning[k], k))
+            single_reduction, use_pm = best
+            if p2p:
+                (ctx.comm_p2p_enable if use_pm else ctx.comm_p2p_disable)()
+                p2p = use_pm
     barrier()
     ctx.sync()
     t_begin = time.perf_counter()
@@ -300,6 +329,9 @@ def main():
         c16 = ctx.spmv_info()
         out["config"]["spmv_column_stream"] = (f"16-bit band codes ({c16[1]} offset bits), {c16[2]} of {c16[3]} tiles on int32 columns"
                                                if c16[0] else "int32")
+        if tuning:
+            out["config"]["cg_form_tuning_s"] = {("single_reduction" if sr else "classical") + ("+peer_memory" if pm else "+ncclAllReduce"): v
+                                                 for (sr, pm), v in tuning.items()}
         if world > 1 or a.force_comm:
             out["config"]["scalar_allreduce"] = ("peer-memory mailboxes over xGMI (one kernel: reduce + exchange)" if p2p
                                                  else "ncclAllReduce")

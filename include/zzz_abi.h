@@ -271,6 +271,8 @@ int zzz_comm_init_peer_only(zzz_ctx* ctx, int nranks, int rank);
 int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle /* ZZZ_P2P_HANDLE_BYTES */);
 int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles /* nranks x ZZZ_P2P_HANDLE_BYTES */, int* enabled);
 int zzz_comm_p2p_disable(zzz_ctx* ctx);
+/* back on after zzz_comm_p2p_disable, only if attach had succeeded; every rank must make the same call */
+int zzz_comm_p2p_enable(zzz_ctx* ctx, int* enabled);
 
 /* The forward scatter of common::Scatterer / IndexMap (src/cgpoisson_problem.cpp:187-190,
  * 225-229): for neighbour k, this rank sends x[send_idx[send_off[k]..send_off[k+1])] (owned

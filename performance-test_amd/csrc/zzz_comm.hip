@@ -150,6 +150,7 @@ struct P2P
   zzz::DevBuf<int32_t> fail;            // device flag: a poll timed out
   int64_t seq = 0;                      // round counter = tag; identical call sequence on every rank
   bool enabled = false;
+  bool verified = false;                // attach passed on every rank: may be switched on and off
 };
 constexpr long long P2P_TIMEOUT_TICKS = 300000000LL; // 3 s
 constexpr int P2P_SLOT = 4;                          // doubles per mailbox slot
@@ -701,7 +702,7 @@ int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles, int* enabled)
     if (nbad != 0.0)
       verdict = 0.0;
   }
-  P->enabled = verdict == 1.0;
+  P->enabled = P->verified = verdict == 1.0;
   if (enabled)
     *enabled = P->enabled ? 1 : 0;
   return ZZZ_OK;
@@ -713,6 +714,17 @@ int zzz_comm_p2p_disable(zzz_ctx* ctx)
     return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
   if (ctx->comm && ctx->comm->p2p)
     ctx->comm->p2p->enabled = false;
+  return ZZZ_OK;
+}
+
+int zzz_comm_p2p_enable(zzz_ctx* ctx, int* enabled)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  if (ctx->comm && ctx->comm->p2p && ctx->comm->p2p->verified)
+    ctx->comm->p2p->enabled = true;
+  if (enabled)
+    *enabled = comm_p2p_enabled(ctx) ? 1 : 0;
   return ZZZ_OK;
 }
 

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_spmv_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
-    "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable",
+    "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
     "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_part_create", "zzzh_part_destroy",
@@ -123,6 +123,7 @@ def hip():
         L.zzz_comm_p2p_export.argtypes = [C.c_void_p, C.c_void_p]
         L.zzz_comm_p2p_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.zzz_comm_p2p_disable.argtypes = [C.c_void_p]
+        L.zzz_comm_p2p_enable.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.zzz_halo_upload.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, _i32p, _i64p]
         _HIP = L
     return _HIP
@@ -405,6 +406,11 @@ class Context:
 
     def comm_p2p_disable(self):
         self._ck(self.L.zzz_comm_p2p_disable(self.h))
+
+    def comm_p2p_enable(self):
+        en = C.c_int(0)
+        self._ck(self.L.zzz_comm_p2p_enable(self.h, C.byref(en)))
+        return bool(en.value)
 
     def upload_halo(self, P):
         nn = len(P.neigh)
