@@ -25,6 +25,7 @@
 
 namespace zzz
 {
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr int VB = 256;        // threads per workgroup of the vector kernels
 constexpr int VGRID_MAX = 2048; // 8 workgroups per CU
 
@@ -200,10 +201,32 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
   }
   const double alpha = alpha_hist[it - 1];
   const double bcoef = rz / bprev;
-  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  // two entries per lane and load (16-B accesses); the arithmetic per entry is unchanged
+  const int64_t n2 = n >> 1;
+  dbl2* __restrict__ p2 = reinterpret_cast<dbl2*>(p);
+  dbl2* __restrict__ x2 = reinterpret_cast<dbl2*>(x);
+  const dbl2* __restrict__ z2 = reinterpret_cast<const dbl2*>(z);
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
+    const dbl2 pi = p2[i];
+    dbl2 xi = x2[i];
+    xi.x = alpha * pi.x + xi.x; // src/cg.h:68, one kernel late
+    xi.y = alpha * pi.y + xi.y;
+    x2[i] = xi;
+    if (dir)
+    {
+      const dbl2 zi = z2[i];
+      dbl2 pn;
+      pn.x = bcoef * pi.x + zi.x;
+      pn.y = bcoef * pi.y + zi.y;
+      p2[i] = pn;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    const int64_t i = n - 1;
     const double pi = p[i];
-    x[i] = alpha * pi + x[i]; // src/cg.h:68, one kernel late
+    x[i] = alpha * pi + x[i];
     if (dir)
       p[i] = bcoef * pi + z[i];
   }
@@ -234,9 +257,38 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   if (blockIdx.x == 0 && threadIdx.x == 0)
     alpha_hist[it] = alpha; // x += alpha p: applied by k_update_p(it + 1)
   double sa = 0, sb = 0;
-  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  const int64_t n2 = n >> 1;
+  const dbl2* __restrict__ w2 = reinterpret_cast<const dbl2*>(w);
+  const dbl2* __restrict__ d2 = reinterpret_cast<const dbl2*>(dinv);
+  dbl2* __restrict__ r2 = reinterpret_cast<dbl2*>(r);
+  dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
-    const double ri = -alpha * w[i] + r[i]; // src/cg.h:71
+    const dbl2 wi = w2[i], di = d2[i];
+    dbl2 ri = r2[i], zi;
+    ri.x = -alpha * wi.x + ri.x; // src/cg.h:71
+    ri.y = -alpha * wi.y + ri.y;
+    zi.x = di.x * ri.x;
+    zi.y = di.y * ri.y;
+    r2[i] = ri;
+    z2[i] = zi;
+    sa += ri.x * zi.x;
+    sa += ri.y * zi.y;
+    if (norm == ZZZ_NORM_UNPRECONDITIONED)
+    {
+      sb += ri.x * ri.x;
+      sb += ri.y * ri.y;
+    }
+    else
+    {
+      sb += zi.x * zi.x;
+      sb += zi.y * zi.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    const int64_t i = n - 1;
+    const double ri = -alpha * w[i] + r[i];
     const double zi = dinv[i] * ri;
     r[i] = ri;
     z[i] = zi;
@@ -310,8 +362,7 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
   }
   if (conv || scalars_only)
     return;
-  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
-  {
+  auto one = [&](int64_t i) {
     const double pn = (it == 0) ? z[i] : b * p[i] + z[i];
     const double wn = (it == 0) ? s[i] : b * w[i] + s[i];
     p[i] = pn;
@@ -320,7 +371,39 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     const double ri = -a * wn + r[i];
     r[i] = ri;
     z[i] = dinv[i] * ri;
+  };
+  const int64_t n2 = n >> 1;
+  const dbl2* __restrict__ s2 = reinterpret_cast<const dbl2*>(s);
+  const dbl2* __restrict__ d2 = reinterpret_cast<const dbl2*>(dinv);
+  dbl2 *__restrict__ z2 = reinterpret_cast<dbl2*>(z), *__restrict__ p2 = reinterpret_cast<dbl2*>(p),
+                     *__restrict__ w2 = reinterpret_cast<dbl2*>(w), *__restrict__ x2 = reinterpret_cast<dbl2*>(x),
+                     *__restrict__ r2 = reinterpret_cast<dbl2*>(r);
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
+  {
+    const dbl2 zi = z2[i], si = s2[i], di = d2[i];
+    dbl2 pn = zi, wn = si, xi = x2[i], ri = r2[i], zn;
+    if (it != 0)
+    {
+      const dbl2 po = p2[i], wo = w2[i];
+      pn.x = b * po.x + zi.x;
+      pn.y = b * po.y + zi.y;
+      wn.x = b * wo.x + si.x;
+      wn.y = b * wo.y + si.y;
+    }
+    xi.x = a * pn.x + xi.x;
+    xi.y = a * pn.y + xi.y;
+    ri.x = -a * wn.x + ri.x;
+    ri.y = -a * wn.y + ri.y;
+    zn.x = di.x * ri.x;
+    zn.y = di.y * ri.y;
+    p2[i] = pn;
+    w2[i] = wn;
+    x2[i] = xi;
+    r2[i] = ri;
+    z2[i] = zn;
   }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    one(n - 1);
 }
 
 __device__ inline double reduce_parts(const double* __restrict__ parts, int np, double* sh)
