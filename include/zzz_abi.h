@@ -234,8 +234,11 @@ int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);
 /* Storage the CG SpMV streams for the current matrix (no reference counterpart: MatMult on AIJ reads
  * 12 B per nonzero, src/poisson_problem.cpp:168-177 [EXT]).  info[0] = 1 when the column stream is the
  * 16-bit band code (10 B per nonzero), 0 for int32 columns; info[1] = offset bits of the code;
- * info[2] = tiles left on int32 columns; info[3] = number of tiles. */
-int zzz_spmv_info(zzz_ctx* ctx, int64_t info[4]);
+ * info[2] = tiles left on int32 columns; info[3] = number of tiles; info[4] = lanes per row of the row sums
+ * (1: a row's products are added in column order like the scalar CPU loop; L > 1, chosen for rows of
+ * >= 128 nonzeros on average: lane j adds the j-th contiguous chunk of ceil(len/L) products in column
+ * order, chunk sums combined pairwise ((c0+c1)+(c2+c3))+...); info[5..7] = 0. */
+int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
 
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */
 

@@ -1350,6 +1350,33 @@ int zo_pcg(i64 n, const i64* rowptr_in, const i32* cols_in, const double* vals_i
   return it;
 }
 
+/* y = A x with the summation order of the GPU row phase for long rows (csrc/zzz_spmv.hip, lpr_shift > 0):
+ * `lanes` (a power of two) partial sums over contiguous chunks of ceil(len/lanes) products, each in column
+ * order, combined by a butterfly: ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)).  lanes == 1 is zo_spmv.  No
+ * reference counterpart (MatMult adds serially): it exists so that the parity test of that kernel mode can
+ * stay bit-exact; the results differ from zo_spmv by round-off only. */
+void zo_spmv_chunked(i64 n, const i64* rowptr, const i32* cols, const double* vals, const double* x, double* y, int lanes)
+{
+  for (i64 r = 0; r < n; ++r)
+  {
+    const i64 a = rowptr[r], b = rowptr[r + 1];
+    const i64 chunk = (b - a + lanes - 1) / lanes;
+    double c[64];
+    for (int j = 0; j < lanes; ++j)
+    {
+      i64 ka = a + j * chunk, kb = ka + chunk < b ? ka + chunk : b;
+      double s = 0.0;
+      for (i64 k = ka; k < kb; ++k)
+        s += vals[k] * x[cols[k]];
+      c[j] = s;
+    }
+    for (int o = 1; o < lanes; o <<= 1)
+      for (int j = 0; j < lanes; j += 2 * o)
+        c[j] = c[j] + c[j + o];
+    y[r] = c[0];
+  }
+}
+
 /* KSPCG with -ksp_cg_single_reduction (KSPCGUseSingleReduction; PETSc cg.c, the branches guarded by
  * cg->singlereduction) [EXT, restated from the published algorithm]: the same iteration with
  *   s = A z kept beside z,  w = s + b w (= A p by recurrence),  delta = (z,s),

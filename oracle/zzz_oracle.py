@@ -64,6 +64,7 @@ def lib():
         L.zo_pcg.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_double,
                              C.c_int, f64p]
         L.zo_pcg_sr.argtypes = L.zo_pcg.argtypes
+        L.zo_spmv_chunked.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int]
         L.zo_norm2.restype = C.c_double
         L.zo_norm2.argtypes = [C.c_int64, f64p]
         L.zo_set_num_threads.argtypes = [C.c_int]
@@ -226,6 +227,13 @@ def action_poisson(order, x, cells, cell_dofs, bc, u):
 def spmv(rowptr, cols, vals, x):
     y = np.zeros(rowptr.shape[0] - 1)
     lib().zo_spmv(y.shape[0], rowptr, cols, vals, x, y)
+    return y
+
+
+def spmv_chunked(rowptr, cols, vals, x, lanes):
+    """y = A x in the summation order of the GPU's multi-lane row phase (lanes = 1: spmv)"""
+    y = np.zeros(rowptr.shape[0] - 1)
+    lib().zo_spmv_chunked(y.shape[0], rowptr, cols, vals, x, y, int(lanes))
     return y
 
 

@@ -116,6 +116,13 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->spmv_auto = false;
   }
   ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
+  if (const char* e = getenv("ZZZ_SPMV_LPR")) // lanes per row of the SpMV row phase: 1, 2, 4, 8, 16
+  {
+    const int v = atoi(e);
+    for (int sft = 0; sft <= 4; ++sft)
+      if (v == (1 << sft))
+        ctx->spmv_lpr_forced = sft;
+  }
   if (const char* e = getenv("ZZZ_COLS16")) // 0: keep the SpMV on the int32 columns; 10..13: force the offset width
   {
     const int v = atoi(e);
@@ -678,7 +685,7 @@ int zzz_cg_history(zzz_ctx* ctx, int n, double* out)
   return ZZZ_OK;
 }
 
-int zzz_spmv_info(zzz_ctx* ctx, int64_t info[4])
+int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
 {
   ZZZ_ENTER(ctx);
   if (!info || !ctx->have_pattern)
@@ -687,6 +694,8 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[4])
   info[1] = ctx->cols16_offb;
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
   info[3] = ctx->ntiles;
+  info[4] = (int64_t)1 << ctx->spmv_lpr_shift;
+  info[5] = info[6] = info[7] = 0;
   return ZZZ_OK;
 }
 

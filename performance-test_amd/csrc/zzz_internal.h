@@ -133,6 +133,7 @@ struct zzz_ctx
   int64_t n_tiles_interior = 0, n_tiles_boundary = 0;
   bool have_tile_split = false;
   int spmv_tile = 2048;  // nonzeros per tile (2048 | 4096), fixed at pattern build
+  int spmv_lpr_shift = 0, spmv_lpr_forced = -1; // log2(lanes per row) of the SpMV row phase
   bool spmv_auto = true; // choose bit 0 from the matrix size (off when ZZZ_SPMV_VARIANT / zzz_spmv_time force one)
   int spmv_variant = 1;  // bit 0: non-temporal matrix loads, bit 1: pipelined CSR tiles,
                          // bit 3: build and use the SELL-64 copy (measured 13 % slower than the CSR

@@ -372,6 +372,12 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   const int maxrow = max_block_cols * bs;           // longest scalar row
   const int maxblock = max_block_cols * bs * bs;    // nonzeros of the bs rows of one block dof
   ctx->max_row_nnz = maxrow;
+  // lanes per row of the SpMV row phase: one (the serial CPU order) unless the rows are very long --
+  // measured: 8 lanes pay from ~128 nonzeros per row on average (P3 elasticity 0.47 -> 0.40 ms), cost below
+  {
+    const double avg = ctx->nrows > 0 ? (double)ctx->nnz / (double)ctx->nrows : 0.0;
+    ctx->spmv_lpr_shift = ctx->spmv_lpr_forced >= 0 ? ctx->spmv_lpr_forced : (avg >= 128.0 ? 3 : 0);
+  }
   const int64_t Ws = (int64_t)ctx->spmv_tile - maxrow - 2;
   const int64_t Wa = (int64_t)asm_tile_nnz() - maxblock;
   if (Ws < maxrow || Wa < maxblock || Wa < 1)

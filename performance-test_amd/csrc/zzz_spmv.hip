@@ -63,8 +63,11 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
                                                                const double* __restrict__ rvec, int pstride,
                                                                int nn_is_rr, const uint16_t* __restrict__ cols16,
                                                                const int32_t* __restrict__ tile_base, int offb,
-                                                               int col_max)
+                                                               int col_max, int lpr_shift)
 {
+  // lpr_shift > 0 (long rows: high order, vector-valued): 2^lpr_shift lanes share a row; lane j adds the
+  // j-th contiguous chunk of ceil(len / lanes) products in column order and the chunk sums are combined by a
+  // butterfly ((c0+c1)+(c2+c3))+...: a fixed order, restated by the oracle's zo_spmv_chunked.
   // cols16 != nullptr: 16-bit column codes (zzz_pattern.hip, k_tile_encode_cols): column = band base
   // of the tile [code >> offb] + (code & mask); the 2^(16-offb) band bases of a tile sit one per lane
   // in a register and are looked up with ds_bpermute.  Tiles whose columns do not fit (descriptor
@@ -160,33 +163,75 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
       lds_barrier();
     else
       __syncthreads();
-    for (int rr = r; rr < r1; rr += SPMV_BLOCK) // one row per thread unless the rows are very short
+    if (lpr_shift == 0)
     {
-      const int ra_ = (rr == r) ? ra : rowptr[rr] - s_al, rb_ = (rr == r) ? rb : rowptr[rr + 1] - s_al;
-      const double xr_ = (rr == r) ? xr : (DOT ? x[rr] : 0.0);
-      // products are added in column order (the serial CPU order); 8 LDS reads in flight at a time
-      double sum = 0.0;
-      constexpr int QB = PIPE ? 4 : 8; // the pipelined form holds the next tile's loads in registers meanwhile
-      for (int k = ra_; k < rb_; k += QB)
+      for (int rr = r; rr < r1; rr += SPMV_BLOCK) // one row per thread unless the rows are very short
       {
-        double q[QB];
-#pragma unroll
-        for (int u = 0; u < QB; ++u)
-          q[u] = prod[k + u]; // may run past the row: within the padded LDS array, masked below
-#pragma unroll
-        for (int u = 0; u < QB; ++u)
-          if (k + u < rb_)
-            sum += q[u];
-      }
-      y[rr] = sum;
-      if (DOT)
-      {
-        dot += sum * xr_;
-        if (rvec)
+        const int ra_ = (rr == r) ? ra : rowptr[rr] - s_al, rb_ = (rr == r) ? rb : rowptr[rr + 1] - s_al;
+        const double xr_ = (rr == r) ? xr : (DOT ? x[rr] : 0.0);
+        // products are added in column order (the serial CPU order); 8 LDS reads in flight at a time
+        double sum = 0.0;
+        constexpr int QB = PIPE ? 4 : 8; // the pipelined form holds the next tile's loads in registers meanwhile
+        for (int k = ra_; k < rb_; k += QB)
         {
-          const double rr_ = (rr == r) ? rv : rvec[rr];
-          dot_rx += rr_ * xr_;
-          dot_nn += nn_is_rr ? rr_ * rr_ : xr_ * xr_;
+          double q[QB];
+  #pragma unroll
+          for (int u = 0; u < QB; ++u)
+            q[u] = prod[k + u]; // may run past the row: within the padded LDS array, masked below
+  #pragma unroll
+          for (int u = 0; u < QB; ++u)
+            if (k + u < rb_)
+              sum += q[u];
+        }
+        y[rr] = sum;
+        if (DOT)
+        {
+          dot += sum * xr_;
+          if (rvec)
+          {
+            const double rr_ = (rr == r) ? rv : rvec[rr];
+            dot_rx += rr_ * xr_;
+            dot_nn += nn_is_rr ? rr_ * rr_ : xr_ * xr_;
+          }
+        }
+      }
+    }
+    else
+    {
+      const int lanes = 1 << lpr_shift, sub = (int)threadIdx.x & (lanes - 1);
+      for (int rr = r0 + ((int)threadIdx.x >> lpr_shift); rr < r1; rr += SPMV_BLOCK >> lpr_shift)
+      {
+        const int ra_ = rowptr[rr] - s_al, rb_ = rowptr[rr + 1] - s_al;
+        const int chunk = (rb_ - ra_ + lanes - 1) >> lpr_shift;
+        const int ka = ra_ + sub * chunk, kb = min(ka + chunk, rb_);
+        double sum = 0.0;
+        for (int k = ka; k < kb; k += 4)
+        {
+          double q[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            q[u] = prod[min(k + u, TILE + 15)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k + u < kb)
+              sum += q[u];
+        }
+        for (int o = 1; o < lanes; o <<= 1)
+          sum += __shfl_xor(sum, o);
+        if (sub == 0)
+        {
+          y[rr] = sum;
+          if (DOT)
+          {
+            const double xr_ = x[rr];
+            dot += sum * xr_;
+            if (rvec)
+            {
+              const double rr_ = rvec[rr];
+              dot_rx += rr_ * xr_;
+              dot_nn += nn_is_rr ? rr_ * rr_ : xr_ * xr_;
+            }
+          }
         }
       }
     }
@@ -432,7 +477,7 @@ static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, d
 #define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
   hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
                      ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list,    \
-                     rvec, SPMV_PSTRIDE, nn_is_rr, c16, ctx->tile_base.p, ctx->cols16_offb, col_max)
+                     rvec, SPMV_PSTRIDE, nn_is_rr, c16, ctx->tile_base.p, ctx->cols16_offb, col_max, ctx->spmv_lpr_shift)
   // bit 0: non-temporal matrix loads, bit 1: pipelined tiles.  Unless a variant was forced, the load
   // policy follows the matrix size: a matrix that fits the 256 MiB Infinity Cache is re-read from it
   // every CG iteration, and non-temporal loads would throw that away (measured, 1.25 M-dof P1 matrix,

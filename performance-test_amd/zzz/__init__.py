@@ -371,9 +371,14 @@ class Context:
 
     def spmv_info(self):
         """(packed 16-bit columns in use, offset bits, tiles on int32 columns, tiles)"""
-        info = (C.c_int64 * 4)()
+        info = (C.c_int64 * 8)()
         self._ck(self.L.zzz_spmv_info(self.h, info))
-        return tuple(int(v) for v in info)
+        return tuple(int(v) for v in info[:4])
+
+    def spmv_lanes_per_row(self):
+        info = (C.c_int64 * 8)()
+        self._ck(self.L.zzz_spmv_info(self.h, info))
+        return int(info[4])
 
     def profile(self):
         ms, n = C.c_double(), C.c_int64()

@@ -837,3 +837,46 @@ def test_full_size_baseline_config_properties():
         assert abs(it_s - it_p) <= 2 and np.linalg.norm(us - up) <= 1e-7 * np.linalg.norm(up)
         assert np.linalg.norm(u - up) <= 1e-6 * np.linalg.norm(up)
         del X
+
+
+@pytest.mark.parametrize("lpr", ["auto", "2", "4", "8", "16"])
+def test_spmv_lanes_per_row(lpr):
+    """Row sums with several lanes per row (chosen automatically for rows of >= 128 nonzeros on average,
+    forced here through ZZZ_SPMV_LPR): bit-identical to the oracle's restatement of that summation order
+    (zo_spmv_chunked), round-off close to the serial order, and the solve is unaffected."""
+    old = os.environ.get("ZZZ_SPMV_LPR")
+    if lpr == "auto":
+        os.environ.pop("ZZZ_SPMV_LPR", None)
+    else:
+        os.environ["ZZZ_SPMV_LPR"] = lpr
+    try:
+        zo.set_num_threads(4)
+        rng = np.random.default_rng(int(lpr) if lpr != "auto" else 1)
+        with zzz.Context(0) as c:
+            for problem, order, dims in (("elasticity", 3, (5, 5, 6)), ("poisson", 3, (5, 4, 5)), ("poisson", 1, (9, 8, 7))):
+                P = zzz.Part(problem, order, *dims)
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                lanes = c.spmv_lanes_per_row()
+                rp, cl, v = c.csr_download()
+                rp = rp.astype(np.int64)
+                if lpr != "auto":
+                    assert lanes == int(lpr)
+                else:
+                    assert lanes == (8 if cl.shape[0] / (rp.shape[0] - 1) >= 128 else 1)
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                y = c.spmv(xv)
+                np.testing.assert_array_equal(y, zo.spmv_chunked(rp, cl, v, xv, lanes))
+                ys = zo.spmv(rp, cl, v, xv)
+                assert np.abs(y - ys).max() <= 4e-15 * np.abs(ys).max()
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                oit, ou, _, _ = zo.pcg(rp, cl, v, c.vec_download(zzz.VEC_B), rtol=1e-8)
+                assert abs(it - oit) <= 2
+                assert np.linalg.norm(c.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_SPMV_LPR", None)
+        else:
+            os.environ["ZZZ_SPMV_LPR"] = old

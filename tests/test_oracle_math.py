@@ -226,3 +226,16 @@ def test_single_reduction_pcg_equals_classical(problem, order, dims, norm):
     assert it2 == 3
     it3, u3, rn3, _ = zo.pcg_single_reduction(P.rowptr, P.cols, P.vals, np.zeros_like(P.b))
     assert it3 == 0 and rn3 == 0.0 and not u3.any()
+
+
+def test_chunked_spmv_is_the_serial_spmv_to_roundoff():
+    """zo_spmv_chunked restates the GPU's multi-lane row sums: lanes = 1 IS zo_spmv, more lanes change
+    only the association of the additions."""
+    P = zo.Problem("elasticity", 2, 3, 3, 3)
+    P.assemble()
+    x = np.random.default_rng(0).standard_normal(P.rowptr.shape[0] - 1)
+    y1 = zo.spmv(P.rowptr, P.cols, P.vals, x)
+    np.testing.assert_array_equal(zo.spmv_chunked(P.rowptr, P.cols, P.vals, x, 1), y1)
+    for lanes in (2, 4, 8, 16):
+        y = zo.spmv_chunked(P.rowptr, P.cols, P.vals, x, lanes)
+        assert 0 < np.abs(y - y1).max() <= 2e-15 * np.abs(y1).max()
