@@ -6,7 +6,8 @@
 //    src/mesh.cpp:184-186): simplex q of a sub-cube follows the lattice path origin -> +e_PERM[q][0]
 //    -> +e_PERM[q][1] -> +e_PERM[q][2]; its vertices are therefore in ascending global order;
 //  * P1..P3 Lagrange dofs (src/poisson_problem.cpp:35-38) numbered in "level units": for k = 0..nz
-//    the dofs of plane z = k (vertices, in-plane edges, in-plane faces) then those of layer k;
+//    the dofs of plane z = k (vertices, in-plane edges, in-plane faces) then those of layer k, inside
+//    each block lattice point by lattice point (struct Layout);
 //  * z-slab partition: part p owns sub-cube layers [zs, ze) and one contiguous global dof range;
 //    ghosts = plane zs (from p-1) and layer ze + plane ze+1 (from p+1), in that order.
 #pragma once
@@ -26,50 +27,56 @@ struct Layout
 {
   int64_t nx, ny, nz, PX, PY;
   int order, npe, nfd;
-  int64_t offP[5], NP, offL[7], NL;
+  // Within the plane block and within the layer block of a level the dofs are numbered lattice point by
+  // lattice point (iy major, ix minor): all entities anchored at (ix, iy) are consecutive -- vertex, x-edge,
+  // y-edge, xy-edge, in-plane faces; resp. z-edge, xz-, yz-, xyz-edge, xz-faces, yz-faces, the six other
+  // faces.  Entities that would stick out of the cube at ix == nx / iy == ny do not exist, so the last
+  // point of a row and the last row are shorter.  Mesh neighbours are memory neighbours for every order:
+  // a matrix row of a P3 dof touches ~15 contiguous column clusters instead of ~90.
+  int64_t KA, KC, RA; // plane: slots of a full point, of a point in the last row; length of a full row
+  int64_t LA, LC, RL; // layer: the same
+  int64_t NP, NL;
 
   ZZZ_HD Layout(int64_t nx_, int64_t ny_, int64_t nz_, int order_)
       : nx(nx_), ny(ny_), nz(nz_), PX(nx_ + 1), PY(ny_ + 1), order(order_), npe(order_ - 1), nfd(order_ == 3 ? 1 : 0)
   {
-    const int64_t cntP[5] = {PX * PY, nx * PY * npe, PX * ny * npe, nx * ny * npe, 2 * nx * ny * nfd};
-    NP = 0;
-    for (int t = 0; t < 5; ++t)
-    {
-      offP[t] = NP;
-      NP += cntP[t];
-    }
-    const int64_t cntL[7] = {PX * PY * npe,     nx * PY * npe,     PX * ny * npe,    nx * ny * npe,
-                             2 * nx * PY * nfd, 2 * PX * ny * nfd, 6 * nx * ny * nfd};
-    NL = 0;
-    for (int t = 0; t < 7; ++t)
-    {
-      offL[t] = NL;
-      NL += cntL[t];
-    }
+    KA = 1 + 3 * npe + 2 * nfd;
+    KC = 1 + npe;
+    RA = nx * KA + (1 + npe);
+    NP = ny * RA + nx * KC + 1;
+    LA = 4 * npe + 10 * nfd;
+    LC = 2 * npe + 2 * nfd;
+    RL = nx * LA + (2 * npe + 2 * nfd);
+    NL = ny * RL + nx * LC + npe;
   }
   ZZZ_HD int64_t level_base(int64_t k) const { return k * (NP + NL); }
   ZZZ_HD int64_t total() const { return (nz + 1) * NP + nz * NL; }
+  // first slot of lattice point (ix, iy) in the plane / layer block
+  ZZZ_HD int64_t pbase(const int64_t a[3]) const { return a[1] < ny ? a[1] * RA + a[0] * KA : ny * RA + a[0] * KC; }
+  ZZZ_HD int64_t lbase(const int64_t a[3]) const { return a[1] < ny ? a[1] * RL + a[0] * LA : ny * RL + a[0] * LC; }
 
-  ZZZ_HD int64_t vertex(const int64_t a[3]) const { return level_base(a[2]) + offP[0] + a[1] * PX + a[0]; }
-  // edge anchored at lattice point a with axis mask m (x=1, y=2, z=4), sub-dof s
+  ZZZ_HD int64_t vertex(const int64_t a[3]) const { return level_base(a[2]) + pbase(a); }
+  // edge anchored at lattice point a (its lowest vertex) with axis mask m (x=1, y=2, z=4), sub-dof s
   ZZZ_HD int64_t edge(const int64_t a[3], int m, int s) const
   {
+    const int hx = a[0] < nx ? 1 : 0, hy = a[1] < ny ? 1 : 0;
     switch (m)
     {
     case 1:
-      return level_base(a[2]) + offP[1] + (a[1] * nx + a[0]) * npe + s;
+      return level_base(a[2]) + pbase(a) + 1 + s;
     case 2:
-      return level_base(a[2]) + offP[2] + (a[1] * PX + a[0]) * npe + s;
+      return level_base(a[2]) + pbase(a) + 1 + hx * npe + s;
     case 3:
-      return level_base(a[2]) + offP[3] + (a[1] * nx + a[0]) * npe + s;
+      return level_base(a[2]) + pbase(a) + 1 + 2 * npe + s;
     case 4:
-      return level_base(a[2]) + NP + offL[0] + (a[1] * PX + a[0]) * npe + s;
+      return level_base(a[2]) + NP + lbase(a) + s;
     case 5:
-      return level_base(a[2]) + NP + offL[1] + (a[1] * nx + a[0]) * npe + s;
+      return level_base(a[2]) + NP + lbase(a) + npe + s;
     case 6:
-      return level_base(a[2]) + NP + offL[2] + (a[1] * PX + a[0]) * npe + s;
+      return level_base(a[2]) + NP + lbase(a) + (1 + hx) * npe + s;
     default:
-      return level_base(a[2]) + NP + offL[3] + (a[1] * nx + a[0]) * npe + s;
+      (void)hy;
+      return level_base(a[2]) + NP + lbase(a) + 3 * npe + s;
     }
   }
   // face with vertices a, a+S1, a+S1+S2 (axis masks)
@@ -77,17 +84,19 @@ struct Layout
   {
     const int u = S1 | S2;
     if (u == 3)
-      return level_base(a[2]) + offP[4] + (a[1] * nx + a[0]) * 2 + (S1 == 1 ? 0 : 1);
+      return level_base(a[2]) + pbase(a) + 1 + 3 * npe + (S1 == 1 ? 0 : 1);
+    const int hx = a[0] < nx ? 1 : 0, hy = a[1] < ny ? 1 : 0;
+    const int64_t f0 = level_base(a[2]) + NP + lbase(a) + (int64_t)npe * (1 + hx + hy + hx * hy); // after the edges
     if (u == 5)
-      return level_base(a[2]) + NP + offL[4] + (a[1] * nx + a[0]) * 2 + (S1 == 1 ? 0 : 1);
+      return f0 + (S1 == 1 ? 0 : 1);
     if (u == 6)
-      return level_base(a[2]) + NP + offL[5] + (a[1] * PX + a[0]) * 2 + (S1 == 2 ? 0 : 1);
+      return f0 + 2 * hx + (S1 == 2 ? 0 : 1);
     int t;
     if (S1 == 1 || S1 == 2 || S1 == 4)
       t = S1 == 1 ? 0 : (S1 == 2 ? 1 : 2);
     else
       t = 3 + (S2 == 1 ? 0 : (S2 == 2 ? 1 : 2));
-    return level_base(a[2]) + NP + offL[6] + (a[1] * nx + a[0]) * 6 + t;
+    return f0 + 4 + t;
   }
 };
 
