@@ -371,7 +371,9 @@ int comm_halo_begin(zzz_ctx* ctx, double* vec)
     return halo_on_stream(ctx, vec, ctx->stream); // nothing to overlap, same results
   if (!ctx->comm_stream)
   {
-    ZZZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // hi = numerically smallest = most urgent
+    ZZZ_HIP(ctx, hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, prio_hi));
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_x_ready, hipEventDisableTiming));
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_halo_done, hipEventDisableTiming));
   }

@@ -568,7 +568,13 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1);
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   const int64_t n_in = ctx->n_tiles_interior, n_bd = ctx->n_tiles_boundary;
-  const int g_in = n_in ? grid_for_tiles(n_in) : 0, g_bd = n_bd ? grid_for_tiles(n_bd) : 0;
+  // The interior launch leaves one workgroup slot per CU free (7 of 8): at full occupancy the persistent
+  // SpMV workgroups hold every wave slot until the launch ends and RCCL's send/recv kernel, although
+  // enqueued first on a high-priority stream, could not start beside them -- no overlap at all.
+  int g_in = n_in ? grid_for_tiles(n_in) : 0;
+  if (g_in > 256 * 7 && ctx->nneigh > 0)
+    g_in = 256 * 7;
+  const int g_bd = n_bd ? grid_for_tiles(n_bd) : 0;
   if (partials && (size_t)(g_in + g_bd) > ctx->part_a.n)
     return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
   int rc = comm_halo_begin(ctx, x);
