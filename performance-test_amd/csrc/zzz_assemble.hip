@@ -25,6 +25,7 @@ namespace zzz
 {
 constexpr int ASM_BLOCK = 256;
 constexpr int ASM_NNZ = 4096; // LDS: 32 KiB values + 16 KiB columns per workgroup
+constexpr int ASM_ORD_CAP = 512; // block dofs of a tile that the high-order kernel sorts by cell count
 
 struct Geom
 {
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
                                                            const int32_t* __restrict__ adjT_off,
                                                            const int32_t* __restrict__ adjT_cells,
                                                            const uint8_t* __restrict__ adj_li,
+                                                           const int32_t* __restrict__ adj_off,
                                                            const uint8_t* __restrict__ bc,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
@@ -417,11 +419,41 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
     cols_s[k] = cols[s + k];
     vals_s[k] = 0.0;
   }
+  // Block dofs of the tile in order of descending cell count (counting sort in LDS): with the point-major
+  // numbering a tile mixes vertex rows (24 cells) with face rows (2 cells), and a wavefront takes as long as
+  // its heaviest row.  Which lane group computes a row changes nothing in the result.
+  __shared__ int ord_s[ASM_ORD_CAP];
+  __shared__ int hist_s[34];
+  const int nt = d1 - d0;
+  const bool sorted = nt <= ASM_ORD_CAP;
+  if (sorted)
+  {
+    if (threadIdx.x < 34)
+      hist_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += ASM_BLOCK)
+      atomicAdd(&hist_s[32 - min(adj_off[d0 + k + 1] - adj_off[d0 + k], 32)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int acc = 0;
+      for (int b = 0; b < 33; ++b)
+      {
+        const int h = hist_s[b];
+        hist_s[b] = acc;
+        acc += h;
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += ASM_BLOCK)
+      ord_s[atomicAdd(&hist_s[32 - min(adj_off[d0 + k + 1] - adj_off[d0 + k], 32)], 1)] = k;
+  }
   __syncthreads();
   const int lane = (int)threadIdx.x % LPR;
-  for (int r = row0 + (int)threadIdx.x / LPR; r < row1; r += ASM_BLOCK / LPR)
+  for (int q = (int)threadIdx.x / LPR; q < nt * BS; q += ASM_BLOCK / LPR)
   {
-    const int i = r / BS, c = r % BS;
+    const int i = d0 + (sorted ? ord_s[q / BS] : q / BS), c = q % BS;
+    const int r = i * BS + c;
     const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
     const bool bcr = bc[r] != 0;
     constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
@@ -611,8 +643,8 @@ static int launch_matrix_pk(zzz_ctx* ctx)
     ctx->lds_attr_set |= bit;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)xcd_grid(ctx->n_asm_tiles)), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
-                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p,
-                     ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p);
+                     ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->adj_off.p, ctx->bc.p,
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p);
   return ZZZ_OK;
 }
 
