@@ -880,3 +880,42 @@ def test_spmv_lanes_per_row(lpr):
             os.environ.pop("ZZZ_SPMV_LPR", None)
         else:
             os.environ["ZZZ_SPMV_LPR"] = old
+
+
+def test_randomized_small_problems(ctx):
+    """Seeded sweep over odd little boxes (down to ONE sub-cube in a direction), every problem and order:
+    pattern bit-exact, values and right-hand side to 1e-12, Jacobi-CG iteration count and solution against
+    the oracle -- the structured feed, the pattern builder's per-row paths, the packed columns and the tile
+    logic all see shapes the fixed cases do not (rows of 4..500 nonzeros, tiles with a single row, ...)."""
+    zo.set_num_threads(2)
+    rng = np.random.default_rng(20261003)
+    cases = [("poisson", 1, (1, 1, 1)), ("elasticity", 3, (1, 1, 1)), ("poisson", 3, (1, 2, 1)), ("elasticity", 1, (1, 1, 2))]
+    for _ in range(14):
+        problem = ("poisson", "elasticity")[int(rng.integers(2))]
+        order = int(rng.integers(1, 4))
+        hi = 7 if order == 1 else (5 if order == 2 else 4)
+        cases.append((problem, order, tuple(int(v) for v in rng.integers(1, hi, 3))))
+    for problem, order, dims in cases:
+        P = zzz.Part(problem, order, *dims)
+        ctx.upload_part(P)
+        ctx.pattern_build()
+        ctx.assemble_matrix(P.form)
+        ctx.assemble_vector(P.form)
+        rp, cl, v = ctx.csr_download()
+        b = ctx.vec_download(zzz.VEC_B)
+        orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, P.bs)
+        np.testing.assert_array_equal(rp, orp, err_msg=str((problem, order, dims)))
+        np.testing.assert_array_equal(cl, ocl, err_msg=str((problem, order, dims)))
+        bcm = P.bc_marker()
+        ov = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, bcm, orp, ocl)
+        ob = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets if problem == "poisson" else None, bcm)
+        assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max(), (problem, order, dims)
+        assert np.abs(b - ob).max() <= 1e-12 * max(np.abs(ob).max(), 1e-300), (problem, order, dims)
+        xv = rng.standard_normal(rp.shape[0] - 1)
+        lanes = ctx.spmv_lanes_per_row()
+        np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv_chunked(orp, ocl, v, xv, lanes))
+        it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        oit, ou, _, _ = zo.pcg(orp, ocl, v, b, rtol=1e-8)
+        assert abs(it - oit) <= 2, (problem, order, dims, it, oit)
+        if np.linalg.norm(ou) > 0:
+            assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou), (problem, order, dims)
