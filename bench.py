@@ -269,15 +269,35 @@ def main():
             if p2p:
                 (ctx.comm_p2p_enable if use_pm else ctx.comm_p2p_disable)()
                 p2p = use_pm
-    barrier()
-    ctx.sync()
-    t_begin = time.perf_counter()
-    phases = []
-    for _ in range(a.steps):
-        phases.append(step(profile=True))
-    ctx.sync()
-    barrier()
-    elapsed = time.perf_counter() - t_begin
+    def timed_region():
+        """EXACTLY a.steps steps between barrier + device sync on both sides; None if the peer-memory all-reduce
+        failed on some rank (every rank then fails within one round of it and all meet at the closing vote)"""
+        barrier()
+        ctx.sync()
+        t_begin = time.perf_counter()
+        phases, ok = [], 1
+        try:
+            for _ in range(a.steps):
+                phases.append(step(profile=True))
+            ctx.sync()
+        except zzz.ZzzError:
+            if not (p2p and dist is not None):
+                raise
+            ok = 0
+        if p2p and dist is not None:
+            vote = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)  # takes the place of the closing barrier
+            if int(vote.item()) == 0:
+                return None, None
+        else:
+            barrier()
+        return phases, time.perf_counter() - t_begin
+
+    phases, elapsed = timed_region()
+    if phases is None:  # never seen; kept so that a transport problem costs a repeat, not the measurement
+        ctx.comm_p2p_disable()
+        p2p = False
+        phases, elapsed = timed_region()
     if dist is not None:
         import torch
 
