@@ -537,6 +537,13 @@ def test_driver_multi_rank_threads_on_one_gpu():
     assert w.returncode == 0 and "Num processes:   2" in w.stdout, w.stderr
     tot = int(w.stdout.split("Total degrees of freedom:")[1].split()[0])
     assert 15000 < tot < 21000
+    # cgpoisson (matrix-free action + src/cg.h, 100 iterations) partitioned: same norm as on one rank
+    mf = [exe, "--problem_type", "cgpoisson", "--scaling_type", "strong", "--ndofs", "40000", "--order", "2"]
+    m1 = subprocess.run(mf, capture_output=True, text=True, timeout=300)
+    m2 = subprocess.run(mf + ["--ngpus", "2", "--comm", "local"], capture_output=True, text=True, timeout=300)
+    assert m1.returncode == 0 and m2.returncode == 0, m2.stderr
+    (j1, q1), (j2, q2) = parse(m1.stdout), parse(m2.stdout)
+    assert j1 == j2 == 100 and abs(q2 - q1) <= 1e-9 * q1
 
 
 def test_run_to_run_reproducibility(ctx):
