@@ -432,6 +432,30 @@ __global__ __launch_bounds__(1024) void k_reduce_plain(const double* __restrict_
     out[0] = s;
 }
 
+// the polling events of one solve: destroyed on every exit path
+template <int N>
+struct EventRing
+{
+  hipEvent_t ev[N] = {};
+  int created = 0;
+  hipError_t create()
+  {
+    for (; created < N; ++created)
+    {
+      hipError_t e = hipEventCreateWithFlags(&ev[created], hipEventDisableTiming);
+      if (e != hipSuccess)
+        return e;
+    }
+    return hipSuccess;
+  }
+  ~EventRing()
+  {
+    for (int i = 0; i < created; ++i)
+      (void)hipEventDestroy(ev[i]);
+  }
+  hipEvent_t& operator[](int i) { return ev[i]; }
+};
+
 static int vgrid(int64_t n)
 {
   int64_t g = (n + VB - 1) / VB;
@@ -556,9 +580,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 
   // host polling: copy the state every CHECK iterations, look at it NSLOT-1 batches later
   constexpr int CHECK = 8, NSLOT = 4;
-  hipEvent_t chk_ev[NSLOT];
-  for (int i = 0; i < NSLOT; ++i)
-    ZZZ_HIP(ctx, hipEventCreateWithFlags(&chk_ev[i], hipEventDisableTiming));
+  EventRing<NSLOT> chk_ev;
+  ZZZ_HIP(ctx, chk_ev.create());
   int nchk = 0;
   bool stop = false;
 
@@ -618,8 +641,6 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  for (int i = 0; i < NSLOT; ++i)
-    (void)hipEventDestroy(chk_ev[i]);
   if (int rc = comm_p2p_check(ctx))
     return rc;
 
@@ -732,9 +753,8 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
       return rc;
   }
   constexpr int CHECK = 8, NSLOT = 4;
-  hipEvent_t chk_ev[NSLOT];
-  for (int i = 0; i < NSLOT; ++i)
-    ZZZ_HIP(ctx, hipEventCreateWithFlags(&chk_ev[i], hipEventDisableTiming));
+  EventRing<NSLOT> chk_ev;
+  ZZZ_HIP(ctx, chk_ev.create());
   int nchk = 0;
   bool stop = false;
   int it = 0;
@@ -778,8 +798,6 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  for (int i = 0; i < NSLOT; ++i)
-    (void)hipEventDestroy(chk_ev[i]);
   if (int rc = comm_p2p_check(ctx))
     return rc;
   const int its = fin.converged ? fin.iters : max_it;
