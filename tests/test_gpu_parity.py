@@ -621,6 +621,18 @@ def test_bench_contract_line():
         if not extra:
             c = d["cpu_baseline"]
             assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the N > 1 machinery on one GPU (1-rank communicator): mailbox attach, warm-up probe, CG-form tuning
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ndofs", "60000", "--steps", "2", "--warmup", "1",
+                          "--no_cpu_baseline", "--force_comm"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    cfg = d["config"]
+    assert set(cfg["cg_form_tuning_s"]) == {"single_reduction+peer_memory", "classical+peer_memory",
+                                            "single_reduction+ncclAllReduce", "classical+ncclAllReduce"}
+    assert all(v > 0 for v in cfg["cg_form_tuning_s"].values())
+    assert cfg["scalar_allreduce"] in ("ncclAllReduce", "peer-memory mailboxes over xGMI (one kernel: reduce + exchange)")
+    assert ("-ksp_cg_single_reduction" in cfg["workload"]) == min(
+        cfg["cg_form_tuning_s"], key=cfg["cg_form_tuning_s"].get).startswith("single_reduction")
 
 
 @pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (12, 10, 14)), ("poisson", 2, (6, 5, 7)),
