@@ -209,10 +209,10 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
     const dbl2 pi = p2[i];
-    dbl2 xi = x2[i];
+    dbl2 xi = __builtin_nontemporal_load(x2 + i); // x is touched once per iteration: keep the cache for p, z, w
     xi.x = alpha * pi.x + xi.x; // src/cg.h:68, one kernel late
     xi.y = alpha * pi.y + xi.y;
-    x2[i] = xi;
+    __builtin_nontemporal_store(xi, x2 + i);
     if (dir)
     {
       const dbl2 zi = z2[i];
@@ -264,13 +264,13 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
-    const dbl2 wi = w2[i], di = d2[i];
-    dbl2 ri = r2[i], zi;
+    const dbl2 wi = w2[i], di = __builtin_nontemporal_load(d2 + i);
+    dbl2 ri = __builtin_nontemporal_load(r2 + i), zi; // r and D^-1 are touched once per iteration
     ri.x = -alpha * wi.x + ri.x; // src/cg.h:71
     ri.y = -alpha * wi.y + ri.y;
     zi.x = di.x * ri.x;
     zi.y = di.y * ri.y;
-    r2[i] = ri;
+    __builtin_nontemporal_store(ri, r2 + i);
     z2[i] = zi;
     sa += ri.x * zi.x;
     sa += ri.y * zi.y;
