@@ -215,7 +215,7 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
     __builtin_nontemporal_store(xi, x2 + i);
     if (dir)
     {
-      const dbl2 zi = z2[i];
+      const dbl2 zi = __builtin_nontemporal_load(z2 + i); // last use of z
       dbl2 pn;
       pn.x = bcoef * pi.x + zi.x;
       pn.y = bcoef * pi.y + zi.y;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
-    const dbl2 wi = w2[i], di = __builtin_nontemporal_load(d2 + i);
+    const dbl2 wi = __builtin_nontemporal_load(w2 + i) /* last use of w */, di = __builtin_nontemporal_load(d2 + i);
     dbl2 ri = __builtin_nontemporal_load(r2 + i), zi; // r and D^-1 are touched once per iteration
     ri.x = -alpha * wi.x + ri.x; // src/cg.h:71
     ri.y = -alpha * wi.y + ri.y;
