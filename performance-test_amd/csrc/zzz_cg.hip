@@ -380,11 +380,13 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
                      *__restrict__ r2 = reinterpret_cast<dbl2*>(r);
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
-    const dbl2 zi = z2[i], si = s2[i], di = d2[i];
-    dbl2 pn = zi, wn = si, xi = x2[i], ri = r2[i], zn;
+    // cache policy: only z (gathered by the next SpMV) and s (its output) are worth keeping; p, w, x, r, D^-1
+    // are touched by this kernel alone, once per iteration
+    const dbl2 zi = z2[i], si = __builtin_nontemporal_load(s2 + i), di = __builtin_nontemporal_load(d2 + i);
+    dbl2 pn = zi, wn = si, xi = __builtin_nontemporal_load(x2 + i), ri = __builtin_nontemporal_load(r2 + i), zn;
     if (it != 0)
     {
-      const dbl2 po = p2[i], wo = w2[i];
+      const dbl2 po = __builtin_nontemporal_load(p2 + i), wo = __builtin_nontemporal_load(w2 + i);
       pn.x = b * po.x + zi.x;
       pn.y = b * po.y + zi.y;
       wn.x = b * wo.x + si.x;
@@ -396,10 +398,10 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     ri.y = -a * wn.y + ri.y;
     zn.x = di.x * ri.x;
     zn.y = di.y * ri.y;
-    p2[i] = pn;
-    w2[i] = wn;
-    x2[i] = xi;
-    r2[i] = ri;
+    __builtin_nontemporal_store(pn, p2 + i);
+    __builtin_nontemporal_store(wn, w2 + i);
+    __builtin_nontemporal_store(xi, x2 + i);
+    __builtin_nontemporal_store(ri, r2 + i);
     z2[i] = zn;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
