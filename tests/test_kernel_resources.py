@@ -1,0 +1,40 @@
+"""Build-time guard: the CG SpMV kernel owes ~20 % of its speed to running 8 wavefronts per SIMD
+(measured: a change that raised it from 64 to 78 VGPRs took the 10 M-dof SpMV from 0.396 to 0.486 ms), and
+it sits exactly at the 64-VGPR limit of that occupancy.  hipcc cross-compiles without a GPU, so the register
+count of the shipped variants is checked here, where a regression is cheap to see."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_spmv_kernel_keeps_full_occupancy(tmp_path):
+    src = os.path.join(ROOT, "performance-test_amd", "csrc", "zzz_spmv.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I" + os.path.dirname(src),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "performance-test_amd", "host"), "-c", src, "-o",
+           str(tmp_path / "spmv.o"), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # remarks come in blocks: "Function Name: <mangled>" followed by the resource lines of that kernel
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        # spmv_tile_kernel<DOT, NT, PIPE=false, TILE=2048>: the variants the solver launches by default
+        m = re.match(r"_ZN3zzz16spmv_tile_kernelILb([01])ELb([01])ELb0ELi2048EEE", name)
+        if not m:
+            continue
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vgprs <= 64 and occ == 8 and spill == 0, (name, vgprs, occ, spill)
+        assert lds * 8 <= 160 * 1024, (name, lds)  # eight workgroups per CU must fit the 160 KB of LDS
+        seen += 1
+    assert seen == 4
