@@ -873,7 +873,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void matfree_gather(const int32_t* __res
 }
 
 // slice-transposed adjacency with local indices: built once per pattern, read by every row-gather kernel
-int build_adjT(zzz_ctx* ctx)
+// slice offsets of the transposed adjacency and its (unfilled) arrays
+int build_adjT_offsets(zzz_ctx* ctx)
 {
   const int64_t nrows = ctx->n_owned;
   const int64_t nsl = (nrows + 63) / 64;
@@ -908,6 +909,20 @@ int build_adjT(zzz_ctx* ctx)
       return fail(ctx, ZZZ_ERR_LIMIT, "transposed adjacency exceeds int32");
     ZZZ_HIP(ctx, ctx->adjT_cells.alloc((size_t)total + 64));
     ZZZ_HIP(ctx, ctx->adj_li.alloc((size_t)total + 64));
+  }
+  return ZZZ_OK;
+}
+
+int build_adjT(zzz_ctx* ctx)
+{
+  if (ctx->have_adj_li) // the P1 pattern kernel has written it already
+    return ZZZ_OK;
+  int rc = build_adjT_offsets(ctx);
+  if (rc)
+    return rc;
+  const int64_t nrows = ctx->n_owned;
+  const int64_t nsl = (nrows + 63) / 64;
+  {
     int g1 = (int)((nsl + 3) / 4);
     if (g1 > 8192)
       g1 = 8192;

@@ -201,6 +201,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback);
 int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
 int asm_tile_nnz();
 int build_adjT(zzz_ctx* ctx);
+int build_adjT_offsets(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);
 // kernels_spmv
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>

@@ -138,19 +138,37 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
 // 10 M rows.  Same outputs: cnt[r], the sorted unique columns at stage[adj_off[r]*4 ...], the maximum count.
 // A row with more than ROW_T_CAP unique columns raises `overflow` and the caller uses the wavefront kernel.
 constexpr int ROW_T_BLOCK = 128, ROW_T_CAP = 64;
+// The kernel has every (row, cell, local index) triple in hand, so it also writes the transposed adjacency of
+// the assembly kernels (zzz_assemble.hip: entry a of row 64 s + lane at adjT_off[s] + 64 a + lane), which
+// saves the separate gather pass (k_adjT_fill, 3.7 ms at 10 M rows).
 __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32_t* __restrict__ cell_dofs,
                                                                      const int32_t* __restrict__ adj_off,
                                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
                                                                      int32_t* __restrict__ cnt, int32_t* __restrict__ maxcnt,
                                                                      int32_t* __restrict__ overflow,
-                                                                     int32_t* __restrict__ stage)
+                                                                     int32_t* __restrict__ stage,
+                                                                     const int32_t* __restrict__ adjT_off,
+                                                                     int32_t* __restrict__ cellT, uint8_t* __restrict__ liT)
 {
   __shared__ int32_t u[ROW_T_CAP * ROW_T_BLOCK];
   int32_t* mine = u + threadIdx.x;
   int wmax = 0;
   bool over = false;
-  for (int64_t r = blockIdx.x * (int64_t)ROW_T_BLOCK + threadIdx.x; r < nb; r += (int64_t)gridDim.x * ROW_T_BLOCK)
+  const int64_t nb64 = ((int64_t)nb + 63) / 64 * 64; // the last slice is padded to 64 rows
+  for (int64_t r = blockIdx.x * (int64_t)ROW_T_BLOCK + threadIdx.x; r < nb64; r += (int64_t)gridDim.x * ROW_T_BLOCK)
   {
+    const int to = adjT_off[r >> 6], tlen = (adjT_off[(r >> 6) + 1] - to) >> 6;
+    int32_t* ct = cellT + to + (r & 63);
+    uint8_t* lt = liT + to + (r & 63);
+    if (r >= nb)
+    {
+      for (int a = 0; a < tlen; ++a)
+      {
+        ct[a * 64] = -1;
+        lt[a * 64] = 0;
+      }
+      continue;
+    }
     const int a0 = adj_off[r], na = adj_off[r + 1] - a0;
     int m = 0;
     // eight cells at a time: their indices, then their dof quadruples, are in flight together (two memory
@@ -171,6 +189,8 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
         if (ab + q >= na)
           break;
         const int32_t v4[4] = {d[q].x, d[q].y, d[q].z, d[q].w};
+        ct[(ab + q) * 64] = cell[q];
+        lt[(ab + q) * 64] = (uint8_t)(v4[1] == (int32_t)r ? 1 : (v4[2] == (int32_t)r ? 2 : (v4[3] == (int32_t)r ? 3 : 0)));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
@@ -196,6 +216,11 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
     }
     if (over)
       break;
+    for (int a = na; a < tlen; ++a)
+    {
+      ct[a * 64] = -1;
+      lt[a * 64] = 0;
+    }
     cnt[r] = m;
     int32_t* out = stage + 4 * (int64_t)a0;
     for (int k = 0; k < m; ++k)
@@ -531,11 +556,16 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   if (nd == 4 && stage && !getenv("ZZZ_PATTERN_WAVE"))
   {
     // P1: one thread per row; scal[2] = "a row has more than ROW_T_CAP unique columns"
+    int rc = build_adjT_offsets(ctx);
+    if (rc)
+      return rc;
     hipLaunchKernelGGL(k_row_pattern_thread4, dim3(grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 5)), dim3(ROW_T_BLOCK), 0, s,
-                       ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage);
+                       ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage,
+                       ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
     ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
     counted = h[2] == 0;
+    ctx->have_adj_li = counted; // complete only if no row overflowed
     if (!counted)
       ZZZ_HIP(ctx, hipMemsetAsync(scal.p, 0, 4 * sizeof(int32_t), s));
   }
