@@ -132,15 +132,18 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
 }
 
 // P1 (4 dofs per cell, rows of ~15 unique columns out of ~100 candidates): one THREAD per block row keeps its
-// sorted unique columns in a private LDS column (u[k][thread]: conflict-free) and inserts the candidates as
-// they come -- they arrive nearly ascending, so an insertion moves a few entries.  A wavefront per row
-// (k_row_pattern) spends 28 bitonic stages on 128 keys with most lanes idle: 13.9 ms against ~3 ms here at
-// 10 M rows.  Same outputs: cnt[r], the sorted unique columns at stage[adj_off[r]*4 ...], the maximum count.
-// A row with more than ROW_T_CAP unique columns raises `overflow` and the caller uses the wavefront kernel.
-constexpr int ROW_T_BLOCK = 128, ROW_T_CAP = 64;
-// The kernel has every (row, cell, local index) triple in hand, so it also writes the transposed adjacency of
-// the assembly kernels (zzz_assemble.hip: entry a of row 64 s + lane at adjT_off[s] + 64 a + lane), which
-// saves the separate gather pass (k_adjT_fill, 3.7 ms at 10 M rows).
+// sorted unique columns in a private LDS column (u[k][thread], stride 129: conflict-free both for the owner
+// and for the transposed read-out) and inserts the candidates as they come -- they arrive nearly ascending, so
+// an insertion moves a few entries.  A wavefront per row (k_row_pattern) spends 28 bitonic stages on 128 keys
+// with most lanes idle.  Everything that is row-major in memory moves through LDS so that the global accesses
+// are dense: the block's slice of adj_cells is loaded cooperatively, and the unique columns are written out one
+// row per wavefront instruction (contiguous), not one row per lane.  Same outputs as k_row_pattern<false>:
+// cnt[r], the sorted unique columns at stage[adj_off[r]*4 ...], the maximum count.  The kernel has every
+// (row, cell, local index) triple in hand, so it also writes the transposed adjacency of the assembly kernels
+// (zzz_assemble.hip: entry a of row 64 s + lane at adjT_off[s] + 64 a + lane), which saves a separate gather pass.
+// A row with more than ROW_T_CAP unique columns or a block with more than ROW_T_ADJ adjacency entries raises
+// `overflow` and the caller uses the wavefront kernel.
+constexpr int ROW_T_BLOCK = 128, ROW_T_CAP = 32, ROW_T_LD = ROW_T_BLOCK + 1, ROW_T_ADJ = 4096;
 __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32_t* __restrict__ cell_dofs,
                                                                      const int32_t* __restrict__ adj_off,
                                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
@@ -150,89 +153,111 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
                                                                      const int32_t* __restrict__ adjT_off,
                                                                      int32_t* __restrict__ cellT, uint8_t* __restrict__ liT)
 {
-  __shared__ int32_t u[ROW_T_CAP * ROW_T_BLOCK];
+  __shared__ int32_t u[ROW_T_CAP * ROW_T_LD];
+  __shared__ int32_t adj_s[ROW_T_ADJ];
+  __shared__ int32_t a0_s[ROW_T_BLOCK], m_s[ROW_T_BLOCK];
   int32_t* mine = u + threadIdx.x;
   int wmax = 0;
-  bool over = false;
-  const int64_t nb64 = ((int64_t)nb + 63) / 64 * 64; // the last slice is padded to 64 rows
-  for (int64_t r = blockIdx.x * (int64_t)ROW_T_BLOCK + threadIdx.x; r < nb64; r += (int64_t)gridDim.x * ROW_T_BLOCK)
+  const int64_t nblk = ((int64_t)nb + ROW_T_BLOCK - 1) / ROW_T_BLOCK; // nb64 <= nblk * ROW_T_BLOCK
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x)
   {
-    const int to = adjT_off[r >> 6], tlen = (adjT_off[(r >> 6) + 1] - to) >> 6;
-    int32_t* ct = cellT + to + (r & 63);
-    uint8_t* lt = liT + to + (r & 63);
-    if (r >= nb)
+    const int64_t rbase = blk * ROW_T_BLOCK, r = rbase + threadIdx.x;
+    const int64_t rend = min((int64_t)nb, rbase + ROW_T_BLOCK);
+    const int ab0 = adj_off[rbase], nadj = adj_off[rend] - ab0;
+    if (nadj > ROW_T_ADJ) // uniform over the block
     {
-      for (int a = 0; a < tlen; ++a)
+      if (threadIdx.x == 0)
+        atomicMax(overflow, 1);
+      continue;
+    }
+    for (int k = threadIdx.x; k < nadj; k += ROW_T_BLOCK)
+      adj_s[k] = adj_cells[ab0 + k];
+    __syncthreads();
+    int m = 0, a0 = 0;
+    bool over = false;
+    const bool padrow = r >= nb && r < ((int64_t)nb + 63) / 64 * 64; // the last slice is padded to 64 rows
+    if (r < nb || padrow)
+    {
+      const int to = adjT_off[r >> 6], tlen = (adjT_off[(r >> 6) + 1] - to) >> 6;
+      int32_t* ct = cellT + to + (r & 63);
+      uint8_t* lt = liT + to + (r & 63);
+      int na = 0;
+      if (r < nb)
+      {
+        a0 = adj_off[r];
+        na = adj_off[r + 1] - a0;
+        const int32_t* myadj = adj_s + (a0 - ab0);
+        // eight cells at a time: their dof quadruples are in flight together
+        for (int ab = 0; ab < na && !over; ab += 8)
+        {
+          int32_t cell[8];
+          int4 d[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            cell[q] = myadj[min(ab + q, na - 1)];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            d[q] = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell[q]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+          {
+            if (ab + q >= na)
+              break;
+            const int32_t v4[4] = {d[q].x, d[q].y, d[q].z, d[q].w};
+            ct[(ab + q) * 64] = cell[q];
+            lt[(ab + q) * 64] = (uint8_t)(v4[1] == (int32_t)r ? 1 : (v4[2] == (int32_t)r ? 2 : (v4[3] == (int32_t)r ? 3 : 0)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+              const int32_t v = v4[j];
+              int k = m;
+              while (k > 0 && mine[(k - 1) * ROW_T_LD] > v)
+                --k;
+              if (k > 0 && mine[(k - 1) * ROW_T_LD] == v)
+                continue;
+              if (m == ROW_T_CAP)
+              {
+                over = true;
+                break;
+              }
+              for (int qq = m; qq > k; --qq)
+                mine[qq * ROW_T_LD] = mine[(qq - 1) * ROW_T_LD];
+              mine[k * ROW_T_LD] = v;
+              ++m;
+            }
+            if (over)
+              break;
+          }
+        }
+      }
+      for (int a = na; a < tlen; ++a)
       {
         ct[a * 64] = -1;
         lt[a * 64] = 0;
       }
-      continue;
-    }
-    const int a0 = adj_off[r], na = adj_off[r + 1] - a0;
-    int m = 0;
-    // eight cells at a time: their indices, then their dof quadruples, are in flight together (two memory
-    // latencies per batch instead of two per cell)
-    for (int ab = 0; ab < na && !over; ab += 8)
-    {
-      int32_t cell[8];
-      int4 d[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        cell[q] = adj_cells[a0 + min(ab + q, na - 1)];
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        d[q] = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell[q]);
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-      {
-        if (ab + q >= na)
-          break;
-        const int32_t v4[4] = {d[q].x, d[q].y, d[q].z, d[q].w};
-        ct[(ab + q) * 64] = cell[q];
-        lt[(ab + q) * 64] = (uint8_t)(v4[1] == (int32_t)r ? 1 : (v4[2] == (int32_t)r ? 2 : (v4[3] == (int32_t)r ? 3 : 0)));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-          const int32_t v = v4[j];
-          int k = m;
-          while (k > 0 && mine[(k - 1) * ROW_T_BLOCK] > v)
-            --k;
-          if (k > 0 && mine[(k - 1) * ROW_T_BLOCK] == v)
-            continue;
-          if (m == ROW_T_CAP)
-          {
-            over = true;
-            break;
-          }
-          for (int qq = m; qq > k; --qq)
-            mine[qq * ROW_T_BLOCK] = mine[(qq - 1) * ROW_T_BLOCK];
-          mine[k * ROW_T_BLOCK] = v;
-          ++m;
-        }
-        if (over)
-          break;
-      }
+      if (r < nb && !over)
+        cnt[r] = m;
     }
     if (over)
-      break;
-    for (int a = na; a < tlen; ++a)
-    {
-      ct[a * 64] = -1;
-      lt[a * 64] = 0;
-    }
-    cnt[r] = m;
-    int32_t* out = stage + 4 * (int64_t)a0;
-    for (int k = 0; k < m; ++k)
-      out[k] = mine[k * ROW_T_BLOCK];
+      atomicMax(overflow, 1);
+    a0_s[threadIdx.x] = a0;
+    m_s[threadIdx.x] = (r < nb && !over) ? m : 0;
     wmax = max(wmax, m);
+    __syncthreads();
+    // read-out: one row per wavefront instruction, lanes = entries (contiguous in `stage`)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wv * 64; t < wv * 64 + 64; ++t)
+    {
+      const int mt = m_s[t];
+      if (lane < mt)
+        stage[4 * (int64_t)a0_s[t] + lane] = u[lane * ROW_T_LD + t];
+    }
+    __syncthreads();
   }
   for (int o = 32; o; o >>= 1)
     wmax = max(wmax, __shfl_xor(wmax, o));
   if ((threadIdx.x & 63) == 0 && wmax > 0)
     atomicMax(maxcnt, wmax);
-  if (over)
-    atomicMax(overflow, 1);
 }
 
 // fill pass when the count pass staged the sorted unique columns: expand block (r, col) to bs x bs
@@ -559,7 +584,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     int rc = build_adjT_offsets(ctx);
     if (rc)
       return rc;
-    hipLaunchKernelGGL(k_row_pattern_thread4, dim3(grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 5)), dim3(ROW_T_BLOCK), 0, s,
+    hipLaunchKernelGGL(k_row_pattern_thread4, dim3(grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 4)), dim3(ROW_T_BLOCK), 0, s,
                        ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage,
                        ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
     ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
