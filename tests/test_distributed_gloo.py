@@ -94,7 +94,33 @@ def _worker(rank, world, port, problem, order, dims, q):
         beta, zz = allsum(r @ z, z @ z)
         dp = np.sqrt(zz)
         it += 1
-    q.put((rank, it, P.own_offset, x))
+    # the same solve in the single-reduction form (KSPCGUseSingleReduction, as zo_pcg_sr): s = A z beside z,
+    # w = s + b w, <p,w> by recurrence -- ONE all-reduce of three scalars per iteration, the form the N > 1
+    # bench may select
+    xs = np.zeros(no)
+    r = b[:no].copy()
+    zf = np.zeros(P.nloc * bs)
+    zf[:no] = r / diag
+    s = matvec(zf)
+    beta, zz, delta = allsum(r @ zf[:no], zf[:no] @ zf[:no], zf[:no] @ s)
+    dp = np.sqrt(zz)
+    ttol = max(1e-8 * dp, 1e-50)
+    p, w = np.zeros(no), np.zeros(no)
+    its, betaold, dpi = 0, 1.0, 0.0
+    while its < 10000 and dp > ttol:
+        bb = 0.0 if its == 0 else beta / betaold
+        p, w = zf[:no] + bb * p, s + bb * w
+        dpi = delta if its == 0 else delta - beta * beta * dpi / (betaold * betaold)
+        betaold = beta
+        a = beta / dpi
+        xs += a * p
+        r -= a * w
+        zf[:no] = r / diag
+        s = matvec(zf)
+        beta, zz, delta = allsum(r @ zf[:no], zf[:no] @ zf[:no], zf[:no] @ s)
+        dp = np.sqrt(zz)
+        its += 1
+    q.put((rank, it, P.own_offset, x, its, xs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -130,6 +156,11 @@ def test_two_rank_pcg_matches_serial_oracle(problem, order, dims):
     assert res[0][2] == 0 and res[1][2] * G.bs == res[0][3].size
     assert abs(res[0][1] - it) <= 2 and res[0][1] == res[1][1]
     assert np.linalg.norm(ug - u) <= 1e-7 * np.linalg.norm(u)
+    # single-reduction form, partitioned, against its serial oracle restatement
+    its, us, _, _ = zo.pcg_single_reduction(rp, cl, v, b, rtol=1e-8)
+    ugs = np.concatenate([r[5] for r in res])
+    assert abs(res[0][4] - its) <= 2 and res[0][4] == res[1][4]
+    assert np.linalg.norm(ugs - us) <= 1e-7 * np.linalg.norm(us)
 
 
 def test_bench_launch_plumbing_under_torchrun():
