@@ -208,6 +208,47 @@ static int local_allreduce(zzz_ctx* ctx, double* dev, int n)
   return ZZZ_OK;
 }
 
+// val[j] = sum of partial array j (j < nv <= 3) in ONE pass and one barrier pair: every thread strides over the
+// arrays, the wavefronts combine with shuffles, wavefront 0 adds the per-wavefront sums in order (fixed tree).
+// On return val[] is valid in every thread.
+__device__ inline void reduce3(const double* __restrict__ pa, const double* __restrict__ pb, const double* __restrict__ pc,
+                               int np, int nv, double* val /* shared, 3 */)
+{
+  __shared__ double part[3][16];
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x)
+  {
+    s0 += pa[i];
+    if (nv > 1)
+      s1 += pb[i];
+    if (nv > 2)
+      s2 += pc[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    s0 += __shfl_down(s0, o, 64);
+    s1 += __shfl_down(s1, o, 64);
+    s2 += __shfl_down(s2, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0)
+  {
+    part[0][wv] = s0;
+    part[1][wv] = s1;
+    part[2][wv] = s2;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nv)
+  {
+    double t = 0;
+    for (int w = 0; w < nw; ++w)
+      t += part[threadIdx.x][w];
+    val[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
 // one workgroup: out[j] = sum over ranks of (sum of partial array j), j < nv <= 3
 __global__ __launch_bounds__(1024) void k_allreduce_p2p(const int* __restrict__ stop, const double* __restrict__ pa,
                                                         const double* __restrict__ pb, const double* __restrict__ pc,
@@ -217,22 +258,11 @@ __global__ __launch_bounds__(1024) void k_allreduce_p2p(const int* __restrict__ 
 {
   if (stop && *stop) // CG already converged (the same on every rank: identical scalars everywhere)
     return;
-  __shared__ double sh[16];
   __shared__ double val[3];
   __shared__ int timed_out;
-  const double* parts[3] = {pa, pb, pc};
   if (threadIdx.x == 0)
     timed_out = 0;
-  for (int j = 0; j < nv; ++j)
-  {
-    double s = 0;
-    for (int i = threadIdx.x; i < np; i += blockDim.x)
-      s += parts[j][i];
-    const double t = block_reduce_sum(s, sh);
-    if (threadIdx.x == 0)
-      val[j] = t;
-    __syncthreads();
-  }
+  reduce3(pa, pb, pc, np, nv, val);
   const int par = (int)(seq & 1);
   if ((int)threadIdx.x < nranks)
   {
@@ -280,18 +310,10 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const int* __restrict_
 {
   if (stop && *stop)
     return;
-  __shared__ double sh[16];
-  const double* parts[3] = {pa, pb, pc};
-  for (int j = 0; j < nv; ++j)
-  {
-    double s = 0;
-    for (int i = threadIdx.x; i < np; i += blockDim.x)
-      s += parts[j][i];
-    const double t = block_reduce_sum(s, sh);
-    if (threadIdx.x == 0)
-      out[j] = t;
-    __syncthreads();
-  }
+  __shared__ double val[3];
+  reduce3(pa, pb, pc, np, nv, val);
+  if ((int)threadIdx.x < nv)
+    out[threadIdx.x] = val[threadIdx.x];
 }
 
 bool comm_p2p_enabled(const zzz_ctx* ctx) { return ctx->comm && ctx->comm->p2p && ctx->comm->p2p->enabled; }
@@ -306,12 +328,12 @@ int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const
   {
     P2P* P = ctx->comm->p2p;
     const long long seq = ++P->seq;
-    hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(1024), 0, s, stop, pa, pb, pc, np, nv, out, P->peer_dev.p, P->box,
+    hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(512), 0, s, stop, pa, pb, pc, np, nv, out, P->peer_dev.p, P->box,
                        P->nranks, P->rank, seq, P->fail.p, P2P_TIMEOUT_TICKS);
     ZZZ_HIP(ctx, hipGetLastError());
     return ZZZ_OK;
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, stop, pa, pb, pc, np, nv, out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(512), 0, s, stop, pa, pb, pc, np, nv, out);
   ZZZ_HIP(ctx, hipGetLastError());
   return comm_allreduce_sum(ctx, out, nv);
 }
