@@ -938,3 +938,38 @@ def test_randomized_small_problems(ctx):
         assert abs(it - oit) <= 2, (problem, order, dims, it, oit)
         if np.linalg.norm(ou) > 0:
             assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou), (problem, order, dims)
+
+
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (60, 58, 62)), ("poisson", 2, (30, 29, 31)),
+                                                ("poisson", 3, (20, 19, 21)), ("elasticity", 1, (40, 39, 41)),
+                                                ("poisson", 1, (125, 124, 127))])
+def test_medium_sizes_against_oracle(ctx, problem, order, dims):
+    """~200 k dofs per case (2 M for the last), fed by the DEVICE generator on the GPU side and by the host generator on the
+    oracle side: thousands of SpMV / assembly tiles, several pattern slices per workgroup, hundreds of CG
+    iterations -- index arithmetic that the small cases cannot reach, still seconds for the oracle."""
+    zo.set_num_threads(8)
+    try:
+        P = zzz.Part(problem, order, *dims)
+        info = ctx.cube_generate(problem, order, *dims, 1, 0)
+        assert int(info[0]) == P.global_dofs_total and int(info[1]) == P.global_cells
+        ctx.pattern_build()
+        ctx.assemble_matrix(P.form)
+        ctx.assemble_vector(P.form)
+        rp, cl, v = ctx.csr_download()
+        b = ctx.vec_download(zzz.VEC_B)
+        orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, P.bs)
+        np.testing.assert_array_equal(rp, orp)
+        np.testing.assert_array_equal(cl, ocl)
+        bcm = P.bc_marker()
+        ov = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, bcm, orp, ocl)
+        ob = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets if problem == "poisson" else None, bcm)
+        assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+        assert np.abs(b - ob).max() <= 1e-12 * np.abs(ob).max()
+        xv = np.random.default_rng(order).standard_normal(rp.shape[0] - 1)
+        np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv_chunked(orp, ocl, v, xv, ctx.spmv_lanes_per_row()))
+        it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        oit, ou, _, _ = zo.pcg(orp, ocl, v, b, rtol=1e-8)
+        assert abs(it - oit) <= 2, (it, oit)
+        assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        zo.set_num_threads(1)
