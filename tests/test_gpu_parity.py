@@ -973,3 +973,42 @@ def test_medium_sizes_against_oracle(ctx, problem, order, dims):
         assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
     finally:
         zo.set_num_threads(1)
+
+
+def test_full_size_baseline_config_against_oracle():
+    """BASELINE configs[1] at FULL size, compared directly (not through properties): the 10 016 937-dof problem
+    is generated on the device for the GPU and by the C++ host feed for the oracle; sparsity pattern bit-exact
+    (149 140 873 column indices), matrix values and right-hand side to 1e-12, SpMV bit-exact, and the 975-iteration
+    Jacobi-CG solve against the oracle's (iteration count +-2, solution 1e-6).  About a minute of host time."""
+    import os as _os
+
+    zo.set_num_threads(min(32, _os.cpu_count() or 1))
+    try:
+        nx, ny, nz, r = zzz.mesh_size(10000000, True, 1, 1, 1)
+        dims = (nx << r, ny << r, nz << r)
+        P = zzz.Part("poisson", 1, *dims)
+        with zzz.Context(0) as c:
+            c.cube_generate("poisson", 1, *dims, 1, 0)
+            c.pattern_build()
+            c.assemble_matrix(zzz.FORM_POISSON)
+            c.assemble_vector(zzz.FORM_POISSON)
+            rp, cl, v = c.csr_download()
+            b = c.vec_download(zzz.VEC_B)
+            orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, 1)
+            assert np.array_equal(rp, orp) and np.array_equal(cl, ocl)
+            bcm = P.bc_marker()
+            ov = zo.assemble_matrix(P.form, 1, P.x, P.cells, P.cell_dofs, bcm, orp, ocl)
+            assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+            del ov
+            ob = zo.assemble_vector(P.form, 1, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets, bcm)
+            assert np.abs(b - ob).max() <= 1e-12 * np.abs(ob).max()
+            xv = np.random.default_rng(1).standard_normal(rp.shape[0] - 1)
+            assert np.array_equal(c.spmv(xv), zo.spmv(orp, ocl, v, xv))
+            it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+            u = c.vec_download(zzz.VEC_U)
+        oit, ou, orn, or0 = zo.pcg(orp, ocl, v, b, rtol=1e-8)
+        assert abs(it - oit) <= 2 and abs(oit - 975) <= 2, (it, oit)
+        assert abs(r0 - or0) <= 1e-12 * or0
+        assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        zo.set_num_threads(1)
