@@ -1012,3 +1012,43 @@ def test_full_size_baseline_config_against_oracle():
         assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
     finally:
         zo.set_num_threads(1)
+
+
+@pytest.mark.parametrize("name,problem,order,ndofs,strong,nproc", [("C4 elasticity P1 weak 8 x 500 k: total size on one GPU", "elasticity", 1, 500000, False, 8),
+                                                                   ("C5 Poisson P3 50 M over 8 GPUs: per-GPU size", "poisson", 3, 6250000, True, 1)])
+def test_other_baseline_configs_against_oracle(name, problem, order, ndofs, strong, nproc):
+    """The other BASELINE configs at the largest size one GPU holds, against the oracle directly: pattern
+    bit-exact, values / right-hand side 1e-12, SpMV bit-exact; the solve is checked through its TRUE residual
+    (an oracle solve of these sizes would take minutes of host time)."""
+    import os as _os
+
+    zo.set_num_threads(min(32, _os.cpu_count() or 1))
+    try:
+        bs = 3 if problem == "elasticity" else 1
+        nx, ny, nz, r = zzz.mesh_size(ndofs, strong, nproc, bs, order)
+        dims = (nx << r, ny << r, nz << r)
+        P = zzz.Part(problem, order, *dims)
+        with zzz.Context(0) as c:
+            info = c.cube_generate(problem, order, *dims, 1, 0)
+            assert int(info[0]) == P.global_dofs_total
+            c.pattern_build()
+            c.assemble_matrix(P.form)
+            c.assemble_vector(P.form)
+            rp, cl, v = c.csr_download()
+            b = c.vec_download(zzz.VEC_B)
+            orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, bs)
+            assert np.array_equal(rp, orp) and np.array_equal(cl, ocl)
+            bcm = P.bc_marker()
+            ov = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, bcm, orp, ocl)
+            assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+            del ov
+            ob = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets if bs == 1 else None, bcm)
+            assert np.abs(b - ob).max() <= 1e-12 * np.abs(ob).max()
+            xv = np.random.default_rng(2).standard_normal(rp.shape[0] - 1)
+            assert np.array_equal(c.spmv(xv), zo.spmv_chunked(orp, ocl, v, xv, c.spmv_lanes_per_row()))
+            it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, norm=zzz.NORM_UNPRECONDITIONED, rtol=1e-8)
+            u = c.vec_download(zzz.VEC_U)
+            res = b - zo.spmv(orp, ocl, v, u)
+            assert np.linalg.norm(res) <= 1.05e-8 * np.linalg.norm(b) and 0 < it < 10000
+    finally:
+        zo.set_num_threads(1)
