@@ -1052,3 +1052,24 @@ def test_other_baseline_configs_against_oracle(name, problem, order, ndofs, stro
             assert np.linalg.norm(res) <= 1.05e-8 * np.linalg.norm(b) and 0 < it < 10000
     finally:
         zo.set_num_threads(1)
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_full_size_partitioned_runs_on_one_gpu(nranks):
+    """The exact partitions of the 2/4/8-GPU strong-scaling runs of BASELINE configs[1] (10 016 937 dofs), with
+    every rank's context on THIS GPU and the host-mediated communicator in place of RCCL: z-slab feeds generated
+    on the device at their real sizes, ghost layers, halo plans, interior/boundary tile splits, all-reduced
+    scalars.  Both CG forms must reproduce the single-GPU solve: 975 iterations, |u| = 673.434."""
+    import subprocess
+
+    exe = os.path.join(zzz.PKG, "dolfinx-scaling-test")
+    base = [exe, "--problem_type", "poisson", "--scaling_type", "strong", "--ndofs", "10000000", "--ngpus", str(nranks),
+            "--comm", "local", "--allreduce", "comm", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-8"]
+    for extra in ([], ["-ksp_cg_single_reduction"]):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert f"Num processes:   {nranks}" in out.stdout
+        its = int(out.stdout.split("*** Number of Krylov iterations: ")[1].split()[0])
+        nrm = float(out.stdout.split("*** Solution norm:  ")[1].split()[0])
+        assert abs(its - 975) <= 2 and abs(nrm - 673.434) < 2e-3, (its, nrm)
+        assert int(out.stdout.split("Total degrees of freedom:")[1].split()[0]) == 10016937
