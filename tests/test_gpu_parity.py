@@ -1073,3 +1073,24 @@ def test_full_size_partitioned_runs_on_one_gpu(nranks):
         nrm = float(out.stdout.split("*** Solution norm:  ")[1].split()[0])
         assert abs(its - 975) <= 2 and abs(nrm - 673.434) < 2e-3, (its, nrm)
         assert int(out.stdout.split("Total degrees of freedom:")[1].split()[0]) == 10016937
+
+
+@pytest.mark.parametrize("args,dofs,its,norm", [
+    (["--problem_type", "elasticity", "--scaling_type", "weak", "--ndofs", "500000"], 3993000, 1881, 0.000426088),
+    (["--problem_type", "poisson", "--order", "3", "--scaling_type", "strong", "--ndofs", "50000000"], 49834930, 2304, 1502.04)],
+    ids=["C4-elasticity-P1-weak-8x500k", "C5-poisson-P3-50M"])
+def test_baseline_multi_gpu_configs_partitioned_on_one_gpu(args, dofs, its, norm):
+    """BASELINE configs[3] and configs[4] in their exact 8-way partitions, all eight contexts on THIS GPU with the
+    host-mediated communicator: global sizes of SURVEY.md section 8, and the iteration count / solution norm the
+    un-partitioned solve of the same system gives (C4: 1881 / 4.26088e-4 from the single-context run of the same
+    3.99 M-dof problem; C5's 2.4 G nonzeros exceed one context, its values are the recorded ones of this run)."""
+    import subprocess
+
+    exe = os.path.join(zzz.PKG, "dolfinx-scaling-test")
+    out = subprocess.run([exe] + args + ["--ngpus", "8", "--comm", "local", "--allreduce", "comm", "-ksp_type", "cg", "-pc_type",
+                                         "jacobi", "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert int(out.stdout.split("Total degrees of freedom:")[1].split()[0]) == dofs
+    got_its = int(out.stdout.split("*** Number of Krylov iterations: ")[1].split()[0])
+    got_norm = float(out.stdout.split("*** Solution norm:  ")[1].split()[0])
+    assert abs(got_its - its) <= 3 and abs(got_norm - norm) <= 2e-5 * norm, (got_its, got_norm)
