@@ -143,8 +143,10 @@ def main():
     # other.  torch is used for gloo plumbing only and never touches the GPU in this process.
     zzz.hip()
     uid_bytes = None
+    if world > 1 or a.force_comm:
+        zzz.comm_load()  # EVERY rank binds /opt/rocm's librccl.so.1 before torch's bundled copy can be loaded
     if world > 1 and rank == 0:
-        uid_bytes = zzz.comm_unique_id()  # ncclGetUniqueId (dlopens librccl.so.1)
+        uid_bytes = zzz.comm_unique_id()  # ncclGetUniqueId
     dist = None
     if world > 1:
         import torch

@@ -244,6 +244,12 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
 
 #define ZZZ_UNIQUE_ID_BYTES 128
 
+/* dlopen librccl.so.1 now (it is otherwise loaded by the first zzz_comm_* call).  For processes that also
+ * hold another copy of RCCL -- a Python process that imports torch, which bundles its own -- so that every
+ * rank binds the SAME library: call it on every rank before that other copy is loaded.  No reference
+ * counterpart (MPI_Init, src/main.cpp:42 [EXT], is the closest). */
+int zzz_comm_load(void);
+
 /* ncclGetUniqueId on the root; ship the bytes to the other ranks out of band (the driver's
  * threads share memory; bench.py broadcasts them).  Replaces MPI_COMM_WORLD bootstrap. */
 int zzz_comm_unique_id(void* id /* ZZZ_UNIQUE_ID_BYTES */);

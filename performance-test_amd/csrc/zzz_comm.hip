@@ -512,6 +512,13 @@ using namespace zzz;
 
 extern "C" {
 
+int zzz_comm_load(void)
+{
+  if (const char* e = load_rccl())
+    return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, dlerror() ? dlerror() : "");
+  return ZZZ_OK;
+}
+
 int zzz_comm_unique_id(void* id)
 {
   if (!id)

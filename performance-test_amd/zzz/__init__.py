@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_spmv_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_profile_get", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
@@ -425,6 +425,13 @@ class Context:
 
 
 P2P_HANDLE_BYTES = 128
+
+
+def comm_load():
+    """bind /opt/rocm's librccl now (before anything else in the process brings its own copy)"""
+    rc = hip().zzz_comm_load()
+    if rc:
+        raise ZzzError(rc, hip().zzz_last_error(None).decode())
 
 
 def comm_unique_id():
