@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none"])
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--force_dist", action="store_true",
+                    help="N=1 only: take the whole N > 1 code path (gloo process group, unique-id broadcast, 1-rank RCCL "
+                         "communicator, mailbox handle all_gather, warm-up vote, tuning) -- what a 1-GPU box can run of it")
     ap.add_argument("--force_comm", action="store_true",
                     help="N=1 only: attach a 1-rank RCCL communicator to time the multi-GPU code path's fixed costs")
     ap.add_argument("--cg", default="auto", choices=["auto", "classical", "single_reduction"],
@@ -143,12 +146,13 @@ def main():
     # other.  torch is used for gloo plumbing only and never touches the GPU in this process.
     zzz.hip()
     uid_bytes = None
-    if world > 1 or a.force_comm:
+    multi = world > 1 or a.force_dist
+    if multi or a.force_comm:
         zzz.comm_load()  # EVERY rank binds /opt/rocm's librccl.so.1 before torch's bundled copy can be loaded
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         uid_bytes = zzz.comm_unique_id()  # ncclGetUniqueId
     dist = None
-    if world > 1:
+    if multi:
         import torch
         import torch.distributed as dist
 
@@ -165,10 +169,10 @@ def main():
     form = zzz.FORM_ELASTICITY if a.problem_type == "elasticity" else zzz.FORM_POISSON
     # host feed (C++ generator + upload) only when the CPU baseline needs the host arrays; otherwise the
     # feed is generated on the device (zzz_cube_generate) -- identical problem, no PCIe traffic
-    need_host_arrays = world == 1 and not a.no_cpu_baseline
+    need_host_arrays = not multi and not a.no_cpu_baseline
     P = zzz.Part(a.problem_type, a.order, nx, ny, nz, world, rank) if need_host_arrays else None
     ctx = zzz.Context(local_rank)
-    if world > 1:
+    if multi:
         import torch
 
         uid = torch.zeros(128, dtype=torch.uint8)
@@ -179,12 +183,12 @@ def main():
     # CG scalar all-reduces through peer-memory mailboxes when every rank can map every peer (the library
     # tests the transport and makes the ranks agree); otherwise ncclAllReduce.  ZZZ_P2P=0 keeps RCCL.
     p2p = False
-    if world > 1 and os.environ.get("ZZZ_P2P", "1") != "0":
+    if multi and os.environ.get("ZZZ_P2P", "1") != "0":
         mine = torch.frombuffer(bytearray(ctx.comm_p2p_export()), dtype=torch.uint8).clone()
         allh = [torch.zeros(zzz.P2P_HANDLE_BYTES, dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(allh, mine)
         p2p = ctx.comm_p2p_attach(b"".join(bytes(h.numpy().tobytes()) for h in allh))
-    if world == 1 and a.force_comm:
+    if not multi and a.force_comm:
         ctx.comm_init(1, 0, zzz.comm_unique_id())
         if os.environ.get("ZZZ_P2P", "1") != "0":
             p2p = ctx.comm_p2p_attach(ctx.comm_p2p_export())
@@ -199,7 +203,7 @@ def main():
     ctx.pattern_build()  # once up front so that sizes are known; rebuilt inside every timed step
     nrows, ncols, nnz = ctx.csr_sizes()
     pc = zzz.PC_JACOBI if a.pc == "jacobi" else zzz.PC_NONE
-    single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and (world > 1 or a.force_comm))
+    single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and (multi or a.force_comm))
 
     def step(profile=False):
         t = {}
@@ -354,11 +358,11 @@ def main():
         if tuning:
             out["config"]["cg_form_tuning_s"] = {("single_reduction" if sr else "classical") + ("+peer_memory" if pm else "+ncclAllReduce"): v
                                                  for (sr, pm), v in tuning.items()}
-        if world > 1 or a.force_comm:
+        if multi or a.force_comm:
             out["config"]["scalar_allreduce"] = ("peer-memory mailboxes over xGMI (one kernel: reduce + exchange)" if p2p
                                                  else "ncclAllReduce")
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
-        if world == 1 and not a.no_cpu_baseline:
+        if not multi and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, ctx, iters)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["gpu_over_cpu_zzz_solve"] = out["cpu_baseline"]["solve_s_extrapolated"] / avg("solve")

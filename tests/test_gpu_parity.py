@@ -1094,3 +1094,33 @@ def test_baseline_multi_gpu_configs_partitioned_on_one_gpu(args, dofs, its, norm
     got_its = int(out.stdout.split("*** Number of Krylov iterations: ")[1].split()[0])
     got_norm = float(out.stdout.split("*** Solution norm:  ")[1].split()[0])
     assert abs(got_its - its) <= 3 and abs(got_norm - norm) <= 2e-5 * norm, (got_its, got_norm)
+
+
+def test_bench_multi_gpu_process_layout_on_one_gpu():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per GPU,
+    env:// rendezvous on 127.0.0.1) with --force_dist: libzzz_hip and /opt/rocm's RCCL bound before torch's own
+    copies, gloo process group, unique-id broadcast, ncclCommInitRank + ncclCommSplit, mailbox handle all_gather and
+    attach, device-generated slab feed, warm-up vote, CG-form / transport tuning, max-over-ranks timing.  One rank is
+    what a 1-GPU box can run of it; the partition logic itself is covered by the *_partitioned_* tests."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(zzz.PKG)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--force_dist", "--ndofs", "200000",
+           "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" not in d
+    assert cfg["feed"].startswith("generated on the device") and len(cfg["cg_form_tuning_s"]) == 4
+    assert cfg["scalar_allreduce"] in ("ncclAllReduce", "peer-memory mailboxes over xGMI (one kernel: reduce + exchange)")
+    assert abs(cfg["krylov_iterations"] - 306) <= 40 and cfg["relative_residual"] <= 1e-8
