@@ -16,8 +16,11 @@ coefficients) are resident in HBM before the timed region.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 For N > 1 the cube is cut into N z-slabs, one per GPU (strong scaling: the total problem is
-fixed); halo exchange and the CG all-reduces run on RCCL inside libzzz_hip; torch.distributed
-(gloo) is plumbing only: unique-id broadcast, barrier, max over ranks.
+fixed); inside libzzz_hip the halo exchange runs on RCCL and the CG scalars are reduced through
+peer-memory mailboxes over xGMI (ncclAllReduce as fallback); torch.distributed (gloo) is plumbing
+only: unique-id broadcast, mailbox-handle all_gather, votes, barrier, max over ranks.  The first
+warm-up step also times the two CG forms (classical / -ksp_cg_single_reduction) on both all-reduce
+transports; the timed steps use the fastest (config.cg_form_tuning_s, config.workload).
 """
 import argparse
 import json
