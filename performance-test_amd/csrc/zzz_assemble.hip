@@ -24,7 +24,9 @@
 namespace zzz
 {
 constexpr int ASM_BLOCK = 256;
-constexpr int ASM_NNZ = 4096; // LDS: 32 KiB values + 16 KiB columns per workgroup
+constexpr int ASM_NNZ = 4096; // LDS: 32 KiB values + 16 KiB columns per workgroup ...
+constexpr int ASM_NNZ_SMALL = 2048; // ... or half of that for scalar P1/P2 (short rows): twice the workgroups per CU
+                                    // (measured: Poisson P1 6.6 -> 5.6 ms, P2 6.4 -> 4.5 ms; elasticity and P3 lose)
 constexpr int ASM_ORD_CAP = 512; // block dofs of a tile that the high-order kernel sorts by cell count
 
 struct Geom
@@ -168,7 +170,7 @@ struct AdjIter
 };
 
 // ---- matrix, P1, BS = 1 (Poisson a1, src/Poisson.py:31) or 3 (Elasticity a1, src/Elasticity.py:39)
-template <int BS>
+template <int BS, int NNZ>
 __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restrict__ x,
                                                            const int32_t* __restrict__ cell_verts,
                                                            const int32_t* __restrict__ cell_dofs,
@@ -180,8 +182,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
                                                            const int32_t* __restrict__ tiles, int64_t ntiles)
 {
-  __shared__ double vals_s[ASM_NNZ];
-  __shared__ int32_t cols_s[ASM_NNZ];
+  __shared__ double vals_s[NNZ];
+  __shared__ int32_t cols_s[NNZ];
   const int64_t tile = xcd_item(ntiles);
   if (tile < 0)
     return;
@@ -388,13 +390,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
                                                            const int32_t* __restrict__ tiles, int64_t ntiles,
-                                                           const double* __restrict__ tab)
+                                                           const double* __restrict__ tab, int cap)
 {
   constexpr int NT = (BS == 1) ? 6 : 9;
   constexpr int NN = ND * ND;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* vals_s = reinterpret_cast<double*>(lds_raw);
-  double* T_s = vals_s + ASM_NNZ;
+  double* T_s = vals_s + cap; // cap = nonzeros a tile may hold (asm_tile_nnz)
   int32_t* cols_s = reinterpret_cast<int32_t*>(T_s + NT * NN);
   for (int k = threadIdx.x; k < NT * NN; k += ASM_BLOCK)
   {
@@ -627,13 +629,14 @@ int ensure_tables(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-int asm_tile_nnz() { return ASM_NNZ; }
+int asm_tile_nnz(const zzz_ctx* ctx) { return (ctx->bs == 1 && ctx->order <= 2) ? ASM_NNZ_SMALL : ASM_NNZ; }
 
 template <int ND, int BS, int LPR>
 static int launch_matrix_pk(zzz_ctx* ctx)
 {
   constexpr int NT = (BS == 1) ? 6 : 9;
-  const size_t lds = (size_t)ASM_NNZ * 8 + (size_t)NT * ND * ND * 8 + (size_t)ASM_NNZ * 4;
+  const int cap = asm_tile_nnz(ctx);
+  const size_t lds = (size_t)cap * 8 + (size_t)NT * ND * ND * 8 + (size_t)cap * 4;
   auto kern = asm_matrix_pk<ND, BS, LPR>;
   // the attribute belongs to (kernel, device): set it once per context, outside the hot path
   const unsigned bit = 1u << ((ND == 10 ? 0 : 2) + (BS == 1 ? 0 : 1));
@@ -644,7 +647,7 @@ static int launch_matrix_pk(zzz_ctx* ctx)
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)xcd_grid(ctx->n_asm_tiles)), dim3(ASM_BLOCK), lds, ctx->stream, ctx->x.p,
                      ctx->cell_verts.p, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->adj_off.p, ctx->bc.p,
-                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p);
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p, cap);
   return ZZZ_OK;
 }
 
@@ -666,11 +669,11 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
   if (ctx->order == 1)
   {
     if (bs == 1)
-      hipLaunchKernelGGL(asm_matrix_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_SMALL>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
     else
-      hipLaunchKernelGGL(asm_matrix_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
   }

@@ -199,7 +199,7 @@ int alloc_problem_vectors(zzz_ctx* ctx);
 // pattern (zzz_pattern.hip)
 int pattern_build_device(zzz_ctx* ctx, bool* fallback);
 int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
-int asm_tile_nnz();
+int asm_tile_nnz(const zzz_ctx* ctx); // nonzeros an assembly tile may hold (LDS budget of the matrix kernels)
 int build_adjT(zzz_ctx* ctx);
 int build_adjT_offsets(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);

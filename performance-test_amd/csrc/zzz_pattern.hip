@@ -508,7 +508,7 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
     ctx->spmv_lpr_shift = ctx->spmv_lpr_forced >= 0 ? ctx->spmv_lpr_forced : (avg >= 128.0 ? 3 : 0);
   }
   const int64_t Ws = (int64_t)ctx->spmv_tile - maxrow - 2;
-  const int64_t Wa = (int64_t)asm_tile_nnz() - maxblock;
+  const int64_t Wa = (int64_t)asm_tile_nnz(ctx) - maxblock;
   if (Ws < maxrow || Wa < maxblock || Wa < 1)
     return fail(ctx, ZZZ_ERR_LIMIT, "matrix rows too long for the kernel tiles (%d nonzeros per row)", maxrow);
   ctx->ntiles = (ctx->nnz + Ws - 1) / Ws;
