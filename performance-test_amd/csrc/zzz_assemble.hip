@@ -25,6 +25,7 @@ namespace zzz
 {
 constexpr int ASM_BLOCK = 256;
 constexpr int ASM_NNZ = 4096; // LDS: 32 KiB values + 16 KiB columns per workgroup ...
+constexpr int ASM_NNZ_P1 = 1920;    // scalar P1: ~126 rows per tile for a 128-thread workgroup (one thread per row)
 constexpr int ASM_NNZ_SMALL = 2048; // ... or half of that for scalar P1/P2 (short rows): twice the workgroups per CU
                                     // (measured: Poisson P1 6.6 -> 5.6 ms, P2 6.4 -> 4.5 ms; elasticity and P3 lose)
 constexpr int ASM_ORD_CAP = 512; // block dofs of a tile that the high-order kernel sorts by cell count
@@ -170,8 +171,8 @@ struct AdjIter
 };
 
 // ---- matrix, P1, BS = 1 (Poisson a1, src/Poisson.py:31) or 3 (Elasticity a1, src/Elasticity.py:39)
-template <int BS, int NNZ>
-__global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restrict__ x,
+template <int BS, int NNZ, int BLK>
+__global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ x,
                                                            const int32_t* __restrict__ cell_verts,
                                                            const int32_t* __restrict__ cell_dofs,
                                                            const int32_t* __restrict__ adjT_off,
@@ -190,13 +191,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
   const int d0 = tiles[tile], d1 = tiles[tile + 1];
   const int row0 = d0 * BS, row1 = d1 * BS;
   const int s = rowptr[row0], e = rowptr[row1];
-  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+  for (int k = threadIdx.x; k < e - s; k += BLK)
   {
     cols_s[k] = cols[s + k];
     vals_s[k] = 0.0;
   }
   __syncthreads();
-  for (int r = row0 + (int)threadIdx.x; r < row1; r += ASM_BLOCK)
+  for (int r = row0 + (int)threadIdx.x; r < row1; r += BLK)
   {
     const int i = r / BS, c = r % BS;
     const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_p1(const double* __restr
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+  for (int k = threadIdx.x; k < e - s; k += BLK)
     vals[s + k] = vals_s[k];
 }
 
@@ -629,7 +630,12 @@ int ensure_tables(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-int asm_tile_nnz(const zzz_ctx* ctx) { return (ctx->bs == 1 && ctx->order <= 2) ? ASM_NNZ_SMALL : ASM_NNZ; }
+int asm_tile_nnz(const zzz_ctx* ctx)
+{
+  if (ctx->bs == 1 && ctx->order == 1)
+    return ASM_NNZ_P1;
+  return (ctx->bs == 1 && ctx->order == 2) ? ASM_NNZ_SMALL : ASM_NNZ;
+}
 
 template <int ND, int BS, int LPR>
 static int launch_matrix_pk(zzz_ctx* ctx)
@@ -669,11 +675,12 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
   if (ctx->order == 1)
   {
     if (bs == 1)
-      hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_SMALL>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      // one thread per row: a 1920-nonzero tile holds ~126 rows of 15, so 128 threads leave no lane idle
+      hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_P1, 128>), grid, dim3(128), 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
     else
-      hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ, ASM_BLOCK>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
   }
