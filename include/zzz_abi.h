@@ -237,7 +237,9 @@ int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);
  * info[2] = tiles left on int32 columns; info[3] = number of tiles; info[4] = lanes per row of the row sums
  * (1: a row's products are added in column order like the scalar CPU loop; L > 1, chosen for rows of
  * >= 128 nonzeros on average: lane j adds the j-th contiguous chunk of ceil(len/L) products in column
- * order, chunk sums combined pairwise ((c0+c1)+(c2+c3))+...); info[5..7] = 0. */
+ * order, chunk sums combined pairwise ((c0+c1)+(c2+c3))+...); info[5] = 1 when the SpMV runs on the sliced-ELL
+ * copy (chosen for matrices small enough to stay cache-resident between CG iterations; same column-order row
+ * sums, bit-identical results) instead of the CSR tile kernel; info[6..7] = 0. */
 int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
 
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */

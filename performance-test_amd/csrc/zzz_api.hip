@@ -576,7 +576,7 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, ctx->p.n * sizeof(double), ctx->stream));
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->p.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   int rc;
-  if (ctx->comm && ctx->overlap && ctx->have_tile_split && !(ctx->spmv_variant & 8))
+  if (ctx->comm && ctx->overlap && ctx->have_tile_split)
     rc = launch_spmv_overlapped(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
   else
   {
@@ -695,7 +695,8 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
   info[3] = ctx->ntiles;
   info[4] = (int64_t)1 << ctx->spmv_lpr_shift;
-  info[5] = info[6] = info[7] = 0;
+  info[5] = (ctx->have_sell && (ctx->spmv_variant & 8 || (ctx->sell_auto_on && ctx->spmv_auto))) ? 1 : 0;
+  info[6] = info[7] = 0;
   return ZZZ_OK;
 }
 

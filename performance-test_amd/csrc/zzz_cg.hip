@@ -518,7 +518,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 
   auto apply = [&](double* x, double* y, double* parts, int* np) -> int {
     // partitioned CSR operator: halo of x overlapped with the interior tiles
-    if (multi && o->op == ZZZ_OP_CSR && ctx->overlap && ctx->have_tile_split && !(ctx->spmv_variant & 8))
+    if (multi && o->op == ZZZ_OP_CSR && ctx->overlap && ctx->have_tile_split)
       return launch_spmv_overlapped(ctx, x, y, parts, np);
     if (multi)
     {

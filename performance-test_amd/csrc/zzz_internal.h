@@ -145,6 +145,10 @@ struct zzz_ctx
   bool have_sell = false;    // structure built
   bool sell_current = false; // values match the CSR values
   bool sell_requested = false;
+  bool sell_auto_on = false; // cache-resident matrix: the SELL copy is the default SpMV
+  zzz::DevBuf<int32_t> groups_interior, groups_boundary; // groups of 4 slices without / with ghost columns
+  int64_t n_groups_interior = 0, n_groups_boundary = 0;
+  bool have_group_split = false;
   // assembly tiling: contiguous owned block-dof ranges whose CSR segment fits LDS
   zzz::DevBuf<int32_t> asm_tile;
   int64_t n_asm_tiles = 0;

@@ -13,6 +13,8 @@
 // the x window they share stays in that XCD's 4 MiB L2 instead of being fetched by all eight.
 #include <cstring>
 
+#include <vector>
+
 #include "zzz_device.h"
 #include "zzz_internal.h"
 
@@ -323,19 +325,25 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_sell_kernel(const int32_t* __
                                                                const double* __restrict__ svals,
                                                                const double* __restrict__ x, double* __restrict__ y,
                                                                int nrows, int64_t nslices, double* __restrict__ partials,
-                                                               const int* __restrict__ stop_flag)
+                                                               const int* __restrict__ stop_flag,
+                                                               const int32_t* __restrict__ group_list, int64_t nlist,
+                                                               const double* __restrict__ rvec, int pstride, int nn_is_rr)
 {
+  // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
+  // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
+  // spmv_tile_kernel
   if (stop_flag && *stop_flag)
     return;
   __shared__ double red[SPMV_BLOCK / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ngroups = (nslices + 3) / 4; // a workgroup takes 4 consecutive slices (256 rows)
-  double dot = 0.0;
+  const int64_t ngroups = group_list ? nlist : (nslices + 3) / 4; // a workgroup takes 4 consecutive slices (256 rows)
+  double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
   for (int i = 0;; ++i)
   {
-    const int64_t g = xcd_tile(ngroups, blockIdx.x, gridDim.x, i);
-    if (g < 0)
+    const int64_t gi = xcd_tile(ngroups, blockIdx.x, gridDim.x, i);
+    if (gi < 0)
       break;
+    const int64_t g = group_list ? group_list[gi] : gi;
     const int64_t s = 4 * g + wv;
     if (s >= nslices)
       continue;
@@ -372,7 +380,15 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_sell_kernel(const int32_t* __
     {
       y[r] = sum;
       if (DOT)
+      {
         dot += sum * xr;
+        if (rvec)
+        {
+          const double rr_ = rvec[r];
+          dot_rx += rr_ * xr;
+          dot_nn += nn_is_rr ? rr_ * rr_ : xr * xr;
+        }
+      }
     }
   }
   if (DOT)
@@ -380,14 +396,51 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_sell_kernel(const int32_t* __
     const double sres = block_reduce_sum(dot, red);
     if (threadIdx.x == 0)
       partials[blockIdx.x] = sres;
+    if (rvec)
+    {
+      const double s1 = block_reduce_sum(dot_rx, red);
+      const double s2 = block_reduce_sum(dot_nn, red);
+      if (threadIdx.x == 0)
+      {
+        partials[pstride + blockIdx.x] = s1;
+        partials[2 * pstride + blockIdx.x] = s2;
+      }
+    }
+  }
+}
+
+// Which groups of 4 slices (256 rows) reference a ghost column?  One wavefront per group over its CSR rows.
+__global__ __launch_bounds__(256) void k_group_ghost_flag(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                          int32_t nrows, int64_t ngroups, uint8_t* __restrict__ flag)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += (int64_t)gridDim.x * 4)
+  {
+    const int r0 = (int)min((int64_t)nrows, g * 256), r1 = (int)min((int64_t)nrows, g * 256 + 256);
+    bool gh = false;
+    for (int k = rowptr[r0] + lane; k < rowptr[r1]; k += 64)
+      gh |= cols[k] >= nrows;
+    const unsigned long long m = __ballot(gh);
+    if (lane == 0)
+      flag[g] = m != 0ull;
   }
 }
 
 // (re)build the SELL copy: structure when `structure` is set (after the pattern build), values always
 int sell_update(zzz_ctx* ctx, bool structure)
 {
-  if (!(ctx->spmv_variant & 8) && !ctx->sell_requested) // only built for A/B runs
+  // Built when forced (ZZZ_SPMV_VARIANT bit 3) or, by default, for matrices that stay in the Infinity Cache
+  // from one CG iteration to the next (same size rule as the load policy of the tile kernel): there the
+  // barrier-free one-lane-per-row walk is faster than the tile kernel (1.25 M-dof P1: 37.5 vs 41.4 us,
+  // 0.5 M: 16.9 vs 21.0 us), while for matrices streamed from HBM the tile kernel wins (10 M: 0.39 vs 0.42 ms).
+  // Long rows that use several lanes per row keep the tile kernel.
+  const bool cache_resident = 12.0 * (double)ctx->nnz <= 300.0e6;
+  ctx->sell_auto_on = ctx->spmv_auto && cache_resident && ctx->spmv_lpr_shift == 0;
+  if (!(ctx->spmv_variant & 8) && !ctx->sell_requested && !ctx->sell_auto_on)
+  {
+    ctx->have_sell = false;
     return ZZZ_OK;
+  }
   hipStream_t s = ctx->stream;
   const int nrows = (int)ctx->nrows;
   const int64_t nsl = (ctx->nrows + 63) / 64;
@@ -435,20 +488,71 @@ int sell_update(zzz_ctx* ctx, bool structure)
                        ctx->nslices, ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p);
   ZZZ_HIP(ctx, hipGetLastError());
   ctx->have_sell = true;
+  if (structure)
+  {
+    // interior / boundary groups for the halo-compute overlap of a partitioned matrix
+    ctx->n_groups_interior = ctx->n_groups_boundary = 0;
+    ctx->have_group_split = false;
+    const int64_t ng = (ctx->nslices + 3) / 4;
+    if (ctx->n_ghost > 0 && ng > 0)
+    {
+      DevBuf<uint8_t> flag;
+      ZZZ_HIP(ctx, flag.alloc((size_t)ng));
+      int gg = (int)((ng + 3) / 4);
+      if (gg > 4096)
+        gg = 4096;
+      hipLaunchKernelGGL(k_group_ghost_flag, dim3(gg), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, (int32_t)ctx->nrows, ng, flag.p);
+      std::vector<uint8_t> h((size_t)ng);
+      ZZZ_HIP(ctx, hipMemcpyAsync(h.data(), flag.p, h.size(), hipMemcpyDeviceToHost, s));
+      ZZZ_HIP(ctx, hipStreamSynchronize(s));
+      std::vector<int32_t> in, bd;
+      for (int64_t g2 = 0; g2 < ng; ++g2)
+        (h[(size_t)g2] ? bd : in).push_back((int32_t)g2);
+      ZZZ_HIP(ctx, ctx->groups_interior.alloc(in.size()));
+      ZZZ_HIP(ctx, ctx->groups_boundary.alloc(bd.size()));
+      if (!in.empty())
+        ZZZ_HIP(ctx, hipMemcpy(ctx->groups_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      if (!bd.empty())
+        ZZZ_HIP(ctx, hipMemcpy(ctx->groups_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      ctx->n_groups_interior = (int64_t)in.size();
+      ctx->n_groups_boundary = (int64_t)bd.size();
+      ctx->have_group_split = true;
+    }
+  }
   return ZZZ_OK;
 }
 
-template <bool DOT>
-static void launch_sell(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop)
+// the SELL copy is the SpMV of this matrix: forced by the variant, or chosen for cache-resident matrices
+static bool use_sell(const zzz_ctx* ctx)
 {
-  if (ctx->spmv_variant & 1)
+  return ((ctx->spmv_variant & 8) || (ctx->sell_auto_on && ctx->spmv_auto)) && ctx->have_sell && ctx->sell_current;
+}
+
+template <bool DOT>
+static void launch_sell(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
+                        const int32_t* group_list = nullptr, int64_t nlist = 0, const double* rvec = nullptr, int nn_is_rr = 0)
+{
+  // the automatic choice is for cache-resident matrices: plain loads; a forced variant decides itself
+  const bool nt = (ctx->spmv_variant & 8) ? (ctx->spmv_variant & 1) != 0 : false;
+  if (nt)
     hipLaunchKernelGGL((spmv_sell_kernel<DOT, true>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream, ctx->rowptr.p,
                        ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p, x, y, (int)ctx->nrows, ctx->nslices, partials,
-                       stop);
+                       stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr);
   else
     hipLaunchKernelGGL((spmv_sell_kernel<DOT, false>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream, ctx->rowptr.p,
                        ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p, x, y, (int)ctx->nrows, ctx->nslices, partials,
-                       stop);
+                       stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr);
+}
+
+static int sell_grid(int64_t ngroups)
+{
+  int64_t gs = 256 * 8;
+  const int64_t need = (ngroups + 7) / 8 * 8;
+  if (gs > need)
+    gs = need;
+  if (gs < 8)
+    gs = 8;
+  return (int)gs;
 }
 
 static int spmv_grid(const zzz_ctx* ctx)
@@ -514,22 +618,17 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
   const int grid = spmv_grid(ctx);
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1); // last valid clamped index (arrays are padded by 8)
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
-  if ((ctx->spmv_variant & 8) && ctx->have_sell && ctx->sell_current && !rvec)
+  if (use_sell(ctx))
   {
-    int64_t gs = 256 * 8;
-    const int64_t need = ((ctx->nslices + 3) / 4 + 7) / 8 * 8;
-    if (gs > need)
-      gs = need;
-    if (gs < 8)
-      gs = 8;
+    const int gs = sell_grid((ctx->nslices + 3) / 4);
     if (partials)
     {
-      launch_sell<true>(ctx, (int)gs, x, y, partials, stop);
+      launch_sell<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr);
       if (npartials)
-        *npartials = (int)gs;
+        *npartials = gs;
     }
     else
-      launch_sell<false>(ctx, (int)gs, x, y, nullptr, stop);
+      launch_sell<false>(ctx, gs, x, y, nullptr, stop);
     ZZZ_HIP(ctx, hipGetLastError());
     return ZZZ_OK;
   }
@@ -567,6 +666,41 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
 {
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1);
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
+  if (use_sell(ctx) && ctx->have_group_split)
+  {
+    // same scheme on the SELL copy: groups of 256 rows take the place of the tiles
+    const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
+    int g_in = gi ? sell_grid(gi) : 0;
+    if (g_in > 256 * 7 && ctx->nneigh > 0)
+      g_in = 256 * 7; // room for RCCL's kernel beside the persistent workgroups (see below)
+    const int g_bd = gb ? sell_grid(gb) : 0;
+    if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
+      return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
+    int rc = comm_halo_begin(ctx, x);
+    if (rc)
+      return rc;
+    if (gi)
+    {
+      if (partials)
+        launch_sell<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr);
+      else
+        launch_sell<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi);
+    }
+    rc = comm_halo_end(ctx);
+    if (rc)
+      return rc;
+    if (gb)
+    {
+      if (partials)
+        launch_sell<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr);
+      else
+        launch_sell<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb);
+    }
+    if (npartials)
+      *npartials = g_in + g_bd;
+    ZZZ_HIP(ctx, hipGetLastError());
+    return ZZZ_OK;
+  }
   const int64_t n_in = ctx->n_tiles_interior, n_bd = ctx->n_tiles_boundary;
   // The interior launch leaves one workgroup slot per CU free (7 of 8): at full occupancy the persistent
   // SpMV workgroups hold every wave slot until the launch ends and RCCL's send/recv kernel, although

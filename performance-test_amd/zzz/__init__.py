@@ -375,6 +375,11 @@ class Context:
         self._ck(self.L.zzz_spmv_info(self.h, info))
         return tuple(int(v) for v in info[:4])
 
+    def spmv_uses_sell(self):
+        info = (C.c_int64 * 8)()
+        self._ck(self.L.zzz_spmv_info(self.h, info))
+        return bool(info[5])
+
     def spmv_lanes_per_row(self):
         info = (C.c_int64 * 8)()
         self._ck(self.L.zzz_spmv_info(self.h, info))

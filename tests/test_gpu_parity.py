@@ -820,6 +820,7 @@ def test_full_size_baseline_config_properties():
         assert (nrows, ncols, nnz) == (10016937, 10016937, 149140873)
         packed, offb, nfb, ntiles = c.spmv_info()
         assert packed and nfb == 0
+        assert not c.spmv_uses_sell()  # 1.5 GB of matrix: streamed from HBM by the CSR tile kernel
         c.assemble_matrix(zzz.FORM_POISSON)
         c.assemble_vector(zzz.FORM_POISSON)
         b = c.vec_download(zzz.VEC_B)
@@ -1124,3 +1125,20 @@ def test_bench_multi_gpu_process_layout_on_one_gpu():
     assert cfg["feed"].startswith("generated on the device") and len(cfg["cg_form_tuning_s"]) == 4
     assert cfg["scalar_allreduce"] in ("ncclAllReduce", "peer-memory mailboxes over xGMI (one kernel: reduce + exchange)")
     assert abs(cfg["krylov_iterations"] - 306) <= 40 and cfg["relative_residual"] <= 1e-8
+
+
+def test_spmv_kernel_selection(ctx):
+    """Cache-resident matrices with short, even rows run on the sliced-ELL copy, everything else on the CSR
+    tile kernel (HBM-streamed matrices: see the full-size test; rows of very different lengths would pad the
+    slices; several lanes per row exist in the tile kernel only) -- and both give the oracle's bits."""
+    rng = np.random.default_rng(8)
+    for problem, order, dims, sell in (("poisson", 1, (30, 31, 29), True), ("elasticity", 1, (12, 13, 11), True),
+                                       ("poisson", 3, (8, 7, 8), False), ("elasticity", 3, (5, 5, 6), False)):
+        P = zzz.Part(problem, order, *dims)
+        ctx.upload_part(P)
+        ctx.pattern_build()
+        ctx.assemble_matrix(P.form)
+        assert ctx.spmv_uses_sell() == sell, (problem, order)
+        rp, cl, v = ctx.csr_download()
+        xv = rng.standard_normal(P.n_owned * P.bs)
+        np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv_chunked(rp.astype(np.int64), cl, v, xv, ctx.spmv_lanes_per_row()))
