@@ -278,9 +278,11 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
 //     so y is bit-identical (padding entries are loaded but never added).
 // Rows of one slice have near-equal length in FE matrices numbered entity-type by entity-type; the
 // builder reports the padding and the CSR tile kernel remains the fallback when it is large.
-// MEASURED (MI355X, 10 M-dof P1 Poisson, same process): 0.420 ms against 0.372 ms for the CSR tile
-// kernel -- the 8-B / 4-B per-lane reads cost more than the coalesced gather saves.  The tile kernel
-// is the default; this format is built only when ZZZ_SPMV_VARIANT has bit 3 set.
+// MEASURED (MI355X, P1 Poisson, same process): at 10 M dofs (matrix streamed from HBM) 0.420 ms against
+// 0.372 ms for the CSR tile kernel -- the 8-B / 4-B per-lane reads cost more than the coalesced gather
+// saves; at 1.25 M dofs (matrix resident in the Infinity Cache) 37.5 us against 41.4 us, at 0.5 M dofs
+// 16.9 against 21.0 us -- no barrier, no LDS round trip.  So the copy is built, and used, for
+// cache-resident matrices (sell_update) and on request (ZZZ_SPMV_VARIANT bit 3).
 __global__ void k_sell_slice_len(const int32_t* __restrict__ rowptr, int nrows, int64_t nslices,
                                  int32_t* __restrict__ slen)
 {
