@@ -436,8 +436,11 @@ int sell_update(zzz_ctx* ctx, bool structure)
   // barrier-free one-lane-per-row walk is faster than the tile kernel (1.25 M-dof P1: 37.5 vs 41.4 us,
   // 0.5 M: 16.9 vs 21.0 us), while for matrices streamed from HBM the tile kernel wins (10 M: 0.39 vs 0.42 ms).
   // Long rows that use several lanes per row keep the tile kernel.
+  // ... and so do rows of more than ~32 nonzeros (elasticity P1, 45 per row, 0.5 M dofs: 46.7 us against 43.8 us
+  // for the tile kernel -- the serial walk of a lane gets long)
   const bool cache_resident = 12.0 * (double)ctx->nnz <= 300.0e6;
-  ctx->sell_auto_on = ctx->spmv_auto && cache_resident && ctx->spmv_lpr_shift == 0;
+  const bool short_rows = ctx->nrows > 0 && (double)ctx->nnz <= 32.0 * (double)ctx->nrows;
+  ctx->sell_auto_on = ctx->spmv_auto && cache_resident && short_rows && ctx->spmv_lpr_shift == 0;
   if (!(ctx->spmv_variant & 8) && !ctx->sell_requested && !ctx->sell_auto_on)
   {
     ctx->have_sell = false;
