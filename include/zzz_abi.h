@@ -30,6 +30,7 @@
 #ifndef ZZZ_ABI_H
 #define ZZZ_ABI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,6 +117,8 @@ typedef struct
 
 /* Number of visible GPUs; 0 when there is none (then zzz_ctx_create fails with ZZZ_ERR_NO_GPU). */
 int zzz_device_count(void);
+/* hipMemGetInfo of a device in bytes (for the driver's --memory_profiling log, src/mem.cpp:18-38). */
+int zzz_device_memory(int device, size_t* free_bytes, size_t* total_bytes);
 
 /* Creates a context on `device`.  Replaces MPI_Init/PetscInitialize as far as this path needs
  * them (src/main.cpp:245-258). */

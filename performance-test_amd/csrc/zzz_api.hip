@@ -77,6 +77,22 @@ int zzz_device_count(void)
   return n;
 }
 
+int zzz_device_memory(int device, size_t* free_bytes, size_t* total_bytes)
+{
+  if (!free_bytes || !total_bytes)
+    return fail(nullptr, ZZZ_ERR_ARG, "zzz_device_memory: NULL argument");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    (void)hipSetDevice(prev);
+    return fail(nullptr, ZZZ_ERR_HIP, "hipMemGetInfo failed on device %d", device);
+  }
+  (void)hipSetDevice(prev);
+  return ZZZ_OK;
+}
+
 int zzz_ctx_create(int device, zzz_ctx** out)
 {
   if (!out)

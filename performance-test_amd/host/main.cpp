@@ -25,6 +25,10 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <atomic>
+#include <ctime>
+#include <fstream>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -520,6 +524,36 @@ void solve(int argc, char** argv)
   S.p2p_handles.assign((size_t)S.nranks * ZZZ_P2P_HANDLE_BYTES, 0);
   S.p2p_enabled.assign(S.nranks, 0);
 
+  // --memory_profiling (src/main.cpp:102-107,236-240; src/mem.cpp:18-38): a thread logs VSIZE and RSS of the
+  // process from /proc/self/stat every 100 ms; the used HBM of GPU 0 is appended (the device side is where
+  // this build keeps its data)
+  std::atomic<bool> mem_quit{false};
+  std::thread mem_thread;
+  if (o.mem_profile)
+    mem_thread = std::thread([&mem_quit] {
+      const long page_kb = sysconf(_SC_PAGE_SIZE) / 1024;
+      while (!mem_quit.load())
+      {
+        std::ifstream f("/proc/self/stat");
+        std::string tok;
+        for (int i = 0; i < 22 && (f >> tok); ++i)
+        {
+        }
+        unsigned long long vsize = 0, rss = 0;
+        f >> vsize >> rss;
+        size_t hbm_free = 0, hbm_total = 0;
+        zzz_device_memory(0, &hbm_free, &hbm_total);
+        const auto now = std::chrono::system_clock::now();
+        const std::time_t tt = std::chrono::system_clock::to_time_t(now);
+        const int ms = (int)(std::chrono::duration_cast<std::chrono::milliseconds>(now.time_since_epoch()).count() % 1000);
+        char stamp[32];
+        std::strftime(stamp, sizeof(stamp), "%Y-%m-%d %H:%M:%S", std::localtime(&tt));
+        std::fprintf(stderr, "[%s.%03d] [MEM] [warning] VSIZE=%llu, RSS=%llu, HBM=%zu\n", stamp, ms, vsize / 1024, rss * page_kb,
+                     (hbm_total - hbm_free) / 1024);
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      }
+    });
+
   std::barrier<> bar(S.nranks);
   std::vector<std::thread> th;
   for (int r = 1; r < S.nranks; ++r)
@@ -527,6 +561,11 @@ void solve(int argc, char** argv)
   run_rank(S, bar, 0);
   for (auto& t : th)
     t.join();
+  if (mem_thread.joinable())
+  {
+    mem_quit.store(true);
+    mem_thread.join();
+  }
   if (S.local_group)
     zzz_local_group_destroy(S.local_group);
   for (int r = 0; r < S.nranks; ++r)

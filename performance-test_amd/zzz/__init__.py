@@ -24,7 +24,7 @@ OP_CSR, OP_MATFREE = 0, 1
 ERR_NO_GPU = 4
 
 ABI_SYMBOLS = [
-    "zzz_device_count", "zzz_ctx_create", "zzz_ctx_destroy", "zzz_last_error", "zzz_sync", "zzz_mesh_upload",
+    "zzz_device_count", "zzz_device_memory", "zzz_ctx_create", "zzz_ctx_destroy", "zzz_last_error", "zzz_sync", "zzz_mesh_upload",
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",

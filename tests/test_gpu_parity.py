@@ -284,6 +284,13 @@ def test_driver_binary_surface():
     for bad in (["--scaling_type", "sideways"], ["--problem_type", "stokes"], ["--order", "4"]):
         out = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
         assert out.returncode != 0
+    # --memory_profiling: the logging thread of src/mem.cpp (VSIZE / RSS in kB every 100 ms, here plus used HBM)
+    out = subprocess.run([exe, "--problem_type", "poisson", "--ndofs", "2000000", "--memory_profiling", "-pc_type", "jacobi",
+                          "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    mem = [ln for ln in out.stderr.splitlines() if "[MEM] [warning] VSIZE=" in ln]
+    assert mem and all("RSS=" in ln and "HBM=" in ln for ln in mem)
+    assert int(mem[-1].split("HBM=")[1]) > 100000  # kB: the 2 M-dof problem is resident on the device
 
 
 @pytest.mark.parametrize("problem,order", [("poisson", 1), ("poisson", 2), ("poisson", 3), ("elasticity", 1),
