@@ -131,7 +131,13 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->spmv_variant = atoi(e) & 27;
     ctx->spmv_auto = false;
   }
-  ctx->sell_requested = (ctx->spmv_variant & 8) != 0;
+  if (const char* e = getenv("ZZZ_SELLP")) // operator stream: 0 off, 1 automatic, 2 natural row order, 3 sorted rows
+  {
+    const int v = atoi(e);
+    ctx->sellp_mode = v >= 0 && v <= 3 ? v : 1;
+  }
+  if (const char* e = getenv("ZZZ_SELLP_DROP"))
+    ctx->sellp_drop = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SPMV_LPR")) // lanes per row of the SpMV row phase: 1, 2, 4, 8, 16
   {
     const int v = atoi(e);
@@ -341,10 +347,7 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
     rc = ensure_tables(ctx); // reference tensors of the element: resident before the assembly timers start
   if (rc)
     return rc;
-  ctx->sell_current = false;
-  rc = sell_update(ctx, true);
-  if (rc)
-    return rc;
+  ctx->have_sell = ctx->sell_current = false; // the operator stream is packed from the values: after assembly
   ctx->have_pattern = true;
   return ZZZ_OK;
 }
@@ -512,7 +515,6 @@ int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals)
     return rc;
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_matrix = true;
-  ctx->sell_current = ctx->have_sell;
   return ZZZ_OK;
 }
 
@@ -527,10 +529,7 @@ int zzz_assemble_matrix(zzz_ctx* ctx, int form)
   if (!rc)
     rc = sell_update(ctx, false); // MatAssemblyEnd-like finalisation: refresh the SpMV copy
   if (!rc)
-  {
     ctx->have_matrix = true;
-    ctx->sell_current = ctx->have_sell;
-  }
   return rc;
 }
 
@@ -711,8 +710,9 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
   info[3] = ctx->ntiles;
   info[4] = (int64_t)1 << ctx->spmv_lpr_shift;
-  info[5] = (ctx->have_sell && (ctx->spmv_variant & 8 || (ctx->sell_auto_on && ctx->spmv_auto))) ? 1 : 0;
-  info[6] = info[7] = 0;
+  info[5] = sellp_active(ctx) ? (ctx->sp_sorted ? 2 : 1) : 0;
+  info[6] = sellp_active(ctx) ? sellp_stream_bytes(ctx) : 0; // bytes of the operator stream read per product
+  info[7] = sellp_active(ctx) ? ctx->sp_chunks * 512 : 0;     // its entries, padding included
   return ZZZ_OK;
 }
 

@@ -136,16 +136,18 @@ struct zzz_ctx
   int spmv_lpr_shift = 0, spmv_lpr_forced = -1; // log2(lanes per row) of the SpMV row phase
   bool spmv_auto = true; // choose bit 0 from the matrix size (off when ZZZ_SPMV_VARIANT / zzz_spmv_time force one)
   int spmv_variant = 1;  // bit 0: non-temporal matrix loads, bit 1: pipelined CSR tiles,
-                         // bit 3: build and use the SELL-64 copy (measured 13 % slower than the CSR
-                         // tile kernel on the 10 M-dof P1 matrix; kept as an A/B variant only)
-  // SELL-64 copy of the matrix for the CG SpMV (zzz_spmv.hip)
-  zzz::DevBuf<int32_t> slice_off, sell_cols;
-  zzz::DevBuf<double> sell_vals;
-  int64_t nslices = 0, sell_entries = 0;
-  bool have_sell = false;    // structure built
-  bool sell_current = false; // values match the CSR values
-  bool sell_requested = false;
-  bool sell_auto_on = false; // cache-resident matrix: the SELL copy is the default SpMV
+                         // bit 3: the sliced-ELL operator stream (zzz_sellp.hip) instead of the CSR tile kernel
+  // Operator stream of the CG SpMV (zzz_sellp.hip): sliced-ELL copy in chunks of 8 entries per row, exact zeros
+  // dropped, 16-bit slot-relative column codes; rebuilt from the CSR values after every assembly
+  zzz::DevBuf<int32_t> sp_rownnz, sp_nch, sp_chunk_off, sp_perm, sp_codes32, sp_meta;
+  zzz::DevBuf<uint16_t> sp_codes16;
+  zzz::DevBuf<double> sp_vals;
+  int64_t nslices = 0, sp_chunks = 0;
+  bool sp_sorted = false;    // rows ordered by length inside windows (SELL-C-sigma)
+  int sellp_mode = 1;        // ZZZ_SELLP: 0 off, 1 automatic, 2 natural row order always, 3 sorted rows always
+  bool sellp_drop = true;    // ZZZ_SELLP_DROP=0: keep the exact zeros of the pattern in the stream
+  bool have_sell = false;    // stream built
+  bool sell_current = false; // ... from the current CSR values
   zzz::DevBuf<int32_t> groups_interior, groups_boundary; // groups of 4 slices without / with ghost columns
   int64_t n_groups_interior = 0, n_groups_boundary = 0;
   bool have_group_split = false;
@@ -211,7 +213,13 @@ int ensure_tables(zzz_ctx* ctx);
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
 int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec = nullptr,
                 int nn_is_rr = 0);
+// operator stream (zzz_sellp.hip)
 int sell_update(zzz_ctx* ctx, bool structure);
+bool sellp_active(const zzz_ctx* ctx);
+int64_t sellp_stream_bytes(const zzz_ctx* ctx);
+int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr);
+int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,
+                            int nn_is_rr);
 
 // kernels_assemble
 int launch_assemble_matrix(zzz_ctx* ctx, int form);

@@ -1,0 +1,580 @@
+// The CG operator stream: a sliced-ELL copy of the assembled matrix, built for how gfx950 reads memory.
+//
+// Replaces PETSc MatMult inside KSPSolve (src/poisson_problem.cpp:177) and the `action` of linalg::cg
+// (src/cg.h:62) for matrices whose rows have similar lengths; the CSR tile kernel (zzz_spmv.hip) stays
+// the operator for the others.  The CSR arrays remain the matrix of record (zzz_csr_download, Jacobi,
+// parity); after every assembly (MatAssemblyEnd) the values are re-packed into this stream:
+//
+//   * rows in slices of 64 (one wavefront, one lane per row); optionally the rows of a window of
+//     SIGMA rows are ordered by length first (SELL-C-sigma), so that rows of very different lengths
+//     (P2/P3 vertex / edge / face dofs) do not pad each other;
+//   * entries whose assembled value is exactly zero are left out.  On the Kuhn mesh more than half of
+//     the P1 Laplacian's pattern is exact zeros (the face- and body-diagonal couplings)
+//     which PETSc stores and multiplies; 0 * x adds nothing to a row sum, so y keeps its bits as long
+//     as x is finite (PETSc's MAT_IGNORE_ZERO_ENTRIES has the same effect on MatMult);
+//   * a slice is a sequence of CHUNKS of 8 entries per row.  A chunk is 4 KiB of values laid out
+//     [4][64 lanes][2] (four 16-B loads per lane, each one dense 1-KiB wave read), 1 KiB of 16-bit column
+//     codes [64 lanes][8] (ONE 16-B load per lane) and 8 slot bases (scalar loads): the column of
+//     (lane, slot e) is base[e] + code.  Lanes are consecutive rows, so the e-th entries of a chunk are
+//     (nearly) consecutive columns: the codes are small and the x gather of one wave instruction is
+//     (nearly) one dense read.  A chunk whose slot range exceeds 16 bits keeps int32 columns (flag in
+//     the sign bit of base[0]) -- the scheme never fails, it only stops paying;
+//   * no LDS, no barrier; each row is summed in ascending column order like the scalar CPU loop
+//     (mul and add rounded separately), so y is bit-identical to the CSR product.
+//
+// Padding entries carry the value +0.0 and a valid column.
+#include <climits>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+
+#include "zzz_device.h"
+#include "zzz_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace zzz
+{
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+constexpr int SP_BLOCK = 256;
+constexpr int SP_SIGMA = 512; // sorting window (rows) of the sorted form: one workgroup
+
+// tile index for (workgroup b, step i): XCD x = b % 8 owns items [x*T/8, (x+1)*T/8)   (as in zzz_spmv.hip)
+__device__ inline int64_t sp_xcd_item(int64_t n, int b, int nb, int i)
+{
+  const int xcd = b & 7;
+  const int64_t lo = n * xcd / 8, hi = n * (xcd + 1) / 8;
+  const int wg_in_xcd = b >> 3, n_in_xcd = (nb + 7 - xcd) >> 3;
+  const int64_t t = lo + wg_in_xcd + (int64_t)i * n_in_xcd;
+  return t < hi ? t : -1;
+}
+
+__device__ inline int wave_min_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline int wave_max_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- build ------------------------------------------------------------------------------------------
+// entries of each row that the stream keeps
+__global__ __launch_bounds__(256) void k_sp_count(const int32_t* __restrict__ rowptr, const double* __restrict__ vals,
+                                                  int nrows, int drop, int32_t* __restrict__ rownnz)
+{
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    int n = b - a;
+    if (drop)
+    {
+      n = 0;
+      for (int k = a; k < b; ++k)
+        n += vals[k] != 0.0 ? 1 : 0;
+    }
+    rownnz[r] = n;
+  }
+}
+
+// natural row order: chunks of slice s = ceil(longest of its 64 rows / 8); entry nslices = 0 (scan sentinel)
+__global__ __launch_bounds__(256) void k_sp_slice_len(const int32_t* __restrict__ rownnz, int nrows, int64_t nslices,
+                                                      int32_t* __restrict__ nch)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s <= nslices; s += (int64_t)gridDim.x * 4)
+  {
+    const int64_t r = s * 64 + lane;
+    const int m = wave_max_i((s < nslices && r < nrows) ? rownnz[r] : 0);
+    if (lane == 0)
+      nch[s] = (m + 7) >> 3;
+  }
+}
+
+// sorted form: one workgroup orders the SP_SIGMA rows of its window by length (descending, ties by row:
+// a stable counting rank), writes the row of every (slice, lane) and the slice lengths
+__global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict__ rownnz, int nrows, int64_t nslices,
+                                                      int32_t* __restrict__ perm, int32_t* __restrict__ nch)
+{
+  __shared__ int len[SP_SIGMA];
+  __shared__ int srt[SP_SIGMA];
+  const int64_t w = blockIdx.x;
+  const int t = threadIdx.x;
+  const int64_t r = w * SP_SIGMA + t;
+  const int mine = r < nrows ? rownnz[r] : -1;
+  len[t] = mine;
+  __syncthreads();
+  int rank = 0;
+  for (int j = 0; j < SP_SIGMA; ++j)
+  {
+    const int lj = len[j];
+    rank += (lj > mine || (lj == mine && j < t)) ? 1 : 0;
+  }
+  srt[rank] = mine;
+  const int64_t slot = w * SP_SIGMA + rank;
+  if (slot < nslices * 64)
+    perm[slot] = r < nrows ? (int32_t)r : -1;
+  __syncthreads();
+  // slice lengths: the first row of a sorted slice is its longest
+  if (t < SP_SIGMA / 64)
+  {
+    const int64_t s = w * (SP_SIGMA / 64) + t;
+    if (s < nslices)
+      nch[s] = (max(srt[t * 64], 0) + 7) >> 3;
+  }
+  if (w == 0 && t == 0)
+    nch[nslices] = 0;
+}
+
+// One wavefront packs one slice.  ghost_flag (or null): does the slice reference a column >= nrows?
+template <bool PERM>
+__global__ __launch_bounds__(256) void k_sp_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                 const double* __restrict__ vals, int nrows, int64_t nslices, int drop,
+                                                 const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_off,
+                                                 double* __restrict__ svals, uint16_t* __restrict__ c16,
+                                                 int32_t* __restrict__ c32, int32_t* __restrict__ meta,
+                                                 uint8_t* __restrict__ ghost_flag)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
+    if (!PERM && r >= nrows)
+      r = -1;
+    int k = r >= 0 ? rowptr[r] : 0;
+    const int end = r >= 0 ? rowptr[r + 1] : 0;
+    const int c0 = chunk_off[s], c1 = chunk_off[s + 1];
+    bool gh = false;
+    for (int c = c0; c < c1; ++c)
+    {
+      double v[8];
+      int cl[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        v[e] = 0.0;
+        cl[e] = INT_MAX;
+        while (k < end)
+        {
+          const double t = vals[k];
+          const int kk = k++;
+          if (!drop || t != 0.0)
+          {
+            v[e] = t;
+            cl[e] = cols[kk];
+            break;
+          }
+        }
+      }
+      int base[8];
+      bool wide = false;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        const bool has = cl[e] != INT_MAX;
+        gh |= has && cl[e] >= nrows;
+        int mn = wave_min_i(cl[e]);
+        const int mx = wave_max_i(has ? cl[e] : -1);
+        if (mn == INT_MAX)
+          mn = 0; // no lane has an entry in this slot
+        wide |= mx - mn > 65535;
+        base[e] = mn;
+        if (!has)
+          cl[e] = mn; // padding: value +0.0, a column some lane reads anyway
+      }
+      dbl2* vp = reinterpret_cast<dbl2*>(svals + (size_t)c * 512) + lane;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        dbl2 q;
+        q.x = v[2 * j];
+        q.y = v[2 * j + 1];
+        vp[64 * j] = q;
+      }
+      if (!wide)
+      {
+        uint4v q;
+        q.x = (unsigned)(cl[0] - base[0]) | ((unsigned)(cl[1] - base[1]) << 16);
+        q.y = (unsigned)(cl[2] - base[2]) | ((unsigned)(cl[3] - base[3]) << 16);
+        q.z = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 16);
+        q.w = (unsigned)(cl[6] - base[6]) | ((unsigned)(cl[7] - base[7]) << 16);
+        reinterpret_cast<uint4v*>(c16 + (size_t)c * 512)[lane] = q;
+      }
+      else
+      {
+        int4v q0, q1;
+        q0.x = cl[0], q0.y = cl[1], q0.z = cl[2], q0.w = cl[3];
+        q1.x = cl[4], q1.y = cl[5], q1.z = cl[6], q1.w = cl[7];
+        int4v* cp = reinterpret_cast<int4v*>(c32 + (size_t)c * 512) + 2 * lane;
+        cp[0] = q0;
+        cp[1] = q1;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (lane == e)
+          meta[(size_t)c * 8 + e] = (e == 0 && wide) ? (base[e] | (int)0x80000000) : base[e];
+    }
+    if (ghost_flag)
+    {
+      const unsigned long long m = __ballot(gh);
+      if (lane == 0)
+        ghost_flag[s] = m != 0ull;
+    }
+  }
+}
+
+// ---- the product --------------------------------------------------------------------------------------
+template <bool NT, typename T>
+__device__ inline T sp_load(const T* p)
+{
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+// x[col] with a 32-bit byte offset: one shift per gather instead of a 64-bit address computation
+// (the launcher guarantees 8 * ncols < 2^32)
+__device__ inline double gather(const double* __restrict__ x, int col)
+{
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
+}
+
+template <bool DOT, bool NT, bool PERM>
+__global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int32_t* __restrict__ chunk_off,
+                                                              const double* __restrict__ svals,
+                                                              const uint16_t* __restrict__ c16,
+                                                              const int32_t* __restrict__ c32,
+                                                              const int32_t* __restrict__ meta,
+                                                              const int32_t* __restrict__ perm,
+                                                              const double* __restrict__ x, double* __restrict__ y,
+                                                              int nrows, int64_t nslices, double* __restrict__ partials,
+                                                              const int* __restrict__ stop_flag,
+                                                              const int32_t* __restrict__ group_list, int64_t nlist,
+                                                              const double* __restrict__ rvec, int pstride, int nn_is_rr)
+{
+  // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
+  // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
+  // spmv_tile_kernel
+  if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
+    return;
+  __shared__ double red[SP_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ngroups = group_list ? nlist : (nslices + 3) / 4; // a workgroup takes 4 consecutive slices
+  double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
+  for (int i = 0;; ++i)
+  {
+    const int64_t gi = sp_xcd_item(ngroups, blockIdx.x, gridDim.x, i);
+    if (gi < 0)
+      break;
+    const int64_t g = group_list ? group_list[gi] : gi;
+    const int s = __builtin_amdgcn_readfirstlane((int)(4 * g + wv));
+    if (s >= nslices)
+      continue;
+    const int c0 = chunk_off[s], c1 = chunk_off[s + 1];
+    int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
+    if (!PERM && r >= nrows)
+      r = -1;
+    const double xr = (DOT && r >= 0) ? x[r] : 0.0;
+    double sum = 0.0;
+    for (int c = c0; c < c1; ++c)
+    {
+      const dbl2* __restrict__ vp = reinterpret_cast<const dbl2*>(svals + (size_t)c * 512) + lane;
+      const dbl2 v0 = sp_load<NT>(vp), v1 = sp_load<NT>(vp + 64), v2 = sp_load<NT>(vp + 128), v3 = sp_load<NT>(vp + 192);
+      const int32_t* __restrict__ mp = meta + (size_t)c * 8;
+      const int b0 = mp[0];
+      int cl[8];
+      if (b0 >= 0)
+      {
+        const uint4v q = sp_load<NT>(reinterpret_cast<const uint4v*>(c16 + (size_t)c * 512) + lane);
+        cl[0] = b0 + (int)(q.x & 0xffffu);
+        cl[1] = mp[1] + (int)(q.x >> 16);
+        cl[2] = mp[2] + (int)(q.y & 0xffffu);
+        cl[3] = mp[3] + (int)(q.y >> 16);
+        cl[4] = mp[4] + (int)(q.z & 0xffffu);
+        cl[5] = mp[5] + (int)(q.z >> 16);
+        cl[6] = mp[6] + (int)(q.w & 0xffffu);
+        cl[7] = mp[7] + (int)(q.w >> 16);
+      }
+      else
+      {
+        const int4v* __restrict__ cp = reinterpret_cast<const int4v*>(c32 + (size_t)c * 512) + 2 * lane;
+        const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
+        cl[0] = q0.x, cl[1] = q0.y, cl[2] = q0.z, cl[3] = q0.w;
+        cl[4] = q1.x, cl[5] = q1.y, cl[6] = q1.z, cl[7] = q1.w;
+      }
+      double xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        xv[e] = gather(x, cl[e]);
+      // ascending column order, mul and add rounded separately: the scalar CPU loop's bits
+      sum += v0.x * xv[0];
+      sum += v0.y * xv[1];
+      sum += v1.x * xv[2];
+      sum += v1.y * xv[3];
+      sum += v2.x * xv[4];
+      sum += v2.y * xv[5];
+      sum += v3.x * xv[6];
+      sum += v3.y * xv[7];
+    }
+    if (r >= 0)
+    {
+      y[r] = sum;
+      if (DOT)
+      {
+        dot += sum * xr;
+        if (rvec)
+        {
+          const double rr_ = rvec[r];
+          dot_rx += rr_ * xr;
+          dot_nn += nn_is_rr ? rr_ * rr_ : xr * xr;
+        }
+      }
+    }
+  }
+  if (DOT)
+  {
+    const double sres = block_reduce_sum(dot, red);
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = sres;
+    if (rvec)
+    {
+      const double s1 = block_reduce_sum(dot_rx, red);
+      const double s2 = block_reduce_sum(dot_nn, red);
+      if (threadIdx.x == 0)
+      {
+        partials[pstride + blockIdx.x] = s1;
+        partials[2 * pstride + blockIdx.x] = s2;
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+static int grid_cap(int64_t items, int per, int cap)
+{
+  int64_t g = (items + per - 1) / per;
+  if (g > cap)
+    g = cap;
+  if (g < 1)
+    g = 1;
+  return (int)g;
+}
+
+// (Re)build the operator stream from the CSR values.  `structure`: the pattern is new (the scratch sizes
+// change); the stream itself always depends on the values (zeros are dropped), so every call re-packs.
+// One 8-byte read-back per call (the chunk totals, needed to size the stream).
+int sell_update(zzz_ctx* ctx, bool structure)
+{
+  (void)structure;
+  ctx->have_sell = false;
+  ctx->sell_current = false;
+  const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
+  if (ctx->sellp_mode == 0 || (!ctx->spmv_auto && !forced) || !ctx->vals.p)
+    return ZZZ_OK;
+  if (ctx->nloc() >= ((int64_t)1 << 29)) // 32-bit byte offsets of the x gather
+    return ZZZ_OK;
+  hipStream_t s = ctx->stream;
+  const int nrows = (int)ctx->nrows;
+  const int64_t nsl = (ctx->nrows + 63) / 64;
+  ctx->nslices = nsl;
+  const int drop = ctx->sellp_drop ? 1 : 0;
+  ZZZ_HIP(ctx, ctx->sp_rownnz.alloc((size_t)nrows + 1));
+  ZZZ_HIP(ctx, ctx->sp_nch.alloc(2 * ((size_t)nsl + 1)));
+  ZZZ_HIP(ctx, ctx->sp_chunk_off.alloc(2 * ((size_t)nsl + 1)));
+  ZZZ_HIP(ctx, ctx->sp_perm.alloc((size_t)nsl * 64));
+  hipLaunchKernelGGL(k_sp_count, dim3(grid_cap(nrows, 256, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, drop,
+                     ctx->sp_rownnz.p);
+  // both orders are priced: natural rows, and rows sorted by length inside windows of SP_SIGMA
+  int32_t* nch0 = ctx->sp_nch.p;
+  int32_t* nch1 = ctx->sp_nch.p + nsl + 1;
+  int32_t* off0 = ctx->sp_chunk_off.p;
+  int32_t* off1 = ctx->sp_chunk_off.p + nsl + 1;
+  hipLaunchKernelGGL(k_sp_slice_len, dim3(grid_cap(nsl + 1, 4, 8192)), dim3(256), 0, s, ctx->sp_rownnz.p, nrows, nsl, nch0);
+  const int64_t nwin = (ctx->nrows + SP_SIGMA - 1) / SP_SIGMA;
+  hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p, nch1);
+  size_t tb = 0;
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, nch0, off0, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
+  ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, nch0, off0, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, nch1, off1, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
+  int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 4); // pinned scratch
+  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[0], off0 + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[1], off1 + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  const int64_t t0 = tot[0], t1 = tot[1];
+  if (t0 < 0 || t1 < 0)
+    return ZZZ_OK; // chunk count beyond int32: keep the CSR tile kernel
+  // sorted rows cost a permuted y store and 4 B per row: only when they save a tenth of the stream
+  bool sorted = ctx->sellp_mode == 3 || (ctx->sellp_mode != 2 && (double)t1 < 0.9 * (double)t0);
+  const int64_t total = sorted ? t1 : t0;
+  // the stream must not be (much) longer than what the CSR tile kernel reads: 512 entries per chunk
+  if (!forced && ctx->sellp_mode == 1 && (double)total * 512.0 > 1.05 * (double)ctx->nnz + 64.0 * 512.0)
+    return ZZZ_OK;
+  ctx->sp_sorted = sorted;
+  ctx->sp_chunks = total;
+  const size_t ne = (size_t)total * 512 + 512;
+  ZZZ_HIP(ctx, ctx->sp_vals.alloc(ne));
+  ZZZ_HIP(ctx, ctx->sp_codes16.alloc(ne));
+  ZZZ_HIP(ctx, ctx->sp_codes32.alloc(ne)); // touched only by chunks that need int32 columns
+  ZZZ_HIP(ctx, ctx->sp_meta.alloc((size_t)total * 8 + 8));
+  uint8_t* gflag = nullptr;
+  DevBuf<uint8_t> flag;
+  if (ctx->n_ghost > 0)
+  {
+    ZZZ_HIP(ctx, flag.alloc((size_t)nsl));
+    gflag = flag.p;
+  }
+  const int gf = grid_cap(nsl, 4, 16384);
+  if (sorted)
+    hipLaunchKernelGGL(k_sp_fill<true>, dim3(gf), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows, nsl, drop,
+                       ctx->sp_perm.p, off1, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  else
+    hipLaunchKernelGGL(k_sp_fill<false>, dim3(gf), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows, nsl, drop,
+                       (const int32_t*)nullptr, off0, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  ZZZ_HIP(ctx, hipGetLastError());
+  // interior / boundary groups of 4 slices for the halo-compute overlap of a partitioned matrix
+  ctx->n_groups_interior = ctx->n_groups_boundary = 0;
+  ctx->have_group_split = false;
+  if (gflag)
+  {
+    std::vector<uint8_t> h((size_t)nsl);
+    ZZZ_HIP(ctx, hipMemcpyAsync(h.data(), gflag, h.size(), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    const int64_t ng = (nsl + 3) / 4;
+    std::vector<int32_t> in, bd;
+    for (int64_t g2 = 0; g2 < ng; ++g2)
+    {
+      bool gh = false;
+      for (int64_t q = 4 * g2; q < std::min(nsl, 4 * g2 + 4); ++q)
+        gh |= h[(size_t)q] != 0;
+      (gh ? bd : in).push_back((int32_t)g2);
+    }
+    ZZZ_HIP(ctx, ctx->groups_interior.alloc(in.size()));
+    ZZZ_HIP(ctx, ctx->groups_boundary.alloc(bd.size()));
+    if (!in.empty())
+      ZZZ_HIP(ctx, hipMemcpyAsync(ctx->groups_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (!bd.empty())
+      ZZZ_HIP(ctx, hipMemcpyAsync(ctx->groups_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    ctx->n_groups_interior = (int64_t)in.size();
+    ctx->n_groups_boundary = (int64_t)bd.size();
+    ctx->have_group_split = true;
+  }
+  ctx->have_sell = true;
+  ctx->sell_current = true;
+  return ZZZ_OK;
+}
+
+bool sellp_active(const zzz_ctx* ctx)
+{
+  if (!ctx->have_sell || !ctx->sell_current)
+    return false;
+  return ctx->spmv_auto || (ctx->spmv_variant & 8) != 0;
+}
+
+// bytes one product reads from the stream (values + codes + bases; int32 chunks are not counted separately)
+int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_chunks * (4096 + 1024 + 32) + (ctx->nslices + 1) * 4; }
+
+static int sp_grid(int64_t ngroups)
+{
+  int64_t gs = 256 * 8;
+  const int64_t need = (ngroups + 7) / 8 * 8;
+  if (gs > need)
+    gs = need;
+  if (gs < 8)
+    gs = 8;
+  return (int)gs;
+}
+
+template <bool DOT>
+static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
+                       const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr)
+{
+  // load policy by stream size, as for the tile kernel: a stream that stays in the 256 MiB Infinity Cache from
+  // one CG iteration to the next is read with plain loads, a larger one with non-temporal loads
+  bool nt = (double)sellp_stream_bytes(ctx) > 300.0e6;
+  if (!ctx->spmv_auto)
+    nt = (ctx->spmv_variant & 1) != 0;
+  const int32_t* off = ctx->sp_chunk_off.p + (ctx->sp_sorted ? ctx->nslices + 1 : 0);
+#define ZZZ_SP_GO(NT, PERM)                                                                                            \
+  hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off, ctx->sp_vals.p,     \
+                     ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y, (int)ctx->nrows,          \
+                     ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr)
+  if (ctx->sp_sorted)
+  {
+    if (nt)
+      ZZZ_SP_GO(true, true);
+    else
+      ZZZ_SP_GO(false, true);
+  }
+  else
+  {
+    if (nt)
+      ZZZ_SP_GO(true, false);
+    else
+      ZZZ_SP_GO(false, false);
+  }
+#undef ZZZ_SP_GO
+}
+
+int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr)
+{
+  const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
+  const int gs = sp_grid((ctx->nslices + 3) / 4);
+  if (partials)
+  {
+    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr);
+    if (npartials)
+      *npartials = gs;
+  }
+  else
+    launch_one<false>(ctx, gs, x, y, nullptr, stop, nullptr, 0, nullptr, 0);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+
+// Partitioned matrix: forward halo of x overlapped with the groups that reference no ghost column
+// (scheme and the 7-of-8 workgroup slots: launch_spmv_overlapped in zzz_spmv.hip)
+int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,
+                            int nn_is_rr)
+{
+  const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
+  const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
+  int g_in = gi ? sp_grid(gi) : 0;
+  if (g_in > 256 * 7 && ctx->nneigh > 0)
+    g_in = 256 * 7;
+  const int g_bd = gb ? sp_grid(gb) : 0;
+  if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
+    return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
+  int rc = comm_halo_begin(ctx, x);
+  if (rc)
+    return rc;
+  if (gi)
+  {
+    if (partials)
+      launch_one<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr);
+    else
+      launch_one<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi, nullptr, 0);
+  }
+  rc = comm_halo_end(ctx);
+  if (rc)
+    return rc;
+  if (gb)
+  {
+    if (partials)
+      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr);
+    else
+      launch_one<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb, nullptr, 0);
+  }
+  if (npartials)
+    *npartials = g_in + g_bd;
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+} // namespace zzz

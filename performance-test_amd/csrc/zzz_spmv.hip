@@ -18,8 +18,6 @@
 #include "zzz_device.h"
 #include "zzz_internal.h"
 
-#include <rocprim/rocprim.hpp>
-
 namespace zzz
 {
 constexpr int SPMV_BLOCK = 256;
@@ -267,299 +265,6 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
   }
 }
 
-// ---- sliced-ELL (SELL-64) copy of the matrix for the CG SpMV --------------------------------------
-// The CSR arrays stay the matrix of record (zzz_csr_download, Jacobi, parity); after each assembly
-// the values are also scattered into slices of 64 consecutive rows stored column-major: entry k of
-// row (64 s + lane) sits at slice_off[s] + 64 k + lane.  One lane owns one row:
-//   * the matrix stream is one dense 512-B (values) + 256-B (columns) read per wave instruction;
-//   * for mesh-ordered rows the 64 gathered x entries of one instruction are (nearly) consecutive,
-//     so the gather is coalesced too -- in the CSR tile kernel it costs ~13 % of the run time;
-//   * no LDS, no barriers; each row is summed in ascending column order, exactly like the CSR loop,
-//     so y is bit-identical (padding entries are loaded but never added).
-// Rows of one slice have near-equal length in FE matrices numbered entity-type by entity-type; the
-// builder reports the padding and the CSR tile kernel remains the fallback when it is large.
-// MEASURED (MI355X, P1 Poisson, same process): at 10 M dofs (matrix streamed from HBM) 0.420 ms against
-// 0.372 ms for the CSR tile kernel -- the 8-B / 4-B per-lane reads cost more than the coalesced gather
-// saves; at 1.25 M dofs (matrix resident in the Infinity Cache) 37.5 us against 41.4 us, at 0.5 M dofs
-// 16.9 against 21.0 us -- no barrier, no LDS round trip.  So the copy is built, and used, for
-// cache-resident matrices (sell_update) and on request (ZZZ_SPMV_VARIANT bit 3).
-__global__ void k_sell_slice_len(const int32_t* __restrict__ rowptr, int nrows, int64_t nslices,
-                                 int32_t* __restrict__ slen)
-{
-  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s <= nslices; s += (int64_t)gridDim.x * blockDim.x)
-  {
-    int m = 0;
-    if (s < nslices)
-      for (int r = (int)s * 64; r < min(nrows, (int)s * 64 + 64); ++r)
-        m = max(m, rowptr[r + 1] - rowptr[r]);
-    slen[s] = m * 64; // entries of the slice (exclusive scan -> slice_off)
-  }
-}
-
-// FILL_COLS: also write the column indices (pattern build); always copies the values
-template <bool FILL_COLS>
-__global__ __launch_bounds__(256) void k_sell_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                   const double* __restrict__ vals, int nrows, int64_t nslices,
-                                                   const int32_t* __restrict__ slice_off, int32_t* __restrict__ scols,
-                                                   double* __restrict__ svals)
-{
-  const int lane = threadIdx.x & 63;
-  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
-  {
-    const int off = slice_off[s], len = (slice_off[s + 1] - off) >> 6;
-    const int r = (int)s * 64 + lane;
-    const int a = r < nrows ? rowptr[r] : 0, n = r < nrows ? rowptr[r + 1] - a : 0;
-    const int32_t pad_col = n > 0 ? cols[a] : 0; // a column of the row itself (or 0 for rows past the end)
-    for (int k = 0; k < len; ++k)
-    {
-      const int idx = off + k * 64 + lane;
-      svals[idx] = k < n ? vals[a + k] : 0.0;
-      if (FILL_COLS)
-        scols[idx] = k < n ? cols[a + k] : pad_col;
-    }
-  }
-}
-
-template <bool DOT, bool NT>
-__global__ __launch_bounds__(SPMV_BLOCK) void spmv_sell_kernel(const int32_t* __restrict__ rowptr,
-                                                               const int32_t* __restrict__ slice_off,
-                                                               const int32_t* __restrict__ scols,
-                                                               const double* __restrict__ svals,
-                                                               const double* __restrict__ x, double* __restrict__ y,
-                                                               int nrows, int64_t nslices, double* __restrict__ partials,
-                                                               const int* __restrict__ stop_flag,
-                                                               const int32_t* __restrict__ group_list, int64_t nlist,
-                                                               const double* __restrict__ rvec, int pstride, int nn_is_rr)
-{
-  // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
-  // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
-  // spmv_tile_kernel
-  if (stop_flag && *stop_flag)
-    return;
-  __shared__ double red[SPMV_BLOCK / 64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ngroups = group_list ? nlist : (nslices + 3) / 4; // a workgroup takes 4 consecutive slices (256 rows)
-  double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
-  for (int i = 0;; ++i)
-  {
-    const int64_t gi = xcd_tile(ngroups, blockIdx.x, gridDim.x, i);
-    if (gi < 0)
-      break;
-    const int64_t g = group_list ? group_list[gi] : gi;
-    const int64_t s = 4 * g + wv;
-    if (s >= nslices)
-      continue;
-    const int off = slice_off[s], len = (slice_off[s + 1] - off) >> 6;
-    const int r = (int)s * 64 + lane;
-    const int rc = min(r, nrows - 1);
-    const int n = r < nrows ? rowptr[rc + 1] - rowptr[rc] : 0;
-    const double xr = DOT ? x[rc] : 0.0;
-    const double* __restrict__ vp = svals + off + lane;
-    const int32_t* __restrict__ cp = scols + off + lane;
-    double sum = 0.0;
-    // chunks of 8 entries, all loads of a chunk in flight together; indices are clamped into the
-    // slice so there is no serial tail (a clamped reload is masked out of the sum)
-    for (int k = 0; k < len; k += 8)
-    {
-      double v[8], xv[8];
-      int32_t c[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-      {
-        const int kk = min(k + u, len - 1) * 64;
-        v[u] = stream_load<NT>(vp + kk);
-        c[u] = stream_load<NT>(cp + kk);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        xv[u] = x[c[u]];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k + u < n)
-          sum += v[u] * xv[u];
-    }
-    if (r < nrows)
-    {
-      y[r] = sum;
-      if (DOT)
-      {
-        dot += sum * xr;
-        if (rvec)
-        {
-          const double rr_ = rvec[r];
-          dot_rx += rr_ * xr;
-          dot_nn += nn_is_rr ? rr_ * rr_ : xr * xr;
-        }
-      }
-    }
-  }
-  if (DOT)
-  {
-    const double sres = block_reduce_sum(dot, red);
-    if (threadIdx.x == 0)
-      partials[blockIdx.x] = sres;
-    if (rvec)
-    {
-      const double s1 = block_reduce_sum(dot_rx, red);
-      const double s2 = block_reduce_sum(dot_nn, red);
-      if (threadIdx.x == 0)
-      {
-        partials[pstride + blockIdx.x] = s1;
-        partials[2 * pstride + blockIdx.x] = s2;
-      }
-    }
-  }
-}
-
-// Which groups of 4 slices (256 rows) reference a ghost column?  One wavefront per group over its CSR rows.
-__global__ __launch_bounds__(256) void k_group_ghost_flag(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                          int32_t nrows, int64_t ngroups, uint8_t* __restrict__ flag)
-{
-  const int lane = threadIdx.x & 63;
-  for (int64_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += (int64_t)gridDim.x * 4)
-  {
-    const int r0 = (int)min((int64_t)nrows, g * 256), r1 = (int)min((int64_t)nrows, g * 256 + 256);
-    bool gh = false;
-    for (int k = rowptr[r0] + lane; k < rowptr[r1]; k += 64)
-      gh |= cols[k] >= nrows;
-    const unsigned long long m = __ballot(gh);
-    if (lane == 0)
-      flag[g] = m != 0ull;
-  }
-}
-
-// (re)build the SELL copy: structure when `structure` is set (after the pattern build), values always
-int sell_update(zzz_ctx* ctx, bool structure)
-{
-  // Built when forced (ZZZ_SPMV_VARIANT bit 3) or, by default, for matrices that stay in the Infinity Cache
-  // from one CG iteration to the next (same size rule as the load policy of the tile kernel): there the
-  // barrier-free one-lane-per-row walk is faster than the tile kernel (1.25 M-dof P1: 37.5 vs 41.4 us,
-  // 0.5 M: 16.9 vs 21.0 us), while for matrices streamed from HBM the tile kernel wins (10 M: 0.39 vs 0.42 ms).
-  // Long rows that use several lanes per row keep the tile kernel.
-  // ... and so do rows of more than ~32 nonzeros (elasticity P1, 45 per row, 0.5 M dofs: 46.7 us against 43.8 us
-  // for the tile kernel -- the serial walk of a lane gets long)
-  const bool cache_resident = 12.0 * (double)ctx->nnz <= 300.0e6;
-  const bool short_rows = ctx->nrows > 0 && (double)ctx->nnz <= 32.0 * (double)ctx->nrows;
-  ctx->sell_auto_on = ctx->spmv_auto && cache_resident && short_rows && ctx->spmv_lpr_shift == 0;
-  if (!(ctx->spmv_variant & 8) && !ctx->sell_requested && !ctx->sell_auto_on)
-  {
-    ctx->have_sell = false;
-    return ZZZ_OK;
-  }
-  hipStream_t s = ctx->stream;
-  const int nrows = (int)ctx->nrows;
-  const int64_t nsl = (ctx->nrows + 63) / 64;
-  if (structure)
-  {
-    ctx->have_sell = false;
-    ctx->nslices = nsl;
-    DevBuf<int32_t> slen;
-    ZZZ_HIP(ctx, slen.alloc((size_t)nsl + 1));
-    ZZZ_HIP(ctx, ctx->slice_off.alloc((size_t)nsl + 1));
-    int g = (int)((nsl + 256) / 256);
-    if (g > 4096)
-      g = 4096;
-    hipLaunchKernelGGL(k_sell_slice_len, dim3(g), dim3(256), 0, s, ctx->rowptr.p, nrows, nsl, slen.p);
-    size_t tb = 0;
-    ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, slen.p, ctx->slice_off.p, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
-    DevBuf<unsigned char> tmp;
-    ZZZ_HIP(ctx, tmp.alloc(tb));
-    // total entries must fit int32: check with 64-bit arithmetic on the host side of the last offset
-    ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, slen.p, ctx->slice_off.p, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
-    int32_t total = 0;
-    ZZZ_HIP(ctx, hipMemcpyAsync(&total, ctx->slice_off.p + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    ZZZ_HIP(ctx, hipStreamSynchronize(s));
-    // padding beyond 25 % (or int32 overflow, seen as a non-monotone total): keep the CSR tile kernel
-    if (total < ctx->nnz || (double)total > 1.25 * (double)ctx->nnz + 64.0 * 64.0)
-    {
-      ctx->sell_entries = 0;
-      ctx->slice_off.release();
-      return ZZZ_OK;
-    }
-    ctx->sell_entries = total;
-    ZZZ_HIP(ctx, ctx->sell_cols.alloc((size_t)total + 64));
-    ZZZ_HIP(ctx, ctx->sell_vals.alloc((size_t)total + 64));
-  }
-  if (ctx->sell_entries == 0)
-    return ZZZ_OK;
-  int g = (int)((ctx->nslices + 3) / 4);
-  if (g > 8192)
-    g = 8192;
-  if (structure)
-    hipLaunchKernelGGL(k_sell_fill<true>, dim3(g), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows,
-                       ctx->nslices, ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p);
-  else
-    hipLaunchKernelGGL(k_sell_fill<false>, dim3(g), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows,
-                       ctx->nslices, ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p);
-  ZZZ_HIP(ctx, hipGetLastError());
-  ctx->have_sell = true;
-  if (structure)
-  {
-    // interior / boundary groups for the halo-compute overlap of a partitioned matrix
-    ctx->n_groups_interior = ctx->n_groups_boundary = 0;
-    ctx->have_group_split = false;
-    const int64_t ng = (ctx->nslices + 3) / 4;
-    if (ctx->n_ghost > 0 && ng > 0)
-    {
-      DevBuf<uint8_t> flag;
-      ZZZ_HIP(ctx, flag.alloc((size_t)ng));
-      int gg = (int)((ng + 3) / 4);
-      if (gg > 4096)
-        gg = 4096;
-      hipLaunchKernelGGL(k_group_ghost_flag, dim3(gg), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, (int32_t)ctx->nrows, ng, flag.p);
-      std::vector<uint8_t> h((size_t)ng);
-      ZZZ_HIP(ctx, hipMemcpyAsync(h.data(), flag.p, h.size(), hipMemcpyDeviceToHost, s));
-      ZZZ_HIP(ctx, hipStreamSynchronize(s));
-      std::vector<int32_t> in, bd;
-      for (int64_t g2 = 0; g2 < ng; ++g2)
-        (h[(size_t)g2] ? bd : in).push_back((int32_t)g2);
-      ZZZ_HIP(ctx, ctx->groups_interior.alloc(in.size()));
-      ZZZ_HIP(ctx, ctx->groups_boundary.alloc(bd.size()));
-      if (!in.empty())
-        ZZZ_HIP(ctx, hipMemcpy(ctx->groups_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      if (!bd.empty())
-        ZZZ_HIP(ctx, hipMemcpy(ctx->groups_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      ctx->n_groups_interior = (int64_t)in.size();
-      ctx->n_groups_boundary = (int64_t)bd.size();
-      ctx->have_group_split = true;
-    }
-  }
-  return ZZZ_OK;
-}
-
-// the SELL copy is the SpMV of this matrix: forced by the variant, or chosen for cache-resident matrices
-static bool use_sell(const zzz_ctx* ctx)
-{
-  return ((ctx->spmv_variant & 8) || (ctx->sell_auto_on && ctx->spmv_auto)) && ctx->have_sell && ctx->sell_current;
-}
-
-template <bool DOT>
-static void launch_sell(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
-                        const int32_t* group_list = nullptr, int64_t nlist = 0, const double* rvec = nullptr, int nn_is_rr = 0)
-{
-  // the automatic choice is for cache-resident matrices: plain loads; a forced variant decides itself
-  const bool nt = (ctx->spmv_variant & 8) ? (ctx->spmv_variant & 1) != 0 : false;
-  if (nt)
-    hipLaunchKernelGGL((spmv_sell_kernel<DOT, true>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream, ctx->rowptr.p,
-                       ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p, x, y, (int)ctx->nrows, ctx->nslices, partials,
-                       stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr);
-  else
-    hipLaunchKernelGGL((spmv_sell_kernel<DOT, false>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream, ctx->rowptr.p,
-                       ctx->slice_off.p, ctx->sell_cols.p, ctx->sell_vals.p, x, y, (int)ctx->nrows, ctx->nslices, partials,
-                       stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr);
-}
-
-static int sell_grid(int64_t ngroups)
-{
-  int64_t gs = 256 * 8;
-  const int64_t need = (ngroups + 7) / 8 * 8;
-  if (gs > need)
-    gs = need;
-  if (gs < 8)
-    gs = 8;
-  return (int)gs;
-}
-
 static int spmv_grid(const zzz_ctx* ctx)
 {
   // 8 workgroups of 256 threads per CU; always a multiple of 8 so that every XCD residue
@@ -623,20 +328,8 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
   const int grid = spmv_grid(ctx);
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1); // last valid clamped index (arrays are padded by 8)
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
-  if (use_sell(ctx))
-  {
-    const int gs = sell_grid((ctx->nslices + 3) / 4);
-    if (partials)
-    {
-      launch_sell<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr);
-      if (npartials)
-        *npartials = gs;
-    }
-    else
-      launch_sell<false>(ctx, gs, x, y, nullptr, stop);
-    ZZZ_HIP(ctx, hipGetLastError());
-    return ZZZ_OK;
-  }
+  if (sellp_active(ctx))
+    return launch_sellp(ctx, x, y, partials, npartials, rvec, nn_is_rr);
   if (partials)
   {
     if ((size_t)grid > ctx->part_a.n)
@@ -671,41 +364,8 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
 {
   const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1);
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
-  if (use_sell(ctx) && ctx->have_group_split)
-  {
-    // same scheme on the SELL copy: groups of 256 rows take the place of the tiles
-    const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
-    int g_in = gi ? sell_grid(gi) : 0;
-    if (g_in > 256 * 7 && ctx->nneigh > 0)
-      g_in = 256 * 7; // room for RCCL's kernel beside the persistent workgroups (see below)
-    const int g_bd = gb ? sell_grid(gb) : 0;
-    if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
-      return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
-    int rc = comm_halo_begin(ctx, x);
-    if (rc)
-      return rc;
-    if (gi)
-    {
-      if (partials)
-        launch_sell<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr);
-      else
-        launch_sell<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi);
-    }
-    rc = comm_halo_end(ctx);
-    if (rc)
-      return rc;
-    if (gb)
-    {
-      if (partials)
-        launch_sell<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr);
-      else
-        launch_sell<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb);
-    }
-    if (npartials)
-      *npartials = g_in + g_bd;
-    ZZZ_HIP(ctx, hipGetLastError());
-    return ZZZ_OK;
-  }
+  if (sellp_active(ctx) && ctx->have_group_split)
+    return launch_sellp_overlapped(ctx, x, y, partials, npartials, rvec, nn_is_rr);
   const int64_t n_in = ctx->n_tiles_interior, n_bd = ctx->n_tiles_boundary;
   // The interior launch leaves one workgroup slot per CU free (7 of 8): at full occupancy the persistent
   // SpMV workgroups hold every wave slot until the launch ends and RCCL's send/recv kernel, although
