@@ -43,13 +43,13 @@ def spmv_algorithmic_bytes(n, nnz):
     return 12 * nnz + 4 * (n + 1) + 16 * n
 
 
-def pmc_traffic(nrows, nnz):
+def pmc_traffic(nrows, nnz, tag="r02"):
     """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command (they cannot share a pass and PMC
     collection cannot run inside a timed benchmark), corrected as MI355X_MICROARCH.md prescribes for
     gfx950 (FETCH_SIZE counts half of a coalesced stream: x2; KiB units).  Only reported when the
     profile was taken on the same matrix."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench10m.json")
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_bench10m.json")
     try:
         d = json.load(open(path))
         if d["rows"] != nrows or d["nnz"] != nnz:
@@ -324,6 +324,13 @@ def main():
         alg_bytes = spmv_algorithmic_bytes(nrows, nnz) + (8 * nrows if single_reduction else 0)  # + read of r
         traffic, traffic_src = pmc_traffic(nrows, nnz)
         achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+        sinfo = ctx.spmv_info_raw()
+        if sinfo[5]:
+            kernel_name = "spmv_sellp_kernel (CG SpMV on the sliced-ELL operator stream + <p,Ap> partials)"
+            streamed = sinfo[6] + 16 * nrows + (8 * nrows if single_reduction else 0)
+        else:
+            kernel_name = "spmv_tile_kernel (CG SpMV + <p,Ap> partials)"
+            streamed = (10 if sinfo[0] else 12) * nnz + 4 * (nrows + 1) + 16 * nrows + (8 * nrows if single_reduction else 0)
         avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
         out = {
             "metric": "DoF/s for ZZZ Assemble + ZZZ Solve; CG-SpMV achieved HBM GB/s vs peak",
@@ -350,12 +357,24 @@ def main():
                            "ZZZ Assemble vector": ndofs_global / avg("assemble_vector"),
                            "ZZZ Solve": ndofs_global / avg("solve"),
                            "iterations x dofs / ZZZ Solve": iters * ndofs_global / avg("solve")},
-            "roofline": {"bound": "hbm", "kernel": "spmv_tile_kernel (CG SpMV + <p,Ap> partials)",
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n,
+                         # what the kernel addresses: the operator stream (or packed CSR) + row pointers + x, y (+ r);
+                         # below the algorithmic bytes because exact zeros of the pattern are not streamed and
+                         # columns are 16-bit codes.  achieved_streamed / peak is the kernel's real HBM efficiency.
+                         "bytes_streamed_per_launch": streamed,
+                         "achieved_streamed": streamed / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+                         "frac_streamed": streamed / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if spmv_ms > 0 else 0.0},
         }
         c16 = ctx.spmv_info()
+        if sinfo[5]:
+            out["config"]["spmv_operator"] = (f"sliced-ELL operator stream, {'length-sorted' if sinfo[5] == 2 else 'natural'} row order: "
+                                              f"{sinfo[7]} entries ({sinfo[7] / nnz:.3f} of the {nnz}-entry pattern; exact zeros "
+                                              f"dropped, chunks of 8 padded), {sinfo[6]} B per product")
+        else:
+            out["config"]["spmv_operator"] = "CSR tile kernel"
         out["config"]["spmv_column_stream"] = (f"16-bit band codes ({c16[1]} offset bits), {c16[2]} of {c16[3]} tiles on int32 columns"
                                                if c16[0] else "int32")
         if tuning:

@@ -168,6 +168,8 @@ void zzz_ctx_destroy(zzz_ctx* ctx)
   comm_destroy(ctx);
   for (hipEvent_t ev : ctx->ev)
     (void)hipEventDestroy(ev);
+  if (ctx->sp_event)
+    (void)hipEventDestroy(ctx->sp_event);
   if (ctx->h_state)
     (void)hipHostFree(ctx->h_state);
   if (ctx->stream)
@@ -347,7 +349,14 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
     rc = ensure_tables(ctx); // reference tensors of the element: resident before the assembly timers start
   if (rc)
     return rc;
-  ctx->have_sell = ctx->sell_current = false; // the operator stream is packed from the values: after assembly
+  ctx->have_sell = ctx->sell_current = ctx->sp_pending = false; // the operator stream is packed from the values: after assembly
+  ctx->sp_bounds_ok = false;
+  if (ctx->sellp_mode != 0)
+  {
+    rc = sellp_pattern_bounds(ctx);
+    if (rc)
+      return rc;
+  }
   ctx->have_pattern = true;
   return ZZZ_OK;
 }
@@ -709,7 +718,7 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   info[1] = ctx->cols16_offb;
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
   info[3] = ctx->ntiles;
-  info[4] = (int64_t)1 << ctx->spmv_lpr_shift;
+  info[4] = sellp_active(ctx) ? 1 : (int64_t)1 << ctx->spmv_lpr_shift; // the stream sums a row serially
   info[5] = sellp_active(ctx) ? (ctx->sp_sorted ? 2 : 1) : 0;
   info[6] = sellp_active(ctx) ? sellp_stream_bytes(ctx) : 0; // bytes of the operator stream read per product
   info[7] = sellp_active(ctx) ? ctx->sp_chunks * 512 : 0;     // its entries, padding included

@@ -139,7 +139,12 @@ struct zzz_ctx
                          // bit 3: the sliced-ELL operator stream (zzz_sellp.hip) instead of the CSR tile kernel
   // Operator stream of the CG SpMV (zzz_sellp.hip): sliced-ELL copy in chunks of 8 entries per row, exact zeros
   // dropped, 16-bit slot-relative column codes; rebuilt from the CSR values after every assembly
-  zzz::DevBuf<int32_t> sp_rownnz, sp_nch, sp_chunk_off, sp_perm, sp_codes32, sp_meta;
+  zzz::DevBuf<int32_t> sp_rownnz, sp_nch, sp_chunk_off, sp_perm, sp_codes32, sp_meta, sp_desc, sp_counter;
+  zzz::DevBuf<uint8_t> sp_gflag;
+  hipEvent_t sp_event = nullptr;
+  bool sp_pending = false, sp_forced = false, sp_bounds_ok = false, sp_lds_attr = false;
+  int sp_max_range = 0;       // longest CSR range of a 64-row slice
+  int64_t sp_chunk_bound = 0; // chunks of the natural-order stream if no entry were zero
   zzz::DevBuf<uint16_t> sp_codes16;
   zzz::DevBuf<double> sp_vals;
   int64_t nslices = 0, sp_chunks = 0;
@@ -215,7 +220,9 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
                 int nn_is_rr = 0);
 // operator stream (zzz_sellp.hip)
 int sell_update(zzz_ctx* ctx, bool structure);
-bool sellp_active(const zzz_ctx* ctx);
+bool sellp_active(zzz_ctx* ctx);
+int sellp_resolve(zzz_ctx* ctx);
+int sellp_pattern_bounds(zzz_ctx* ctx);
 int64_t sellp_stream_bytes(const zzz_ctx* ctx);
 int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr);
 int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,

@@ -231,6 +231,166 @@ __global__ __launch_bounds__(256) void k_sp_fill(const int32_t* __restrict__ row
   }
 }
 
+// Slice bounds from the pattern alone (once per pattern): the longest CSR range of a slice (LDS staging of
+// k_sp_pack) and the number of chunks the natural-order stream can need at most (no zero dropped).
+__global__ __launch_bounds__(256) void k_sp_bounds(const int32_t* __restrict__ rowptr, int nrows, int64_t nslices,
+                                                   int* __restrict__ out /* [0] max range, [1],[2] chunk bound lo/hi */)
+{
+  const int lane = threadIdx.x & 63;
+  int mr = 0;
+  unsigned long long ch = 0;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    const int r0 = (int)(s * 64), r = min(r0 + lane, nrows - 1);
+    const int len = (r0 + lane < nrows) ? rowptr[r + 1] - rowptr[r] : 0;
+    const int m = wave_max_i(len);
+    mr = max(mr, rowptr[min(r0 + 64, nrows)] - rowptr[r0]);
+    ch += (unsigned long long)((m + 7) >> 3);
+  }
+  if (lane == 0)
+  {
+    atomicMax(&out[0], mr);
+    atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), ch);
+  }
+}
+
+// One pass from the CSR arrays to the stream, natural row order.  One wavefront per slice:
+//   1. sweeps the slice's CSR range with dense loads, keeps the entries that are not exactly zero (all of
+//      them when !drop) and parks them, compacted, in LDS; a row's first parked entry is found from the same
+//      ballots (no search);
+//   2. takes ceil(longest row / 8) chunks from a bump allocator (chunks of concurrently packed slices are
+//      neighbours in memory; where a slice lands does not change any result);
+//   3. every lane reads its row's entries back from LDS, chunk by chunk, and the chunk is written exactly as
+//      k_sp_fill writes it.
+// desc[s] = {first chunk, chunks}.  ghost_flag as in k_sp_fill.
+__global__ __launch_bounds__(256) void k_sp_pack(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                 const double* __restrict__ vals, int nrows, int64_t nslices, int drop, int cap,
+                                                 int* __restrict__ counter, int2* __restrict__ desc,
+                                                 double* __restrict__ svals, uint16_t* __restrict__ c16,
+                                                 int32_t* __restrict__ c32, int32_t* __restrict__ meta,
+                                                 uint8_t* __restrict__ ghost_flag)
+{
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  double* lv = reinterpret_cast<double*>(sp_smem + (size_t)wv * cap * 12);
+  int* lc = reinterpret_cast<int*>(sp_smem + (size_t)wv * cap * 12 + (size_t)cap * 8);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int64_t s = (int64_t)blockIdx.x * nwv + wv; s < nslices; s += (int64_t)gridDim.x * nwv)
+  {
+    const int r0 = (int)(s * 64);
+    const int a = rowptr[r0], b = rowptr[min(r0 + 64, nrows)];
+    const int my_start = rowptr[min(r0 + lane, nrows)];
+    int running = 0, cstart = 0;
+    for (int g = a; g < b; g += 64)
+    {
+      const int k = g + lane;
+      const bool in = k < b;
+      const double v = in ? __builtin_nontemporal_load(vals + k) : 0.0;
+      const int c = in ? __builtin_nontemporal_load(cols + k) : 0;
+      const bool nz = in && (!drop || v != 0.0);
+      const unsigned long long m = __ballot(nz);
+      if (my_start >= g && my_start < g + 64)
+        cstart = running + __popcll(m & ((1ull << (my_start - g)) - 1ull));
+      if (nz)
+      {
+        const int pos = running + __popcll(m & lt);
+        lv[pos] = v;
+        lc[pos] = c;
+      }
+      running += __popcll(m);
+    }
+    if (my_start >= b)
+      cstart = running;
+    const int nxt = __shfl_down(cstart, 1, 64);
+    const int cnt = (lane == 63 ? running : nxt) - cstart;
+    const int nch = (wave_max_i(cnt) + 7) >> 3;
+    int c0 = 0;
+    if (lane == 0)
+    {
+      c0 = nch ? atomicAdd(counter, nch) : 0;
+      desc[s] = make_int2(c0, nch);
+    }
+    c0 = __shfl(c0, 0, 64);
+    __builtin_amdgcn_wave_barrier();
+    bool gh = false;
+    for (int j = 0; j < nch; ++j)
+    {
+      const int c = c0 + j;
+      double v[8];
+      int cl[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        const int q = 8 * j + e;
+        const bool has = q < cnt;
+        v[e] = has ? lv[cstart + q] : 0.0;
+        cl[e] = has ? lc[cstart + q] : INT_MAX;
+      }
+      int base[8];
+      bool wide = false;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        const bool has = cl[e] != INT_MAX;
+        gh |= has && cl[e] >= nrows;
+        int mn = wave_min_i(cl[e]);
+        const int mx = wave_max_i(has ? cl[e] : -1);
+        if (mn == INT_MAX)
+          mn = 0;
+        wide |= mx - mn > 65535;
+        base[e] = mn;
+        if (!has)
+          cl[e] = mn;
+      }
+      dbl2* vp = reinterpret_cast<dbl2*>(svals + (size_t)c * 512) + lane;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+      {
+        dbl2 q;
+        q.x = v[2 * jj];
+        q.y = v[2 * jj + 1];
+        vp[64 * jj] = q;
+      }
+      if (!wide)
+      {
+        uint4v q;
+        q.x = (unsigned)(cl[0] - base[0]) | ((unsigned)(cl[1] - base[1]) << 16);
+        q.y = (unsigned)(cl[2] - base[2]) | ((unsigned)(cl[3] - base[3]) << 16);
+        q.z = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 16);
+        q.w = (unsigned)(cl[6] - base[6]) | ((unsigned)(cl[7] - base[7]) << 16);
+        reinterpret_cast<uint4v*>(c16 + (size_t)c * 512)[lane] = q;
+      }
+      else
+      {
+        int4v q0, q1;
+        q0.x = cl[0], q0.y = cl[1], q0.z = cl[2], q0.w = cl[3];
+        q1.x = cl[4], q1.y = cl[5], q1.z = cl[6], q1.w = cl[7];
+        int4v* cp = reinterpret_cast<int4v*>(c32 + (size_t)c * 512) + 2 * lane;
+        cp[0] = q0;
+        cp[1] = q1;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (lane == e)
+          meta[(size_t)c * 8 + e] = (e == 0 && wide) ? (base[e] | (int)0x80000000) : base[e];
+    }
+    if (ghost_flag)
+    {
+      const unsigned long long m = __ballot(gh);
+      if (lane == 0)
+        ghost_flag[s] = m != 0ull;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// sorted form: {first chunk, chunks} of every slice from the scanned offsets
+__global__ void k_sp_desc(const int32_t* __restrict__ off, int64_t nslices, int2* __restrict__ desc)
+{
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nslices; s += (int64_t)gridDim.x * blockDim.x)
+    desc[s] = make_int2(off[s], off[s + 1] - off[s]);
+}
+
 // ---- the product --------------------------------------------------------------------------------------
 template <bool NT, typename T>
 __device__ inline T sp_load(const T* p)
@@ -246,7 +406,7 @@ __device__ inline double gather(const double* __restrict__ x, int col)
 }
 
 template <bool DOT, bool NT, bool PERM>
-__global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int32_t* __restrict__ chunk_off,
+__global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __restrict__ desc,
                                                               const double* __restrict__ svals,
                                                               const uint16_t* __restrict__ c16,
                                                               const int32_t* __restrict__ c32,
@@ -276,7 +436,8 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int32_t* 
     const int s = __builtin_amdgcn_readfirstlane((int)(4 * g + wv));
     if (s >= nslices)
       continue;
-    const int c0 = chunk_off[s], c1 = chunk_off[s + 1];
+    const int2 ds = desc[s];
+    const int c0 = ds.x, c1 = ds.x + ds.y;
     int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
     if (!PERM && r >= nrows)
       r = -1;
@@ -366,120 +527,273 @@ static int grid_cap(int64_t items, int per, int cap)
   return (int)g;
 }
 
-// (Re)build the operator stream from the CSR values.  `structure`: the pattern is new (the scratch sizes
-// change); the stream itself always depends on the values (zeros are dropped), so every call re-packs.
-// One 8-byte read-back per call (the chunk totals, needed to size the stream).
-int sell_update(zzz_ctx* ctx, bool structure)
+// Chunk storage for `total` chunks.
+static int sp_alloc_stream(zzz_ctx* ctx, int64_t total)
 {
-  (void)structure;
-  ctx->have_sell = false;
-  ctx->sell_current = false;
-  const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
-  if (ctx->sellp_mode == 0 || (!ctx->spmv_auto && !forced) || !ctx->vals.p)
-    return ZZZ_OK;
-  if (ctx->nloc() >= ((int64_t)1 << 29)) // 32-bit byte offsets of the x gather
-    return ZZZ_OK;
-  hipStream_t s = ctx->stream;
-  const int nrows = (int)ctx->nrows;
-  const int64_t nsl = (ctx->nrows + 63) / 64;
-  ctx->nslices = nsl;
-  const int drop = ctx->sellp_drop ? 1 : 0;
-  ZZZ_HIP(ctx, ctx->sp_rownnz.alloc((size_t)nrows + 1));
-  ZZZ_HIP(ctx, ctx->sp_nch.alloc(2 * ((size_t)nsl + 1)));
-  ZZZ_HIP(ctx, ctx->sp_chunk_off.alloc(2 * ((size_t)nsl + 1)));
-  ZZZ_HIP(ctx, ctx->sp_perm.alloc((size_t)nsl * 64));
-  hipLaunchKernelGGL(k_sp_count, dim3(grid_cap(nrows, 256, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, drop,
-                     ctx->sp_rownnz.p);
-  // both orders are priced: natural rows, and rows sorted by length inside windows of SP_SIGMA
-  int32_t* nch0 = ctx->sp_nch.p;
-  int32_t* nch1 = ctx->sp_nch.p + nsl + 1;
-  int32_t* off0 = ctx->sp_chunk_off.p;
-  int32_t* off1 = ctx->sp_chunk_off.p + nsl + 1;
-  hipLaunchKernelGGL(k_sp_slice_len, dim3(grid_cap(nsl + 1, 4, 8192)), dim3(256), 0, s, ctx->sp_rownnz.p, nrows, nsl, nch0);
-  const int64_t nwin = (ctx->nrows + SP_SIGMA - 1) / SP_SIGMA;
-  hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p, nch1);
-  size_t tb = 0;
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, nch0, off0, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
-  ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, nch0, off0, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, nch1, off1, 0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
-  int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 4); // pinned scratch
-  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[0], off0 + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[1], off1 + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  const int64_t t0 = tot[0], t1 = tot[1];
-  if (t0 < 0 || t1 < 0)
-    return ZZZ_OK; // chunk count beyond int32: keep the CSR tile kernel
-  // sorted rows cost a permuted y store and 4 B per row: only when they save a tenth of the stream
-  bool sorted = ctx->sellp_mode == 3 || (ctx->sellp_mode != 2 && (double)t1 < 0.9 * (double)t0);
-  const int64_t total = sorted ? t1 : t0;
-  // the stream must not be (much) longer than what the CSR tile kernel reads: 512 entries per chunk
-  if (!forced && ctx->sellp_mode == 1 && (double)total * 512.0 > 1.05 * (double)ctx->nnz + 64.0 * 512.0)
-    return ZZZ_OK;
-  ctx->sp_sorted = sorted;
-  ctx->sp_chunks = total;
   const size_t ne = (size_t)total * 512 + 512;
   ZZZ_HIP(ctx, ctx->sp_vals.alloc(ne));
   ZZZ_HIP(ctx, ctx->sp_codes16.alloc(ne));
   ZZZ_HIP(ctx, ctx->sp_codes32.alloc(ne)); // touched only by chunks that need int32 columns
   ZZZ_HIP(ctx, ctx->sp_meta.alloc((size_t)total * 8 + 8));
-  uint8_t* gflag = nullptr;
+  return ZZZ_OK;
+}
+
+// interior / boundary groups of 4 slices for the halo-compute overlap of a partitioned matrix
+static int sp_group_split(zzz_ctx* ctx, const uint8_t* gflag)
+{
+  hipStream_t s = ctx->stream;
+  const int64_t nsl = ctx->nslices;
+  ctx->n_groups_interior = ctx->n_groups_boundary = 0;
+  ctx->have_group_split = false;
+  if (!gflag)
+    return ZZZ_OK;
+  std::vector<uint8_t> h((size_t)nsl);
+  ZZZ_HIP(ctx, hipMemcpyAsync(h.data(), gflag, h.size(), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  const int64_t ng = (nsl + 3) / 4;
+  std::vector<int32_t> in, bd;
+  for (int64_t g2 = 0; g2 < ng; ++g2)
+  {
+    bool gh = false;
+    for (int64_t q = 4 * g2; q < std::min(nsl, 4 * g2 + 4); ++q)
+      gh |= h[(size_t)q] != 0;
+    (gh ? bd : in).push_back((int32_t)g2);
+  }
+  ZZZ_HIP(ctx, ctx->groups_interior.alloc(in.size()));
+  ZZZ_HIP(ctx, ctx->groups_boundary.alloc(bd.size()));
+  if (!in.empty())
+    ZZZ_HIP(ctx, hipMemcpyAsync(ctx->groups_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (!bd.empty())
+    ZZZ_HIP(ctx, hipMemcpyAsync(ctx->groups_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  ctx->n_groups_interior = (int64_t)in.size();
+  ctx->n_groups_boundary = (int64_t)bd.size();
+  ctx->have_group_split = true;
+  return ZZZ_OK;
+}
+
+// Rows ordered by length inside windows (SELL-C-sigma): count, sort, scan, fill -- a synchronous build, used only
+// for matrices whose natural-order stream would be padded beyond use.
+static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out)
+{
+  hipStream_t s = ctx->stream;
+  const int nrows = (int)ctx->nrows;
+  const int64_t nsl = ctx->nslices;
+  const int drop = ctx->sellp_drop ? 1 : 0;
+  ZZZ_HIP(ctx, ctx->sp_rownnz.alloc((size_t)nrows + 1));
+  ZZZ_HIP(ctx, ctx->sp_nch.alloc((size_t)nsl + 1));
+  ZZZ_HIP(ctx, ctx->sp_chunk_off.alloc((size_t)nsl + 1));
+  ZZZ_HIP(ctx, ctx->sp_perm.alloc((size_t)nsl * 64));
+  hipLaunchKernelGGL(k_sp_count, dim3(grid_cap(nrows, 256, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, drop,
+                     ctx->sp_rownnz.p);
+  const int64_t nwin = (ctx->nrows + SP_SIGMA - 1) / SP_SIGMA;
+  hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p,
+                     ctx->sp_nch.p);
+  size_t tb = 0;
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->sp_nch.p, ctx->sp_chunk_off.p, 0, (size_t)nsl + 1,
+                                       rocprim::plus<int32_t>(), s));
+  ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->sp_nch.p, ctx->sp_chunk_off.p, 0, (size_t)nsl + 1,
+                                       rocprim::plus<int32_t>(), s));
+  int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 4); // pinned scratch
+  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[0], ctx->sp_chunk_off.p + nsl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  *total_out = tot[0];
+  return ZZZ_OK;
+}
+
+static int sp_fill_sorted(zzz_ctx* ctx, int64_t total)
+{
+  hipStream_t s = ctx->stream;
+  const int nrows = (int)ctx->nrows;
+  const int64_t nsl = ctx->nslices;
+  int rc = sp_alloc_stream(ctx, total);
+  if (rc)
+    return rc;
   DevBuf<uint8_t> flag;
+  uint8_t* gflag = nullptr;
   if (ctx->n_ghost > 0)
   {
     ZZZ_HIP(ctx, flag.alloc((size_t)nsl));
     gflag = flag.p;
   }
-  const int gf = grid_cap(nsl, 4, 16384);
-  if (sorted)
-    hipLaunchKernelGGL(k_sp_fill<true>, dim3(gf), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows, nsl, drop,
-                       ctx->sp_perm.p, off1, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
-  else
-    hipLaunchKernelGGL(k_sp_fill<false>, dim3(gf), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows, nsl, drop,
-                       (const int32_t*)nullptr, off0, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                     nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, ctx->sp_chunk_off.p, ctx->sp_vals.p, ctx->sp_codes16.p,
+                     ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  hipLaunchKernelGGL(k_sp_desc, dim3(grid_cap(nsl, 256, 4096)), dim3(256), 0, s, ctx->sp_chunk_off.p, nsl,
+                     reinterpret_cast<int2*>(ctx->sp_desc.p));
   ZZZ_HIP(ctx, hipGetLastError());
-  // interior / boundary groups of 4 slices for the halo-compute overlap of a partitioned matrix
-  ctx->n_groups_interior = ctx->n_groups_boundary = 0;
-  ctx->have_group_split = false;
-  if (gflag)
-  {
-    std::vector<uint8_t> h((size_t)nsl);
-    ZZZ_HIP(ctx, hipMemcpyAsync(h.data(), gflag, h.size(), hipMemcpyDeviceToHost, s));
-    ZZZ_HIP(ctx, hipStreamSynchronize(s));
-    const int64_t ng = (nsl + 3) / 4;
-    std::vector<int32_t> in, bd;
-    for (int64_t g2 = 0; g2 < ng; ++g2)
-    {
-      bool gh = false;
-      for (int64_t q = 4 * g2; q < std::min(nsl, 4 * g2 + 4); ++q)
-        gh |= h[(size_t)q] != 0;
-      (gh ? bd : in).push_back((int32_t)g2);
-    }
-    ZZZ_HIP(ctx, ctx->groups_interior.alloc(in.size()));
-    ZZZ_HIP(ctx, ctx->groups_boundary.alloc(bd.size()));
-    if (!in.empty())
-      ZZZ_HIP(ctx, hipMemcpyAsync(ctx->groups_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (!bd.empty())
-      ZZZ_HIP(ctx, hipMemcpyAsync(ctx->groups_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    ZZZ_HIP(ctx, hipStreamSynchronize(s));
-    ctx->n_groups_interior = (int64_t)in.size();
-    ctx->n_groups_boundary = (int64_t)bd.size();
-    ctx->have_group_split = true;
-  }
-  ctx->have_sell = true;
-  ctx->sell_current = true;
+  ctx->sp_sorted = true;
+  ctx->sp_chunks = total;
+  return sp_group_split(ctx, gflag);
+}
+
+// Pattern-only bounds of the natural-order stream (once per pattern; one small read-back).
+int sellp_pattern_bounds(zzz_ctx* ctx)
+{
+  ctx->sp_bounds_ok = false;
+  ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
+  if (ctx->nrows <= 0)
+    return ZZZ_OK;
+  hipStream_t s = ctx->stream;
+  const int64_t nsl = (ctx->nrows + 63) / 64;
+  ctx->nslices = nsl;
+  ZZZ_HIP(ctx, ctx->sp_counter.alloc(8));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 8 * sizeof(int), s));
+  hipLaunchKernelGGL(k_sp_bounds, dim3(grid_cap(nsl, 4, 4096)), dim3(256), 0, s, ctx->rowptr.p, (int)ctx->nrows, nsl,
+                     ctx->sp_counter.p + 4);
+  int h[4] = {0, 0, 0, 0};
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, ctx->sp_counter.p + 4, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  ctx->sp_max_range = h[0];
+  unsigned long long ch = 0;
+  memcpy(&ch, &h[2], sizeof(ch));
+  ctx->sp_chunk_bound = (int64_t)ch;
+  ctx->sp_bounds_ok = true;
   return ZZZ_OK;
 }
 
-bool sellp_active(const zzz_ctx* ctx)
+// (Re)build the operator stream from the CSR values (MatAssemblyEnd).  The natural-order stream is packed by ONE
+// kernel without waiting for the host; how many chunks it took (the allocator's counter) travels to pinned memory
+// behind it and is looked at when the first product is launched (sellp_resolve).
+int sell_update(zzz_ctx* ctx, bool structure)
 {
+  (void)structure;
+  ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
+  const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
+  if (ctx->sellp_mode == 0 || (!ctx->spmv_auto && !forced) || !ctx->vals.p)
+    return ZZZ_OK;
+  if (ctx->spmv_lpr_forced >= 0) // ZZZ_SPMV_LPR: an A/B knob of the CSR tile kernel's row phase
+    return ZZZ_OK;
+  if (ctx->nloc() >= ((int64_t)1 << 29)) // 32-bit byte offsets of the x gather
+    return ZZZ_OK;
+  if (!ctx->sp_bounds_ok)
+  {
+    int rc = sellp_pattern_bounds(ctx);
+    if (rc)
+      return rc;
+  }
+  hipStream_t s = ctx->stream;
+  const int nrows = (int)ctx->nrows;
+  const int64_t nsl = ctx->nslices;
+  ZZZ_HIP(ctx, ctx->sp_desc.alloc(2 * (size_t)nsl + 2));
+  ctx->sp_forced = forced;
+  if (ctx->sellp_mode == 3)
+  {
+    int64_t t1 = 0;
+    int rc = sp_build_sorted(ctx, &t1);
+    if (!rc)
+      rc = sp_fill_sorted(ctx, t1);
+    if (rc)
+      return rc;
+    ctx->have_sell = ctx->sell_current = true;
+    return ZZZ_OK;
+  }
+  // natural order.  Not worth packing when even the pattern bound is hopeless (rows of very different lengths)
+  const double full = (double)ctx->nnz + 64.0 * 512.0;
+  const bool long_rows = (double)ctx->nnz >= 100.0 * (double)ctx->nrows;
+  const bool always = ctx->sellp_mode == 2 || forced;
+  if (ctx->sp_chunk_bound >= INT32_MAX)
+    return ZZZ_OK;
+  size_t lds = (size_t)((ctx->sp_max_range + 63) & ~63) * 12;
+  int waves = 4;
+  while (waves > 1 && lds * waves > 64 * 1024)
+    waves >>= 1;
+  if (lds * waves > 160 * 1024 || (!always && (double)ctx->sp_chunk_bound * 512.0 > 1.5 * full))
+  {
+    // no natural-order stream; long rows may still pay in the sorted form
+    if (!always && !long_rows)
+      return ZZZ_OK;
+    int64_t t1 = 0;
+    int rc = sp_build_sorted(ctx, &t1);
+    if (rc)
+      return rc;
+    if (!always && (double)t1 * 512.0 > 0.97 * full)
+      return ZZZ_OK;
+    rc = sp_fill_sorted(ctx, t1);
+    if (rc)
+      return rc;
+    ctx->have_sell = ctx->sell_current = true;
+    return ZZZ_OK;
+  }
+  int rc = sp_alloc_stream(ctx, ctx->sp_chunk_bound);
+  if (rc)
+    return rc;
+  uint8_t* gflag = nullptr;
+  if (ctx->n_ghost > 0)
+  {
+    ZZZ_HIP(ctx, ctx->sp_gflag.alloc((size_t)nsl));
+    gflag = ctx->sp_gflag.p;
+  }
+  if (lds * waves > 64 * 1024 && !ctx->sp_lds_attr)
+  {
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+    ctx->sp_lds_attr = true;
+  }
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, sizeof(int), s));
+  const int cap = (ctx->sp_max_range + 63) & ~63;
+  hipLaunchKernelGGL(k_sp_pack, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p, ctx->cols.p,
+                     ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p, reinterpret_cast<int2*>(ctx->sp_desc.p),
+                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  ZZZ_HIP(ctx, hipGetLastError());
+  if (!ctx->sp_event)
+    ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));
+  int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 5); // pinned
+  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipEventRecord(ctx->sp_event, s));
+  ctx->sp_sorted = false;
+  ctx->sp_pending = true;
+  ctx->have_sell = ctx->sell_current = true; // provisional until sellp_resolve has seen the size
+  if (gflag)
+    return sellp_resolve(ctx);
+  return ZZZ_OK;
+}
+
+// The packed stream's size is known: keep it, or fall back (sorted form for long rows, else the CSR tile kernel).
+int sellp_resolve(zzz_ctx* ctx)
+{
+  if (!ctx->sp_pending)
+    return ZZZ_OK;
+  ctx->sp_pending = false;
+  ZZZ_HIP(ctx, hipEventSynchronize(ctx->sp_event));
+  const int64_t t0 = reinterpret_cast<int32_t*>(ctx->h_state + 5)[0];
+  ctx->sp_chunks = t0;
+  const double full = (double)ctx->nnz + 64.0 * 512.0;
+  const bool always = ctx->sellp_mode == 2 || ctx->sp_forced;
+  // Natural row order when the stream is no longer than the pattern the CSR tile kernel would read.  Rows sorted by
+  // length lose the dense x gather (measured: 3.4-3.8 TB/s of stream against 5-5.4 in natural order), so that form
+  // must be clearly shorter, and it only pays for long rows (elasticity P3: 365 against 394-410 us; Poisson P2/P3
+  // stay on the tile kernel: 460 against 346 us, 1002 against 770 us).
+  if (always || (double)t0 * 512.0 <= full)
+    return ctx->n_ghost > 0 ? sp_group_split(ctx, ctx->sp_gflag.p) : ZZZ_OK;
+  ctx->have_sell = ctx->sell_current = false;
+  if ((double)ctx->nnz < 100.0 * (double)ctx->nrows)
+    return ZZZ_OK;
+  int64_t t1 = 0;
+  int rc = sp_build_sorted(ctx, &t1);
+  if (rc)
+    return rc;
+  if ((double)t1 * 512.0 > 0.97 * full)
+    return ZZZ_OK;
+  rc = sp_fill_sorted(ctx, t1);
+  if (rc)
+    return rc;
+  ctx->have_sell = ctx->sell_current = true;
+  return ZZZ_OK;
+}
+
+bool sellp_active(zzz_ctx* ctx)
+{
+  if (ctx->sp_pending)
+    (void)sellp_resolve(ctx);
   if (!ctx->have_sell || !ctx->sell_current)
     return false;
   return ctx->spmv_auto || (ctx->spmv_variant & 8) != 0;
 }
 
 // bytes one product reads from the stream (values + codes + bases; int32 chunks are not counted separately)
-int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_chunks * (4096 + 1024 + 32) + (ctx->nslices + 1) * 4; }
+int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_chunks * (4096 + 1024 + 32) + ctx->nslices * 8; }
 
 static int sp_grid(int64_t ngroups)
 {
@@ -501,7 +815,7 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
   bool nt = (double)sellp_stream_bytes(ctx) > 300.0e6;
   if (!ctx->spmv_auto)
     nt = (ctx->spmv_variant & 1) != 0;
-  const int32_t* off = ctx->sp_chunk_off.p + (ctx->sp_sorted ? ctx->nslices + 1 : 0);
+  const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
 #define ZZZ_SP_GO(NT, PERM)                                                                                            \
   hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off, ctx->sp_vals.p,     \
                      ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y, (int)ctx->nrows,          \

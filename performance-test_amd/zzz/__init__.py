@@ -375,10 +375,14 @@ class Context:
         self._ck(self.L.zzz_spmv_info(self.h, info))
         return tuple(int(v) for v in info[:4])
 
-    def spmv_uses_sell(self):
+    def spmv_operator_form(self):
+        """0: CSR tile kernel, 1: sliced-ELL operator stream in natural row order, 2: ... rows sorted by length"""
+        return self.spmv_info_raw()[5]
+
+    def spmv_info_raw(self):
         info = (C.c_int64 * 8)()
         self._ck(self.L.zzz_spmv_info(self.h, info))
-        return bool(info[5])
+        return [int(v) for v in info]
 
     def spmv_lanes_per_row(self):
         info = (C.c_int64 * 8)()

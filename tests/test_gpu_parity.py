@@ -827,8 +827,9 @@ def test_full_size_baseline_config_properties():
         assert (nrows, ncols, nnz) == (10016937, 10016937, 149140873)
         packed, offb, nfb, ntiles = c.spmv_info()
         assert packed and nfb == 0
-        assert not c.spmv_uses_sell()  # 1.5 GB of matrix: streamed from HBM by the CSR tile kernel
         c.assemble_matrix(zzz.FORM_POISSON)
+        assert c.spmv_operator_form() == 1  # the sliced-ELL operator stream, natural row order
+        assert 0.5 * nnz < c.spmv_info_raw()[7] < 0.56 * nnz  # 7 of the 15 entries of an interior row are not zero
         c.assemble_vector(zzz.FORM_POISSON)
         b = c.vec_download(zzz.VEC_B)
         xv, yv = rng.standard_normal(nrows), rng.standard_normal(nrows)
@@ -1135,17 +1136,79 @@ def test_bench_multi_gpu_process_layout_on_one_gpu():
 
 
 def test_spmv_kernel_selection(ctx):
-    """Cache-resident matrices with short (<= 32 nonzeros on average), even rows run on the sliced-ELL copy,
-    everything else on the CSR tile kernel (HBM-streamed matrices: see the full-size test; long rows; rows of
-    very different lengths would pad the slices) -- and both give the oracle's bits."""
+    """Matrices whose rows have similar lengths run on the sliced-ELL operator stream (exact zeros dropped, natural
+    row order), very long rows of mixed lengths on its length-sorted form, the rest on the CSR tile kernel -- and
+    all of them give the oracle's bits (the stream sums a row serially in column order: zo.spmv)."""
     rng = np.random.default_rng(8)
-    for problem, order, dims, sell in (("poisson", 1, (30, 31, 29), True), ("elasticity", 1, (12, 13, 11), False),
-                                       ("poisson", 3, (8, 7, 8), False), ("elasticity", 3, (5, 5, 6), False)):
+    for problem, order, dims, form in (("poisson", 1, (30, 31, 29), 1), ("elasticity", 1, (12, 13, 11), 1),
+                                       ("poisson", 3, (8, 7, 8), 0), ("poisson", 2, (9, 8, 10), 0)):
         P = zzz.Part(problem, order, *dims)
         ctx.upload_part(P)
         ctx.pattern_build()
+        assert ctx.spmv_operator_form() == 0  # the stream is packed from the assembled values
         ctx.assemble_matrix(P.form)
-        assert ctx.spmv_uses_sell() == sell, (problem, order)
+        assert ctx.spmv_operator_form() == form, (problem, order)
         rp, cl, v = ctx.csr_download()
         xv = rng.standard_normal(P.n_owned * P.bs)
         np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv_chunked(rp.astype(np.int64), cl, v, xv, ctx.spmv_lanes_per_row()))
+
+
+@pytest.mark.parametrize("mode,drop", [(2, 1), (3, 1), (2, 0), (3, 0)])
+def test_operator_stream_forms_are_bit_exact(mode, drop):
+    """The operator stream in natural and in length-sorted row order, with and without the exact zeros of the
+    pattern, gives the bits of the serial CSR loop for every element family -- also where a chunk's columns do
+    not fit 16 bits (random renumbering: int32 chunks) and for rows that are entirely zero."""
+    old = {k: os.environ.get(k) for k in ("ZZZ_SELLP", "ZZZ_SELLP_DROP")}
+    os.environ["ZZZ_SELLP"], os.environ["ZZZ_SELLP_DROP"] = str(mode), str(drop)
+    try:
+        zo.set_num_threads(1)
+        rng = np.random.default_rng(100 * mode + drop)
+        for problem, order, dims in (("poisson", 1, (13, 9, 11)), ("elasticity", 1, (5, 6, 4)), ("poisson", 2, (5, 4, 6)),
+                                     ("elasticity", 2, (3, 3, 4)), ("poisson", 3, (3, 4, 3)), ("elasticity", 3, (2, 3, 2))):
+            P = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                assert c.spmv_operator_form() == (2 if mode == 3 else 1)
+                rp, cl, v = c.csr_download()
+                info = c.spmv_info_raw()
+                kept = np.count_nonzero(v) if drop else v.size
+                assert kept <= info[7] <= 8 * 64 * ((rp.size - 1 + 63) // 64) * ((np.diff(rp).max() + 7) // 8)
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                oit, ou, _, _ = zo.pcg(rp.astype(np.int64), cl, v, c.vec_download(zzz.VEC_B), rtol=1e-8)
+                assert abs(it - oit) <= 2
+                assert np.linalg.norm(c.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+                # values uploaded by the caller: a matrix with whole zero rows and wide column ranges
+                v2 = v.copy()
+                zero_rows = rng.choice(rp.size - 1, size=max(1, (rp.size - 1) // 7), replace=False)
+                for r in zero_rows:
+                    v2[rp[r]:rp[r + 1]] = 0.0
+                v2[rng.random(v2.size) < 0.3] = 0.0
+                c.csr_upload_values(v2)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v2, xv))
+        # random global numbering of a 97 k-dof P1 problem: the columns of a slot span more than 16 bits
+        O = zo.Problem("poisson", 1, 45, 45, 45)
+        perm = rng.permutation(O.n).astype(np.int32)
+        cell_dofs = np.ascontiguousarray(perm[O.cell_dofs])
+        bc = np.zeros_like(O.bc)
+        bc[perm] = O.bc
+        with zzz.Context(0) as c:
+            c.upload_mesh(O.x, O.cells)
+            c.upload_dofmap(1, 1, cell_dofs, O.nblock, 0)
+            c.upload_bc(np.nonzero(bc)[0].astype(np.int32))
+            c.pattern_build()
+            c.assemble_matrix(zzz.FORM_POISSON)
+            assert c.spmv_operator_form() == (2 if mode == 3 else 1)
+            rp, cl, v = c.csr_download()
+            xv = rng.standard_normal(O.n)
+            np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
