@@ -111,6 +111,10 @@ typedef struct
   int32_t reserved; /* keep 0 */
   double rtol;      /* -ksp_rtol / rtol */
   double atol;      /* -ksp_atol (PETSc default 1e-50); unused by ZZZ_CG_CGH */
+  double dtol;      /* -ksp_divtol: KSPConvergedDefault stops with KSP_DIVERGED_DTOL once the norm reaches
+                     * dtol x the initial norm (the solve then fails with ZZZ_ERR_DIVERGED, where the reference's
+                     * KSPSolve returns a negative reason); <= 0 selects PETSc's default 1e4 (KSPCreate sets
+                     * divtol = 1.e4); unused by ZZZ_CG_CGH (src/cg.h has no such test) */
 } zzz_solver_opts;
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -254,6 +258,9 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
  * rank binds the SAME library: call it on every rank before that other copy is loaded.  No reference
  * counterpart (MPI_Init, src/main.cpp:42 [EXT], is the closest). */
 int zzz_comm_load(void);
+/* File the bound librccl was loaded from (dladdr), "" before zzz_comm_load.  Every rank of a job must report the
+ * same library: bench.py compares them before the first collective and exits non-zero on a mismatch. */
+const char* zzz_comm_library_path(void);
 
 /* ncclGetUniqueId on the root; ship the bytes to the other ranks out of band (the driver's
  * threads share memory; bench.py broadcasts them).  Replaces MPI_COMM_WORLD bootstrap. */

@@ -36,6 +36,12 @@ void zzzh_num_entities(int64_t i, int64_t j, int64_t k, int nrefine, int64_t out
 void zzzh_mesh_size(int64_t ndofs, int strong, int64_t num_processes, int64_t dofs_per_node, int order,
                     int64_t out[4]);
 
+/* The suffix the "Test problem summary" prints after a count (int64_to_human, src/main.cpp:31-50):
+ * "" up to 1000, else " (<3 significant digits> thousand|million|billion|trillion)", the count being divided
+ * by 1000 while it EXCEEDS 1000 (so 1 000 000 prints " (1e+03 thousand)", as the reference does).  Writes at most
+ * `cap` bytes incl. the terminator; returns the length, or -1 for a number too big (the reference throws). */
+int zzzh_count_suffix(int64_t n, char* out, int cap);
+
 enum
 {
   ZZZH_POISSON = 0,   /* scalar P_k, Dirichlet on x = 0 and x = 1, coefficients f and g */

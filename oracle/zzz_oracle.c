@@ -110,8 +110,9 @@ void zo_mesh_size(i64 target_dofs, int target_total, i64 num_processes, i64 dofs
   Ny = Nx;
   Nz = Nx;
   uint64_t mindiff = 1000000;
-  const i64 Nx0 = Nx;
-  for (i64 i = Nx0 - 10; i < Nx0 + 10; ++i)
+  /* src/mesh.cpp:135 literally: the start Nx - 10 is evaluated once, the bound `i < Nx + 10` on the LIVE Nx that
+   * the body overwrites -- the search ends 10 past the best i found so far, not 10 past the cubic guess */
+  for (i64 i = Nx - 10; i < Nx + 10; ++i)
     for (i64 j = i - 5; j < i + 5; ++j)
       for (i64 k = i - 5; k < i + 5; ++k)
       {

@@ -29,10 +29,27 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr int VB = 256;        // threads per workgroup of the vector kernels
 constexpr int VGRID_MAX = 2048; // 8 workgroups per CU
 
+// Non-temporal access for data touched once per iteration pays only when the working set of the loop exceeds the
+// 256 MiB Infinity Cache; a loop that fits (the 8-GPU per-rank size: ~100 MB of operator stream + 60 MB of vectors)
+// keeps everything on-die with plain accesses.
+template <bool NT, typename T>
+__device__ inline T vload(const T* p)
+{
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT, typename T>
+__device__ inline void vstore(T v, T* p)
+{
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
 struct CgParams
 {
   int variant, pc, norm;
-  double rtol, atol;
+  double rtol, atol, dtol;
 };
 
 __global__ void k_extract_dinv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
@@ -124,6 +141,7 @@ __device__ inline double reduce_parts_bcast(const double* __restrict__ parts, in
 // anyway) instead of in k_update_xr: one vector read less per iteration, same operations on the same
 // operands, so x is bit-identical.  It must be applied by the launch that detects convergence too; only
 // launches enqueued after that one skip it (conv_it1).  update_dir == 0: the final test after max_it.
+template <bool NT>
 __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, double* __restrict__ beta_hist,
                                                  double* __restrict__ dp_hist, const double* __restrict__ alpha_hist,
                                                  int it, CgParams P, const double* __restrict__ pa,
@@ -172,6 +190,8 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
       conv = 2;
     else if (dp <= ttol) // KSPConvergedDefault
       conv = 1;
+    else if (dp >= P.dtol * dp0) // ... KSP_DIVERGED_DTOL
+      conv = 3;
   }
   const double bprev = (it == 0) ? 1.0 : beta_hist[it - 1];
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -209,13 +229,13 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
     const dbl2 pi = p2[i];
-    dbl2 xi = __builtin_nontemporal_load(x2 + i); // x is touched once per iteration: keep the cache for p, z, w
+    dbl2 xi = vload<NT>(x2 + i); // x is touched once per iteration: keep the cache for p, z, w
     xi.x = alpha * pi.x + xi.x; // src/cg.h:68, one kernel late
     xi.y = alpha * pi.y + xi.y;
-    __builtin_nontemporal_store(xi, x2 + i);
+    vstore<NT>(xi, x2 + i);
     if (dir)
     {
-      const dbl2 zi = __builtin_nontemporal_load(z2 + i); // last use of z
+      const dbl2 zi = vload<NT>(z2 + i); // last use of z
       dbl2 pn;
       pn.x = bcoef * pi.x + zi.x;
       pn.y = bcoef * pi.y + zi.y;
@@ -232,19 +252,22 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
   }
 }
 
+template <bool NT>
 __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, const double* __restrict__ beta_hist,
                                                   double* __restrict__ alpha_hist, int it,
                                                   const double* __restrict__ pw_parts, int npw,
                                                   const double* __restrict__ w, const double* __restrict__ dinv,
                                                   double* __restrict__ r, double* __restrict__ z, int64_t n, int norm,
-                                                  double* __restrict__ pa, double* __restrict__ pb)
+                                                  double* __restrict__ pa, double* __restrict__ pb, int variant)
 {
   if (block_converged(st))
     return;
   __shared__ double sh[VB / 64];
   const double pw = reduce_parts_bcast(pw_parts, npw, sh);
   const double alpha = beta_hist[it] / pw; // src/cg.h:65
-  if (!isfinite(alpha))
+  // KSPCG stops on a non-finite scalar (KSP_DIVERGED_NANORINF / _BREAKDOWN); linalg::cg has no such guard: with
+  // rnorm0 == 0 its alpha is 0/0, every comparison with NaN is false and the loop runs kmax times (src/cg.h:58-83)
+  if (variant != ZZZ_CG_CGH && !isfinite(alpha))
   {
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {
@@ -264,13 +287,13 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
   {
-    const dbl2 wi = __builtin_nontemporal_load(w2 + i) /* last use of w */, di = __builtin_nontemporal_load(d2 + i);
-    dbl2 ri = __builtin_nontemporal_load(r2 + i), zi; // r and D^-1 are touched once per iteration
+    const dbl2 wi = vload<NT>(w2 + i) /* last use of w */, di = vload<NT>(d2 + i);
+    dbl2 ri = vload<NT>(r2 + i), zi; // r and D^-1 are touched once per iteration
     ri.x = -alpha * wi.x + ri.x; // src/cg.h:71
     ri.y = -alpha * wi.y + ri.y;
     zi.x = di.x * ri.x;
     zi.y = di.y * ri.y;
-    __builtin_nontemporal_store(ri, r2 + i);
+    vstore<NT>(ri, r2 + i);
     z2[i] = zi;
     sa += ri.x * zi.x;
     sa += ri.y * zi.y;
@@ -310,6 +333,7 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
 //   p = z + b p;  w = s + b w  (= A p by recurrence);  x += a p;  r -= a w;  z = D^-1 r
 // so a whole iteration has ONE reduction point (after the SpMV) instead of two.
 // pa/pb/pc: partials (or the single all-reduced values) of <r,z>, the test norm^2 and <z,s>.
+template <bool NT>
 __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, double* __restrict__ beta_hist,
                                                   double* __restrict__ dpi_hist, double* __restrict__ dp_hist, int it,
                                                   CgParams P, const double* __restrict__ pa, const double* __restrict__ pb,
@@ -333,6 +357,8 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     conv = 2;
   else if (dp <= ttol) // KSPConvergedDefault
     conv = 1;
+  else if (dp >= P.dtol * (it == 0 ? dp : st->dp0)) // ... KSP_DIVERGED_DTOL
+    conv = 3;
   double b = 0.0, dpi = zs;
   if (it > 0)
   {
@@ -382,11 +408,11 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
   {
     // cache policy: only z (gathered by the next SpMV) and s (its output) are worth keeping; p, w, x, r, D^-1
     // are touched by this kernel alone, once per iteration
-    const dbl2 zi = z2[i], si = __builtin_nontemporal_load(s2 + i), di = __builtin_nontemporal_load(d2 + i);
-    dbl2 pn = zi, wn = si, xi = __builtin_nontemporal_load(x2 + i), ri = __builtin_nontemporal_load(r2 + i), zn;
+    const dbl2 zi = z2[i], si = vload<NT>(s2 + i), di = vload<NT>(d2 + i);
+    dbl2 pn = zi, wn = si, xi = vload<NT>(x2 + i), ri = vload<NT>(r2 + i), zn;
     if (it != 0)
     {
-      const dbl2 po = __builtin_nontemporal_load(p2 + i), wo = __builtin_nontemporal_load(w2 + i);
+      const dbl2 po = vload<NT>(p2 + i), wo = vload<NT>(w2 + i);
       pn.x = b * po.x + zi.x;
       pn.y = b * po.y + zi.y;
       wn.x = b * wo.x + si.x;
@@ -398,10 +424,10 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     ri.y = -a * wn.y + ri.y;
     zn.x = di.x * ri.x;
     zn.y = di.y * ri.y;
-    __builtin_nontemporal_store(pn, p2 + i);
-    __builtin_nontemporal_store(wn, w2 + i);
-    __builtin_nontemporal_store(xi, x2 + i);
-    __builtin_nontemporal_store(ri, r2 + i);
+    vstore<NT>(pn, p2 + i);
+    vstore<NT>(wn, w2 + i);
+    vstore<NT>(xi, x2 + i);
+    vstore<NT>(ri, r2 + i);
     z2[i] = zn;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
@@ -458,6 +484,13 @@ struct EventRing
   hipEvent_t& operator[](int i) { return ev[i]; }
 };
 
+// bytes one CG iteration touches (operator + `nvec` vectors) against the Infinity Cache
+static bool loop_exceeds_cache(zzz_ctx* ctx, int nvec)
+{
+  const double op = sellp_active(ctx) ? (double)sellp_stream_bytes(ctx) : 10.0 * (double)ctx->nnz;
+  return op + 8.0 * nvec * (double)ctx->nloc() > 200.0e6;
+}
+
 static int vgrid(int64_t n)
 {
   int64_t g = (n + VB - 1) / VB;
@@ -497,10 +530,13 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     return cg_solve_single_reduction(ctx, o, iters, rnorm);
   const int64_t n = ctx->n_owned * ctx->bs; // owned scalar rows
   const int max_it = o->max_it;
-  CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol};
+  CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol, o->dtol > 0.0 ? o->dtol : 1.0e4};
   const bool multi = ctx->comm != nullptr;
   const int g = vgrid(n);
   hipStream_t s = ctx->stream;
+  const bool nt = loop_exceeds_cache(ctx, 6);
+  auto kern_update_p = nt ? k_update_p<true> : k_update_p<false>;
+  auto kern_update_xr = nt ? k_update_xr<true> : k_update_xr<false>;
 
   ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
@@ -591,7 +627,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   for (; it < max_it && !stop; ++it)
   {
     // convergence test of iteration `it` and the new search direction
-    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
+    hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
                        ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
     int np = 0;
     if (nprof < max_prof)
@@ -613,8 +649,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
         return rc;
       np = 1;
     }
-    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->alpha_hist.p, it, pw_src,
-                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
+    hipLaunchKernelGGL(kern_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->alpha_hist.p, it, pw_src,
+                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb, P.variant);
     {
       int rc = allreduce_beta();
       if (rc)
@@ -637,7 +673,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   }
   // the test of the last completed iteration (it == max_it when the loop ran out) and its pending
   // solution update; no new direction
-  hipLaunchKernelGGL(k_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
+  hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
                      ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 0);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
@@ -674,6 +710,9 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
   if (fin.converged == 2)
     return fail(ctx, ZZZ_ERR_DIVERGED, "CG broke down: non-finite scalar at iteration %d", fin.iters);
+  if (fin.converged == 3)
+    return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_DTOL: norm %g >= divtol x initial norm %g at iteration %d", fin.dp, fin.dp0,
+                fin.iters);
   return ZZZ_OK;
 }
 
@@ -682,11 +721,12 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
 {
   const int64_t n = ctx->n_owned * ctx->bs;
   const int max_it = o->max_it;
-  CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol};
+  CgParams P{o->variant, o->pc, o->norm, o->rtol, o->atol, o->dtol > 0.0 ? o->dtol : 1.0e4};
   const bool multi = ctx->comm != nullptr;
   const int g = vgrid(n);
   hipStream_t s = ctx->stream;
   const int nn_is_rr = o->norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
+  auto kern_sr_update = loop_exceeds_cache(ctx, 8) ? k_sr_update<true> : k_sr_update<false>;
 
   ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
@@ -762,7 +802,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   int it = 0;
   for (; it < max_it && !stop; ++it)
   {
-    hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p,
+    hipLaunchKernelGGL(kern_sr_update, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p,
                        it, P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p,
                        ctx->r.p, n, 0);
     if (nprof < max_prof)
@@ -793,7 +833,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
     }
   }
   // convergence test of the last completed iteration: scalars only
-  hipLaunchKernelGGL(k_sr_update, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p, it,
+  hipLaunchKernelGGL(kern_sr_update, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p, it,
                      P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p, ctx->r.p,
                      n, 1);
   ZZZ_HIP(ctx, hipGetLastError());
@@ -829,6 +869,9 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
     ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
   if (fin.converged == 2)
     return fail(ctx, ZZZ_ERR_DIVERGED, "CG broke down: non-finite scalar at iteration %d", fin.iters);
+  if (fin.converged == 3)
+    return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_DTOL: norm %g >= divtol x initial norm %g at iteration %d", fin.dp, fin.dp0,
+                fin.iters);
   return ZZZ_OK;
 }
 } // namespace zzz

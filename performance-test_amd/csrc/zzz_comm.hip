@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace zzz
@@ -61,21 +62,34 @@ static const char* load_rccl()
   return load_rccl_once();
 }
 
+static std::string g_rccl_err;  // why the last load failed (dlerror text), under load_rccl's mutex
+static std::string g_rccl_path; // file the bound librccl was loaded from (dladdr)
+
 static const char* load_rccl_once()
 {
   if (g_rccl.h)
     return nullptr;
   const char* names[] = {"librccl.so.1", "librccl.so"};
   void* h = nullptr;
+  g_rccl_err.clear();
   for (const char* n : names)
+  {
     if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
       break;
+    const char* de = dlerror(); // ONE call: dlerror clears the message it returns
+    g_rccl_err += std::string(g_rccl_err.empty() ? "" : "; ") + (de ? de : "dlopen failed");
+  }
   if (!h)
     return "cannot dlopen librccl.so.1";
 #define ZZZ_SYM(field, name)                                   \
   *(void**)(&g_rccl.field) = dlsym(h, name);                   \
   if (!g_rccl.field)                                           \
-    return "librccl lacks " name;
+  {                                                            \
+    g_rccl = Rccl();                                           \
+    dlclose(h);                                                \
+    g_rccl_err = "symbol missing";                             \
+    return "librccl lacks " name;                              \
+  }
   ZZZ_SYM(GetUniqueId, "ncclGetUniqueId")
   ZZZ_SYM(CommInitRank, "ncclCommInitRank")
   ZZZ_SYM(CommDestroy, "ncclCommDestroy")
@@ -88,29 +102,57 @@ static const char* load_rccl_once()
 #undef ZZZ_SYM
   *(void**)(&g_rccl.CommSplit) = dlsym(h, "ncclCommSplit"); // absent in old RCCL: then no halo overlap
   g_rccl.h = h;
+  Dl_info di;
+  if (dladdr(reinterpret_cast<void*>(g_rccl.AllReduce), &di) && di.dli_fname)
+    g_rccl_path = di.dli_fname;
   return nullptr;
 }
 
 // RCCL (ROCm 7.2) prints a version banner with printf to STDOUT while a communicator is created.
 // Programs whose stdout is parsed (bench.py prints one JSON line) must not see it: send fd 1 to
 // stderr for the duration of the call.
+// Several rank threads of one process (the driver's --ngpus N) enter the rendezvous calls together: the redirect
+// is counted under a mutex -- the first one in saves the real stdout and redirects, the last one out restores it.
 struct StdoutToStderr
 {
-  int saved = -1;
+  static std::mutex& mtx()
+  {
+    static std::mutex m;
+    return m;
+  }
+  static int& users()
+  {
+    static int n = 0;
+    return n;
+  }
+  static int& saved_fd()
+  {
+    static int fd = -1;
+    return fd;
+  }
   StdoutToStderr()
   {
-    fflush(stdout);
-    saved = dup(1);
-    if (saved >= 0)
-      dup2(2, 1);
+    std::lock_guard<std::mutex> lk(mtx());
+    if (users()++ == 0)
+    {
+      fflush(stdout);
+      saved_fd() = dup(1);
+      if (saved_fd() >= 0)
+        dup2(2, 1);
+    }
   }
   ~StdoutToStderr()
   {
-    fflush(stdout);
-    if (saved >= 0)
+    std::lock_guard<std::mutex> lk(mtx());
+    if (--users() == 0)
     {
-      dup2(saved, 1);
-      close(saved);
+      fflush(stdout);
+      if (saved_fd() >= 0)
+      {
+        dup2(saved_fd(), 1);
+        close(saved_fd());
+        saved_fd() = -1;
+      }
     }
   }
 };
@@ -515,16 +557,19 @@ extern "C" {
 int zzz_comm_load(void)
 {
   if (const char* e = load_rccl())
-    return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, dlerror() ? dlerror() : "");
+    return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, g_rccl_err.c_str());
   return ZZZ_OK;
 }
+
+/* path of the librccl this process bound (dladdr of ncclAllReduce); "" before zzz_comm_load */
+const char* zzz_comm_library_path(void) { return g_rccl_path.c_str(); }
 
 int zzz_comm_unique_id(void* id)
 {
   if (!id)
     return fail(nullptr, ZZZ_ERR_ARG, "zzz_comm_unique_id: NULL buffer");
   if (const char* e = load_rccl())
-    return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, dlerror() ? dlerror() : "");
+    return fail(nullptr, ZZZ_ERR_RCCL, "%s: %s", e, g_rccl_err.c_str());
   ncclUniqueId u;
   StdoutToStderr quiet;
   ncclResult_t r = g_rccl.GetUniqueId(&u);
@@ -542,7 +587,7 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
   if (nranks < 1 || rank < 0 || rank >= nranks || !id)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_init: bad rank %d of %d", rank, nranks);
   if (const char* e = load_rccl())
-    return fail(ctx, ZZZ_ERR_RCCL, "%s", e);
+    return fail(ctx, ZZZ_ERR_RCCL, "%s: %s", e, g_rccl_err.c_str());
   comm_destroy(ctx);
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));

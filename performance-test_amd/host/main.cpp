@@ -88,24 +88,13 @@ struct Timer
   }
 };
 
-// src/main.cpp:31-50
-std::string int64_to_human(std::int64_t n)
+// the " (10 million)" suffix of the summary block (zzzh_count_suffix, include/zzz_host.h)
+std::string count_suffix(std::int64_t n)
 {
-  double r = static_cast<double>(n);
-  const std::string name[] = {"", "thousand", "million", "billion", "trillion"};
-  int i = 0;
-  while (r > 1000.0)
-  {
-    r /= 1000.0;
-    i++;
-  }
-  if (i > 4)
+  char buf[64];
+  if (zzzh_count_suffix(n, buf, (int)sizeof(buf)) < 0)
     throw std::runtime_error("number too big");
-  std::stringstream s;
-  if (i == 0)
-    return s.str();
-  s << " (" << std::setprecision(3) << r << " " << name[i] << ")";
-  return s.str();
+  return buf;
 }
 
 struct Options
@@ -120,7 +109,7 @@ struct Options
   std::string allreduce = "peer"; // CG scalar all-reduces: "peer" memory mailboxes (falls back) | "comm" (RCCL / local)
   // PETSc options database (README.md:66-82)
   std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
-  double ksp_rtol = 1e-5, ksp_atol = 1e-50; // PETSc defaults
+  double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_divtol = 1e4; // PETSc defaults (KSPCreate)
   int ksp_max_it = 10000;
   bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false, ksp_cg_single_reduction = false;
   std::vector<std::string> unused;
@@ -143,7 +132,7 @@ void usage()
                "  --ngpus arg (=1)                number of GPUs (takes the place of mpirun -np)\n"
                "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
                "  --allreduce arg (=peer)         peer (xGMI peer-memory mailboxes, else falls back) | comm\n"
-               "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol\n"
+               "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol -ksp_divtol\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
                "  -ksp_cg_single_reduction\n"
                "  -log_view -options_left\n"
@@ -213,6 +202,8 @@ Options parse(int argc, char** argv)
         o.ksp_rtol = std::stod(next());
       else if (key == "ksp_atol")
         o.ksp_atol = std::stod(next());
+      else if (key == "ksp_divtol")
+        o.ksp_divtol = std::stod(next());
       else if (key == "ksp_max_it")
         o.ksp_max_it = std::stoi(next());
       else if (key == "ksp_norm_type")
@@ -372,8 +363,8 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     std::cout << "  Problem type:    " << o.problem_type << std::endl;
     std::cout << "  Scaling type:    " << o.scaling_type << std::endl;
     std::cout << "  Num processes:   " << S.nranks << std::endl;
-    std::cout << "  Num cells:       " << S.num_cells << int64_to_human(S.num_cells) << std::endl;
-    std::cout << "  Total degrees of freedom:               " << S.num_dofs << int64_to_human(S.num_dofs) << std::endl;
+    std::cout << "  Num cells:       " << S.num_cells << count_suffix(S.num_cells) << std::endl;
+    std::cout << "  Total degrees of freedom:               " << S.num_dofs << count_suffix(S.num_dofs) << std::endl;
     std::cout << "  Average degrees of freedom per process: " << S.num_dofs / S.nranks << std::endl;
     std::cout << "----------------------------------------------------------------" << std::endl;
   }
@@ -400,6 +391,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     so.max_it = o.ksp_max_it;
     so.rtol = o.ksp_rtol;
     so.atol = o.ksp_atol;
+    so.dtol = o.ksp_divtol;
     so.single_reduction = o.ksp_cg_single_reduction ? 1 : 0;
   }
   double solve_s = 0;

@@ -110,8 +110,9 @@ void zzzh_mesh_size(int64_t target_dofs, int strong, int64_t num_processes, int6
   Ny = Nx;
   Nz = Nx;
   uint64_t mindiff = 1000000; // :134
-  const int64_t c = Nx;
-  for (int64_t i = c - 10; i < c + 10; ++i) // :135-151
+  // :135-151.  The bound is the reference's: `i < Nx + 10` on the live Nx (the body overwrites it), so the sweep
+  // stops 10 past the best i found so far; only the start is the cubic guess minus 10.
+  for (int64_t i = Nx - 10; i < Nx + 10; ++i)
     for (int64_t j = i - 5; j < i + 5; ++j)
       for (int64_t k = i - 5; k < i + 5; ++k)
       {
@@ -129,6 +130,25 @@ void zzzh_mesh_size(int64_t target_dofs, int strong, int64_t num_processes, int6
   out[1] = Ny;
   out[2] = Nz;
   out[3] = r;
+}
+
+int zzzh_count_suffix(int64_t n, char* out, int cap)
+{
+  static const char* const unit[] = {"thousand", "million", "billion", "trillion"};
+  if (!out || cap < 1)
+    return -1;
+  out[0] = 0;
+  double scaled = static_cast<double>(n);
+  int group = -1; // how many times a factor 1000 was taken out
+  for (; scaled > 1000.0; scaled /= 1000.0)
+    ++group;
+  if (group < 0)
+    return 0;
+  if (group > 3)
+    return -1;
+  // %.3g is what an ostream prints with setprecision(3) in its default float format
+  const int len = std::snprintf(out, (size_t)cap, " (%.3g %s)", scaled, unit[group]);
+  return len < cap ? len : cap - 1;
 }
 
 const char* zzzh_last_error(void) { return g_err.c_str(); }

@@ -29,11 +29,11 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_profile_get", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
-    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_part_create", "zzzh_part_destroy",
+    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_destroy",
     "zzzh_last_error", "zzzh_part_sizes", "zzzh_part_x", "zzzh_part_cells", "zzzh_part_cell_dofs",
     "zzzh_part_facets", "zzzh_part_bc_dofs", "zzzh_part_dof_x", "zzzh_part_global_dofs", "zzzh_part_coeff",
     "zzzh_part_neigh", "zzzh_part_send_off", "zzzh_part_send_idx", "zzzh_part_recv_cnt",
@@ -46,7 +46,7 @@ HOST_SYMBOLS = [
 class SolverOpts(C.Structure):
     _fields_ = [("variant", C.c_int32), ("pc", C.c_int32), ("norm", C.c_int32), ("op", C.c_int32),
                 ("max_it", C.c_int32), ("profile", C.c_int32), ("single_reduction", C.c_int32), ("reserved", C.c_int32),
-                ("rtol", C.c_double), ("atol", C.c_double)]
+                ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
 
 
 class ZzzError(RuntimeError):
@@ -164,6 +164,13 @@ def device_count():
 
 
 # ------------------------------------------------------------------------------------------------
+def count_suffix(n):
+    buf = C.create_string_buffer(64)
+    if host().zzzh_count_suffix(C.c_int64(int(n)), buf, 64) < 0:
+        raise ValueError("number too big")
+    return buf.value.decode()
+
+
 def mesh_size(ndofs, strong, nproc, dofs_per_node, order):
     out = np.zeros(4, np.int64)
     host().zzzh_mesh_size(int(ndofs), 1 if strong else 0, int(nproc), int(dofs_per_node), int(order), out)
@@ -357,8 +364,8 @@ class Context:
         return y
 
     def cg_solve(self, variant=CG_PETSC, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, op=OP_CSR, rtol=1e-8, atol=1e-50,
-                 max_it=10000, profile=False, single_reduction=False):
-        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0, 0, rtol, atol)
+                 max_it=10000, profile=False, single_reduction=False, dtol=0.0):
+        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0, 0, rtol, atol, dtol)
         it = C.c_int()
         rn = (C.c_double * 2)()
         self._ck(self.L.zzz_cg_solve(self.h, C.byref(o), C.byref(it), rn))
@@ -441,6 +448,12 @@ def comm_load():
     rc = hip().zzz_comm_load()
     if rc:
         raise ZzzError(rc, hip().zzz_last_error(None).decode())
+
+
+def comm_library_path():
+    f = hip().zzz_comm_library_path
+    f.restype = C.c_char_p
+    return f().decode()
 
 
 def comm_unique_id():

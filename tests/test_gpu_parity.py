@@ -142,6 +142,23 @@ def test_solver_edge_cases(ctx):
     it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
     assert it == 0 and rn == 0.0
     assert np.all(ctx.vec_download(zzz.VEC_U) == 0)
+    # ... while linalg::cg has no guard for rnorm0 == 0 (src/cg.h:53-83): alpha = 0/0, every comparison with NaN is
+    # false, the loop runs kmax times and x ends up NaN -- reproduced literally, it is not an error
+    ctx.vec_upload(zzz.VEC_U, np.zeros_like(b))
+    k, rr, rr0 = ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_NONE, rtol=1e-6, max_it=7)
+    assert k == 7 and rr0 == 0.0
+    assert np.all(np.isnan(ctx.vec_download(zzz.VEC_U)))
+    zo.set_num_threads(1)
+    rp, cl, v = ctx.csr_download()
+    ok, ox = zo.cg(rp.astype(np.int64), cl, v, np.zeros_like(b), kmax=7, rtol=1e-6)[:2]
+    assert ok == 7 and np.all(np.isnan(ox))
+    # KSPConvergedDefault's divergence test: norm >= divtol x initial norm -> KSP_DIVERGED_DTOL (both CG forms)
+    ctx.vec_upload(zzz.VEC_B, b)
+    for sr in (False, True):
+        with pytest.raises(zzz.ZzzError, match="DTOL"):
+            ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, dtol=0.5, single_reduction=sr)
+        it, _, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=sr)  # default divtol 1e4: converges
+        assert 0 < it < 100
     # argument errors surface as ZzzError, not crashes
     with pytest.raises(zzz.ZzzError):
         ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_JACOBI)

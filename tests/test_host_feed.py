@@ -22,6 +22,75 @@ def test_mesh_size_search_equals_oracle_and_survey():
     assert zzz.mesh_size(10000000, True, 1, 1, 1) == (108, 103, 111, 1)
 
 
+def _mesh_size_literal(target_dofs, target_dofs_total, num_processes, dofs_per_node, order):
+    """src/mesh.cpp:44-74,86-151 transcribed statement by statement (checker of the two restatements; Python
+    integers, C++ wrap-around never occurs at these sizes).  Note :135: `i < Nx + 10` reads the Nx that the loop
+    body assigns."""
+    def num_pdofs(i, j, k, nrefine, order):
+        i, j, k = i << nrefine, j << nrefine, k << nrefine
+        nv = (i + 1) * (j + 1) * (k + 1)
+        ne = 7 * i * j * k + 3 * (i * j + i * k + j * k) + (i + j + k)
+        nf = 12 * i * j * k + 2 * (i * j + i * k + j * k)
+        nc = 6 * (i * j * k)
+        return {1: nv, 2: nv + ne, 3: nv + 2 * ne + nf, 4: nv + 3 * ne + 3 * nf + nc}[order]
+
+    N = target_dofs // dofs_per_node if target_dofs_total else target_dofs * num_processes // dofs_per_node
+    r, Nx_max, Nx, ndofs = 0, 200, 1, 0
+    while ndofs < N:
+        Nx += 1
+        if Nx > Nx_max:
+            while ndofs < N:
+                r += 1
+                ndofs = num_pdofs(Nx, Nx, Nx, r, order)
+            while ndofs > N:
+                Nx -= 1
+                ndofs = num_pdofs(Nx, Nx, Nx, r, order)
+        ndofs = num_pdofs(Nx, Nx, Nx, r, order)
+    Ny = Nz = Nx
+    mindiff = 1000000
+    i = Nx - 10
+    while i < Nx + 10:  # the live Nx
+        for j in range(i - 5, i + 5):
+            for k in range(i - 5, i + 5):
+                diff = abs(num_pdofs(i, j, k, r, order) - N)
+                if diff < mindiff:
+                    mindiff, Nx, Ny, Nz = diff, i, j, k
+        i += 1
+    return (Nx, Ny, Nz, r)
+
+
+def test_mesh_size_search_against_literal_transcription():
+    """10^4 targets (every BASELINE config among them, all orders, strong and weak, 1-4096 processes, scalar and
+    vector-valued) through the oracle's and the host feed's size search and the literal transcription above."""
+    rng = np.random.default_rng(2)
+    cases = [(500000, True, 1, 1, 1), (10000000, True, 1, 1, 1), (10000000, True, 8, 1, 1), (500000, False, 8, 3, 1),
+             (50000000, True, 8, 1, 3), (50000, False, 1, 1, 1)]
+    while len(cases) < 10000:
+        order = int(rng.integers(1, 5))
+        strong = bool(rng.integers(0, 2))
+        nproc = int(2 ** rng.integers(0, 13))
+        bs = int(rng.choice([1, 3]))
+        nd = int(10 ** rng.uniform(2.5, 9.3 if strong else 6.5))
+        cases.append((nd, strong, nproc, bs, order))
+    for c in cases:
+        ref = _mesh_size_literal(*c)
+        assert zo.mesh_size(*c) == ref, c
+        assert zzz.mesh_size(*c) == ref, c
+
+
+def test_count_suffix_table():
+    """The suffix after `Num cells` / `Total degrees of freedom` of the summary block: outputs of the reference's
+    int64_to_human (src/main.cpp:31-50: division by 1000 while the value EXCEEDS 1000, three significant digits)."""
+    table = {0: "", 999: "", 1000: "", 1001: " (1 thousand)", 1499: " (1.5 thousand)", 50061: " (50.1 thousand)",
+             499280: " (499 thousand)", 999999: " (1e+03 thousand)", 1000000: " (1e+03 thousand)", 1000001: " (1 million)",
+             2883816: " (2.88 million)", 10016937: " (10 million)", 59268672: " (59.3 million)", 49834930: " (49.8 million)",
+             2406964246: " (2.41 billion)", 10 ** 12 + 1: " (1 trillion)", 123456789012345: " (123 trillion)"}
+    for n, s in table.items():
+        assert zzz.count_suffix(n) == s, n
+    with pytest.raises(ValueError):
+        zzz.count_suffix(10 ** 15 + 1000)
+
+
 def _oracle_on(P):
     rp, cl = zo.pattern(P.nloc, P.cell_dofs, P.bs)
     bc = P.bc_marker()
