@@ -43,21 +43,42 @@ def spmv_algorithmic_bytes(n, nnz):
     return 12 * nnz + 4 * (n + 1) + 16 * n
 
 
-def pmc_traffic(nrows, nnz, tag="r02"):
+def pmc_traffic(nrows, nnz):
     """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command (they cannot share a pass and PMC
     collection cannot run inside a timed benchmark), corrected as MI355X_MICROARCH.md prescribes for
-    gfx950 (FETCH_SIZE counts half of a coalesced stream: x2; KiB units).  Only reported when the
-    profile was taken on the same matrix."""
-    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_bench10m.json")
-    try:
-        d = json.load(open(path))
-        if d["rows"] != nrows or d["nnz"] != nnz:
-            return None, None
-        k = d["kernels"]["spmv"]
-        return 2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024, os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    gfx950 (FETCH_SIZE counts half of a coalesced stream: x2; KiB units).  Only reported when a
+    profile of the same matrix (rows, nonzeros) and the same SpMV kernel exists; the latest round wins."""
+    import glob
+
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
+        try:
+            d = json.load(open(path))
+            if d["rows"] != nrows or d["nnz"] != nnz:
+                continue
+            k = d["kernels"]["spmv"]
+            best = (2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024, os.path.relpath(path, ROOT))
+        except Exception:
+            continue
+    return best
+
+
+# BASELINE.json configs as one-GPU workloads (--config): what each one asks of ONE GPU
+CONFIGS = {
+    # configs[0]: the reference's CPU-runnable case
+    "c1": dict(problem_type="poisson", order=1, scaling_type="strong", ndofs=500000, mesh_nproc=1,
+               note="BASELINE configs[0] (500 k dofs) on one GPU"),
+    # configs[1] (and configs[2] at N > 1): the headline
+    "c2": dict(problem_type="poisson", order=1, scaling_type="strong", ndofs=10000000, mesh_nproc=1,
+               note="BASELINE configs[1]"),
+    # configs[3]: elasticity P1 weak, 500 k dofs per GPU x 8 GPUs = 109^3 sub-cubes, 3 993 000 dofs: the TOTAL problem on one GPU
+    "c4_total": dict(problem_type="elasticity", order=1, scaling_type="weak", ndofs=500000, mesh_nproc=8,
+                     note="BASELINE configs[3]: the whole 8-GPU weak-scaling problem (mesh of 8 processes) on one GPU"),
+    # configs[4]: Poisson P3 strong 50 M dofs over 8 GPUs: one GPU's share of the rows
+    "c5_rank": dict(problem_type="poisson", order=3, scaling_type="strong", ndofs=6250000, mesh_nproc=1,
+                    note="BASELINE configs[4]: the per-GPU share (50 M / 8 dofs) of the P3 problem on one GPU"),
+}
 
 
 def cpu_baseline(P, ctx, iters_gpu, sample_iters=60):
@@ -119,10 +140,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="a BASELINE.json configuration as a one-GPU workload (default: c2 = the headline); sets "
+                         "--problem_type/--order/--scaling_type/--ndofs")
     ap.add_argument("--ndofs", type=int, default=10000000)
     ap.add_argument("--problem_type", default="poisson")
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--scaling_type", default="strong")
+    ap.add_argument("--mesh_nproc", type=int, default=0,
+                    help="number of processes the mesh-size search is run for (src/mesh.cpp:87-90; weak scaling: "
+                         "ndofs x processes); 0 = the number of GPUs of this run")
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none"])
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -135,6 +162,12 @@ def main():
                     help="KSPCG form: classical (PETSc default, two reductions per iteration) or "
                          "-ksp_cg_single_reduction (one); auto = classical on one GPU, single_reduction on N > 1")
     a = ap.parse_args()
+    cfg_note = None
+    if a.config:
+        c = CONFIGS[a.config]
+        a.problem_type, a.order, a.scaling_type, a.ndofs = c["problem_type"], c["order"], c["scaling_type"], c["ndofs"]
+        a.mesh_nproc = c["mesh_nproc"] if a.gpus == 1 else 0
+        cfg_note = c["note"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +200,7 @@ def main():
 
     bs = 3 if a.problem_type == "elasticity" else 1
     strong = a.scaling_type == "strong"
-    nx, ny, nz, r = zzz.mesh_size(a.ndofs, strong, world, bs, a.order)
+    nx, ny, nz, r = zzz.mesh_size(a.ndofs, strong, a.mesh_nproc or world, bs, a.order)
     nx, ny, nz = nx << r, ny << r, nz << r
     form = zzz.FORM_ELASTICITY if a.problem_type == "elasticity" else zzz.FORM_POISSON
     # host feed (C++ generator + upload) only when the CPU baseline needs the host arrays; otherwise the
@@ -342,7 +375,9 @@ def main():
             "config": {
                 "workload": (f"--problem_type {a.problem_type} --order {a.order} --scaling_type {a.scaling_type} "
                              f"--ndofs {a.ndofs} -ksp_type cg -pc_type {a.pc} -ksp_rtol {a.rtol:g}"
-                             + (" -ksp_cg_single_reduction" if single_reduction else "")),
+                             + (" -ksp_cg_single_reduction" if single_reduction else "")
+                             + (f" [mesh of {a.mesh_nproc} processes]" if a.mesh_nproc and a.mesh_nproc != world else "")),
+                "baseline_config": (a.config or "c2") + (": " + cfg_note if cfg_note else ""),
                 "mesh": f"{nx}x{ny}x{nz} sub-cubes x 6 tetrahedra", "dofs": ndofs_global,
                 "cells": ncells_global, "nnz_rank0": nnz, "rows_rank0": nrows,
                 "partition": f"{world} z-slab(s)", "krylov_iterations": iters,

@@ -714,6 +714,8 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   ZZZ_ENTER(ctx);
   if (!info || !ctx->have_pattern)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_info: no pattern");
+  if (int rc = ensure_cols16(ctx)) // the packed column stream of the tile kernel is encoded on first use
+    return rc;
   info[0] = ctx->have_cols16 ? 1 : 0;
   info[1] = ctx->cols16_offb;
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;

@@ -35,4 +35,15 @@ __device__ inline int64_t xcd_item(int64_t n)
   const int64_t t = lo + (blockIdx.x >> 3);
   return t < hi ? t : -1;
 }
+// The same for persistent (grid-stride) kernels: item of step i for this workgroup, -1 when its XCD's eighth is
+// exhausted.  Launch with a multiple of 8 workgroups.
+__device__ inline int64_t xcd_stride_item(int64_t n, int i)
+{
+  const int b = blockIdx.x, nb = gridDim.x;
+  const int xcd = b & 7;
+  const int64_t lo = n * xcd / 8, hi = n * (xcd + 1) / 8;
+  const int wg_in_xcd = b >> 3, n_in_xcd = (nb + 7 - xcd) >> 3;
+  const int64_t t = lo + wg_in_xcd + (int64_t)i * n_in_xcd;
+  return t < hi ? t : -1;
+}
 } // namespace zzz

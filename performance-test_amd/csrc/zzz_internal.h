@@ -124,7 +124,7 @@ struct zzz_ctx
   zzz::DevBuf<uint16_t> cols16;   // 16-bit column codes for the SpMV (k_tile_encode_cols); cols stays the matrix of record
   zzz::DevBuf<int32_t> tile_base; // band bases: 2^(16-cols16_offb) per tile
   zzz::DevBuf<int32_t> scr_c16;   // fallback-tile counter
-  bool have_cols16 = false, cols16_enabled = true;
+  bool have_cols16 = false, cols16_enabled = true, cols16_pending = false;
   int cols16_offb = 12, cols16_offb_forced = 0;
   int64_t cols16_fallback_tiles = 0;
   int64_t ntiles = 0;
@@ -210,6 +210,7 @@ int alloc_problem_vectors(zzz_ctx* ctx);
 // pattern (zzz_pattern.hip)
 int pattern_build_device(zzz_ctx* ctx, bool* fallback);
 int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
+int ensure_cols16(zzz_ctx* ctx); // encodes the 16-bit column stream of the CSR tile kernel on first use
 int asm_tile_nnz(const zzz_ctx* ctx); // nonzeros an assembly tile may hold (LDS budget of the matrix kernels)
 int build_adjT(zzz_ctx* ctx);
 int build_adjT_offsets(zzz_ctx* ctx);

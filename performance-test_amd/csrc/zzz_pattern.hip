@@ -159,8 +159,13 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
   int32_t* mine = u + threadIdx.x;
   int wmax = 0;
   const int64_t nblk = ((int64_t)nb + ROW_T_BLOCK - 1) / ROW_T_BLOCK; // nb64 <= nblk * ROW_T_BLOCK
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x)
+  // XCD-aware walk: the blocks of one XCD cover one contiguous eighth of the rows, so the cells that
+  // neighbouring blocks share (rows one mesh line apart) are fetched into ONE L2, not into all eight
+  for (int it = 0;; ++it)
   {
+    const int64_t blk = xcd_stride_item(nblk, it);
+    if (blk < 0)
+      break;
     const int64_t rbase = blk * ROW_T_BLOCK, r = rbase + threadIdx.x;
     const int64_t rend = min((int64_t)nb, rbase + ROW_T_BLOCK);
     const int ab0 = adj_off[rbase], nadj = adj_off[rend] - ab0;
@@ -430,9 +435,13 @@ static int grid_for(int64_t n, int block = 256, int cap = 4096)
 }
 
 // packed column stream of the SpMV tiles; the offset width is the first of four candidates (10..13 bits)
-// that leaves no tile on int32 columns, else the one that leaves the fewest
-static int encode_cols16(zzz_ctx* ctx)
+// that leaves no tile on int32 columns, else the one that leaves the fewest.  Encoded when the CSR tile kernel is
+// first used on this pattern (matrices that run on the operator stream of zzz_sellp.hip never need it).
+int ensure_cols16(zzz_ctx* ctx)
 {
+  if (!ctx->cols16_pending)
+    return ZZZ_OK;
+  ctx->cols16_pending = false;
   ctx->have_cols16 = false;
   ctx->cols16_fallback_tiles = 0;
   if (!ctx->cols16_enabled || ctx->ntiles == 0)
@@ -523,7 +532,9 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   int rc = build_tile_split(ctx);
   if (rc)
     return rc;
-  return encode_cols16(ctx);
+  ctx->have_cols16 = false;
+  ctx->cols16_pending = true;
+  return ZZZ_OK;
 }
 
 // returns ZZZ_OK, or ZZZ_ERR_LIMIT with *fallback = true when a row has more candidates than the
@@ -584,7 +595,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     int rc = build_adjT_offsets(ctx);
     if (rc)
       return rc;
-    hipLaunchKernelGGL(k_row_pattern_thread4, dim3(grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 4)), dim3(ROW_T_BLOCK), 0, s,
+    hipLaunchKernelGGL(k_row_pattern_thread4, dim3((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 4) + 7) / 8 * 8), dim3(ROW_T_BLOCK), 0, s,
                        ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage,
                        ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
     ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));

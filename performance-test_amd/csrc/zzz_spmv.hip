@@ -330,6 +330,8 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   if (sellp_active(ctx))
     return launch_sellp(ctx, x, y, partials, npartials, rvec, nn_is_rr);
+  if (int rc = ensure_cols16(ctx))
+    return rc;
   if (partials)
   {
     if ((size_t)grid > ctx->part_a.n)
@@ -366,6 +368,8 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   if (sellp_active(ctx) && ctx->have_group_split)
     return launch_sellp_overlapped(ctx, x, y, partials, npartials, rvec, nn_is_rr);
+  if (int rc = ensure_cols16(ctx))
+    return rc;
   const int64_t n_in = ctx->n_tiles_interior, n_bd = ctx->n_tiles_boundary;
   // The interior launch leaves one workgroup slot per CU free (7 of 8): at full occupancy the persistent
   // SpMV workgroups hold every wave slot until the launch ends and RCCL's send/recv kernel, although

@@ -2,7 +2,7 @@
 """Post-processing of tools/profile_bench.sh.
 
 reduce <dir> <COUNTER>   per-kernel mean of a rocprofv3 --pmc counter (KiB) -> JSON on stdout (GPU box)
-merge <profile_dir> <tag>  write profiles/<tag>_*.{json,csv} from gpurun_out/profile_<tag>/ (here)
+merge <profile_dir> <tag> [cfg]  write profiles/<tag>_*_<cfg>.{json,csv} from gpurun_out/profile_<tag>_<cfg>/ (here)
 
 HBM bytes follow MI355X_MICROARCH.md's rocprofv3 section: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950
 FETCH_SIZE under-reports coalesced streams by 2x (corrected here), calibrated on the CG vector kernels
@@ -41,16 +41,17 @@ def reduce_counter(d, counter):
     return {k: {counter + "_KiB": v[0] / v[1], "dispatches": v[1]} for k, v in acc.items()}
 
 
-def merge(pdir, tag):
+def merge(pdir, tag, cfg="c2"):
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = os.path.join(root, "profiles")
     bench = json.loads(open(os.path.join(pdir, "bench_plain.json")).read().strip().splitlines()[-1])
-    json.dump(bench, open(os.path.join(out, f"{tag}_bench_default.json"), "w"), indent=1)
+    cfg_name = cfg
+    json.dump(bench, open(os.path.join(out, f"{tag}_bench_{cfg}.json"), "w"), indent=1)
     under = json.loads(open(os.path.join(pdir, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
-    json.dump(under, open(os.path.join(out, f"{tag}_bench_default_under_rocprof.json"), "w"), indent=1)
+    json.dump(under, open(os.path.join(out, f"{tag}_bench_{cfg}_under_rocprof.json"), "w"), indent=1)
     stats = glob.glob(os.path.join(pdir, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.reader(open(stats, newline="")))
-    with open(os.path.join(out, f"{tag}_bench_default_kernel_stats.csv"), "w", newline="") as fh:
+    with open(os.path.join(out, f"{tag}_bench_{cfg}_kernel_stats.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         for r in rows:
             r[0] = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", r[0])[:160]  # keep names readable
@@ -69,7 +70,8 @@ def merge(pdir, tag):
            "correction": "gfx950: FETCH_SIZE x2 for coalesced streams (MI355X_MICROARCH.md, HBM); check: the CG vector kernels "
                          "move 40 B/row each (k_update_p: x, p, z in, x, p out; k_update_xr: w, r, dinv in, r, z out). "
                          "Scattered-access kernels (assembly, pattern) are uncalibrated: read their numbers as relative.",
-           "rows": cfg["rows_rank0"], "nnz": cfg["nnz_rank0"], "spmv_column_stream": cfg.get("spmv_column_stream"),
+           "rows": cfg["rows_rank0"], "nnz": cfg["nnz_rank0"], "spmv_operator": cfg.get("spmv_operator"),
+           "spmv_bytes_streamed": bench["roofline"].get("bytes_streamed_per_launch"),
            "kernels": kern}
     n = cfg["rows_rank0"]
     for k in ("k_update_p", "k_update_xr"):
@@ -80,7 +82,11 @@ def merge(pdir, tag):
         alg = 12 * cfg["nnz_rank0"] + 4 * (n + 1) + 16 * n
         kern["spmv"]["algorithmic_bytes"] = alg
         kern["spmv"]["corrected_over_algorithmic"] = kern["spmv"]["hbm_bytes_corrected"] / alg
-    json.dump(doc, open(os.path.join(out, f"{tag}_pmc_bench10m.json"), "w"), indent=1)
+        st = bench["roofline"].get("bytes_streamed_per_launch")
+        if st:
+            kern["spmv"]["bytes_streamed"] = st
+            kern["spmv"]["corrected_over_streamed"] = kern["spmv"]["hbm_bytes_corrected"] / st
+    json.dump(doc, open(os.path.join(out, f"{tag}_pmc_{cfg_name}.json"), "w"), indent=1)
     print(json.dumps({k: {"GB": round(v["hbm_bytes_corrected"] / 1e9, 3),
                           "ratio": round(v.get("corrected_over_algorithmic", 0), 3)} for k, v in kern.items()}, indent=1))
 
@@ -89,4 +95,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "reduce":
         print(json.dumps(reduce_counter(sys.argv[2], sys.argv[3])))
     else:
-        merge(sys.argv[2], sys.argv[3])
+        merge(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))
