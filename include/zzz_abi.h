@@ -234,6 +234,11 @@ int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* opts, int* iters, double* 
 /* Residual-norm history of the last solve (KSPGetResidualHistory): copies min(n, iters+1). */
 int zzz_cg_history(zzz_ctx* ctx, int n, double* out);
 
+/* About the last zzz_cg_solve: info[0] = 1 when the iteration ran as two kernels (product fused with the
+ * direction update p = z + b p, x += a p: the A/B variant ZZZ_CG_FUSED=2), 0 for the three-kernel form;
+ * info[1] = its iteration count.  Same iterates, bit for bit, either way. */
+int zzz_cg_info(zzz_ctx* ctx, int64_t info[4]);
+
 /* Average duration (ms) and count of the SpMV launches event-timed during the last
  * zzz_cg_solve with opts.profile != 0. */
 int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);

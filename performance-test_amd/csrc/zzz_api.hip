@@ -727,6 +727,16 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   return ZZZ_OK;
 }
 
+int zzz_cg_info(zzz_ctx* ctx, int64_t info[4])
+{
+  if (!ctx || !info)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_info: bad arguments");
+  info[0] = ctx->last_solve_fused ? 1 : 0;
+  info[1] = ctx->last_iters;
+  info[2] = info[3] = 0;
+  return ZZZ_OK;
+}
+
 int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count)
 {
   if (!ctx)

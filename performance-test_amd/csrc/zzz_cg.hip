@@ -20,8 +20,10 @@
 // HBM traffic per iteration beyond the SpMV: 40 B/row (x and p update) + 40 B/row (r, z update).
 #include "zzz_device.h"
 #include "zzz_internal.h"
+#include "zzz_cg_device.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace zzz
 {
@@ -46,11 +48,6 @@ __device__ inline void vstore(T v, T* p)
     *p = v;
 }
 
-struct CgParams
-{
-  int variant, pc, norm;
-  double rtol, atol, dtol;
-};
 
 __global__ void k_extract_dinv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                const double* __restrict__ vals, double* __restrict__ dinv, int64_t n, int jacobi)
@@ -121,21 +118,6 @@ __device__ inline int block_converged(const CgState* st)
   return flag;
 }
 
-// one workgroup-wide sum of parts[0..np) (fixed order); result in every thread
-__device__ inline double reduce_parts_bcast(const double* __restrict__ parts, int np, double* sh)
-{
-  double s = 0;
-  for (int i = threadIdx.x; i < np; i += blockDim.x)
-    s += parts[i];
-  const double t = block_reduce_sum(s, sh);
-  __shared__ double bc;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    bc = t;
-  __syncthreads();
-  return bc;
-}
-
 // `it` = number of completed iterations.  pa/pb: partials of <r,z> and of the test norm (np each).
 // The solution update of the PREVIOUS iteration, x += alpha_{it-1} p_{it-1}, is applied here (p is read
 // anyway) instead of in k_update_xr: one vector read less per iteration, same operations on the same
@@ -149,68 +131,12 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
                                                  double* __restrict__ p, double* __restrict__ x, int64_t n,
                                                  int update_dir)
 {
-  {
-    __shared__ int flag;
-    if (threadIdx.x == 0)
-    {
-      const int c = __atomic_load_n(&st->conv_it1, __ATOMIC_RELAXED);
-      flag = c != 0 && c - 1 < it;
-    }
-    __syncthreads();
-    if (flag)
-      return;
-  }
   __shared__ double sh[VB / 64];
-  const double rz = reduce_parts_bcast(pa, np, sh);
-  const double nn = reduce_parts_bcast(pb, np, sh);
-  // scalar logic, identical in every workgroup; workgroup 0 records it
-  double dp, dp0 = st->dp0, ttol = st->ttol;
-  int conv = 0;
-  if (P.variant == ZZZ_CG_CGH)
-  {
-    // src/cg.h:53-55,74-79: rnorm = <r,r>; break when rnorm/rnorm0 < rtol^2 (strict), no test at k = 0
-    dp = rz;
-    if (it == 0)
-    {
-      dp0 = rz;
-      ttol = P.rtol * P.rtol;
-    }
-    else if (rz / dp0 < P.rtol * P.rtol)
-      conv = 1;
-  }
-  else
-  {
-    dp = (P.norm == ZZZ_NORM_NATURAL) ? sqrt(fabs(rz)) : sqrt(nn);
-    if (it == 0)
-    {
-      dp0 = dp;
-      ttol = fmax(P.rtol * dp, P.atol);
-    }
-    if (!isfinite(dp))
-      conv = 2;
-    else if (dp <= ttol) // KSPConvergedDefault
-      conv = 1;
-    else if (dp >= P.dtol * dp0) // ... KSP_DIVERGED_DTOL
-      conv = 3;
-  }
-  const double bprev = (it == 0) ? 1.0 : beta_hist[it - 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    beta_hist[it] = rz;
-    dp_hist[it] = dp;
-    st->dp = dp;
-    if (it == 0)
-    {
-      st->dp0 = dp0;
-      st->ttol = ttol;
-    }
-    if (conv)
-    {
-      st->iters = it;
-      st->converged = conv; // the other workgroups reach the same verdict from the same partials
-      __atomic_store_n(&st->conv_it1, it + 1, __ATOMIC_RELAXED);
-    }
-  }
+  DirScalars S;
+  if (!cg_direction_scalars(st, beta_hist, dp_hist, it, P, pa, pb, np, sh, S))
+    return;
+  const int conv = S.conv;
+  const double rz = S.rz, bprev = S.bprev;
   const bool dir = !conv && update_dir;
   if (it == 0)
   {
@@ -537,6 +463,19 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   const bool nt = loop_exceeds_cache(ctx, 6);
   auto kern_update_p = nt ? k_update_p<true> : k_update_p<false>;
   auto kern_update_xr = nt ? k_update_xr<true> : k_update_xr<false>;
+  // A/B knob ZZZ_CG_FUSED=2: two kernels per iteration (product fused with the direction update, zzz_sellp.hip).
+  // Bit-identical, but MEASURED slower wherever it was tried: at the 8-GPU per-rank size (1.25 M rows, loop resident
+  // in the Infinity Cache) the fused kernel takes 39-41 us against 14.7 + 19.6 us for k_update_p + product (the
+  // second gather and the row updates lengthen every wavefront's dependent chain, and at that size the product is
+  // latency-bound: ~2.4 slices per wavefront); for HBM-sized loops it saves 4 % of the bytes at best.  Off by default.
+  int fused_mode = 0;
+  if (const char* e = getenv("ZZZ_CG_FUSED"))
+    fused_mode = atoi(e);
+  const bool fused = o->op == ZZZ_OP_CSR && fused_mode == 2 && sellp_active(ctx);
+  ctx->last_solve_fused = fused;
+  if (fused)
+    ZZZ_HIP(ctx, ctx->p_alt.alloc((size_t)ctx->nloc()));
+  double* pbuf[2] = {ctx->p.p, fused ? ctx->p_alt.p : ctx->p.p};
 
   ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
@@ -627,13 +566,16 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   for (; it < max_it && !stop; ++it)
   {
     // convergence test of iteration `it` and the new search direction
-    hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
-                       ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
+    if (!fused)
+      hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
+                         ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
     int np = 0;
     if (nprof < max_prof)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
     {
-      int rc = apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+      int rc = fused ? launch_sellp_dir(ctx, ctx->z.p, pbuf[it & 1], pbuf[(it + 1) & 1], ctx->u.p, ctx->w.p, ctx->part_a.p, &np,
+                                        it, P, rz_src, nn_src, n_rz, multi && ctx->overlap)
+                     : apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
       if (rc)
         return rc;
     }
@@ -674,7 +616,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   // the test of the last completed iteration (it == max_it when the loop ran out) and its pending
   // solution update; no new direction
   hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
-                     ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 0);
+                     ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, pbuf[it & 1], ctx->u.p, n, 0);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
@@ -727,6 +669,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   hipStream_t s = ctx->stream;
   const int nn_is_rr = o->norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
   auto kern_sr_update = loop_exceeds_cache(ctx, 8) ? k_sr_update<true> : k_sr_update<false>;
+  ctx->last_solve_fused = false;
 
   ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));

@@ -68,6 +68,11 @@ struct CgState
   int pad;
 };
 
+struct CgParams
+{
+  int variant, pc, norm;
+  double rtol, atol, dtol;
+};
 } // namespace zzz
 
 struct zzz_ctx
@@ -163,6 +168,7 @@ struct zzz_ctx
 
   // vectors, (n_owned+n_ghost)*bs each
   zzz::DevBuf<double> b, u, r, z, p, w, dinv;
+  zzz::DevBuf<double> p_alt; // second direction buffer of the fused product + direction kernel (zzz_sellp.hip)
   // reductions
   zzz::DevBuf<double> part_a, part_b, red; // block partials; reduced scalars
   zzz::DevBuf<double> beta_hist, dp_hist, dpi_hist;
@@ -171,6 +177,7 @@ struct zzz_ctx
   zzz::CgState* h_state = nullptr; // pinned
   std::vector<double> history;
   int last_iters = 0;
+  bool last_solve_fused = false; // the last solve ran the fused product + direction kernel
 
   // profiling
   std::vector<hipEvent_t> ev;
@@ -228,6 +235,8 @@ int64_t sellp_stream_bytes(const zzz_ctx* ctx);
 int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr);
 int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,
                             int nn_is_rr);
+int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new, double* xsol, double* y, double* partials,
+                     int* npartials, int it, const zzz::CgParams& P, const double* pa, const double* pb, int np, bool overlap);
 
 // kernels_assemble
 int launch_assemble_matrix(zzz_ctx* ctx, int form);

@@ -30,6 +30,7 @@
 
 #include "zzz_device.h"
 #include "zzz_internal.h"
+#include "zzz_cg_device.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -406,6 +407,34 @@ __device__ inline double gather(const double* __restrict__ x, int col)
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
 }
 
+// columns of chunk c for this lane: 16-bit codes on the slot bases, or int32 (sign bit of base[0])
+template <bool NT>
+__device__ inline void chunk_columns(int c, int lane, const uint16_t* __restrict__ c16, const int32_t* __restrict__ c32,
+                                     const int32_t* __restrict__ meta, int (&cl)[8])
+{
+  const int32_t* __restrict__ mp = meta + (size_t)c * 8;
+  const int b0 = mp[0];
+  if (b0 >= 0)
+  {
+    const uint4v q = sp_load<NT>(reinterpret_cast<const uint4v*>(c16 + (size_t)c * 512) + lane);
+    cl[0] = b0 + (int)(q.x & 0xffffu);
+    cl[1] = mp[1] + (int)(q.x >> 16);
+    cl[2] = mp[2] + (int)(q.y & 0xffffu);
+    cl[3] = mp[3] + (int)(q.y >> 16);
+    cl[4] = mp[4] + (int)(q.z & 0xffffu);
+    cl[5] = mp[5] + (int)(q.z >> 16);
+    cl[6] = mp[6] + (int)(q.w & 0xffffu);
+    cl[7] = mp[7] + (int)(q.w >> 16);
+  }
+  else
+  {
+    const int4v* __restrict__ cp = reinterpret_cast<const int4v*>(c32 + (size_t)c * 512) + 2 * lane;
+    const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
+    cl[0] = q0.x, cl[1] = q0.y, cl[2] = q0.z, cl[3] = q0.w;
+    cl[4] = q1.x, cl[5] = q1.y, cl[6] = q1.z, cl[7] = q1.w;
+  }
+}
+
 template <bool DOT, bool NT, bool PERM>
 __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __restrict__ desc,
                                                               const double* __restrict__ svals,
@@ -448,28 +477,8 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     {
       const dbl2* __restrict__ vp = reinterpret_cast<const dbl2*>(svals + (size_t)c * 512) + lane;
       const dbl2 v0 = sp_load<NT>(vp), v1 = sp_load<NT>(vp + 64), v2 = sp_load<NT>(vp + 128), v3 = sp_load<NT>(vp + 192);
-      const int32_t* __restrict__ mp = meta + (size_t)c * 8;
-      const int b0 = mp[0];
       int cl[8];
-      if (b0 >= 0)
-      {
-        const uint4v q = sp_load<NT>(reinterpret_cast<const uint4v*>(c16 + (size_t)c * 512) + lane);
-        cl[0] = b0 + (int)(q.x & 0xffffu);
-        cl[1] = mp[1] + (int)(q.x >> 16);
-        cl[2] = mp[2] + (int)(q.y & 0xffffu);
-        cl[3] = mp[3] + (int)(q.y >> 16);
-        cl[4] = mp[4] + (int)(q.z & 0xffffu);
-        cl[5] = mp[5] + (int)(q.z >> 16);
-        cl[6] = mp[6] + (int)(q.w & 0xffffu);
-        cl[7] = mp[7] + (int)(q.w >> 16);
-      }
-      else
-      {
-        const int4v* __restrict__ cp = reinterpret_cast<const int4v*>(c32 + (size_t)c * 512) + 2 * lane;
-        const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
-        cl[0] = q0.x, cl[1] = q0.y, cl[2] = q0.z, cl[3] = q0.w;
-        cl[4] = q1.x, cl[5] = q1.y, cl[6] = q1.z, cl[7] = q1.w;
-      }
+      chunk_columns<NT>(c, lane, c16, c32, meta, cl);
       double xv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -515,6 +524,94 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
       }
     }
   }
+}
+
+// ---- product fused with the direction update -------------------------------------------------------------
+// One CG iteration as TWO kernels instead of three: the head of iteration `it` (convergence test, k_update_p of
+// zzz_cg.hip) and the product w = A p, with p = z + b p_old formed on the fly where the product gathers it
+// (the same two roundings as k_update_p, so p, w and every scalar keep their bits), written once per owned row
+// into the OTHER p buffer (the gathers of other workgroups still read p_old), together with the pending
+// solution update x += alpha_{it-1} p_old (src/cg.h:68,82).  Ghost entries of p follow the same recurrence from the
+// ghost values of z, so the halo exchange of an iteration moves z instead of p.  An A/B variant (ZZZ_CG_FUSED=2):
+// measured slower than the three-kernel form at every size tried (cg_solve has the numbers), kept because it
+// pins the iteration's arithmetic from a second side -- tests demand identical bits from both forms.
+template <bool NT, bool PERM>
+__global__ __launch_bounds__(SP_BLOCK, 4) void spmv_sellp_dir_kernel(
+    const int2* __restrict__ desc, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
+    const int32_t* __restrict__ c32, const int32_t* __restrict__ meta, const int32_t* __restrict__ perm,
+    const double* __restrict__ z, const double* __restrict__ p_old, double* __restrict__ p_new, double* __restrict__ xsol,
+    double* __restrict__ y, int nrows, int ncols, int64_t nslices, double* __restrict__ partials,
+    const int32_t* __restrict__ group_list, int64_t nlist, int ghost_update, CgState* __restrict__ st,
+    double* __restrict__ beta_hist, double* __restrict__ dp_hist, const double* __restrict__ alpha_hist, int it, CgParams P,
+    const double* __restrict__ pa, const double* __restrict__ pb, int np)
+{
+  __shared__ double red[SP_BLOCK / 64];
+  DirScalars S;
+  if (!cg_direction_scalars(st, beta_hist, dp_hist, it, P, pa, pb, np, red, S))
+    return;
+  const double bcoef = S.rz / S.bprev;
+  const double alpha = it > 0 ? alpha_hist[it - 1] : 0.0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ngroups = group_list ? nlist : (nslices + 3) / 4;
+  double dot = 0.0;
+  for (int i = 0;; ++i)
+  {
+    const int64_t gi = sp_xcd_item(ngroups, blockIdx.x, gridDim.x, i);
+    if (gi < 0)
+      break;
+    const int64_t g = group_list ? group_list[gi] : gi;
+    const int s = __builtin_amdgcn_readfirstlane((int)(4 * g + wv));
+    if (s >= nslices)
+      continue;
+    int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
+    if (!PERM && r >= nrows)
+      r = -1;
+    const double po = r >= 0 ? p_old[r] : 0.0;
+    if (r >= 0 && it > 0)
+      xsol[r] = alpha * po + xsol[r]; // the previous iteration's solution update, also by the launch that stops
+    if (S.conv)
+      continue;
+    const double pn = r >= 0 ? bcoef * po + z[r] : 0.0;
+    const int2 ds = desc[s];
+    const int c0 = ds.x, c1 = ds.x + ds.y;
+    double sum = 0.0;
+    for (int c = c0; c < c1; ++c)
+    {
+      const dbl2* __restrict__ vp = reinterpret_cast<const dbl2*>(svals + (size_t)c * 512) + lane;
+      const dbl2 v0 = sp_load<NT>(vp), v1 = sp_load<NT>(vp + 64), v2 = sp_load<NT>(vp + 128), v3 = sp_load<NT>(vp + 192);
+      int cl[8];
+      chunk_columns<NT>(c, lane, c16, c32, meta, cl);
+      double zv[8], pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        zv[e] = gather(z, cl[e]);
+        pv[e] = gather(p_old, cl[e]);
+      }
+      sum += v0.x * (bcoef * pv[0] + zv[0]);
+      sum += v0.y * (bcoef * pv[1] + zv[1]);
+      sum += v1.x * (bcoef * pv[2] + zv[2]);
+      sum += v1.y * (bcoef * pv[3] + zv[3]);
+      sum += v2.x * (bcoef * pv[4] + zv[4]);
+      sum += v2.y * (bcoef * pv[5] + zv[5]);
+      sum += v3.x * (bcoef * pv[6] + zv[6]);
+      sum += v3.y * (bcoef * pv[7] + zv[7]);
+    }
+    if (r >= 0)
+    {
+      p_new[r] = pn;
+      y[r] = sum;
+      dot += sum * pn;
+    }
+  }
+  if (S.conv)
+    return;
+  if (ghost_update) // ghost entries of the new direction (the launch that runs behind the halo of z)
+    for (int64_t k = nrows + blockIdx.x * (int64_t)SP_BLOCK + threadIdx.x; k < ncols; k += (int64_t)gridDim.x * SP_BLOCK)
+      p_new[k] = bcoef * p_old[k] + z[k];
+  const double sres = block_reduce_sum(dot, red);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = sres;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -926,6 +1023,71 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   }
   if (npartials)
     *npartials = g_in + g_bd;
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+// the fused product + direction kernel on the whole matrix, or (partitioned matrix) interior groups, halo of z,
+// boundary groups.  Partials of <p,w>: interior workgroups first.
+int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new, double* xsol, double* y, double* partials,
+                     int* npartials, int it, const CgParams& P, const double* pa, const double* pb, int np, bool overlap)
+{
+  const bool nt = ctx->spmv_auto ? (double)sellp_stream_bytes(ctx) > 300.0e6 : (ctx->spmv_variant & 1) != 0;
+  const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
+  const int ncols = (int)ctx->nloc();
+  auto go = [&](int grid, const int32_t* list, int64_t nlist, double* parts, int ghost) {
+#define ZZZ_SPD_GO(NT, PERM)                                                                                           \
+  hipLaunchKernelGGL((spmv_sellp_dir_kernel<NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off, ctx->sp_vals.p,  \
+                     ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, z, p_old, p_new, xsol, y,   \
+                     (int)ctx->nrows, ncols, ctx->nslices, parts, list, nlist, ghost, ctx->state.p, ctx->beta_hist.p, \
+                     ctx->dp_hist.p, ctx->alpha_hist.p, it, P, pa, pb, np)
+    if (ctx->sp_sorted)
+    {
+      if (nt)
+        ZZZ_SPD_GO(true, true);
+      else
+        ZZZ_SPD_GO(false, true);
+    }
+    else
+    {
+      if (nt)
+        ZZZ_SPD_GO(true, false);
+      else
+        ZZZ_SPD_GO(false, false);
+    }
+#undef ZZZ_SPD_GO
+  };
+  if (overlap && ctx->have_group_split)
+  {
+    const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
+    int g_in = gi ? sp_grid(gi) : 0;
+    if (g_in > 256 * 7 && ctx->nneigh > 0)
+      g_in = 256 * 7; // room for the exchange's kernel beside the persistent workgroups (launch_spmv_overlapped)
+    const int g_bd = gb ? sp_grid(gb) : 8;
+    if ((size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
+      return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
+    int rc = comm_halo_begin(ctx, z);
+    if (rc)
+      return rc;
+    if (gi)
+      go(g_in, ctx->groups_interior.p, gi, partials, 0);
+    rc = comm_halo_end(ctx);
+    if (rc)
+      return rc;
+    go(g_bd, ctx->groups_boundary.p, gb, partials + g_in, 1); // also with no boundary group: the ghost entries of p
+    *npartials = g_in + g_bd;
+  }
+  else
+  {
+    if (ctx->comm)
+    {
+      int rc = comm_halo_forward(ctx, z);
+      if (rc)
+        return rc;
+    }
+    const int gs = sp_grid((ctx->nslices + 3) / 4);
+    go(gs, nullptr, 0, partials, ctx->n_ghost > 0 ? 1 : 0);
+    *npartials = gs;
+  }
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_profile_get", "zzz_cg_info", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
@@ -395,6 +395,12 @@ class Context:
         info = (C.c_int64 * 8)()
         self._ck(self.L.zzz_spmv_info(self.h, info))
         return int(info[4])
+
+    def cg_fused(self):
+        """did the last solve run the fused product + direction kernel (two kernels per iteration)?"""
+        info = (C.c_int64 * 4)()
+        self._ck(self.L.zzz_cg_info(self.h, info))
+        return bool(info[0])
 
     def profile(self):
         ms, n = C.c_double(), C.c_int64()

@@ -1232,3 +1232,44 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
+
+
+def test_fused_direction_kernel_keeps_every_bit():
+    """Two kernels per iteration (the product fused with p = z + b p and the pending x update, chosen for
+    cache-resident loops) against the three-kernel form: the same operations on the same operands, so the
+    iteration count, the whole residual history and the solution are bit-identical -- for KSPCG with each norm
+    type, for src/cg.h, on natural and length-sorted streams."""
+    keys = ("ZZZ_CG_FUSED", "ZZZ_SELLP")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for problem, order, dims, sellp in (("poisson", 1, (17, 15, 19), "1"), ("elasticity", 1, (7, 6, 8), "1"),
+                                            ("poisson", 2, (7, 6, 5), "3"), ("poisson", 3, (4, 4, 5), "2")):
+            P = zzz.Part(problem, order, *dims)
+            res = {}
+            for fused in ("0", "2"):
+                os.environ["ZZZ_CG_FUSED"], os.environ["ZZZ_SELLP"] = fused, sellp
+                with zzz.Context(0) as c:
+                    c.upload_part(P)
+                    c.pattern_build()
+                    c.assemble_matrix(P.form)
+                    c.assemble_vector(P.form)
+                    out = []
+                    for kw in (dict(pc=zzz.PC_JACOBI, rtol=1e-8), dict(pc=zzz.PC_NONE, norm=zzz.NORM_UNPRECONDITIONED, rtol=1e-7),
+                               dict(pc=zzz.PC_JACOBI, norm=zzz.NORM_NATURAL, rtol=1e-8), dict(pc=zzz.PC_JACOBI, rtol=1e-30, max_it=9),
+                               dict(variant=zzz.CG_CGH, pc=zzz.PC_NONE, rtol=1e-6, max_it=100)):
+                        if kw.get("variant") == zzz.CG_CGH:
+                            c.vec_upload(zzz.VEC_U, np.zeros(P.n_owned * P.bs))
+                        it, rn, r0 = c.cg_solve(**kw)
+                        assert c.cg_fused() == (fused == "2")
+                        out.append((it, rn, r0, c.cg_history(it + 1), c.vec_download(zzz.VEC_U)))
+                    res[fused] = out
+            for a, b in zip(res["0"], res["2"]):
+                assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+                np.testing.assert_array_equal(a[3], b[3])
+                np.testing.assert_array_equal(a[4], b[4])
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
