@@ -223,6 +223,27 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms);
  * of x updated first.  Needs zzz_csr_pattern_build (for the dof->cell adjacency), not the matrix. */
 int zzz_action(zzz_ctx* ctx, const double* x, double* y);
 
+/* ---- the reference's native partition ----------------------------------------------------- */
+
+/* Global indices of the local block dofs (index_map.local_to_global: owned, then ghosts) and of the local mesh
+ * vertices: what two ranks use to recognise a shared dof or vertex.  Needed by zzz_ghost_layer_build only. */
+int zzz_global_ids_upload(zzz_ctx* ctx, const int64_t* dof_global, const int64_t* vert_global);
+/* ... of the local block dofs as they are now (after zzz_ghost_layer_build: with the new ghosts) */
+int zzz_global_ids_download(zzz_ctx* ctx, int64_t* dof_global);
+
+/* Collective.  For a feed partitioned as the reference partitions it -- mesh::create_cell_partitioner(
+ * GhostMode::none), src/mesh.cpp:182-183: every rank holds its own cells only, so the matrix rows and vector
+ * entries of dofs on the partition interface are incomplete locally and the reference completes them in every
+ * assembly by MatAssemblyBegin/End (src/poisson_problem.cpp:132-133) and b.scatter_rev(std::plus) (:154).
+ * Call after mesh, dofmap, Dirichlet dofs, exterior facets, coefficients, the forward-scatter plan
+ * (zzz_halo_upload) and the global indices have been uploaded: the ranks exchange ONCE the cells that touch a
+ * neighbour's dofs, every rank appends what it receives as ghost cells (new ghost dofs join the forward scatter
+ * of their owners) and from then on assembles complete owned rows with no exchange per assembly: A and b equal
+ * the reference's after its MatAssembly / scatter_rev.  zzz_local_sizes reports the extended sizes. */
+int zzz_ghost_layer_build(zzz_ctx* ctx);
+/* sizes = {vertices, cells, owned block dofs, ghost block dofs, cells the caller uploaded, neighbours} */
+int zzz_local_sizes(const zzz_ctx* ctx, int64_t sizes[6]);
+
 /* ---- solve ----------------------------------------------------------------------------- */
 
 /* solver_function(u, b) (src/poisson_problem.cpp:164-179; src/cgpoisson_problem.cpp:178-244;
@@ -280,6 +301,9 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id);
  * partitioned runs on a single-GPU machine.  Every rank must make the same sequence of calls. */
 int zzz_local_group_create(int nranks, void** group);
 void zzz_local_group_destroy(void* group);
+/* Break the group: every rank waiting in (or later entering) one of its collectives returns ZZZ_ERR_RCCL instead
+ * of waiting for a rank that has failed.  The library does this itself when a rank fails INSIDE a collective. */
+void zzz_local_group_abort(void* group);
 int zzz_comm_init_local(zzz_ctx* ctx, void* group, int rank);
 
 /* Optional: carry the CG's scalar all-reduces (MPI_Allreduce inside la::inner_product /

@@ -71,6 +71,11 @@ enum
 /* Partition `part` of `nparts` z-slabs of the nx*ny*nz unit cube (6 tetrahedra per sub-cube).
  * Returns NULL on bad arguments (message via zzzh_last_error). */
 zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part);
+/* The same partition as the reference's cell partitioner leaves it (GhostMode::none, src/mesh.cpp:182-183): the
+ * partition's own cells only, ghost dofs = those dofs of the own cells that a neighbour owns.  The rows of owned
+ * dofs on the partition interface are then incomplete locally (the reference completes them in MatAssemblyBegin/
+ * End and scatter_rev, src/poisson_problem.cpp:132-137,154); feed for zzz_ghost_layer_build (include/zzz_abi.h). */
+zzzh_part* zzzh_part_create_native(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part);
 void zzzh_part_destroy(zzzh_part* p);
 const char* zzzh_last_error(void);
 
@@ -82,6 +87,7 @@ const int32_t* zzzh_part_facets(const zzzh_part* p);       /* nfacets*2 */
 const int32_t* zzzh_part_bc_dofs(const zzzh_part* p);      /* nbc local scalar dofs */
 const double* zzzh_part_dof_x(const zzzh_part* p);         /* (nowned+nghost)*3 */
 const int64_t* zzzh_part_global_dofs(const zzzh_part* p);  /* (nowned+nghost) global block index */
+const int64_t* zzzh_part_global_verts(const zzzh_part* p); /* nverts global vertex index */
 const double* zzzh_part_coeff(const zzzh_part* p, int which); /* 0: f, 1: g (Poisson only) */
 const int32_t* zzzh_part_neigh(const zzzh_part* p);        /* nneigh ranks */
 const int64_t* zzzh_part_send_off(const zzzh_part* p);     /* nneigh+1 */

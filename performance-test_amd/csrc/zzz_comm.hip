@@ -16,6 +16,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -162,15 +164,57 @@ struct StdoutToStderr
 // and exchanges through host mailboxes.  Slow by design -- it exists so that the partitioned
 // assemble + CG logic (ghost layout, halo plan, multi-rank scalar logic, lock-step convergence
 // polling) can be run with the real kernels on a single-GPU box; production runs use RCCL.
+// A barrier that can be broken: a rank that fails inside a collective (or the driver, for a rank that failed
+// elsewhere) aborts the group and every waiting or later-arriving rank gets an error instead of hanging; waits
+// are also bounded (5 minutes) so that a rank that silently never arrives ends in an error, not a hang.
+struct AbortableBarrier
+{
+  std::mutex m;
+  std::condition_variable cv;
+  int n = 0, count = 0;
+  unsigned long generation = 0;
+  bool aborted = false;
+  bool wait() // true = all ranks arrived
+  {
+    std::unique_lock<std::mutex> lk(m);
+    if (aborted)
+      return false;
+    const unsigned long gen = generation;
+    if (++count == n)
+    {
+      count = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    const bool ok = cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen || aborted; });
+    if (!ok)
+      aborted = true;
+    if (aborted)
+    {
+      cv.notify_all();
+      return false;
+    }
+    return true;
+  }
+  void abort()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    aborted = true;
+    cv.notify_all();
+  }
+};
+
 struct LocalGroup
 {
   int n = 0;
-  pthread_barrier_t bar;
+  AbortableBarrier bar;
   std::vector<std::vector<double>> red;  // per rank: values to reduce
   std::vector<std::vector<double>> mail; // per rank: packed send buffer (all neighbours)
   std::vector<std::vector<int32_t>> neigh;
   std::vector<std::vector<int64_t>> send_off;
   std::vector<int> bs;
+  std::vector<std::vector<std::vector<char>>> xch; // set-up exchanges: [source][destination] byte buffers
 };
 
 // Peer-memory all-reduce of the CG scalars (MPI_Allreduce of la::inner_product / la::squared_norm,
@@ -232,21 +276,39 @@ __global__ void k_pack(const double* __restrict__ v, const int32_t* __restrict__
     out[i] = v[(int64_t)idx[i / bs] * bs + i % bs]; // pack_fn, src/cgpoisson_problem.cpp:32-37
 }
 
+#define ZZZ_LOCAL_WAIT(ctx, G)                                                                                      \
+  do                                                                                                                \
+  {                                                                                                                 \
+    if (!(G)->bar.wait())                                                                                           \
+      return fail(ctx, ZZZ_ERR_RCCL, "local communicator: a rank failed or did not arrive (group aborted)");       \
+  } while (0)
+// a HIP error between two barriers must not leave the peers waiting: break the barrier, then report
+#define ZZZ_LOCAL_HIP(ctx, G, call)                                                                                 \
+  do                                                                                                                \
+  {                                                                                                                 \
+    hipError_t e_ = (call);                                                                                         \
+    if (e_ != hipSuccess)                                                                                           \
+    {                                                                                                               \
+      (G)->bar.abort();                                                                                             \
+      return zzz::fail(ctx, ZZZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                                               \
+  } while (0)
+
 static int local_allreduce(zzz_ctx* ctx, double* dev, int n)
 {
   LocalGroup* G = ctx->comm->local;
   const int me = ctx->comm->rank;
   G->red[me].resize((size_t)n);
-  ZZZ_HIP(ctx, hipMemcpyAsync(G->red[me].data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  pthread_barrier_wait(&G->bar);
+  ZZZ_LOCAL_HIP(ctx, G, hipMemcpyAsync(G->red[me].data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_LOCAL_HIP(ctx, G, hipStreamSynchronize(ctx->stream));
+  ZZZ_LOCAL_WAIT(ctx, G);
   std::vector<double> sum((size_t)n, 0.0);
   for (int r = 0; r < G->n; ++r) // rank order: every rank forms the same sum
     for (int i = 0; i < n; ++i)
       sum[i] += G->red[r][i];
-  pthread_barrier_wait(&G->bar);
-  ZZZ_HIP(ctx, hipMemcpyAsync(dev, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZZZ_LOCAL_WAIT(ctx, G);
+  ZZZ_LOCAL_HIP(ctx, G, hipMemcpyAsync(dev, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_LOCAL_HIP(ctx, G, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
 }
 
@@ -482,10 +544,10 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
     const int me = ctx->comm->rank;
     G->mail[me].resize((size_t)(nsend * bs));
     if (nsend > 0)
-      ZZZ_HIP(ctx, hipMemcpyAsync(G->mail[me].data(), ctx->send_buf.p, sizeof(double) * nsend * bs, hipMemcpyDeviceToHost,
-                                  ctx->stream));
-    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pthread_barrier_wait(&G->bar);
+      ZZZ_LOCAL_HIP(ctx, G, hipMemcpyAsync(G->mail[me].data(), ctx->send_buf.p, sizeof(double) * nsend * bs,
+                                           hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_LOCAL_HIP(ctx, G, hipStreamSynchronize(ctx->stream));
+    ZZZ_LOCAL_WAIT(ctx, G);
     int64_t gh = ctx->n_owned;
     for (int k = 0; k < ctx->nneigh; ++k)
     {
@@ -497,14 +559,17 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
         if (G->neigh[src][q] == me)
           kk = (int)q;
       if (kk < 0 || G->send_off[src][kk + 1] - G->send_off[src][kk] != nr)
+      {
+        G->bar.abort();
         return fail(ctx, ZZZ_ERR_ARG, "local halo: rank %d does not send %lld block dofs to rank %d", src, (long long)nr, me);
+      }
       if (nr > 0)
-        ZZZ_HIP(ctx, hipMemcpyAsync(vec + gh * bs, G->mail[src].data() + G->send_off[src][kk] * bs, sizeof(double) * nr * bs,
-                                    hipMemcpyHostToDevice, ctx->stream));
+        ZZZ_LOCAL_HIP(ctx, G, hipMemcpyAsync(vec + gh * bs, G->mail[src].data() + G->send_off[src][kk] * bs,
+                                             sizeof(double) * nr * bs, hipMemcpyHostToDevice, ctx->stream));
       gh += nr;
     }
-    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pthread_barrier_wait(&G->bar);
+    ZZZ_LOCAL_HIP(ctx, G, hipStreamSynchronize(ctx->stream));
+    ZZZ_LOCAL_WAIT(ctx, G);
     return ZZZ_OK;
   }
   ncclComm_t hc = (st != ctx->stream && ctx->comm->comm_halo) ? ctx->comm->comm_halo : ctx->comm->comm;
@@ -523,6 +588,83 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
     ghost += nr;
   }
   ZZZ_NCCL(ctx, g_rccl.GroupEnd());
+  return ZZZ_OK;
+}
+
+int comm_size(const zzz_ctx* ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
+int comm_rank(const zzz_ctx* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+
+// Set-up exchange of byte buffers of arbitrary sizes between all ranks (send[r] goes to rank r, recv[r] came from
+// rank r; collective).  Host mailboxes with the local backend; with RCCL the sizes travel first, then the
+// payloads, as grouped ncclSend / ncclRecv through device staging buffers.  Not for the solve loop.
+int comm_exchange_bytes(zzz_ctx* ctx, const std::vector<std::vector<char>>& send, std::vector<std::vector<char>>& recv)
+{
+  if (!ctx->comm)
+    return fail(ctx, ZZZ_ERR_ARG, "exchange: no communicator");
+  const int n = ctx->comm->nranks, me = ctx->comm->rank;
+  if ((int)send.size() != n)
+    return fail(ctx, ZZZ_ERR_ARG, "exchange: one send buffer per rank expected");
+  recv.assign((size_t)n, std::vector<char>());
+  if (ctx->comm->local)
+  {
+    LocalGroup* G = ctx->comm->local;
+    G->xch[(size_t)me] = send;
+    ZZZ_LOCAL_WAIT(ctx, G);
+    for (int r = 0; r < n; ++r)
+      recv[(size_t)r] = G->xch[(size_t)r][(size_t)me];
+    ZZZ_LOCAL_WAIT(ctx, G);
+    return ZZZ_OK;
+  }
+  if (!ctx->comm->comm)
+    return fail(ctx, ZZZ_ERR_RCCL, "exchange: this communicator has no transport (peer-only)");
+  hipStream_t st = ctx->stream;
+  std::vector<int64_t> ssz((size_t)n), rsz((size_t)n, 0);
+  for (int r = 0; r < n; ++r)
+    ssz[(size_t)r] = (int64_t)send[(size_t)r].size();
+  DevBuf<int64_t> dsz;
+  ZZZ_HIP(ctx, dsz.alloc(2 * (size_t)n));
+  ZZZ_HIP(ctx, hipMemcpyAsync(dsz.p, ssz.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+  ZZZ_NCCL(ctx, g_rccl.GroupStart());
+  for (int r = 0; r < n; ++r)
+    if (r != me)
+    {
+      ZZZ_NCCL(ctx, g_rccl.Send(dsz.p + r, 8, 0 /* ncclInt8 */, r, ctx->comm->comm, st));
+      ZZZ_NCCL(ctx, g_rccl.Recv(dsz.p + n + r, 8, 0, r, ctx->comm->comm, st));
+    }
+  ZZZ_NCCL(ctx, g_rccl.GroupEnd());
+  ZZZ_HIP(ctx, hipMemcpyAsync(rsz.data(), dsz.p + n, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+  ZZZ_HIP(ctx, hipStreamSynchronize(st));
+  rsz[(size_t)me] = ssz[(size_t)me];
+  std::vector<int64_t> soff((size_t)n + 1, 0), roff((size_t)n + 1, 0);
+  for (int r = 0; r < n; ++r)
+  {
+    soff[(size_t)r + 1] = soff[(size_t)r] + (r == me ? 0 : ssz[(size_t)r]);
+    roff[(size_t)r + 1] = roff[(size_t)r] + (r == me ? 0 : rsz[(size_t)r]);
+  }
+  DevBuf<char> dsend, drecv;
+  ZZZ_HIP(ctx, dsend.alloc((size_t)soff[(size_t)n] + 8));
+  ZZZ_HIP(ctx, drecv.alloc((size_t)roff[(size_t)n] + 8));
+  for (int r = 0; r < n; ++r)
+    if (r != me && ssz[(size_t)r])
+      ZZZ_HIP(ctx, hipMemcpyAsync(dsend.p + soff[(size_t)r], send[(size_t)r].data(), (size_t)ssz[(size_t)r], hipMemcpyHostToDevice, st));
+  ZZZ_NCCL(ctx, g_rccl.GroupStart());
+  for (int r = 0; r < n; ++r)
+    if (r != me)
+    {
+      if (ssz[(size_t)r])
+        ZZZ_NCCL(ctx, g_rccl.Send(dsend.p + soff[(size_t)r], (size_t)ssz[(size_t)r], 0, r, ctx->comm->comm, st));
+      if (rsz[(size_t)r])
+        ZZZ_NCCL(ctx, g_rccl.Recv(drecv.p + roff[(size_t)r], (size_t)rsz[(size_t)r], 0, r, ctx->comm->comm, st));
+    }
+  ZZZ_NCCL(ctx, g_rccl.GroupEnd());
+  for (int r = 0; r < n; ++r)
+  {
+    recv[(size_t)r].resize((size_t)rsz[(size_t)r]);
+    if (r != me && rsz[(size_t)r])
+      ZZZ_HIP(ctx, hipMemcpyAsync(recv[(size_t)r].data(), drecv.p + roff[(size_t)r], (size_t)rsz[(size_t)r], hipMemcpyDeviceToHost, st));
+  }
+  ZZZ_HIP(ctx, hipStreamSynchronize(st));
+  recv[(size_t)me] = send[(size_t)me];
   return ZZZ_OK;
 }
 
@@ -810,12 +952,13 @@ int zzz_local_group_create(int nranks, void** group)
     return fail(nullptr, ZZZ_ERR_ARG, "zzz_local_group_create: bad arguments");
   LocalGroup* G = new LocalGroup();
   G->n = nranks;
-  pthread_barrier_init(&G->bar, nullptr, (unsigned)nranks);
+  G->bar.n = nranks;
   G->red.resize((size_t)nranks);
   G->mail.resize((size_t)nranks);
   G->neigh.resize((size_t)nranks);
   G->send_off.resize((size_t)nranks);
   G->bs.assign((size_t)nranks, 1);
+  G->xch.resize((size_t)nranks);
   *group = G;
   return ZZZ_OK;
 }
@@ -825,8 +968,13 @@ void zzz_local_group_destroy(void* group)
   LocalGroup* G = static_cast<LocalGroup*>(group);
   if (!G)
     return;
-  pthread_barrier_destroy(&G->bar);
   delete G;
+}
+
+void zzz_local_group_abort(void* group)
+{
+  if (LocalGroup* G = static_cast<LocalGroup*>(group))
+    G->bar.abort();
 }
 
 int zzz_comm_init_local(zzz_ctx* ctx, void* group, int rank)

@@ -92,6 +92,9 @@ struct zzz_ctx
   int64_t n_owned = 0, n_ghost = 0; // block dofs
   zzz::DevBuf<int32_t> cell_dofs;   // ncells*nd
   std::vector<int32_t> h_cell_dofs;
+  // global indices of the local block dofs / vertices (zzz_global_ids_upload): only the ghost-layer build needs them
+  std::vector<int64_t> h_dof_global, h_vert_global;
+  int64_t owned_cells = 0; // cells the caller uploaded, when zzz_ghost_layer_build has appended ghost cells
 
   // bc marker per local scalar dof (owned + ghost)
   zzz::DevBuf<uint8_t> bc;

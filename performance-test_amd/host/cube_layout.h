@@ -113,19 +113,23 @@ struct Slab
   bool lower, upper;
   int64_t own_lo, own_hi, n_owned, n_lower, n_upper, up_lo, nloc, nverts, ncubes, ncells;
 
-  ZZZ_HD Slab(int64_t nx, int64_t ny, int64_t nz, int order, int bs_, int nparts_, int part_)
+  // native: the partition as the reference's cell partitioner leaves it (GhostMode::none, src/mesh.cpp:182-183):
+  // own cells only, ghosts = the dofs of the own cells that the lower neighbour owns (plane zs); the rows of the
+  // top plane are then incomplete until the cells above arrive (zzz_ghost_layer_build).
+  ZZZ_HD Slab(int64_t nx, int64_t ny, int64_t nz, int order, int bs_, int nparts_, int part_, bool native = false)
       : L(nx, ny, nz, order), nparts(nparts_), part(part_), bs(bs_), nd(order == 1 ? 4 : (order == 2 ? 10 : 20))
   {
     zs = nz * part / nparts;
     ze = nz * (part + 1) / nparts;
     lower = part > 0;
     upper = part < nparts - 1;
-    zl_end = upper ? ze + 1 : ze;
+    const bool upper_layer = upper && !native;
+    zl_end = upper_layer ? ze + 1 : ze;
     own_lo = L.level_base(zs) + (lower ? L.NP : 0);
     own_hi = L.level_base(ze) + L.NP;
     n_owned = own_hi - own_lo;
     n_lower = lower ? L.NP : 0;
-    n_upper = upper ? L.NL + L.NP : 0;
+    n_upper = upper_layer ? L.NL + L.NP : 0;
     up_lo = L.level_base(ze) + L.NP;
     nloc = n_owned + n_lower + n_upper;
     nverts = (zl_end - zs + 1) * L.PX * L.PY;

@@ -73,7 +73,7 @@ struct zzzh_part
   int64_t sizes[ZZZH_NSIZES];
   std::vector<double> x, dof_x, coeff[2];
   std::vector<int32_t> cells, cell_dofs, facets, bc_dofs, neigh, send_idx;
-  std::vector<int64_t> global_dofs, send_off, recv_cnt;
+  std::vector<int64_t> global_dofs, global_verts, send_off, recv_cnt;
 };
 
 extern "C" {
@@ -153,7 +153,18 @@ int zzzh_count_suffix(int64_t n, char* out, int cap)
 
 const char* zzzh_last_error(void) { return g_err.c_str(); }
 
+static zzzh_part* part_create(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part, bool native);
+
 zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part)
+{
+  return part_create(problem, order, nx, ny, nz, nparts, part, false);
+}
+zzzh_part* zzzh_part_create_native(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part)
+{
+  return part_create(problem, order, nx, ny, nz, nparts, part, true);
+}
+
+static zzzh_part* part_create(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part, bool native)
 {
   if (problem != ZZZH_POISSON && problem != ZZZH_ELASTICITY)
   {
@@ -176,7 +187,7 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
     return nullptr;
   }
   const int bs = problem == ZZZH_ELASTICITY ? 3 : 1;
-  const zzzcube::Slab S(nx, ny, nz, order, bs, nparts, part);
+  const zzzcube::Slab S(nx, ny, nz, order, bs, nparts, part, native);
   const zzzcube::Layout& L = S.L;
   const int nd = S.nd;
   const int64_t zs = S.zs, ze = S.ze, zl_end = S.zl_end;
@@ -202,6 +213,7 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
   // geometry: vertex planes zs .. zl_end
   const int64_t nverts = S.nverts;
   P->x.resize((size_t)(3 * nverts));
+  P->global_verts.resize((size_t)nverts);
   for (int64_t iz = zs; iz <= zl_end; ++iz)
     for (int64_t iy = 0; iy <= ny; ++iy)
       for (int64_t ix = 0; ix <= nx; ++ix)
@@ -211,6 +223,7 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
         P->x[3 * v + 0] = (double)ix / (double)nx;
         P->x[3 * v + 1] = (double)iy / (double)ny;
         P->x[3 * v + 2] = (double)iz / (double)nz;
+        P->global_verts[(size_t)v] = (iz * L.PY + iy) * L.PX + ix;
       }
 
   const int64_t ncells = S.ncells;
@@ -290,9 +303,9 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
   P->send_off.push_back(0);
   if (lower)
   {
-    // rank part-1's upper ghosts = my layer zs and plane zs+1 = my first NL+NP owned dofs
+    // rank part-1's upper ghosts = my layer zs and plane zs+1 = my first NL+NP owned dofs (native: it has none)
     P->neigh.push_back(part - 1);
-    for (int64_t i = 0; i < L.NL + L.NP; ++i)
+    for (int64_t i = 0; i < (native ? 0 : L.NL + L.NP); ++i)
       P->send_idx.push_back((int32_t)i);
     P->send_off.push_back((int64_t)P->send_idx.size());
     P->recv_cnt.push_back(n_lower);
@@ -338,6 +351,7 @@ const int32_t* zzzh_part_facets(const zzzh_part* p) { return p->facets.data(); }
 const int32_t* zzzh_part_bc_dofs(const zzzh_part* p) { return p->bc_dofs.data(); }
 const double* zzzh_part_dof_x(const zzzh_part* p) { return p->dof_x.data(); }
 const int64_t* zzzh_part_global_dofs(const zzzh_part* p) { return p->global_dofs.data(); }
+const int64_t* zzzh_part_global_verts(const zzzh_part* p) { return p->global_verts.data(); }
 const double* zzzh_part_coeff(const zzzh_part* p, int which) { return (which == 0 || which == 1) ? p->coeff[which].data() : nullptr; }
 const int32_t* zzzh_part_neigh(const zzzh_part* p) { return p->neigh.data(); }
 const int64_t* zzzh_part_send_off(const zzzh_part* p) { return p->send_off.data(); }

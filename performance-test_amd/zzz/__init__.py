@@ -29,11 +29,11 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_cg_info", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
-    "zzz_local_group_destroy", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
+    "zzz_profile_get", "zzz_cg_info", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
-    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_destroy",
+    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_create_native", "zzzh_part_destroy", "zzzh_part_global_verts",
     "zzzh_last_error", "zzzh_part_sizes", "zzzh_part_x", "zzzh_part_cells", "zzzh_part_cell_dofs",
     "zzzh_part_facets", "zzzh_part_bc_dofs", "zzzh_part_dof_x", "zzzh_part_global_dofs", "zzzh_part_coeff",
     "zzzh_part_neigh", "zzzh_part_send_off", "zzzh_part_send_idx", "zzzh_part_recv_cnt",
@@ -142,12 +142,14 @@ def host():
         L.zzzh_mesh_size.argtypes = [C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, _i64p]
         L.zzzh_part_create.restype = C.c_void_p
         L.zzzh_part_create.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int]
+        L.zzzh_part_create_native.restype = C.c_void_p
+        L.zzzh_part_create_native.argtypes = L.zzzh_part_create.argtypes
         L.zzzh_part_destroy.argtypes = [C.c_void_p]
         L.zzzh_part_destroy.restype = None
         L.zzzh_last_error.restype = C.c_char_p
         L.zzzh_part_sizes.argtypes = [C.c_void_p, _i64p]
         for name, ty in (("x", C.c_double), ("cells", C.c_int32), ("cell_dofs", C.c_int32), ("facets", C.c_int32),
-                         ("bc_dofs", C.c_int32), ("dof_x", C.c_double), ("global_dofs", C.c_int64),
+                         ("bc_dofs", C.c_int32), ("dof_x", C.c_double), ("global_dofs", C.c_int64), ("global_verts", C.c_int64),
                          ("neigh", C.c_int32), ("send_off", C.c_int64), ("send_idx", C.c_int32),
                          ("recv_cnt", C.c_int64)):
             f = getattr(L, "zzzh_part_" + name)
@@ -188,10 +190,10 @@ def _arr(ptr, n, dtype, shape=None):
 class Part:
     """One z-slab partition of the cube problem (host/mesh_part.cpp)."""
 
-    def __init__(self, problem, order, nx, ny, nz, nparts=1, part=0):
+    def __init__(self, problem, order, nx, ny, nz, nparts=1, part=0, native=False):
         H = host()
         pid = FORM_ELASTICITY if problem == "elasticity" else FORM_POISSON
-        h = H.zzzh_part_create(pid, order, nx, ny, nz, nparts, part)
+        h = (H.zzzh_part_create_native if native else H.zzzh_part_create)(pid, order, nx, ny, nz, nparts, part)
         if not h:
             raise ValueError(H.zzzh_last_error().decode())
         try:
@@ -214,6 +216,7 @@ class Part:
             self.bc_dofs = _arr(H.zzzh_part_bc_dofs(h), int(s[NBC]), np.int32)
             self.dof_x = _arr(H.zzzh_part_dof_x(h), 3 * self.nloc, np.float64, (-1, 3))
             self.global_dofs = _arr(H.zzzh_part_global_dofs(h), self.nloc, np.int64)
+            self.global_verts = _arr(H.zzzh_part_global_verts(h), self.nverts, np.int64)
             self.f = _arr(H.zzzh_part_coeff(h, 0), self.nloc * self.bs, np.float64)
             self.g = _arr(H.zzzh_part_coeff(h, 1), self.nloc, np.float64) if pid == FORM_POISSON else None
             nn = int(s[NNEIGH])
@@ -285,6 +288,29 @@ class Context:
 
     def upload_coeff(self, which, values):
         self._ck(self.L.zzz_coeff_upload(self.h, which, np.ascontiguousarray(values, np.float64)))
+
+    def upload_global_ids(self, dof_global, vert_global):
+        d = np.ascontiguousarray(dof_global, np.int64)
+        v = np.ascontiguousarray(vert_global, np.int64)
+        self._ck(self.L.zzz_global_ids_upload(self.h, d.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+
+    def ghost_layer_build(self):
+        """collective: native (GhostMode::none) feed -> ghost-cell layer; returns the new local sizes"""
+        self._ck(self.L.zzz_ghost_layer_build(self.h))
+        s = self.local_sizes()
+        self.n_ghost = s[3]
+        return s
+
+    def local_sizes(self):
+        s = (C.c_int64 * 6)()
+        self._ck(self.L.zzz_local_sizes(self.h, s))
+        return [int(v) for v in s]
+
+    def global_ids(self):
+        s = self.local_sizes()
+        out = np.zeros(s[2] + s[3], np.int64)
+        self._ck(self.L.zzz_global_ids_download(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def upload_part(self, P):
         """everything problem() sets up before `ZZZ Assemble matrix` (src/poisson_problem.cpp:33-123)"""
@@ -479,6 +505,10 @@ class LocalGroup:
         if rc:
             raise ZzzError(rc, hip().zzz_last_error(None).decode())
         self.n = nranks
+
+    def abort(self):
+        if self.h:
+            hip().zzz_local_group_abort(self.h)
 
     def close(self):
         if self.h:

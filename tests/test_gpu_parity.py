@@ -1273,3 +1273,91 @@ def test_fused_direction_kernel_keeps_every_bit():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
+
+
+@pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (6, 5, 8), 2), ("poisson", 1, (5, 4, 9), 4),
+                                                       ("poisson", 2, (3, 3, 6), 3), ("poisson", 3, (2, 3, 4), 2),
+                                                       ("elasticity", 1, (4, 3, 6), 3), ("elasticity", 2, (2, 2, 4), 2)])
+def test_native_partition_through_ghost_layer_build(problem, order, dims, nparts):
+    """The reference's own partition contract (cells partitioned with GhostMode::none, src/mesh.cpp:182-183; rows
+    completed by MatAssemblyBegin/End and scatter_rev, src/poisson_problem.cpp:132-137,154): every rank uploads its
+    OWN cells only, zzz_ghost_layer_build exchanges the interface cells once, and the assembled owned rows of A
+    and b must equal (1e-13) those of the ghost-layer feed, those of the oracle's global assembly, and the solve
+    the single-rank solve."""
+    import threading
+
+    import scipy.sparse as sp
+
+    zo.set_num_threads(1)
+    G = zzz.Part(problem, order, *dims)
+    bs, N = G.bs, G.n_owned * G.bs
+    orp, ocl = zo.pattern(G.n_owned, G.cell_dofs, bs)
+    ov = zo.assemble_matrix(G.form, order, G.x, G.cells, G.cell_dofs, G.bc_marker(), orp, ocl)
+    ob = zo.assemble_vector(G.form, order, G.x, G.cells, G.cell_dofs, G.f, G.g, G.facets if G.form == 0 else None,
+                            G.bc_marker())
+    A_or = sp.csr_matrix((ov, ocl, orp), shape=(N, N))
+    oit, ou, _, _ = zo.pcg(orp, ocl, ov, ob, rtol=1e-8)
+    grp = zzz.LocalGroup(nparts)
+    out, err = [None] * nparts, []
+
+    def scalar_cols(gids, cols):
+        return gids[cols // bs] * bs + cols % bs
+
+    def run(rank):
+        try:
+            Pn = zzz.Part(problem, order, *dims, nparts, rank, native=True)
+            Pg = zzz.Part(problem, order, *dims, nparts, rank)
+            assert Pn.ncells == Pn.owned_cells and Pn.n_owned == Pg.n_owned
+            with zzz.Context(0) as c, zzz.Context(0) as cg:
+                c.comm_init_local(grp.h, rank)
+                c.upload_part(Pn)
+                c.upload_halo(Pn)
+                c.upload_global_ids(Pn.global_dofs, Pn.global_verts)
+                sizes = c.ghost_layer_build()
+                assert sizes[1] == Pg.ncells and sizes[3] == Pg.n_ghost and sizes[4] == Pn.ncells
+                gid = c.global_ids()
+                assert sorted(gid[Pn.n_owned:]) == sorted(Pg.global_dofs[Pg.n_owned:])
+                c.pattern_build()
+                c.assemble_matrix(Pn.form)
+                c.assemble_vector(Pn.form)
+                rp, cl, v = c.csr_download()
+                b = c.vec_download(zzz.VEC_B)
+                An = sp.csr_matrix((v, scalar_cols(gid, cl), rp), shape=(Pn.n_owned * bs, N))
+                # the ghost-layer feed of the same rank, on a context of its own (no communication needed to assemble)
+                cg.upload_part(Pg)
+                cg.pattern_build()
+                cg.assemble_matrix(Pg.form)
+                cg.assemble_vector(Pg.form)
+                rp2, cl2, v2 = cg.csr_download()
+                Ag = sp.csr_matrix((v2, scalar_cols(Pg.global_dofs, cl2), rp2), shape=(Pg.n_owned * bs, N))
+                b2 = cg.vec_download(zzz.VEC_B)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                out[rank] = (Pn.own_offset * bs, An, Ag, b, b2, it, c.vec_download(zzz.VEC_U))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            err.append((rank, repr(e), traceback.format_exc()))
+            try:
+                grp.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    grp.close()
+    assert not err, err
+    scale = np.abs(ov).max()
+    u = np.zeros(N)
+    for lo, An, Ag, b, b2, it, ur in out:
+        n = An.shape[0]
+        for B in (Ag, A_or[lo:lo + n]):
+            D = (An - B).tocoo()
+            assert D.nnz == 0 or np.abs(D.data).max() <= 1e-13 * scale
+            assert An.nnz == B.nnz  # the same pattern, structural zeros included
+        assert np.abs(b - b2).max() <= 1e-13 * np.abs(ob).max()
+        assert np.abs(b - ob[lo:lo + n]).max() <= 1e-12 * np.abs(ob).max()
+        assert abs(it - oit) <= 2
+        u[lo:lo + n] = ur
+    assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
