@@ -38,6 +38,33 @@ import zzz  # noqa: E402  (ctypes mirror of include/zzz_abi.h; loads libzzz_hip.
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+class deadline:
+    """Bound on a step that other ranks take part in (communicator bootstrap, gloo collectives, a warm-up or timed
+    region whose collectives could block on a rank that has died): when it does not finish in time the process
+    prints why and ends with a NON-ZERO status by a plain exit -- never a hang, never a re-exec."""
+
+    def __init__(self, seconds, what):
+        import threading
+
+        self.what, self.seconds = what, seconds
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+
+    def _fire(self):
+        sys.stderr.write(f"bench.py: '{self.what}' did not finish within {self.seconds} s "
+                         f"(rank {os.environ.get('RANK', '0')}); giving up\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.t.cancel()
+        return False
+
+
 def spmv_algorithmic_bytes(n, nnz):
     # SURVEY.md 8(d): fp64 values + int32 columns + int32 row pointers + x read once + y written
     return 12 * nnz + 4 * (n + 1) + 16 * n
@@ -192,11 +219,24 @@ def main():
         import torch
         import torch.distributed as dist
 
-        dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+        import datetime
+
+        with deadline(600, "gloo process group"):
+            dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank,
+                                    timeout=datetime.timedelta(seconds=600))
+        # every rank must have bound the SAME librccl (torch ships its own copy: load order decides)
+        paths = [None] * world
+        with deadline(120, "all_gather of the bound librccl paths"):
+            dist.all_gather_object(paths, zzz.comm_library_path())
+        if len(set(paths)) != 1:
+            if rank == 0:
+                sys.stderr.write("bench.py: the ranks bound different RCCL libraries: " + repr(paths) + "\n")
+            sys.exit(4)
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            with deadline(900, "barrier"):
+                dist.barrier()
 
     bs = 3 if a.problem_type == "elasticity" else 1
     strong = a.scaling_type == "strong"
@@ -207,23 +247,28 @@ def main():
     # feed is generated on the device (zzz_cube_generate) -- identical problem, no PCIe traffic
     need_host_arrays = not multi and not a.no_cpu_baseline
     P = zzz.Part(a.problem_type, a.order, nx, ny, nz, world, rank) if need_host_arrays else None
-    ctx = zzz.Context(local_rank)
+    # ZZZ_BENCH_DEVICE: all ranks on one device (only for the two-processes-on-one-GPU probe of the RCCL path)
+    ctx = zzz.Context(int(os.environ.get("ZZZ_BENCH_DEVICE", local_rank)))
     if multi:
         import torch
 
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(uid_bytes), dtype=torch.uint8).clone()
-        dist.broadcast(uid, src=0)
-        ctx.comm_init(world, rank, bytes(uid.numpy().tobytes()))
+        with deadline(300, "unique-id broadcast"):
+            dist.broadcast(uid, src=0)
+        with deadline(600, "ncclCommInitRank / ncclCommSplit"):
+            ctx.comm_init(world, rank, bytes(uid.numpy().tobytes()))
     # CG scalar all-reduces through peer-memory mailboxes when every rank can map every peer (the library
     # tests the transport and makes the ranks agree); otherwise ncclAllReduce.  ZZZ_P2P=0 keeps RCCL.
     p2p = False
     if multi and os.environ.get("ZZZ_P2P", "1") != "0":
         mine = torch.frombuffer(bytearray(ctx.comm_p2p_export()), dtype=torch.uint8).clone()
         allh = [torch.zeros(zzz.P2P_HANDLE_BYTES, dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(allh, mine)
-        p2p = ctx.comm_p2p_attach(b"".join(bytes(h.numpy().tobytes()) for h in allh))
+        with deadline(300, "mailbox handle all_gather"):
+            dist.all_gather(allh, mine)
+        with deadline(300, "peer-memory mailbox attach (8 test rounds + agreement)"):
+            p2p = ctx.comm_p2p_attach(b"".join(bytes(h.numpy().tobytes()) for h in allh))
     if not multi and a.force_comm:
         ctx.comm_init(1, 0, zzz.comm_unique_id())
         if os.environ.get("ZZZ_P2P", "1") != "0":
@@ -266,6 +311,9 @@ def main():
         return t
 
     tuning = None
+    guard = deadline(2400, "warm-up steps") if dist is not None else None
+    if guard:
+        guard.__enter__()
     for w in range(a.warmup):
         ok = 1
         try:
@@ -311,6 +359,9 @@ def main():
             if p2p:
                 (ctx.comm_p2p_enable if use_pm else ctx.comm_p2p_disable)()
                 p2p = use_pm
+    if guard:
+        guard.__exit__()
+
     def timed_region():
         """EXACTLY a.steps steps between barrier + device sync on both sides; None if the peer-memory all-reduce
         failed on some rank (every rank then fails within one round of it and all meet at the closing vote)"""
@@ -335,7 +386,12 @@ def main():
             barrier()
         return phases, time.perf_counter() - t_begin
 
+    guard = deadline(2400, "timed region") if dist is not None else None
+    if guard:
+        guard.__enter__()
     phases, elapsed = timed_region()
+    if guard:
+        guard.__exit__()
     if phases is None:  # never seen; kept so that a transport problem costs a repeat, not the measurement
         ctx.comm_p2p_disable()
         p2p = False
@@ -348,7 +404,20 @@ def main():
         elapsed = float(tt[0])
 
     spmv_ms, spmv_n = ctx.profile()
-    unorm = ctx.vec_norm(zzz.VEC_U)
+    with deadline(300, "solution norm (all-reduce)"):
+        unorm = ctx.vec_norm(zzz.VEC_U)
+    # what every rank's multi-GPU path did: one entry per rank in the JSON line, so that a first N > 1 record can be
+    # read without a second run
+    rank_info = None
+    if multi or a.force_comm:
+        mine = ctx.comm_info()
+        mine.update(rows=nrows, nnz=nnz, krylov_iterations=phases[-1]["iters"], spmv_avg_ms=spmv_ms,
+                    solve_s=float(np.mean([p["solve"] for p in phases])), librccl=zzz.comm_library_path())
+        rank_info = [mine]
+        if dist is not None:
+            rank_info = [None] * world
+            with deadline(300, "all_gather of the per-rank diagnostics"):
+                dist.all_gather_object(rank_info, mine)
     ms_per_step = elapsed / a.steps * 1e3
     iters = phases[-1]["iters"]
 
@@ -412,7 +481,12 @@ def main():
             out["config"]["spmv_operator"] = "CSR tile kernel"
         out["config"]["spmv_column_stream"] = (f"16-bit band codes ({c16[1]} offset bits), {c16[2]} of {c16[3]} tiles on int32 columns"
                                                if c16[0] else "int32")
+        if rank_info:
+            out["config"]["ranks"] = rank_info
         if tuning:
+            out["config"]["cg_form_tuning_us_per_iteration"] = {
+                ("single_reduction" if sr else "classical") + ("+peer_memory" if pm else "+ncclAllReduce"):
+                (1e6 * v / max(iters, 1) if v != float("inf") else None) for (sr, pm), v in tuning.items()}
             out["config"]["cg_form_tuning_s"] = {("single_reduction" if sr else "classical") + ("+peer_memory" if pm else "+ncclAllReduce"): v
                                                  for (sr, pm), v in tuning.items()}
         if multi or a.force_comm:

@@ -703,6 +703,30 @@ int zzz_comm_load(void)
   return ZZZ_OK;
 }
 
+int zzz_comm_info(zzz_ctx* ctx, int64_t info[12])
+{
+  if (!ctx || !info)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_comm_info: bad arguments");
+  for (int i = 0; i < 12; ++i)
+    info[i] = 0;
+  info[0] = ctx->comm ? ctx->comm->nranks : 1;
+  info[1] = ctx->comm ? ctx->comm->rank : 0;
+  info[2] = ctx->nneigh;
+  int64_t nrecv = 0;
+  for (int k = 0; k < ctx->nneigh; ++k)
+    nrecv += ctx->recv_cnt[(size_t)k];
+  info[3] = (ctx->nneigh ? ctx->send_off[(size_t)ctx->nneigh] : 0) * ctx->bs * 8; // bytes sent per forward scatter
+  info[4] = nrecv * ctx->bs * 8;
+  info[5] = (ctx->comm && ctx->comm->comm_halo) ? 1 : 0; // second communicator (ncclCommSplit): halo on its own stream
+  info[6] = comm_p2p_enabled(ctx) ? 1 : 0;                // CG scalars through the peer-memory mailboxes
+  const bool stream_split = sellp_active(ctx) && ctx->have_group_split;
+  info[7] = (ctx->comm && ctx->overlap && (stream_split || ctx->have_tile_split)) ? 1 : 0; // halo overlapped with interior rows
+  info[8] = stream_split ? ctx->n_groups_interior : ctx->n_tiles_interior;
+  info[9] = stream_split ? ctx->n_groups_boundary : ctx->n_tiles_boundary;
+  info[10] = ctx->comm && ctx->comm->local ? 1 : 0;
+  return ZZZ_OK;
+}
+
 /* path of the librccl this process bound (dladdr of ncclAllReduce); "" before zzz_comm_load */
 const char* zzz_comm_library_path(void) { return g_rccl_path.c_str(); }
 

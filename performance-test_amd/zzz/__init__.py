@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_cg_info", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_profile_get", "zzz_cg_info", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
@@ -432,6 +432,13 @@ class Context:
         ms, n = C.c_double(), C.c_int64()
         self._ck(self.L.zzz_profile_get(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def comm_info(self):
+        info = (C.c_int64 * 12)()
+        self._ck(self.L.zzz_comm_info(self.h, info))
+        keys = ("ranks", "rank", "neighbours", "halo_bytes_sent", "halo_bytes_received", "halo_own_communicator",
+                "peer_memory_allreduce", "halo_overlapped", "interior_items", "boundary_items", "local_backend")
+        return {k: int(v) for k, v in zip(keys, info)}
 
     def comm_init(self, nranks, rank, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
