@@ -274,7 +274,10 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   const Options& o = S.opt;
   const bool root = rank == 0;
   zzz_ctx* ctx = nullptr;
-  // a rank that fails must keep arriving at the barriers, or the others hang: catch, record, drain
+  // A rank that fails keeps arriving at the DRIVER's barriers (catch, record, drain).  Its peers may meanwhile be
+  // waiting for it inside a collective of the library: with the local communicator the group is broken (every
+  // waiting rank gets an error and drains too); with RCCL nothing can wake them, so the process ends at once
+  // with a non-zero status instead of hanging.
   bool failed = false;
   auto phase = [&](const char* tname, auto&& body) {
     Timer t(tname ? tname : "");
@@ -290,6 +293,17 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
       {
         failed = true;
         S.error[rank] = e.what();
+        if (S.nranks > 1)
+        {
+          if (S.local_group)
+            zzz_local_group_abort(S.local_group);
+          else
+          {
+            std::cerr << "rank " << rank << ": " << e.what() << "\n(other ranks may be waiting in an RCCL collective: aborting)"
+                      << std::endl;
+            std::_Exit(2);
+          }
+        }
       }
     }
     const double s = t.stop();
