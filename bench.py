@@ -103,6 +103,9 @@ CONFIGS = {
     "c4_total": dict(problem_type="elasticity", order=1, scaling_type="weak", ndofs=500000, mesh_nproc=8,
                      note="BASELINE configs[3]: the whole 8-GPU weak-scaling problem (mesh of 8 processes) on one GPU"),
     # configs[4]: Poisson P3 strong 50 M dofs over 8 GPUs: one GPU's share of the rows
+    # ... and the whole of it on ONE GPU: 49 834 930 dofs, 2 406 964 246 nonzeros (64-bit row pointers, operator stream)
+    "c5": dict(problem_type="poisson", order=3, scaling_type="strong", ndofs=50000000, mesh_nproc=1,
+               note="BASELINE configs[4] whole on one GPU (2.4 G nonzeros): the largest single-GPU configuration"),
     "c5_rank": dict(problem_type="poisson", order=3, scaling_type="strong", ndofs=6250000, mesh_nproc=1,
                     note="BASELINE configs[4]: the per-GPU share (50 M / 8 dofs) of the P3 problem on one GPU"),
 }

@@ -185,6 +185,9 @@ int zzz_csr_sizes(const zzz_ctx* ctx, int64_t* nrows, int64_t* ncols, int64_t* n
 /* Copies the CSR arrays to the host (parity checks; MatView-like).  NULL pointers are skipped.
  * rowptr: nrows+1, cols/vals: nnz. */
 int zzz_csr_download(zzz_ctx* ctx, int32_t* rowptr, int32_t* cols, double* vals);
+/* The row pointers in 64 bits (PetscInt of the reference's CI build): the only form for matrices of 2^31 nonzeros
+ * or more (Poisson P3 at 50 M dofs: 2.4 G), where zzz_csr_download(rowptr != NULL) fails with ZZZ_ERR_LIMIT. */
+int zzz_csr_rowptr64_download(zzz_ctx* ctx, int64_t* rowptr);
 
 /* Replaces the matrix values (testing the solver on a given operator). vals: nnz. */
 int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals);

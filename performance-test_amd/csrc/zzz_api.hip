@@ -427,17 +427,15 @@ static int pattern_build_host(zzz_ctx* ctx)
   for (int64_t r = 0; r < nb; ++r)
     nblk += bptr[r + 1];
   const int64_t nnz = nblk * bs * bs;
-  if (nnz > INT32_MAX - 16384)
-    overflow = true;
   if (overflow)
-    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range", (long long)nnz);
+    return fail(ctx, ZZZ_ERR_LIMIT, "pattern too large (%lld nonzeros)", (long long)nnz);
   const int64_t nrows = nb * bs;
-  std::vector<int32_t> rowptr((size_t)nrows + 1);
+  std::vector<rp_t> rowptr((size_t)nrows + 1);
   std::vector<int32_t> cols((size_t)nnz);
   rowptr[0] = 0;
   for (int64_t r = 0; r < nb; ++r)
     for (int c = 0; c < bs; ++c)
-      rowptr[(size_t)(r * bs + c) + 1] = rowptr[(size_t)(r * bs + c)] + bptr[r + 1] * bs;
+      rowptr[(size_t)(r * bs + c) + 1] = rowptr[(size_t)(r * bs + c)] + (rp_t)bptr[r + 1] * bs;
   int maxrow = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(max : maxrow)
   for (int64_t ch = 0; ch < nch; ++ch)
@@ -505,11 +503,31 @@ int zzz_csr_download(zzz_ctx* ctx, int32_t* rowptr, int32_t* cols, double* vals)
     return fail(ctx, ZZZ_ERR_ARG, "no sparsity pattern yet");
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (rowptr)
-    ZZZ_HIP(ctx, hipMemcpy(rowptr, ctx->rowptr.p, ((size_t)ctx->nrows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  {
+    // the matrix of record keeps 64-bit row pointers; this entry point serves the 32-bit form of DOLFINx / the parity
+    // tests and refuses matrices it cannot express (zzz_csr_rowptr64_download takes any)
+    if (ctx->nnz > INT32_MAX)
+      return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros do not fit 32-bit row pointers: use zzz_csr_rowptr64_download",
+                  (long long)ctx->nnz);
+    std::vector<rp_t> h((size_t)ctx->nrows + 1);
+    ZZZ_HIP(ctx, hipMemcpy(h.data(), ctx->rowptr.p, h.size() * sizeof(rp_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i)
+      rowptr[i] = (int32_t)h[i];
+  }
   if (cols)
     ZZZ_HIP(ctx, hipMemcpy(cols, ctx->cols.p, (size_t)ctx->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (vals)
     ZZZ_HIP(ctx, hipMemcpy(vals, ctx->vals.p, (size_t)ctx->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  return ZZZ_OK;
+}
+
+int zzz_csr_rowptr64_download(zzz_ctx* ctx, int64_t* rowptr)
+{
+  ZZZ_ENTER(ctx);
+  if (!ctx->have_pattern || !rowptr)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_rowptr64_download: no sparsity pattern yet / NULL array");
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZZZ_HIP(ctx, hipMemcpy(rowptr, ctx->rowptr.p, ((size_t)ctx->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
   return ZZZ_OK;
 }
 

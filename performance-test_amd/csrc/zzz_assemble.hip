@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
                                                            const int32_t* __restrict__ adjT_cells,
                                                            const uint8_t* __restrict__ adj_li,
                                                            const uint8_t* __restrict__ bc,
-                                                           const int32_t* __restrict__ rowptr,
+                                                           const rp_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
                                                            const int32_t* __restrict__ tiles, int64_t ntiles)
 {
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
     return;
   const int d0 = tiles[tile], d1 = tiles[tile + 1];
   const int row0 = d0 * BS, row1 = d1 * BS;
-  const int s = rowptr[row0], e = rowptr[row1];
-  for (int k = threadIdx.x; k < e - s; k += BLK)
+  const int64_t s = rowptr[row0];
+  const int e = (int)(rowptr[row1] - s); // entries of the tile's CSR segment (fits LDS)
+  for (int k = threadIdx.x; k < e; k += BLK)
   {
     cols_s[k] = cols[s + k];
     vals_s[k] = 0.0;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
   for (int r = row0 + (int)threadIdx.x; r < row1; r += BLK)
   {
     const int i = r / BS, c = r % BS;
-    const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
+    const int a0 = (int)(rowptr[r] - s), len = (int)(rowptr[r + 1] - rowptr[r]);
     const bool bcr = bc[r] != 0;
     constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < e - s; k += BLK)
+  for (int k = threadIdx.x; k < e; k += BLK)
     vals[s + k] = vals_s[k];
 }
 
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
                                                            const uint8_t* __restrict__ adj_li,
                                                            const int32_t* __restrict__ adj_off,
                                                            const uint8_t* __restrict__ bc,
-                                                           const int32_t* __restrict__ rowptr,
+                                                           const rp_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
                                                            const int32_t* __restrict__ tiles, int64_t ntiles,
                                                            const double* __restrict__ tab, int cap)
@@ -416,8 +417,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
     return;
   const int d0 = tiles[tile], d1 = tiles[tile + 1];
   const int row0 = d0 * BS, row1 = d1 * BS;
-  const int s = rowptr[row0], e = rowptr[row1];
-  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+  const int64_t s = rowptr[row0];
+  const int e = (int)(rowptr[row1] - s); // entries of the tile's CSR segment (fits LDS)
+  for (int k = threadIdx.x; k < e; k += ASM_BLOCK)
   {
     cols_s[k] = cols[s + k];
     vals_s[k] = 0.0;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
   {
     const int i = d0 + (sorted ? ord_s[q / BS] : q / BS), c = q % BS;
     const int r = i * BS + c;
-    const int a0 = rowptr[r] - s, len = rowptr[r + 1] - rowptr[r];
+    const int a0 = (int)(rowptr[r] - s), len = (int)(rowptr[r + 1] - rowptr[r]);
     const bool bcr = bc[r] != 0;
     constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < e - s; k += ASM_BLOCK)
+  for (int k = threadIdx.x; k < e; k += ASM_BLOCK)
     vals[s + k] = vals_s[k];
 }
 

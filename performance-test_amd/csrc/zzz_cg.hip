@@ -49,7 +49,7 @@ __device__ inline void vstore(T v, T* p)
 }
 
 
-__global__ void k_extract_dinv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+__global__ void k_extract_dinv(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                const double* __restrict__ vals, double* __restrict__ dinv, int64_t n, int jacobi)
 {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
@@ -58,11 +58,11 @@ __global__ void k_extract_dinv(const int32_t* __restrict__ rowptr, const int32_t
     if (jacobi)
     {
       // columns are ascending: binary search for the diagonal (MatGetDiagonal)
-      int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+      int64_t lo = rowptr[r], hi = rowptr[r + 1] - 1;
       d = 0.0;
       while (lo <= hi)
       {
-        const int mid = (lo + hi) >> 1;
+        const int64_t mid = (lo + hi) >> 1;
         const int32_t cm = cols[mid];
         if (cm == (int32_t)r)
         {
@@ -488,7 +488,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n,
                        o->pc == ZZZ_PC_JACOBI ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, (const int32_t*)nullptr, (const int32_t*)nullptr,
+    hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, (const rp_t*)nullptr, (const int32_t*)nullptr,
                        (const double*)nullptr, ctx->dinv.p, n, 0);
 
   auto apply = [&](double* x, double* y, double* parts, int* np) -> int {

@@ -53,6 +53,8 @@ struct DevBuf
 
 struct Comm; // zzz_comm.cpp
 
+typedef int64_t rp_t; // row pointers of the CSR matrix of record
+
 constexpr int SPMV_PSTRIDE = 4096; // distance between the three partial arrays of the single-reduction SpMV
 
 // CG scalars kept on the device so the iteration loop never waits for the host.
@@ -115,10 +117,12 @@ struct zzz_ctx
 
   // pattern (owned rows) + adjacency
   int64_t nrows = 0, ncols = 0, nnz = 0;
-  zzz::DevBuf<int32_t> rowptr, cols;
+  zzz::DevBuf<zzz::rp_t> rowptr; // 64-bit: 50 M P3 dofs carry 2.4 G nonzeros on one GPU
+  zzz::DevBuf<int32_t> cols;
   zzz::DevBuf<double> vals;
   // scratch of the pattern build (kept: a rebuild of the same problem reuses it)
-  zzz::DevBuf<int32_t> scr_keys_in, scr_keys_out, scr_vals_in, scr_cnt, scr_bptr, scr_stage;
+  zzz::DevBuf<int32_t> scr_keys_in, scr_keys_out, scr_vals_in, scr_cnt, scr_stage;
+  zzz::DevBuf<int64_t> scr_bptr;
   zzz::DevBuf<unsigned char> scr_tmp;
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
   zzz::DevBuf<int32_t> adjT_off, adjT_cells; // the same lists transposed in 64-row slices (dense wave reads)
@@ -168,6 +172,8 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> asm_tile;
   int64_t n_asm_tiles = 0;
   bool have_pattern = false, have_matrix = false;
+  bool tiles_ok = true; // false: 2^31 nonzeros or more -- the CSR tile kernel (32-bit tile windows) is not available,
+                        // the product must run on the operator stream
 
   // vectors, (n_owned+n_ghost)*bs each
   zzz::DevBuf<double> b, u, r, z, p, w, dinv;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
                                                      const int32_t* __restrict__ adj_off,
                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
                                                      int32_t* __restrict__ cnt, int32_t* __restrict__ maxcnt,
-                                                     const int32_t* __restrict__ bptr, int32_t* __restrict__ cols,
+                                                     const int64_t* __restrict__ bptr, int32_t* __restrict__ cols,
                                                      int32_t* __restrict__ overflow, int32_t* __restrict__ stage)
 {
   __shared__ int32_t lds[4][PAT_CAP];
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
       }
     // unique
     int base = 0;
-    const int32_t rp = FILL ? bptr[r] : 0, nu = FILL ? cnt[r] : 0;
+    const int64_t rp = FILL ? bptr[r] : 0;
+    const int32_t nu = FILL ? cnt[r] : 0;
     for (int s = 0; s < n; s += 64)
     {
       const int idx = s + lane;
@@ -268,14 +269,14 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
 // fill pass when the count pass staged the sorted unique columns: expand block (r, col) to bs x bs
 __global__ __launch_bounds__(256) void k_row_copy(const int32_t* __restrict__ stage, const int32_t* __restrict__ adj_off,
                                                   int nd, int bs, int32_t nb, const int32_t* __restrict__ cnt,
-                                                  const int32_t* __restrict__ bptr, int32_t* __restrict__ cols)
+                                                  const int64_t* __restrict__ bptr, int32_t* __restrict__ cols)
 {
   // 16 lanes per row: FE rows have tens of columns, not hundreds
   const int sub = threadIdx.x & 15;
   for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; r < nb; r += ((int64_t)gridDim.x * blockDim.x) >> 4)
   {
     const int nu = cnt[r];
-    const int32_t rp = bptr[r];
+    const int64_t rp = bptr[r];
     const int32_t* src = stage + (int64_t)adj_off[r] * nd;
     for (int k = sub; k < nu; k += 16)
     {
@@ -287,22 +288,22 @@ __global__ __launch_bounds__(256) void k_row_copy(const int32_t* __restrict__ st
   }
 }
 
-__global__ void k_scalar_rowptr(const int32_t* __restrict__ bptr, const int32_t* __restrict__ cnt, int32_t nb, int bs,
-                                int32_t* __restrict__ rowptr)
+__global__ void k_scalar_rowptr(const int64_t* __restrict__ bptr, const int32_t* __restrict__ cnt, int32_t nb, int bs,
+                                rp_t* __restrict__ rowptr)
 {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= nb; r += (int64_t)gridDim.x * blockDim.x)
   {
     if (r == nb)
     {
-      rowptr[(int64_t)nb * bs] = bs * bs * bptr[nb];
+      rowptr[(int64_t)nb * bs] = (int64_t)bs * bs * bptr[nb];
       continue;
     }
     for (int a = 0; a < bs; ++a)
-      rowptr[r * bs + a] = bs * bs * bptr[r] + a * bs * cnt[r];
+      rowptr[r * bs + a] = (int64_t)bs * bs * bptr[r] + (int64_t)a * bs * cnt[r];
   }
 }
 
-__device__ inline int lower_bound_rows(const int32_t* __restrict__ rowptr, int stride, int n, int64_t target)
+__device__ inline int lower_bound_rows(const rp_t* __restrict__ rowptr, int stride, int n, int64_t target)
 {
   // first i in [0, n] with rowptr[i*stride] >= target (rowptr[n*stride] = nnz closes the range)
   int lo = 0, hi = n;
@@ -318,14 +319,14 @@ __device__ inline int lower_bound_rows(const int32_t* __restrict__ rowptr, int s
 }
 
 // SpMV tiles: window t = rows whose first nonzero lies in [t*W, (t+1)*W); descriptor {r0, r1, s, e}
-__global__ void k_spmv_tiles(const int32_t* __restrict__ rowptr, int nrows, int64_t W, int64_t ntiles,
+__global__ void k_spmv_tiles(const rp_t* __restrict__ rowptr, int nrows, int64_t W, int64_t ntiles,
                              int4* __restrict__ tiles)
 {
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * blockDim.x)
   {
     const int r0 = lower_bound_rows(rowptr, 1, nrows, t * W);
     const int r1 = lower_bound_rows(rowptr, 1, nrows, (t + 1) * W);
-    tiles[t] = make_int4(r0, r1, rowptr[r0], rowptr[r1]);
+    tiles[t] = make_int4(r0, r1, (int)rowptr[r0], (int)rowptr[r1]); // only built below 2^31 nonzeros
   }
 }
 
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void k_tile_encode_cols(int4* __restrict__ til
 }
 
 // assembly tiles: boundaries in block dofs; tile t = block dofs whose first nonzero lies in window t
-__global__ void k_asm_tiles(const int32_t* __restrict__ rowptr, int nb, int bs, int64_t W, int64_t ntiles,
+__global__ void k_asm_tiles(const rp_t* __restrict__ rowptr, int nb, int bs, int64_t W, int64_t ntiles,
                             int32_t* __restrict__ tiles)
 {
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= ntiles; t += (int64_t)gridDim.x * blockDim.x)
@@ -520,12 +521,18 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   const int64_t Wa = (int64_t)asm_tile_nnz(ctx) - maxblock;
   if (Ws < maxrow || Wa < maxblock || Wa < 1)
     return fail(ctx, ZZZ_ERR_LIMIT, "matrix rows too long for the kernel tiles (%d nonzeros per row)", maxrow);
-  ctx->ntiles = (ctx->nnz + Ws - 1) / Ws;
+  // the SpMV tile windows are 32-bit offsets into the nonzero stream (head-room of one tile: the kernel forms
+  // indices up to tile start + tile size); beyond that the product runs on the operator stream only
+  ctx->tiles_ok = ctx->nnz <= (int64_t)INT32_MAX - 16384;
+  ctx->ntiles = ctx->tiles_ok ? (ctx->nnz + Ws - 1) / Ws : 0;
   ctx->n_asm_tiles = (ctx->nnz + Wa - 1) / Wa;
+  if (ctx->n_asm_tiles > INT32_MAX - 8)
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld assembly tiles: use more parts", (long long)ctx->n_asm_tiles);
   ZZZ_HIP(ctx, ctx->tile_row.alloc((size_t)ctx->ntiles * 4 + 4));
   ZZZ_HIP(ctx, ctx->asm_tile.alloc((size_t)ctx->n_asm_tiles + 1));
-  hipLaunchKernelGGL(k_spmv_tiles, dim3(grid_for(ctx->ntiles)), dim3(256), 0, s, ctx->rowptr.p, (int)ctx->nrows, Ws,
-                     ctx->ntiles, reinterpret_cast<int4*>(ctx->tile_row.p));
+  if (ctx->ntiles)
+    hipLaunchKernelGGL(k_spmv_tiles, dim3(grid_for(ctx->ntiles)), dim3(256), 0, s, ctx->rowptr.p, (int)ctx->nrows, Ws,
+                       ctx->ntiles, reinterpret_cast<int4*>(ctx->tile_row.p));
   hipLaunchKernelGGL(k_asm_tiles, dim3(grid_for(ctx->n_asm_tiles + 1)), dim3(256), 0, s, ctx->rowptr.p,
                      (int)ctx->n_owned, bs, Wa, ctx->n_asm_tiles, ctx->asm_tile.p);
   ZZZ_HIP(ctx, hipGetLastError());
@@ -550,7 +557,8 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     return fail(ctx, ZZZ_ERR_LIMIT, "dof->cell adjacency exceeds int32");
 
   DevBuf<int32_t>&keys_in = ctx->scr_keys_in, &keys_out = ctx->scr_keys_out, &vals_in = ctx->scr_vals_in,
-  &cnt = ctx->scr_cnt, &bptr = ctx->scr_bptr;
+  &cnt = ctx->scr_cnt;
+  DevBuf<int64_t>& bptr = ctx->scr_bptr;
   DevBuf<unsigned char>& tmp = ctx->scr_tmp;
   DevBuf<int32_t> scal;
   ZZZ_HIP(ctx, keys_in.alloc((size_t)N));
@@ -572,7 +580,11 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   size_t tb = 0, tb2 = 0;
   ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, bptr.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
+  size_t tb3 = 0;
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, ctx->adj_off.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb3, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
+  if (tb3 > tb2)
+    tb2 = tb3;
   ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
   ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, keys_in.p, keys_out.p, vals_in.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
@@ -608,7 +620,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   if (!counted)
   {
     hipLaunchKernelGGL(k_row_pattern<false>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
-                       ctx->adj_cells.p, nb, cnt.p, scal.p, (const int32_t*)nullptr, (int32_t*)nullptr, scal.p + 1, stage);
+                       ctx->adj_cells.p, nb, cnt.p, scal.p, (const int64_t*)nullptr, (int32_t*)nullptr, scal.p + 1, stage);
     ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
   }
@@ -617,14 +629,13 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     *fallback = true;
     return fail(ctx, ZZZ_ERR_LIMIT, "a row gathers %d candidate columns (device limit %d)", h[1], PAT_CAP);
   }
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb2, cnt.p, bptr.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
-  int32_t nblk = 0;
-  ZZZ_HIP(ctx, hipMemcpyAsync(&nblk, bptr.p + nb, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb2, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
+  int64_t nblk = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&nblk, bptr.p + nb, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  const int64_t nnz = (int64_t)nblk * bs * bs;
-  // head-room of one SpMV/assembly tile: the kernels form indices up to (tile start + tile size)
-  if (nnz > INT32_MAX - 16384 || nblk < 0)
-    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros exceed the int32 row pointer range: use more parts", (long long)nnz);
+  const int64_t nnz = nblk * bs * bs;
+  if (nblk < 0 || nnz > ((int64_t)1 << 40))
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros: use more parts", (long long)nnz);
   ctx->nrows = (int64_t)nb * bs;
   ctx->ncols = ctx->nloc();
   ctx->nnz = nnz;

@@ -69,17 +69,17 @@ __device__ inline int wave_max_i(int v)
 
 // ---- build ------------------------------------------------------------------------------------------
 // entries of each row that the stream keeps
-__global__ __launch_bounds__(256) void k_sp_count(const int32_t* __restrict__ rowptr, const double* __restrict__ vals,
+__global__ __launch_bounds__(256) void k_sp_count(const rp_t* __restrict__ rowptr, const double* __restrict__ vals,
                                                   int nrows, int drop, int32_t* __restrict__ rownnz)
 {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x)
   {
-    const int a = rowptr[r], b = rowptr[r + 1];
-    int n = b - a;
+    const int64_t a = rowptr[r], b = rowptr[r + 1];
+    int n = (int)(b - a);
     if (drop)
     {
       n = 0;
-      for (int k = a; k < b; ++k)
+      for (int64_t k = a; k < b; ++k)
         n += vals[k] != 0.0 ? 1 : 0;
     }
     rownnz[r] = n;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict_
 
 // One wavefront packs one slice.  ghost_flag (or null): does the slice reference a column >= nrows?
 template <bool PERM>
-__global__ __launch_bounds__(256) void k_sp_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+__global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                  const double* __restrict__ vals, int nrows, int64_t nslices, int drop,
                                                  const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_off,
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const int32_t* __restrict__ row
     int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
     if (!PERM && r >= nrows)
       r = -1;
-    int k = r >= 0 ? rowptr[r] : 0;
-    const int end = r >= 0 ? rowptr[r + 1] : 0;
+    int64_t k = r >= 0 ? rowptr[r] : 0;
+    const int64_t end = r >= 0 ? rowptr[r + 1] : 0;
     const int c0 = chunk_off[s], c1 = chunk_off[s + 1];
     bool gh = false;
     for (int c = c0; c < c1; ++c)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_sp_fill(const int32_t* __restrict__ row
         while (k < end)
         {
           const double t = vals[k];
-          const int kk = k++;
+          const int64_t kk = k++;
           if (!drop || t != 0.0)
           {
             v[e] = t;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_sp_fill(const int32_t* __restrict__ row
 
 // Slice bounds from the pattern alone (once per pattern): the longest CSR range of a slice (LDS staging of
 // k_sp_pack) and the number of chunks the natural-order stream can need at most (no zero dropped).
-__global__ __launch_bounds__(256) void k_sp_bounds(const int32_t* __restrict__ rowptr, int nrows, int64_t nslices,
+__global__ __launch_bounds__(256) void k_sp_bounds(const rp_t* __restrict__ rowptr, int nrows, int64_t nslices,
                                                    int* __restrict__ out /* [0] max range, [1],[2] chunk bound lo/hi */)
 {
   const int lane = threadIdx.x & 63;
@@ -243,9 +243,9 @@ __global__ __launch_bounds__(256) void k_sp_bounds(const int32_t* __restrict__ r
   for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
   {
     const int r0 = (int)(s * 64), r = min(r0 + lane, nrows - 1);
-    const int len = (r0 + lane < nrows) ? rowptr[r + 1] - rowptr[r] : 0;
+    const int len = (r0 + lane < nrows) ? (int)(rowptr[r + 1] - rowptr[r]) : 0;
     const int m = wave_max_i(len);
-    mr = max(mr, rowptr[min(r0 + 64, nrows)] - rowptr[r0]);
+    mr = max(mr, (int)(rowptr[min(r0 + 64, nrows)] - rowptr[r0]));
     ch += (unsigned long long)((m + 7) >> 3);
   }
   if (lane == 0)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_sp_bounds(const int32_t* __restrict__ r
 //   3. every lane reads its row's entries back from LDS, chunk by chunk, and the chunk is written exactly as
 //      k_sp_fill writes it.
 // desc[s] = {first chunk, chunks}.  ghost_flag as in k_sp_fill.
-__global__ __launch_bounds__(256) void k_sp_pack(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+__global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                  const double* __restrict__ vals, int nrows, int64_t nslices, int drop, int cap,
                                                  int* __restrict__ counter, int2* __restrict__ desc,
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
@@ -279,12 +279,12 @@ __global__ __launch_bounds__(256) void k_sp_pack(const int32_t* __restrict__ row
   for (int64_t s = (int64_t)blockIdx.x * nwv + wv; s < nslices; s += (int64_t)gridDim.x * nwv)
   {
     const int r0 = (int)(s * 64);
-    const int a = rowptr[r0], b = rowptr[min(r0 + 64, nrows)];
-    const int my_start = rowptr[min(r0 + lane, nrows)];
+    const int64_t a = rowptr[r0], b = rowptr[min(r0 + 64, nrows)];
+    const int64_t my_start = rowptr[min(r0 + lane, nrows)];
     int running = 0, cstart = 0;
-    for (int g = a; g < b; g += 64)
+    for (int64_t g = a; g < b; g += 64)
     {
-      const int k = g + lane;
+      const int64_t k = g + lane;
       const bool in = k < b;
       const double v = in ? __builtin_nontemporal_load(vals + k) : 0.0;
       const int c = in ? __builtin_nontemporal_load(cols + k) : 0;

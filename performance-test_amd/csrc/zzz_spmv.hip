@@ -52,7 +52,7 @@ __device__ inline T stream_load(const T* p)
 // One tile descriptor = {first row, end row, first nonzero, end nonzero}: one 16-B load per tile.
 // TILE = nonzeros per tile; PIPE = issue the next tile's matrix loads before reducing this one.
 template <bool DOT, bool NT, bool PIPE, int TILE>
-__global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const rp_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ cols,
                                                                const double* __restrict__ vals,
                                                                const double* __restrict__ x, double* __restrict__ y,
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     // this thread's row bounds (used after the barrier): issue the loads now
     const int r = r0 + (int)threadIdx.x;
     const int rc = min(r, r1 - 1);
-    const int ra = rowptr[rc] - s_al, rb = rowptr[rc + 1] - s_al;
+    const int ra = (int)rowptr[rc] - s_al, rb = (int)rowptr[rc + 1] - s_al; // < 2^31 nonzeros on this path
     const double xr = DOT ? x[rc] : 0.0;
     const double rv = (DOT && rvec) ? rvec[rc] : 0.0;
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
     {
       for (int rr = r; rr < r1; rr += SPMV_BLOCK) // one row per thread unless the rows are very short
       {
-        const int ra_ = (rr == r) ? ra : rowptr[rr] - s_al, rb_ = (rr == r) ? rb : rowptr[rr + 1] - s_al;
+        const int ra_ = (rr == r) ? ra : (int)rowptr[rr] - s_al, rb_ = (rr == r) ? rb : (int)rowptr[rr + 1] - s_al;
         const double xr_ = (rr == r) ? xr : (DOT ? x[rr] : 0.0);
         // products are added in column order (the serial CPU order); 8 LDS reads in flight at a time
         double sum = 0.0;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const int32_t* __
       const int lanes = 1 << lpr_shift, sub = (int)threadIdx.x & (lanes - 1);
       for (int rr = r0 + ((int)threadIdx.x >> lpr_shift); rr < r1; rr += SPMV_BLOCK >> lpr_shift)
       {
-        const int ra_ = rowptr[rr] - s_al, rb_ = rowptr[rr + 1] - s_al;
+        const int ra_ = (int)rowptr[rr] - s_al, rb_ = (int)rowptr[rr + 1] - s_al;
         const int chunk = (rb_ - ra_ + lanes - 1) >> lpr_shift;
         const int ka = ra_ + sub * chunk, kb = min(ka + chunk, rb_);
         double sum = 0.0;
@@ -326,10 +326,13 @@ int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int*
                 int nn_is_rr)
 {
   const int grid = spmv_grid(ctx);
-  const int nnz_even = (int)((ctx->nnz + 1) & ~(int64_t)1); // last valid clamped index (arrays are padded by 8)
+  const int nnz_even = ctx->tiles_ok ? (int)((ctx->nnz + 1) & ~(int64_t)1) : 0; // last valid clamped index (arrays are padded by 8)
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   if (sellp_active(ctx))
     return launch_sellp(ctx, x, y, partials, npartials, rvec, nn_is_rr);
+  if (!ctx->tiles_ok)
+    return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros: the product of a matrix of 2^31 nonzeros or more needs the operator stream "
+                "(zzz_sellp.hip), which this matrix / these settings do not use", (long long)ctx->nnz);
   if (int rc = ensure_cols16(ctx))
     return rc;
   if (partials)

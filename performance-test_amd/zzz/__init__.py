@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "zzz_device_count", "zzz_device_memory", "zzz_ctx_create", "zzz_ctx_destroy", "zzz_last_error", "zzz_sync", "zzz_mesh_upload",
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
     "zzz_csr_pattern_build",
-    "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
+    "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_cg_info", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
@@ -163,6 +163,15 @@ def host():
 
 def device_count():
     return int(hip().zzz_device_count())
+
+
+def device_memory(device=0):
+    """(free, total) bytes of HBM"""
+    f, t = C.c_size_t(), C.c_size_t()
+    rc = hip().zzz_device_memory(int(device), C.byref(f), C.byref(t))
+    if rc:
+        raise ZzzError(rc, hip().zzz_last_error(None).decode())
+    return int(f.value), int(t.value)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -347,6 +356,12 @@ class Context:
         self._ck(self.L.zzz_csr_download(self.h, rowptr.ctypes.data, cols.ctypes.data,
                                          vals.ctypes.data if values else None))
         return rowptr, cols, vals
+
+    def csr_rowptr64(self):
+        nrows, _, _ = self.csr_sizes()
+        out = np.zeros(nrows + 1, np.int64)
+        self._ck(self.L.zzz_csr_rowptr64_download(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def csr_upload_values(self, vals):
         self._ck(self.L.zzz_csr_upload_values(self.h, np.ascontiguousarray(vals, np.float64)))

@@ -168,6 +168,48 @@ def test_solver_edge_cases(ctx):
         ctx.upload_dofmap(4, 1, P.cell_dofs, P.n_owned, 0)  # order 4: reference throws too
 
 
+def test_baseline_config_c1_against_oracle(ctx):
+    """BASELINE configs[0] whole (--ndofs 500000: 78x78x79, 499 280 dofs, 7 339 102 nonzeros) compared DIRECTLY with
+    the oracle: pattern bit-exact, A and b to 1e-12, the product bit-exact, iteration count +-2, solution 1e-6,
+    true residual 1e-8 -- and with the oracle's matrix-free cg.h solve (cgpoisson, kmax 100, rtol 1e-6)."""
+    nx, ny, nz, r = zzz.mesh_size(500000, True, 1, 1, 1)
+    assert (nx, ny, nz, r) == (78, 78, 79, 0)
+    zo.set_num_threads(8)
+    P = zzz.Part("poisson", 1, nx, ny, nz)
+    ctx.upload_part(P)
+    ctx.pattern_build()
+    ctx.assemble_matrix(zzz.FORM_POISSON)
+    ctx.assemble_vector(zzz.FORM_POISSON)
+    rp, cl, v = ctx.csr_download()
+    orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, 1)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(cl, ocl)
+    assert rp.shape[0] - 1 == 499280 and cl.shape[0] == 7339102  # SURVEY.md Appendix B/C
+    ov = zo.assemble_matrix(0, 1, P.x, P.cells, P.cell_dofs, P.bc_marker(), orp, ocl)
+    ob = zo.assemble_vector(0, 1, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets, P.bc_marker())
+    assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+    assert np.count_nonzero(v) == np.count_nonzero(ov)  # the same entries are exactly zero
+    b = ctx.vec_download(zzz.VEC_B)
+    assert np.abs(b - ob).max() <= 1e-12 * np.abs(ob).max()
+    xv = np.random.default_rng(11).standard_normal(P.n_owned)
+    np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv(orp, ocl, v, xv))
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+    u = ctx.vec_download(zzz.VEC_U)
+    oit, ou, orn, or0 = zo.pcg(orp, ocl, ov, ob, rtol=1e-8)
+    assert abs(it - oit) <= 2 and abs(oit - 404) <= 2
+    assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+    assert abs(r0 - or0) <= 1e-12 * or0
+    # (the solve stops on the PRECONDITIONED norm, 1e-8 of its initial value; the true residual follows within 10x)
+    assert np.linalg.norm(ob - zo.spmv(orp, ocl, ov, u)) <= 1e-7 * np.linalg.norm(ob)
+    # --problem_type cgpoisson on the same mesh: linalg::cg(u, b, action, 100, 1e-6) (src/cgpoisson_problem.cpp:233)
+    ctx.vec_upload(zzz.VEC_U, np.zeros(P.n_owned))
+    k, _, _ = ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_NONE, op=zzz.OP_MATFREE, rtol=1e-6, max_it=100)
+    ok, ouk = zo.cg_matfree_poisson(1, P.x, P.cells, P.cell_dofs, P.bc_marker(), ob, kmax=100, rtol=1e-6)
+    assert k == ok == 100
+    uk = ctx.vec_download(zzz.VEC_U)
+    assert np.linalg.norm(uk - ouk) <= 1e-8 * np.linalg.norm(ouk)
+
+
 def test_large_properties(ctx):
     """BASELINE config 1 size (78x78x79, 499 280 dofs): size-independent properties, no oracle."""
     nx, ny, nz, r = zzz.mesh_size(500000, True, 1, 1, 1)
@@ -1397,3 +1439,42 @@ def test_two_processes_real_rccl_on_one_gpu():
     assert len(ranks) == 2 and {r["rank"] for r in ranks} == {0, 1}
     assert all(r["neighbours"] == 1 and r["halo_bytes_sent"] > 0 and r["librccl"] == ranks[0]["librccl"] for r in ranks)
     assert abs(d["config"]["krylov_iterations"] - 306) <= 40 and d["config"]["relative_residual"] <= 1e-8
+
+
+def test_more_than_2_31_nonzeros_on_one_gpu():
+    """BASELINE configs[4] WHOLE on one GPU: Poisson P3, 122x122x123 sub-cubes, 49 834 930 dofs, 2 406 964 246
+    nonzeros -- beyond 32-bit row pointers.  Size-independent properties: sizes, row
+    pointers, symmetry and linearity of the product (which runs on the operator stream: the CSR tile kernel's
+    32-bit windows do not reach), Dirichlet rows, and the full Jacobi-CG solve with its true residual."""
+    nx, ny, nz, r = zzz.mesh_size(50000000, True, 8, 1, 3)
+    assert (nx, ny, nz, r) == (122, 122, 123, 0)
+    free, total = zzz.device_memory(0)
+    if free < 150e9:
+        pytest.skip("needs ~110 GB of free HBM")
+    rng = np.random.default_rng(23)
+    with zzz.Context(0) as c:
+        info = c.cube_generate("poisson", 3, nx, ny, nz, 1, 0)
+        assert int(info[0]) == 49834930 and int(info[1]) == 10984392
+        c.pattern_build()
+        nrows, ncols, nnz = c.csr_sizes()
+        assert (nrows, nnz) == (49834930, 2406964246)
+        rp = c.csr_rowptr64()
+        assert rp[0] == 0 and rp[-1] == nnz and np.all(np.diff(rp) > 0) and np.diff(rp).max() == 175
+        with pytest.raises(zzz.ZzzError):
+            c.csr_download()  # 32-bit row pointers cannot express it
+        c.assemble_matrix(zzz.FORM_POISSON)
+        c.assemble_vector(zzz.FORM_POISSON)
+        assert c.spmv_operator_form() in (1, 2)
+        xv, yv = rng.standard_normal(nrows), rng.standard_normal(nrows)
+        Ax, Ay = c.spmv(xv), c.spmv(yv)
+        assert abs(yv @ Ax - xv @ Ay) <= 1e-9 * abs(yv @ Ax)
+        Axy = c.spmv(2.0 * xv - 0.5 * yv)
+        assert np.abs(Axy - (2.0 * Ax - 0.5 * Ay)).max() <= 1e-11 * np.abs(Ax).max()
+        b = c.vec_download(zzz.VEC_B)
+        it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        u = c.vec_download(zzz.VEC_U)
+        # 2304 iterations and |u| = 1502.04 are this build's own record of the 8-way partitioned run (DESIGN.md 5)
+        assert abs(it - 2304) <= 3 and abs(np.linalg.norm(u) - 1502.04) < 0.01
+        assert np.linalg.norm(b - c.spmv(u)) <= 1e-6 * np.linalg.norm(b)
+        bcrows = np.nonzero(b == 0)[0][:1000]
+        np.testing.assert_array_equal(Ax[bcrows][np.abs(xv[bcrows]) > 0], xv[bcrows][np.abs(xv[bcrows]) > 0])
