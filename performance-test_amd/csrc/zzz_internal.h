@@ -159,9 +159,12 @@ struct zzz_ctx
   int64_t sp_chunk_bound = 0; // chunks of the natural-order stream if no entry were zero
   zzz::DevBuf<uint16_t> sp_codes16;
   zzz::DevBuf<double> sp_vals;
-  int64_t nslices = 0, sp_chunks = 0, sp_kept = 0; // slices, chunks of the stream, matrix entries kept in it
+  int64_t nslices = 0, sp_chunks = 0, sp_kept = 0, sp_bytes = 0; // slices, chunks of the stream, matrix entries kept in it,
+                                                                 // bytes a product reads from it
+  zzz::DevBuf<uint8_t> sp_wlast; // per slice: entries of the longest row in its last chunk (1..8)
   bool sp_sorted = false;    // rows ordered by length inside windows (SELL-C-sigma)
   int sellp_mode = 1;        // ZZZ_SELLP: 0 off, 1 automatic, 2 natural row order always, 3 sorted rows always
+  int sellp_tail = 1;        // 8-bit codes of a narrow chunk go into the free tail of its value block (A/B: no measurable difference)
   bool sellp_drop = true;    // ZZZ_SELLP_DROP=0: keep the exact zeros of the pattern in the stream
   bool have_sell = false;    // stream built
   bool sell_current = false; // ... from the current CSR values

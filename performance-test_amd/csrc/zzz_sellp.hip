@@ -39,6 +39,7 @@ namespace zzz
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 constexpr int SP_BLOCK = 256;
 constexpr int SP_SIGMA = 512; // sorting window (rows) of the sorted form: one workgroup
 
@@ -52,20 +53,19 @@ __device__ inline int64_t sp_xcd_item(int64_t n, int b, int nb, int i)
   return t < hi ? t : -1;
 }
 
+// wave-wide minimum in every lane's hands (a scalar): an inclusive min-scan inside the rows of 16 lanes with DPP
+// row shifts, two row broadcasts, then lane 63 read out -- thirteen vector instructions, no LDS crossbar
 __device__ inline int wave_min_i(int v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-    v = min(v, __shfl_xor(v, o, 64));
-  return v;
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x111, 0xf, 0xf, false)); // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x112, 0xf, 0xf, false)); // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x114, 0xf, 0xf, false)); // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false)); // row_shr:8
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1, 3
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ inline int wave_max_i(int v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-    v = max(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ inline int wave_max_i(int v) { return -wave_min_i(-v); } // |v| < 2^31 - 1 here
 
 // ---- build ------------------------------------------------------------------------------------------
 // entries of each row that the stream keeps
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_sp_count(const rp_t* __restrict__ rowpt
 
 // natural row order: chunks of slice s = ceil(longest of its 64 rows / 8); entry nslices = 0 (scan sentinel)
 __global__ __launch_bounds__(256) void k_sp_slice_len(const int32_t* __restrict__ rownnz, int nrows, int64_t nslices,
-                                                      int32_t* __restrict__ nch)
+                                                      int32_t* __restrict__ nch, uint8_t* __restrict__ wlast)
 {
   const int lane = threadIdx.x & 63;
   for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s <= nslices; s += (int64_t)gridDim.x * 4)
@@ -96,14 +96,19 @@ __global__ __launch_bounds__(256) void k_sp_slice_len(const int32_t* __restrict_
     const int64_t r = s * 64 + lane;
     const int m = wave_max_i((s < nslices && r < nrows) ? rownnz[r] : 0);
     if (lane == 0)
+    {
       nch[s] = (m + 7) >> 3;
+      if (s < nslices)
+        wlast[s] = (uint8_t)(m ? m - 8 * ((m - 1) >> 3) : 8); // entries of the longest row in the last chunk: 1..8
+    }
   }
 }
 
 // sorted form: one workgroup orders the SP_SIGMA rows of its window by length (descending, ties by row:
 // a stable counting rank), writes the row of every (slice, lane) and the slice lengths
 __global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict__ rownnz, int nrows, int64_t nslices,
-                                                      int32_t* __restrict__ perm, int32_t* __restrict__ nch)
+                                                      int32_t* __restrict__ perm, int32_t* __restrict__ nch,
+                                                      uint8_t* __restrict__ wlast)
 {
   __shared__ int len[SP_SIGMA];
   __shared__ int srt[SP_SIGMA];
@@ -129,22 +134,125 @@ __global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict_
   {
     const int64_t s = w * (SP_SIGMA / 64) + t;
     if (s < nslices)
-      nch[s] = (max(srt[t * 64], 0) + 7) >> 3;
+    {
+      const int m = max(srt[t * 64], 0);
+      nch[s] = (m + 7) >> 3;
+      wlast[s] = (uint8_t)(m ? m - 8 * ((m - 1) >> 3) : 8);
+    }
   }
   if (w == 0 && t == 0)
     nch[nslices] = 0;
 }
 
-// One wavefront packs one slice.  ghost_flag (or null): does the slice reference a column >= nrows?
+// Write chunk c of a slice from the lanes' next eight kept entries (v, cl; cl == INT_MAX: no entry).  Only the first
+// w <= 8 slots are in use by any lane (w < 8: the last chunk of a slice): unused value blocks and the unused half of a
+// code block are neither written nor ever read, so a narrow chunk costs its used bytes only -- an interior P1 row
+// (7 entries) streams 3.5 KiB of values instead of 4.  Codes are as narrow as the chunk's slot ranges allow: 8-bit
+// (consecutive rows reach consecutive columns: the usual case), 16-bit, or plain int32 columns.
+// meta[c][0] carries the mode: bit 31 int32 columns, bit 30 8-bit codes.  Returns the bytes a product reads.
+__device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8], int lane, int nrows, bool& gh,
+                                 double* __restrict__ svals, uint16_t* __restrict__ c16, int32_t* __restrict__ c32,
+                                 int32_t* __restrict__ meta, int tail_codes)
+{
+  int base[8];
+  bool over8 = false, over16 = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+  {
+    base[e] = 0;
+    if (e < w) // wave-uniform
+    {
+      const bool has = cl[e] != INT_MAX;
+      gh |= has && cl[e] >= nrows;
+      int mn = wave_min_i(cl[e]);
+      if (mn == INT_MAX)
+        mn = 0;
+      base[e] = mn;
+      if (!has)
+        cl[e] = mn; // padding: value +0.0, a column some lane reads anyway
+      over8 |= cl[e] - mn > 255;
+      over16 |= cl[e] - mn > 65535;
+    }
+    else
+      cl[e] = 0;
+  }
+  const int range = __any(over16) ? 65536 : (__any(over8) ? 256 : 0);
+  double* sp = svals + (size_t)c * 512;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+  {
+    if (2 * j + 1 < w)
+    {
+      dbl2 q;
+      q.x = v[2 * j];
+      q.y = v[2 * j + 1];
+      reinterpret_cast<dbl2*>(sp + 128 * j)[lane] = q;
+    }
+    else if (2 * j < w)
+      sp[128 * j + lane] = v[2 * j]; // odd width: the last entry alone, 8 B per lane
+  }
+  int mode = 0, code_bytes;
+  if (range > 65535)
+  {
+    int4v q0, q1;
+    q0.x = cl[0], q0.y = cl[1], q0.z = cl[2], q0.w = cl[3];
+    q1.x = cl[4], q1.y = cl[5], q1.z = cl[6], q1.w = cl[7];
+    int4v* cp = reinterpret_cast<int4v*>(c32 + (size_t)c * 512) + 2 * lane;
+    cp[0] = q0;
+    cp[1] = q1;
+    mode = (int)0x80000000;
+    code_bytes = 2048;
+  }
+  else if (range > 255)
+  {
+    uint4v q;
+    q.x = (unsigned)(cl[0] - base[0]) | ((unsigned)(cl[1] - base[1]) << 16);
+    q.y = (unsigned)(cl[2] - base[2]) | ((unsigned)(cl[3] - base[3]) << 16);
+    q.z = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 16);
+    q.w = (unsigned)(cl[6] - base[6]) | ((unsigned)(cl[7] - base[7]) << 16);
+    reinterpret_cast<uint4v*>(c16 + (size_t)c * 512)[lane] = q;
+    code_bytes = 1024;
+  }
+  else
+  {
+    uint2v q;
+    q.x = (unsigned)(cl[0] - base[0]) | ((unsigned)(cl[1] - base[1]) << 8) | ((unsigned)(cl[2] - base[2]) << 16)
+          | ((unsigned)(cl[3] - base[3]) << 24);
+    q.y = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 8) | ((unsigned)(cl[6] - base[6]) << 16)
+          | ((unsigned)(cl[7] - base[7]) << 24);
+    if (w <= 7 && tail_codes)
+    {
+      // the chunk's value block has a free last 512 B: codes there, and the chunk is ONE contiguous 4-KiB read
+      reinterpret_cast<uint2v*>(sp + 448)[lane] = q;
+      mode = 0x60000000;
+    }
+    else
+    {
+      reinterpret_cast<uint2v*>(c16 + (size_t)c * 512)[lane] = q; // first half of the chunk's code block
+      mode = 0x40000000;
+    }
+    code_bytes = 512;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (lane == e)
+      meta[(size_t)c * 8 + e] = e == 0 ? (base[e] | mode) : base[e];
+  return (w >> 1) * 1024 + (w & 1) * 512 + code_bytes + 32;
+}
+
+// One wavefront packs one slice, one lane walking one row (rows too long for the LDS staging of k_sp_pack, and the
+// length-sorted form).  desc[s] = {first chunk, chunks | width of the last chunk << 24}.  ghost_flag (or null): does
+// the slice reference a column >= nrows?  bytes: the stream bytes a product will read are added up there.
 template <bool PERM>
 __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                  const double* __restrict__ vals, int nrows, int64_t nslices, int drop,
-                                                 const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_off,
+                                                 const int32_t* __restrict__ perm, const int2* __restrict__ desc,
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
                                                  int32_t* __restrict__ c32, int32_t* __restrict__ meta,
-                                                 uint8_t* __restrict__ ghost_flag)
+                                                 uint8_t* __restrict__ ghost_flag, unsigned long long* __restrict__ bytes, int tail_codes)
 {
   const int lane = threadIdx.x & 63;
+  unsigned long long mine = 0;
   for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
   {
     int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
@@ -152,9 +260,10 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
       r = -1;
     int64_t k = r >= 0 ? rowptr[r] : 0;
     const int64_t end = r >= 0 ? rowptr[r + 1] : 0;
-    const int c0 = chunk_off[s], c1 = chunk_off[s + 1];
+    const int2 ds = desc[s];
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     bool gh = false;
-    for (int c = c0; c < c1; ++c)
+    for (int j = 0; j < nch; ++j)
     {
       double v[8];
       int cl[8];
@@ -175,53 +284,7 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
           }
         }
       }
-      int base[8];
-      bool wide = false;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-      {
-        const bool has = cl[e] != INT_MAX;
-        gh |= has && cl[e] >= nrows;
-        int mn = wave_min_i(cl[e]);
-        const int mx = wave_max_i(has ? cl[e] : -1);
-        if (mn == INT_MAX)
-          mn = 0; // no lane has an entry in this slot
-        wide |= mx - mn > 65535;
-        base[e] = mn;
-        if (!has)
-          cl[e] = mn; // padding: value +0.0, a column some lane reads anyway
-      }
-      dbl2* vp = reinterpret_cast<dbl2*>(svals + (size_t)c * 512) + lane;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-      {
-        dbl2 q;
-        q.x = v[2 * j];
-        q.y = v[2 * j + 1];
-        vp[64 * j] = q;
-      }
-      if (!wide)
-      {
-        uint4v q;
-        q.x = (unsigned)(cl[0] - base[0]) | ((unsigned)(cl[1] - base[1]) << 16);
-        q.y = (unsigned)(cl[2] - base[2]) | ((unsigned)(cl[3] - base[3]) << 16);
-        q.z = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 16);
-        q.w = (unsigned)(cl[6] - base[6]) | ((unsigned)(cl[7] - base[7]) << 16);
-        reinterpret_cast<uint4v*>(c16 + (size_t)c * 512)[lane] = q;
-      }
-      else
-      {
-        int4v q0, q1;
-        q0.x = cl[0], q0.y = cl[1], q0.z = cl[2], q0.w = cl[3];
-        q1.x = cl[4], q1.y = cl[5], q1.z = cl[6], q1.w = cl[7];
-        int4v* cp = reinterpret_cast<int4v*>(c32 + (size_t)c * 512) + 2 * lane;
-        cp[0] = q0;
-        cp[1] = q1;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (lane == e)
-          meta[(size_t)c * 8 + e] = (e == 0 && wide) ? (base[e] | (int)0x80000000) : base[e];
+      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tail_codes);
     }
     if (ghost_flag)
     {
@@ -230,6 +293,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
         ghost_flag[s] = m != 0ull;
     }
   }
+  if (lane == 0 && mine)
+    atomicAdd(bytes, mine);
 }
 
 // Slice bounds from the pattern alone (once per pattern): the longest CSR range of a slice (LDS staging of
@@ -263,61 +328,96 @@ __global__ __launch_bounds__(256) void k_sp_bounds(const rp_t* __restrict__ rowp
 //      neighbours in memory; where a slice lands does not change any result);
 //   3. every lane reads its row's entries back from LDS, chunk by chunk, and the chunk is written exactly as
 //      k_sp_fill writes it.
-// desc[s] = {first chunk, chunks}.  ghost_flag as in k_sp_fill.
+// desc[s] = {first chunk, chunks | width of the last chunk << 24}.  ghost_flag as in k_sp_fill.
 __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                  const double* __restrict__ vals, int nrows, int64_t nslices, int drop, int cap,
                                                  int* __restrict__ counter, int2* __restrict__ desc,
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
                                                  int32_t* __restrict__ c32, int32_t* __restrict__ meta,
-                                                 uint8_t* __restrict__ ghost_flag)
+                                                 uint8_t* __restrict__ ghost_flag, int tail_codes)
 {
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   double* lv = reinterpret_cast<double*>(sp_smem + (size_t)wv * cap * 12);
   int* lc = reinterpret_cast<int*>(sp_smem + (size_t)wv * cap * 12 + (size_t)cap * 8);
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int64_t s = (int64_t)blockIdx.x * nwv + wv; s < nslices; s += (int64_t)gridDim.x * nwv)
+  __shared__ __attribute__((aligned(16))) int wg_sh[8]; // [0..3] chunks per wavefront, [4] the workgroup's first chunk
+                                                          // (32 B: the dynamic region behind it stays 16-B aligned)
+  int* wg_nch = wg_sh;
+  unsigned long long kept_w = 0, bytes_w = 0;
+  // the wavefronts of a workgroup take consecutive slices and walk in step: ONE allocator atomic per workgroup and
+  // round (a returning atomic per slice on one address serialises: 156 k of them cost 2 ms at 10 M dofs, and
+  // three per slice 5.6 ms)
+  for (int64_t s0 = (int64_t)blockIdx.x * nwv; s0 < nslices; s0 += (int64_t)gridDim.x * nwv)
   {
-    const int r0 = (int)(s * 64);
-    const int64_t a = rowptr[r0], b = rowptr[min(r0 + 64, nrows)];
-    const int64_t my_start = rowptr[min(r0 + lane, nrows)];
+    const int64_t s = s0 + wv;
+    const bool live = s < nslices; // wave-uniform
+    const int r0 = live ? (int)(s * 64) : 0;
+    const int64_t a = live ? rowptr[r0] : 0, b = live ? rowptr[min(r0 + 64, nrows)] : 0;
+    const int64_t my_start = live ? rowptr[min(r0 + lane, nrows)] : 0;
     int running = 0, cstart = 0;
-    for (int64_t g = a; g < b; g += 64)
+    // four groups of 64 entries per round: their eight loads are in flight together (the sweep is a chain of
+    // dependent ballots, but the loads depend on nothing)
+    for (int64_t g0 = a; g0 < b; g0 += 256)
     {
-      const int64_t k = g + lane;
-      const bool in = k < b;
-      const double v = in ? __builtin_nontemporal_load(vals + k) : 0.0;
-      const int c = in ? __builtin_nontemporal_load(cols + k) : 0;
-      const bool nz = in && (!drop || v != 0.0);
-      const unsigned long long m = __ballot(nz);
-      if (my_start >= g && my_start < g + 64)
-        cstart = running + __popcll(m & ((1ull << (my_start - g)) - 1ull));
-      if (nz)
+      double vv[4];
+      int cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
       {
-        const int pos = running + __popcll(m & lt);
-        lv[pos] = v;
-        lc[pos] = c;
+        const int64_t k = g0 + 64 * u + lane;
+        const bool in = k < b;
+        vv[u] = in ? __builtin_nontemporal_load(vals + k) : 0.0;
+        cc[u] = in ? __builtin_nontemporal_load(cols + k) : 0;
       }
-      running += __popcll(m);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const int64_t g = g0 + 64 * u;
+        if (g >= b) // wave-uniform
+          break;
+        const bool nz = g + lane < b && (!drop || vv[u] != 0.0);
+        const unsigned long long m = __ballot(nz);
+        if (my_start >= g && my_start < g + 64)
+          cstart = running + __popcll(m & ((1ull << (my_start - g)) - 1ull));
+        if (nz)
+        {
+          const int pos = running + __popcll(m & lt);
+          lv[pos] = vv[u];
+          lc[pos] = cc[u];
+        }
+        running += __popcll(m);
+      }
     }
     if (my_start >= b)
       cstart = running;
     const int nxt = __shfl_down(cstart, 1, 64);
     const int cnt = (lane == 63 ? running : nxt) - cstart;
-    const int nch = (wave_max_i(cnt) + 7) >> 3;
-    int c0 = 0;
+    const int mlen = wave_max_i(cnt);
+    const int nch = (mlen + 7) >> 3, wl = mlen ? mlen - 8 * ((mlen - 1) >> 3) : 8;
     if (lane == 0)
+      wg_nch[wv] = live ? nch : 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
     {
-      c0 = nch ? atomicAdd(counter, nch) : 0;
-      desc[s] = make_int2(c0, nch);
-      atomicAdd(reinterpret_cast<unsigned long long*>(counter + 2), (unsigned long long)running); // entries kept
+      int tot = 0;
+      for (int q = 0; q < nwv; ++q)
+        tot += wg_nch[q];
+      wg_sh[4] = tot ? atomicAdd(counter, tot) : 0;
     }
-    c0 = __shfl(c0, 0, 64);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    int c0 = wg_sh[4];
+    for (int q = 0; q < wv; ++q)
+      c0 += wg_nch[q];
+    __syncthreads(); // wg_sh is rewritten next round
+    if (!live)
+      continue;
+    if (lane == 0)
+      desc[s] = make_int2(c0, nch | (wl << 24));
+    kept_w += (unsigned long long)running;
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
-      const int c = c0 + j;
       double v[8];
       int cl[8];
 #pragma unroll
@@ -328,53 +428,7 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
         v[e] = has ? lv[cstart + q] : 0.0;
         cl[e] = has ? lc[cstart + q] : INT_MAX;
       }
-      int base[8];
-      bool wide = false;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-      {
-        const bool has = cl[e] != INT_MAX;
-        gh |= has && cl[e] >= nrows;
-        int mn = wave_min_i(cl[e]);
-        const int mx = wave_max_i(has ? cl[e] : -1);
-        if (mn == INT_MAX)
-          mn = 0;
-        wide |= mx - mn > 65535;
-        base[e] = mn;
-        if (!has)
-          cl[e] = mn;
-      }
-      dbl2* vp = reinterpret_cast<dbl2*>(svals + (size_t)c * 512) + lane;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-      {
-        dbl2 q;
-        q.x = v[2 * jj];
-        q.y = v[2 * jj + 1];
-        vp[64 * jj] = q;
-      }
-      if (!wide)
-      {
-        uint4v q;
-        q.x = (unsigned)(cl[0] - base[0]) | ((unsigned)(cl[1] - base[1]) << 16);
-        q.y = (unsigned)(cl[2] - base[2]) | ((unsigned)(cl[3] - base[3]) << 16);
-        q.z = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 16);
-        q.w = (unsigned)(cl[6] - base[6]) | ((unsigned)(cl[7] - base[7]) << 16);
-        reinterpret_cast<uint4v*>(c16 + (size_t)c * 512)[lane] = q;
-      }
-      else
-      {
-        int4v q0, q1;
-        q0.x = cl[0], q0.y = cl[1], q0.z = cl[2], q0.w = cl[3];
-        q1.x = cl[4], q1.y = cl[5], q1.z = cl[6], q1.w = cl[7];
-        int4v* cp = reinterpret_cast<int4v*>(c32 + (size_t)c * 512) + 2 * lane;
-        cp[0] = q0;
-        cp[1] = q1;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (lane == e)
-          meta[(size_t)c * 8 + e] = (e == 0 && wide) ? (base[e] | (int)0x80000000) : base[e];
+      bytes_w += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tail_codes);
     }
     if (ghost_flag)
     {
@@ -384,13 +438,19 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0)
+  {
+    atomicAdd(reinterpret_cast<unsigned long long*>(counter + 2), kept_w);  // entries kept
+    atomicAdd(reinterpret_cast<unsigned long long*>(counter + 8), bytes_w); // stream bytes a product reads
+  }
 }
 
 // sorted form: {first chunk, chunks} of every slice from the scanned offsets
-__global__ void k_sp_desc(const int32_t* __restrict__ off, int64_t nslices, int2* __restrict__ desc)
+__global__ void k_sp_desc(const int32_t* __restrict__ off, const uint8_t* __restrict__ wlast, int64_t nslices,
+                          int2* __restrict__ desc)
 {
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nslices; s += (int64_t)gridDim.x * blockDim.x)
-    desc[s] = make_int2(off[s], off[s + 1] - off[s]);
+    desc[s] = make_int2(off[s], (off[s + 1] - off[s]) | ((int)wlast[s] << 24));
 }
 
 // ---- the product --------------------------------------------------------------------------------------
@@ -407,17 +467,56 @@ __device__ inline double gather(const double* __restrict__ x, int col)
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
 }
 
-// columns of chunk c for this lane: 16-bit codes on the slot bases, or int32 (sign bit of base[0])
-template <bool NT>
-__device__ inline void chunk_columns(int c, int lane, const uint16_t* __restrict__ c16, const int32_t* __restrict__ c32,
-                                     const int32_t* __restrict__ meta, int (&cl)[8])
+// Values and columns of chunk c for this lane.  FULL: all eight slots (every chunk but the last of a slice);
+// otherwise only the first w: unused value blocks are not loaded (an odd w loads its last entry with one 8-B load).
+// Columns by the chunk's mode (meta[c][0]: bit 31 int32, bit 30 8-bit codes, else 16-bit codes on the slot bases).
+template <bool NT, bool FULL>
+__device__ inline void read_chunk(int c, int w, int lane, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
+                                  const int32_t* __restrict__ c32, const int32_t* __restrict__ meta, dbl2 (&v)[4], int (&cl)[8])
 {
+  const double* __restrict__ sp = svals + (size_t)c * 512;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+  {
+    if (FULL || 2 * j + 1 < w)
+      v[j] = sp_load<NT>(reinterpret_cast<const dbl2*>(sp + 128 * j) + lane);
+    else if (2 * j < w)
+    {
+      v[j].x = sp_load<NT>(sp + 128 * j + lane);
+      v[j].y = 0.0;
+    }
+    else
+    {
+      v[j].x = 0.0;
+      v[j].y = 0.0;
+    }
+  }
   const int32_t* __restrict__ mp = meta + (size_t)c * 8;
-  const int b0 = mp[0];
-  if (b0 >= 0)
+  const int m0 = mp[0];
+  if (m0 < 0)
+  {
+    const int4v* __restrict__ cp = reinterpret_cast<const int4v*>(c32 + (size_t)c * 512) + 2 * lane;
+    const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
+    cl[0] = q0.x, cl[1] = q0.y, cl[2] = q0.z, cl[3] = q0.w;
+    cl[4] = q1.x, cl[5] = q1.y, cl[6] = q1.z, cl[7] = q1.w;
+  }
+  else if (m0 & 0x40000000)
+  {
+    const uint2v q = (m0 & 0x20000000) ? sp_load<NT>(reinterpret_cast<const uint2v*>(sp + 448) + lane)
+                                       : sp_load<NT>(reinterpret_cast<const uint2v*>(c16 + (size_t)c * 512) + lane);
+    cl[0] = (m0 & 0x1fffffff) + (int)(q.x & 0xffu);
+    cl[1] = mp[1] + (int)((q.x >> 8) & 0xffu);
+    cl[2] = mp[2] + (int)((q.x >> 16) & 0xffu);
+    cl[3] = mp[3] + (int)(q.x >> 24);
+    cl[4] = mp[4] + (int)(q.y & 0xffu);
+    cl[5] = mp[5] + (int)((q.y >> 8) & 0xffu);
+    cl[6] = mp[6] + (int)((q.y >> 16) & 0xffu);
+    cl[7] = mp[7] + (int)(q.y >> 24);
+  }
+  else
   {
     const uint4v q = sp_load<NT>(reinterpret_cast<const uint4v*>(c16 + (size_t)c * 512) + lane);
-    cl[0] = b0 + (int)(q.x & 0xffffu);
+    cl[0] = m0 + (int)(q.x & 0xffffu);
     cl[1] = mp[1] + (int)(q.x >> 16);
     cl[2] = mp[2] + (int)(q.y & 0xffffu);
     cl[3] = mp[3] + (int)(q.y >> 16);
@@ -426,13 +525,25 @@ __device__ inline void chunk_columns(int c, int lane, const uint16_t* __restrict
     cl[6] = mp[6] + (int)(q.w & 0xffffu);
     cl[7] = mp[7] + (int)(q.w >> 16);
   }
-  else
-  {
-    const int4v* __restrict__ cp = reinterpret_cast<const int4v*>(c32 + (size_t)c * 512) + 2 * lane;
-    const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
-    cl[0] = q0.x, cl[1] = q0.y, cl[2] = q0.z, cl[3] = q0.w;
-    cl[4] = q1.x, cl[5] = q1.y, cl[6] = q1.z, cl[7] = q1.w;
-  }
+}
+
+// sum += the chunk's products in ascending column order, mul and add rounded separately (the scalar CPU loop's bits)
+template <bool NT, bool FULL>
+__device__ inline void chunk_product(int c, int w, int lane, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
+                                     const int32_t* __restrict__ c32, const int32_t* __restrict__ meta,
+                                     const double* __restrict__ x, double& sum)
+{
+  dbl2 v[4];
+  int cl[8];
+  read_chunk<NT, FULL>(c, w, lane, svals, c16, c32, meta, v, cl);
+  double xv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    xv[e] = (FULL || e < w) ? gather(x, cl[e]) : 0.0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (FULL || e < w)
+      sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * xv[e];
 }
 
 template <bool DOT, bool NT, bool PERM>
@@ -467,31 +578,20 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     if (s >= nslices)
       continue;
     const int2 ds = desc[s];
-    const int c0 = ds.x, c1 = ds.x + ds.y;
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
     if (!PERM && r >= nrows)
       r = -1;
     const double xr = (DOT && r >= 0) ? x[r] : 0.0;
     double sum = 0.0;
-    for (int c = c0; c < c1; ++c)
+    for (int j = 0; j + 1 < nch; ++j)
+      chunk_product<NT, true>(c0 + j, 8, lane, svals, c16, c32, meta, x, sum);
+    if (nch)
     {
-      const dbl2* __restrict__ vp = reinterpret_cast<const dbl2*>(svals + (size_t)c * 512) + lane;
-      const dbl2 v0 = sp_load<NT>(vp), v1 = sp_load<NT>(vp + 64), v2 = sp_load<NT>(vp + 128), v3 = sp_load<NT>(vp + 192);
-      int cl[8];
-      chunk_columns<NT>(c, lane, c16, c32, meta, cl);
-      double xv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        xv[e] = gather(x, cl[e]);
-      // ascending column order, mul and add rounded separately: the scalar CPU loop's bits
-      sum += v0.x * xv[0];
-      sum += v0.y * xv[1];
-      sum += v1.x * xv[2];
-      sum += v1.y * xv[3];
-      sum += v2.x * xv[4];
-      sum += v2.y * xv[5];
-      sum += v3.x * xv[6];
-      sum += v3.y * xv[7];
+      if (wl == 8)
+        chunk_product<NT, true>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, x, sum);
+      else
+        chunk_product<NT, false>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, x, sum);
     }
     if (r >= 0)
     {
@@ -573,29 +673,25 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void spmv_sellp_dir_kernel(
       continue;
     const double pn = r >= 0 ? bcoef * po + z[r] : 0.0;
     const int2 ds = desc[s];
-    const int c0 = ds.x, c1 = ds.x + ds.y;
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     double sum = 0.0;
-    for (int c = c0; c < c1; ++c)
+    for (int j = 0; j < nch; ++j)
     {
-      const dbl2* __restrict__ vp = reinterpret_cast<const dbl2*>(svals + (size_t)c * 512) + lane;
-      const dbl2 v0 = sp_load<NT>(vp), v1 = sp_load<NT>(vp + 64), v2 = sp_load<NT>(vp + 128), v3 = sp_load<NT>(vp + 192);
+      const int w = j + 1 < nch ? 8 : wl;
+      dbl2 v[4];
       int cl[8];
-      chunk_columns<NT>(c, lane, c16, c32, meta, cl);
+      read_chunk<NT, false>(c0 + j, w, lane, svals, c16, c32, meta, v, cl);
       double zv[8], pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
       {
-        zv[e] = gather(z, cl[e]);
-        pv[e] = gather(p_old, cl[e]);
+        zv[e] = e < w ? gather(z, cl[e]) : 0.0;
+        pv[e] = e < w ? gather(p_old, cl[e]) : 0.0;
       }
-      sum += v0.x * (bcoef * pv[0] + zv[0]);
-      sum += v0.y * (bcoef * pv[1] + zv[1]);
-      sum += v1.x * (bcoef * pv[2] + zv[2]);
-      sum += v1.y * (bcoef * pv[3] + zv[3]);
-      sum += v2.x * (bcoef * pv[4] + zv[4]);
-      sum += v2.y * (bcoef * pv[5] + zv[5]);
-      sum += v3.x * (bcoef * pv[6] + zv[6]);
-      sum += v3.y * (bcoef * pv[7] + zv[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < w)
+          sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * (bcoef * pv[e] + zv[e]);
     }
     if (r >= 0)
     {
@@ -688,15 +784,16 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out, bool sorted = true)
   ZZZ_HIP(ctx, ctx->sp_nch.alloc((size_t)nsl + 1));
   ZZZ_HIP(ctx, ctx->sp_chunk_off.alloc((size_t)nsl + 1));
   ZZZ_HIP(ctx, ctx->sp_perm.alloc((size_t)nsl * 64));
+  ZZZ_HIP(ctx, ctx->sp_wlast.alloc((size_t)nsl + 1));
   hipLaunchKernelGGL(k_sp_count, dim3(grid_cap(nrows, 256, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, drop,
                      ctx->sp_rownnz.p);
   const int64_t nwin = (ctx->nrows + SP_SIGMA - 1) / SP_SIGMA;
   if (sorted)
     hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p,
-                       ctx->sp_nch.p);
+                       ctx->sp_nch.p, ctx->sp_wlast.p);
   else // natural row order, rows too long for the LDS staging of k_sp_pack
     hipLaunchKernelGGL(k_sp_slice_len, dim3(grid_cap(nsl + 1, 4, 8192)), dim3(256), 0, s, ctx->sp_rownnz.p, nrows, nsl,
-                       ctx->sp_nch.p);
+                       ctx->sp_nch.p, ctx->sp_wlast.p);
   size_t tb = 0;
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->sp_nch.p, ctx->sp_chunk_off.p, 0, (size_t)nsl + 1,
                                        rocprim::plus<int32_t>(), s));
@@ -725,17 +822,24 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
     ZZZ_HIP(ctx, flag.alloc((size_t)nsl));
     gflag = flag.p;
   }
+  // descriptors first: the fill reads chunk ranges and last-chunk widths from them
+  int2* desc = reinterpret_cast<int2*>(ctx->sp_desc.p);
+  hipLaunchKernelGGL(k_sp_desc, dim3(grid_cap(nsl, 256, 4096)), dim3(256), 0, s, ctx->sp_chunk_off.p, ctx->sp_wlast.p, nsl, desc);
+  unsigned long long* bytes = reinterpret_cast<unsigned long long*>(ctx->sp_counter.p + 8);
+  ZZZ_HIP(ctx, hipMemsetAsync(bytes, 0, sizeof(unsigned long long), s));
   if (sorted)
     hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                       nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, ctx->sp_chunk_off.p, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+                       nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
   else
     hipLaunchKernelGGL(k_sp_fill<false>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                       nrows, nsl, ctx->sellp_drop ? 1 : 0, (const int32_t*)nullptr, ctx->sp_chunk_off.p, ctx->sp_vals.p,
-                       ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
-  hipLaunchKernelGGL(k_sp_desc, dim3(grid_cap(nsl, 256, 4096)), dim3(256), 0, s, ctx->sp_chunk_off.p, nsl,
-                     reinterpret_cast<int2*>(ctx->sp_desc.p));
+                       nrows, nsl, ctx->sellp_drop ? 1 : 0, (const int32_t*)nullptr, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
   ZZZ_HIP(ctx, hipGetLastError());
+  unsigned long long hb = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&hb, bytes, sizeof(hb), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  ctx->sp_bytes = (int64_t)hb;
   ctx->sp_sorted = sorted;
   ctx->sp_chunks = total;
   return sp_group_split(ctx, gflag);
@@ -751,8 +855,8 @@ int sellp_pattern_bounds(zzz_ctx* ctx)
   hipStream_t s = ctx->stream;
   const int64_t nsl = (ctx->nrows + 63) / 64;
   ctx->nslices = nsl;
-  ZZZ_HIP(ctx, ctx->sp_counter.alloc(8));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 8 * sizeof(int), s));
+  ZZZ_HIP(ctx, ctx->sp_counter.alloc(12)); // [0] chunk allocator, [2,3] entries kept, [4..7] pattern bounds, [8,9] stream bytes
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 12 * sizeof(int), s));
   hipLaunchKernelGGL(k_sp_bounds, dim3(grid_cap(nsl, 4, 4096)), dim3(256), 0, s, ctx->rowptr.p, (int)ctx->nrows, nsl,
                      ctx->sp_counter.p + 4);
   int h[4] = {0, 0, 0, 0};
@@ -861,15 +965,16 @@ int sell_update(zzz_ctx* ctx, bool structure)
     ctx->sp_lds_attr = true;
   }
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 4 * sizeof(int), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p + 8, 0, 2 * sizeof(int), s));
   const int cap = (ctx->sp_max_range + 63) & ~63;
   hipLaunchKernelGGL(k_sp_pack, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p, ctx->cols.p,
                      ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p, reinterpret_cast<int2*>(ctx->sp_desc.p),
-                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag);
+                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, ctx->sellp_tail);
   ZZZ_HIP(ctx, hipGetLastError());
   if (!ctx->sp_event)
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));
   int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 5); // pinned
-  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipEventRecord(ctx->sp_event, s));
   ctx->sp_sorted = false;
   ctx->sp_pending = true;
@@ -891,12 +996,15 @@ int sellp_resolve(zzz_ctx* ctx)
   unsigned long long kept = 0;
   memcpy(&kept, hc + 2, sizeof(kept));
   ctx->sp_kept = (int64_t)kept;
+  unsigned long long hb = 0;
+  memcpy(&hb, hc + 8, sizeof(hb));
+  ctx->sp_bytes = (int64_t)hb;
   ctx->sp_chunks = t0;
   const double full = (double)ctx->nnz + 64.0 * 512.0;
   const bool always = ctx->sellp_mode == 2 || ctx->sp_forced;
   // Natural row order unless its padding makes it slower than the alternatives: the length-sorted form (priced only
   // when the natural stream is padded by more than a third: it costs a synchronous build) or the CSR tile kernel.
-  const double c_nat = cost_stream(t0, false), c_tile = cost_tile(ctx);
+  const double c_nat = (double)(ctx->sp_bytes + ctx->nslices * 8) / 5.0, c_tile = cost_tile(ctx);
   const bool padded = (double)t0 * 512.0 > 1.33 * (double)ctx->sp_kept + 64.0 * 512.0;
   (void)full;
   if (always || (c_nat <= c_tile && !padded))
@@ -928,7 +1036,7 @@ bool sellp_active(zzz_ctx* ctx)
 }
 
 // bytes one product reads from the stream (values + codes + bases; int32 chunks are not counted separately)
-int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_chunks * (4096 + 1024 + 32) + ctx->nslices * 8; }
+int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_bytes + ctx->nslices * 8; }
 
 static int sp_grid(int64_t ngroups)
 {
