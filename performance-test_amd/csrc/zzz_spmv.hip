@@ -52,7 +52,7 @@ __device__ inline T stream_load(const T* p)
 // One tile descriptor = {first row, end row, first nonzero, end nonzero}: one 16-B load per tile.
 // TILE = nonzeros per tile; PIPE = issue the next tile's matrix loads before reducing this one.
 template <bool DOT, bool NT, bool PIPE, int TILE>
-__global__ __launch_bounds__(SPMV_BLOCK) void spmv_tile_kernel(const rp_t* __restrict__ rowptr,
+__global__ __launch_bounds__(SPMV_BLOCK, 8) void spmv_tile_kernel(const rp_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ cols,
                                                                const double* __restrict__ vals,
                                                                const double* __restrict__ x, double* __restrict__ y,

@@ -38,3 +38,29 @@ def test_spmv_kernel_keeps_full_occupancy(tmp_path):
         assert lds * 8 <= 160 * 1024, (name, lds)  # eight workgroups per CU must fit the 160 KB of LDS
         seen += 1
     assert seen == 4
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_operator_stream_kernel_keeps_full_occupancy(tmp_path):
+    """The product on the operator stream (zzz_sellp.hip) has no LDS and must stay at 8 wavefronts per SIMD (<= 64 VGPRs:
+    its launch bound); without spills it would need 74 registers = 6 wavefronts, measured exactly as fast, so the few
+    spilled dwords are tolerated -- but not growth beyond that."""
+    src = os.path.join(ROOT, "performance-test_amd", "csrc", "zzz_sellp.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I" + os.path.dirname(src),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "performance-test_amd", "host"), "-c", src, "-o",
+           str(tmp_path / "sellp.o"), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if not re.match(r"_ZN3zzz17spmv_sellp_kernelILb[01]ELb[01]ELb[01]EEE", name):
+            continue
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vgprs <= 64 and occ == 8 and scratch <= 64 and lds <= 64, (name, vgprs, occ, scratch, lds)
+        seen += 1
+    assert seen == 8
