@@ -916,7 +916,9 @@ int sell_update(zzz_ctx* ctx, bool structure)
   int waves = 4;
   while (waves > 1 && lds * waves > 64 * 1024)
     waves >>= 1;
-  const bool lds_fits = lds * waves <= 160 * 1024 && (waves >= 2 || lds <= 64 * 1024);
+  // (one wavefront per CU with up to 160 KB of staging was tried for the long rows of P3: the packing got 3 ms
+  // faster, but its allocation order made the product 1.3 % slower: a net loss)
+  const bool lds_fits = lds * waves <= 160 * 1024 - 64 && (waves >= 2 || lds <= 64 * 1024);
   if (!lds_fits || (!always && (double)ctx->sp_chunk_bound * 512.0 > 2.2 * full))
   {
     // Synchronous builds (count, scan, read-back, fill): rows too long for the LDS staging of the one-pass packer
@@ -961,7 +963,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
   if (lds * waves > 64 * 1024 && !ctx->sp_lds_attr)
   {
     ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
+                                     160 * 1024 - 64)); // the kernel's 32 B of static LDS count too
     ctx->sp_lds_attr = true;
   }
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 4 * sizeof(int), s));
