@@ -419,7 +419,11 @@ static bool loop_exceeds_cache(zzz_ctx* ctx, int nvec)
 
 static int vgrid(int64_t n)
 {
-  int64_t g = (n + VB - 1) / VB;
+  // at least 8 entries per thread: every workgroup starts by summing the producer's per-workgroup partials, so for
+  // small vectors fewer, longer workgroups are faster (1.25 M rows: 57.8 -> 52.9 us per iteration with 610 instead of
+  // 2048 workgroups, 0.5 M rows 40.8 -> 37.0 us; 16 per thread the same, 32 slower); large vectors keep 8 per CU
+  constexpr int per = 8;
+  int64_t g = (n + VB * per - 1) / (VB * per);
   if (g > VGRID_MAX)
     g = VGRID_MAX;
   if (g < 1)

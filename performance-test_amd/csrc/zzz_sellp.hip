@@ -1042,7 +1042,7 @@ int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_bytes + ctx->nsl
 
 static int sp_grid(int64_t ngroups)
 {
-  int64_t gs = 256 * 8;
+  int64_t gs = 256 * 8; // (1024 or 1536 workgroups at the per-rank size: no faster)
   const int64_t need = (ngroups + 7) / 8 * 8;
   if (gs > need)
     gs = need;
