@@ -144,7 +144,12 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
 // (zzz_assemble.hip: entry a of row 64 s + lane at adjT_off[s] + 64 a + lane), which saves a separate gather pass.
 // A row with more than ROW_T_CAP unique columns or a block with more than ROW_T_ADJ adjacency entries raises
 // `overflow` and the caller uses the wavefront kernel.
-constexpr int ROW_T_BLOCK = 128, ROW_T_CAP = 32, ROW_T_LD = ROW_T_BLOCK + 1, ROW_T_ADJ = 4096;
+constexpr int ROW_T_BLOCK = 128, ROW_T_LD = ROW_T_BLOCK + 1, ROW_T_ADJ = 4096;
+// ROW_T_CAP: unique columns a row may have (16: the sorted list lives in 16 registers; 32: in 32).  Round 1 kept the
+// list in a private LDS column and inserted there: dependent LDS reads at 2 wavefronts per SIMD made that 5 of the
+// kernel's 7 ms at 10 M dofs; a branch-free insertion into a register array (every slot recomputed by two compares)
+// needs no memory at all.
+template <int ROW_T_CAP>
 __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32_t* __restrict__ cell_dofs,
                                                                      const int32_t* __restrict__ adj_off,
                                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
@@ -157,7 +162,6 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
   __shared__ int32_t u[ROW_T_CAP * ROW_T_LD];
   __shared__ int32_t adj_s[ROW_T_ADJ];
   __shared__ int32_t a0_s[ROW_T_BLOCK], m_s[ROW_T_BLOCK];
-  int32_t* mine = u + threadIdx.x;
   int wmax = 0;
   const int64_t nblk = ((int64_t)nb + ROW_T_BLOCK - 1) / ROW_T_BLOCK; // nb64 <= nblk * ROW_T_BLOCK
   // XCD-aware walk: the blocks of one XCD cover one contiguous eighth of the rows, so the cells that
@@ -181,6 +185,10 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
     __syncthreads();
     int m = 0, a0 = 0;
     bool over = false;
+    int32_t cs[ROW_T_CAP];
+#pragma unroll
+    for (int k = 0; k < ROW_T_CAP; ++k)
+      cs[k] = INT_MAX;
     const bool padrow = r >= nb && r < ((int64_t)nb + 63) / 64 * 64; // the last slice is padded to 64 rows
     if (r < nb || padrow)
     {
@@ -216,19 +224,23 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
             for (int j = 0; j < 4; ++j)
             {
               const int32_t v = v4[j];
-              int k = m;
-              while (k > 0 && mine[(k - 1) * ROW_T_LD] > v)
-                --k;
-              if (k > 0 && mine[(k - 1) * ROW_T_LD] == v)
+              bool dup = false;
+#pragma unroll
+              for (int k = 0; k < ROW_T_CAP; ++k)
+                dup |= cs[k] == v;
+              if (dup)
                 continue;
               if (m == ROW_T_CAP)
               {
                 over = true;
                 break;
               }
-              for (int qq = m; qq > k; --qq)
-                mine[qq * ROW_T_LD] = mine[(qq - 1) * ROW_T_LD];
-              mine[k * ROW_T_LD] = v;
+              // slot k of the new list: the old entry if it is smaller than v; v if it is the first that is not;
+              // else the old entry one slot down (unused slots hold INT_MAX)
+#pragma unroll
+              for (int k = ROW_T_CAP - 1; k > 0; --k)
+                cs[k] = cs[k] < v ? cs[k] : (cs[k - 1] < v ? v : cs[k - 1]);
+              cs[0] = cs[0] < v ? cs[0] : v;
               ++m;
             }
             if (over)
@@ -246,6 +258,9 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
     }
     if (over)
       atomicMax(overflow, 1);
+#pragma unroll
+    for (int k = 0; k < ROW_T_CAP; ++k)
+      u[k * ROW_T_LD + threadIdx.x] = cs[k]; // transposed read-out below: one row per wavefront instruction
     a0_s[threadIdx.x] = a0;
     m_s[threadIdx.x] = (r < nb && !over) ? m : 0;
     wmax = max(wmax, m);
@@ -607,11 +622,22 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     int rc = build_adjT_offsets(ctx);
     if (rc)
       return rc;
-    hipLaunchKernelGGL(k_row_pattern_thread4, dim3((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 4) + 7) / 8 * 8), dim3(ROW_T_BLOCK), 0, s,
-                       ctx->cell_dofs.p, ctx->adj_off.p, ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage,
-                       ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
-    ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    const dim3 tg((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 4) + 7) / 8 * 8);
+    // rows of up to 16 unique columns first (the sorted list in 16 registers), then up to 32
+    for (int cap = 16; cap <= 32; cap *= 2)
+    {
+      if (cap == 16)
+        hipLaunchKernelGGL(k_row_pattern_thread4<16>, tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
+                           ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
+      else
+        hipLaunchKernelGGL(k_row_pattern_thread4<32>, tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
+                           ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
+      ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
+      ZZZ_HIP(ctx, hipStreamSynchronize(s));
+      if (h[2] == 0 || cap == 32)
+        break;
+      ZZZ_HIP(ctx, hipMemsetAsync(scal.p, 0, 4 * sizeof(int32_t), s));
+    }
     counted = h[2] == 0;
     ctx->have_adj_li = counted; // complete only if no row overflowed
     if (!counted)
