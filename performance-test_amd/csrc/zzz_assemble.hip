@@ -311,32 +311,51 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
   const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
-  for (int a = 0; a < adj.len; ++a)
+  // two-stage software pipeline over the row's cells (as in asm_matrix_p1): the loads of cell a+1 -- adjacency ->
+  // connectivity -> coordinates and coefficients, a three-deep dependent chain -- are in flight while cell a is summed
+  struct Stage
   {
-    const int cell = adj.cell(a);
-    if (cell < 0)
-      break;
-    const int li = adj.li(a);
-    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
-    const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
-    const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
-    double p[4][3];
+    int cell, li;
+    unsigned mask;
+    int4 dd;
+    double p[4][3], fl[4];
+  };
+  auto fetch = [&](int a, Stage& S) {
+    S.cell = a < adj.len ? adj.cell(a) : -1;
+    if (S.cell < 0)
+      return;
+    S.li = adj.li(a);
+    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)S.cell);
+    S.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)S.cell);
+    S.mask = BS == 1 ? facet_mask[S.cell] : 0u;
+    load_cell(x, v, S.p);
+    const int dj[4] = {S.dd.x, S.dd.y, S.dd.z, S.dd.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      S.fl[j] = f[(int64_t)dj[j] * BS + c];
+  };
+  Stage cur, nxt;
+  fetch(0, cur);
+  for (int a = 0; cur.cell >= 0; ++a)
+  {
+    fetch(a + 1, nxt);
+    const int li = cur.li;
+    const int dofs[4] = {cur.dd.x, cur.dd.y, cur.dd.z, cur.dd.w};
+    double (&p)[4][3] = cur.p;
     Geom G;
-    load_cell(x, v, p);
     geometry(p, G);
-    double fl[4], fs = 0.0, fi = 0.0;
+    double fs = 0.0, fi = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
-      fl[j] = f[(int64_t)dofs[j] * BS + c];
-      fs += fl[j];
+      fs += cur.fl[j];
       if (j == li)
-        fi = fl[j];
+        fi = cur.fl[j];
     }
     sum += G.adet * ((fs + fi) / 120.0); // |detJ| * sum_j (1+delta_ij)/120 f_j
     if (BS == 1)
     {
-      const unsigned m = facet_mask[cell];
+      const unsigned m = cur.mask;
       if (m)
       {
         double gl[4], gi = 0.0;
@@ -368,6 +387,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
           }
       }
     }
+    cur = nxt;
   }
   b[r] = bc[r] ? 0.0 : sum; // bc->set(b), u0 == 0
 }
