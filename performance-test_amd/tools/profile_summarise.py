@@ -14,7 +14,7 @@ import os
 import re
 import sys
 
-KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel"), ("k_sp_fill", r"k_sp_fill"), ("k_sp_count", r"k_sp_count"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
+KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel"), ("k_sp_pack", r"k_sp_pack"), ("k_sp_fill", r"k_sp_fill"), ("k_sp_count", r"k_sp_count"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
         ("k_sr_update", r"k_sr_update"), ("asm_matrix", r"asm_matrix"), ("asm_vector", r"asm_vector"),
         ("k_row_pattern", r"k_row_pattern"), ("k_row_copy", r"k_row_copy"), ("k_tile_encode_cols", r"k_tile_encode_cols"),
         ("k_adjT_fill", r"k_adjT_fill"), ("k_make_pairs", r"k_make_pairs"), ("radix_sort", r"radix_sort_onesweep_iteration"),
