@@ -177,3 +177,37 @@ def test_bad_arguments():
         zzz.Part("poisson", 1, 2, 2, 2, 3, 0)  # fewer layers than parts
     with pytest.raises(ValueError):
         zzz.Part("poisson", 1, 0, 2, 2)
+
+
+@pytest.mark.parametrize("problem,order", [("poisson", 1), ("poisson", 3), ("elasticity", 2)])
+def test_native_partition_feed(problem, order):
+    """zzzh_part_create_native: the partition as the reference's GhostMode::none partitioner leaves it -- own cells only,
+    ghosts = the dofs of own cells that the lower neighbour owns; same owned range, global indices and cell data as
+    the ghost-layer feed; the forward-scatter plans of neighbouring ranks match; every cell is owned exactly once."""
+    dims, nparts = (3, 2, 7), 3
+    seen_cells = 0
+    parts = [zzz.Part(problem, order, *dims, nparts, r, native=True) for r in range(nparts)]
+    for r, Pn in enumerate(parts):
+        Pg = zzz.Part(problem, order, *dims, nparts, r)
+        assert Pn.ncells == Pn.owned_cells == Pg.owned_cells and Pn.n_owned == Pg.n_owned and Pn.own_offset == Pg.own_offset
+        seen_cells += Pn.ncells
+        np.testing.assert_array_equal(Pn.global_dofs[:Pn.n_owned], Pg.global_dofs[:Pg.n_owned])
+        # ghosts: exactly the lower neighbour's top plane
+        assert set(Pn.global_dofs[Pn.n_owned:]) <= set(Pg.global_dofs[Pg.n_owned:])
+        assert (Pn.n_ghost == 0) == (r == 0)
+        # every local dof is referenced by an own cell; cell data agrees with the ghost-layer feed cell by cell
+        assert set(np.unique(Pn.cell_dofs)) == set(range(Pn.nloc))
+        gn = Pn.global_dofs[Pn.cell_dofs]
+        gg = Pg.global_dofs[Pg.cell_dofs]
+        key = lambda a: set(map(tuple, a))  # noqa: E731
+        assert key(gn) <= key(gg)
+        # global vertex indices: one per local vertex, consistent coordinates across ranks
+        assert len(set(Pn.global_verts)) == Pn.nverts
+        # what this rank sends up is what the upper neighbour receives
+        if r + 1 < nparts:
+            up = parts[r + 1]
+            k = list(Pn.neigh).index(r + 1)
+            sent = Pn.global_dofs[Pn.send_idx[Pn.send_off[k]:Pn.send_off[k + 1]]]
+            np.testing.assert_array_equal(sent, up.global_dofs[up.n_owned:])
+            assert up.recv_cnt[list(up.neigh).index(r)] == sent.size
+    assert seen_cells == parts[0].global_cells
