@@ -218,7 +218,8 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y);
 /* Measurement aid: HIP-event time of `reps` back-to-back launches of the CG SpMV kernel
  * (w = A p with the <p,w> partials) on the context's stream; variant < 0 keeps the configured
  * kernel variant; otherwise a bit set for A/B runs: bit 0 non-temporal loads, bit 1 pipelined CSR
- * tiles, bit 3 sliced-ELL copy (default 9 = SELL + non-temporal). */
+ * tiles, bit 3 the operator stream of zzz_sellp.hip when one was built (default 9 = stream + non-temporal),
+ * bit 4 int32 instead of packed 16-bit columns in the tile kernel. */
 int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms);
 
 /* y = action(x): the matrix-free operator lambda of cgpoisson (src/cgpoisson_problem.cpp:193-230):

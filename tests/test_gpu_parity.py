@@ -633,7 +633,7 @@ def test_run_to_run_reproducibility(ctx):
 @pytest.mark.parametrize("tile", [2048, 4096])
 def test_spmv_kernel_variants_are_bit_exact(variant, tile):
     """Every SpMV kernel variant (plain / non-temporal loads, pipelined tiles, 4096-nonzero tiles, the
-    sliced-ELL copy, int32 instead of packed 16-bit columns) adds a row's products in the same column
+    operator stream, int32 instead of packed 16-bit columns) adds a row's products in the same column
     order: bit-identical y, identical solve."""
     old = {k: os.environ.get(k) for k in ("ZZZ_SPMV_VARIANT", "ZZZ_SPMV_TILE")}
     os.environ["ZZZ_SPMV_VARIANT"], os.environ["ZZZ_SPMV_TILE"] = str(variant), str(tile)
