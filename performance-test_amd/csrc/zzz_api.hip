@@ -223,6 +223,7 @@ int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncell
     return rc;
   rc = upload(ctx, ctx->cell_verts, cell_verts, (size_t)(4 * ncells));
   ctx->have_pattern = ctx->have_matrix = false;
+  ctx->xq_valid = false;
   return rc;
 }
 
@@ -263,7 +264,8 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_bc = false;
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
-  return ZZZ_OK;
+  ctx->xq_valid = false;
+  return ensure_p1_coords(ctx); // function-space data (dof coordinates), not assembly work
 }
 
 int zzz_bc_upload(zzz_ctx* ctx, int64_t nbc, const int32_t* bc_dofs)

@@ -13,6 +13,7 @@
 //     the path is bound by the 8 B/nonzero it must write, not by arithmetic).
 // Constrained rows and columns are zeroed as the element tensor is produced, and the diagonal of a
 // constrained row is set to 1.0 (fem::set_diagonal) by the thread that owns the row.
+#include <algorithm>
 #include <climits>
 #include <cstring>
 
@@ -48,6 +49,9 @@ __device__ inline void load_cell(const double* __restrict__ x, const int4 v, dou
     p[k][2] = q[2];
   }
 }
+
+// P1 through the dof-addressed coordinates (zzz_ctx::xq): dd = the cell's four block dofs
+__device__ inline void load_cell_q(const double* __restrict__ xq, const int4 dd, double p[4][3]) { load_cell(xq, dd, p); }
 
 __device__ inline void geometry(const double p[4][3], Geom& G)
 {
@@ -172,8 +176,7 @@ struct AdjIter
 
 // ---- matrix, P1, BS = 1 (Poisson a1, src/Poisson.py:31) or 3 (Elasticity a1, src/Elasticity.py:39)
 template <int BS, int NNZ, int BLK>
-__global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ x,
-                                                           const int32_t* __restrict__ cell_verts,
+__global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ xq,
                                                            const int32_t* __restrict__ cell_dofs,
                                                            const int32_t* __restrict__ adjT_off,
                                                            const int32_t* __restrict__ adjT_cells,
@@ -207,42 +210,69 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
     constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
     const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
-    // Two-stage software pipeline over the row's cells: the loads of cell a+1 (adjacency ->
-    // connectivity -> coordinates and BC flags: a three-deep dependent chain) are in flight while
-    // cell a is evaluated; with the workgroup's CSR segment taking 48 KiB of LDS only three
-    // wavefronts per SIMD are resident, so the chain is not hidden by occupancy alone.
-    struct Stage
+    // Three-stage software pipeline over the row's cells.  A cell needs a chain of three dependent loads (adjacency
+    // -> connectivity -> coordinates and BC flags); each link is issued one iteration ahead of the next: while cell a
+    // is evaluated the coordinates of a+1, the connectivity of a+2 and the adjacency entry a+3 are in flight, so an
+    // iteration waits for one memory round trip, not three (the workgroup's CSR segment in LDS leaves 3-4 wavefronts
+    // per SIMD: occupancy alone does not hide the chain).
+    struct Conn
     {
       int cell, li;
       int4 dd;
+    };
+    struct Data
+    {
       double p[4][3];
       uint8_t bcj[4 * BS];
     };
-    auto fetch = [&](int a, Stage& S) {
-      S.cell = a < adj.len ? adj.cell(a) : -1;
-      if (S.cell < 0)
+    auto adj_at = [&](int a, int& cell, int& li) {
+      const bool in = a < adj.len;
+      cell = in ? adj.cell(a) : -1;
+      li = in ? adj.li(a) : 0;
+    };
+    auto conn_at = [&](int cell, int li, Conn& K) {
+      K.cell = cell;
+      K.li = li;
+      if (cell < 0)
         return;
-      S.li = adj.li(a);
-      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)S.cell);
-      S.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)S.cell);
-      load_cell(x, v, S.p);
-      const int dj[4] = {S.dd.x, S.dd.y, S.dd.z, S.dd.w};
+      K.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
+    };
+    auto data_at = [&](const Conn& K, Data& D) {
+      if (K.cell < 0)
+        return;
+      load_cell_q(xq, K.dd, D.p);
+      const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int d = 0; d < BS; ++d)
-          S.bcj[j * BS + d] = bc[dj[j] * BS + d];
+          D.bcj[j * BS + d] = bc[dj[j] * BS + d];
     };
-    Stage cur, nxt;
-    fetch(0, cur);
-    for (int a = 0; cur.cell >= 0; ++a)
+    Conn K0, K1;
+    Data D0;
+    int c2, l2;
     {
-      fetch(a + 1, nxt);
-      const int li = cur.li;
-      const int dofs[4] = {cur.dd.x, cur.dd.y, cur.dd.z, cur.dd.w};
+      int ca, la;
+      adj_at(0, ca, la);
+      conn_at(ca, la, K0);
+      data_at(K0, D0);
+      adj_at(1, ca, la);
+      conn_at(ca, la, K1);
+      adj_at(2, c2, l2);
+    }
+    for (int a = 0; K0.cell >= 0; ++a)
+    {
+      Data D1;
+      Conn K2;
+      int c3, l3;
+      data_at(K1, D1);
+      conn_at(c2, l2, K2);
+      adj_at(a + 3, c3, l3);
+      const int li = K0.li;
+      const int dofs[4] = {K0.dd.x, K0.dd.y, K0.dd.z, K0.dd.w};
       double g[4][3];
       Geom G;
-      geometry(cur.p, G);
+      geometry(D0.p, G);
       p1_grads(G, g);
       const double w = G.adet / 6.0; // reference volume
 
@@ -263,7 +293,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
         if (BS == 1)
         {
           double val = w * gg;
-          if (bcr || cur.bcj[j])
+          if (bcr || D0.bcj[j])
             val = 0.0;
           vals_s[a0 + pos] += val;
         }
@@ -275,13 +305,17 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
           {
             // mu (delta_cd g_i.g_j + d_d phi_i d_c phi_j) + lambda d_c phi_i d_d phi_j
             double val = w * (mu * ((c == d ? gg : 0.0) + gi[d] * gjc) + lmbda * gic * g[j][d]);
-            if (bcr || cur.bcj[j * BS + d])
+            if (bcr || D0.bcj[j * BS + d])
               val = 0.0;
             vals_s[a0 + pos + d] += val;
           }
         }
       }
-      cur = nxt;
+      K0 = K1;
+      D0 = D1;
+      K1 = K2;
+      c2 = c3;
+      l2 = l3;
     }
     if (bcr) // fem::set_diagonal: 1.0 on constrained rows
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
@@ -293,8 +327,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
 
 // ---- vector, P1: Poisson L1 = f v dx + g v ds (src/Poisson.py:32), Elasticity L1 = f.v dx (:40)
 template <int BS>
-__global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restrict__ x,
-                                                           const int32_t* __restrict__ cell_verts,
+__global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restrict__ xq,
                                                            const int32_t* __restrict__ cell_dofs,
                                                            const int32_t* __restrict__ adjT_off,
                                                            const int32_t* __restrict__ adjT_cells,
@@ -311,51 +344,79 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
   const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
-  // two-stage software pipeline over the row's cells (as in asm_matrix_p1): the loads of cell a+1 -- adjacency ->
-  // connectivity -> coordinates and coefficients, a three-deep dependent chain -- are in flight while cell a is summed
-  struct Stage
+  // Three-stage software pipeline over the row's cells.  A cell needs a chain of three dependent loads (adjacency ->
+  // connectivity -> coordinates and coefficients); each link is issued one iteration ahead of the next, so that while
+  // cell a is summed the coordinates of a+1, the connectivity of a+2 and the adjacency entry a+3 are in flight and an
+  // iteration waits for one memory round trip instead of three.
+  struct Conn
   {
     int cell, li;
     unsigned mask;
     int4 dd;
+  };
+  struct Data
+  {
     double p[4][3], fl[4];
   };
-  auto fetch = [&](int a, Stage& S) {
-    S.cell = a < adj.len ? adj.cell(a) : -1;
-    if (S.cell < 0)
+  auto adj_at = [&](int a, int& cell, int& li) {
+    const bool in = a < adj.len;
+    cell = in ? adj.cell(a) : -1;
+    li = in ? adj.li(a) : 0;
+  };
+  auto conn_at = [&](int cell, int li, Conn& K) {
+    K.cell = cell;
+    K.li = li;
+    if (cell < 0)
       return;
-    S.li = adj.li(a);
-    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)S.cell);
-    S.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)S.cell);
-    S.mask = BS == 1 ? facet_mask[S.cell] : 0u;
-    load_cell(x, v, S.p);
-    const int dj[4] = {S.dd.x, S.dd.y, S.dd.z, S.dd.w};
+    K.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
+    K.mask = BS == 1 ? facet_mask[cell] : 0u;
+  };
+  auto data_at = [&](const Conn& K, Data& D) {
+    if (K.cell < 0)
+      return;
+    load_cell_q(xq, K.dd, D.p);
+    const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      S.fl[j] = f[(int64_t)dj[j] * BS + c];
+      D.fl[j] = f[(int64_t)dj[j] * BS + c];
   };
-  Stage cur, nxt;
-  fetch(0, cur);
-  for (int a = 0; cur.cell >= 0; ++a)
+  Conn K0, K1;
+  Data D0;
+  int c2, l2;
   {
-    fetch(a + 1, nxt);
-    const int li = cur.li;
-    const int dofs[4] = {cur.dd.x, cur.dd.y, cur.dd.z, cur.dd.w};
-    double (&p)[4][3] = cur.p;
+    int ca, la;
+    adj_at(0, ca, la);
+    conn_at(ca, la, K0);
+    data_at(K0, D0);
+    adj_at(1, ca, la);
+    conn_at(ca, la, K1);
+    adj_at(2, c2, l2);
+  }
+  for (int a = 0; K0.cell >= 0; ++a)
+  {
+    Data D1;
+    Conn K2;
+    int c3, l3;
+    data_at(K1, D1);
+    conn_at(c2, l2, K2);
+    adj_at(a + 3, c3, l3);
+    const int li = K0.li;
+    const int dofs[4] = {K0.dd.x, K0.dd.y, K0.dd.z, K0.dd.w};
+    double (&p)[4][3] = D0.p;
     Geom G;
     geometry(p, G);
     double fs = 0.0, fi = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
-      fs += cur.fl[j];
+      fs += D0.fl[j];
       if (j == li)
-        fi = cur.fl[j];
+        fi = D0.fl[j];
     }
     sum += G.adet * ((fs + fi) / 120.0); // |detJ| * sum_j (1+delta_ij)/120 f_j
     if (BS == 1)
     {
-      const unsigned m = cur.mask;
+      const unsigned m = K0.mask;
       if (m)
       {
         double gl[4], gi = 0.0;
@@ -387,7 +448,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
           }
       }
     }
-    cur = nxt;
+    K0 = K1;
+    D0 = D1;
+    K1 = K2;
+    c2 = c3;
+    l2 = l3;
   }
   b[r] = bc[r] ? 0.0 : sum; // bc->set(b), u0 == 0
 }
@@ -640,6 +705,61 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restr
   b[r] = bc[r] ? 0.0 : sum;
 }
 
+// P1: a cell's four block dofs are its four vertices in some numbering.  When the dofmap numbers them as the mesh
+// numbers its vertices (any feed of this repository) the coordinate array serves as it is; otherwise the coordinates
+// are copied once into dof order.  Either way the P1 assembly kernels read ONE 16-B connectivity record per cell and
+// gather coordinates by dof -- the second record was half of their connectivity traffic.  Runs when the dofmap is
+// uploaded (function-space data, as tabulate_dof_coordinates is in the reference), not inside the assembly timers.
+__global__ void k_conn_differs(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int64_t n, int* __restrict__ flag)
+{
+  bool d = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d |= a[i] != b[i];
+  if (__any(d) && (threadIdx.x & 63) == 0)
+    *flag = 1;
+}
+
+__global__ void k_dof_coords(const double* __restrict__ x, const int32_t* __restrict__ cv, const int32_t* __restrict__ cd,
+                             int64_t n, double* __restrict__ xd)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  {
+    const double* q = x + 3 * (int64_t)cv[i];
+    double* o = xd + 3 * (int64_t)cd[i]; // every writer of a dof stores the same three values
+    o[0] = q[0];
+    o[1] = q[1];
+    o[2] = q[2];
+  }
+}
+
+int ensure_p1_coords(zzz_ctx* ctx)
+{
+  if (ctx->xq_valid || ctx->order != 1 || ctx->ncells == 0 || !ctx->cell_dofs.p || !ctx->cell_verts.p)
+    return ZZZ_OK;
+  const int64_t n = 4 * ctx->ncells, nblock = ctx->n_owned + ctx->n_ghost;
+  const int g = (int)std::min<int64_t>((n + 255) / 256, 8192);
+  DevBuf<int> flag;
+  ZZZ_HIP(ctx, flag.alloc(1));
+  ZZZ_HIP(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_conn_differs, dim3(g), dim3(256), 0, ctx->stream, ctx->cell_verts.p, ctx->cell_dofs.p, n, flag.p);
+  int differs = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&differs, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!differs && ctx->nverts >= nblock)
+    ctx->xq = ctx->x.p;
+  else
+  {
+    ZZZ_HIP(ctx, ctx->xdof.alloc((size_t)(3 * nblock)));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->xdof.p, 0, sizeof(double) * 3 * (size_t)nblock, ctx->stream));
+    hipLaunchKernelGGL(k_dof_coords, dim3(g), dim3(256), 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p, n,
+                       ctx->xdof.p);
+    ZZZ_HIP(ctx, hipGetLastError());
+    ctx->xq = ctx->xdof.p;
+  }
+  ctx->xq_valid = true;
+  return ZZZ_OK;
+}
+
 int ensure_tables(zzz_ctx* ctx)
 {
   if (ctx->tables_order == ctx->order)
@@ -694,15 +814,17 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
   if (bs != ctx->bs)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
   const dim3 grid((unsigned)xcd_grid(ctx->n_asm_tiles)), block(ASM_BLOCK);
+  if (int rc = ensure_p1_coords(ctx))
+    return rc;
   if (ctx->order == 1)
   {
     if (bs == 1)
       // one thread per row: a 1920-nonzero tile holds ~126 rows of 15, so 128 threads leave no lane idle
-      hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_P1, 128>), grid, dim3(128), 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_P1, 128>), grid, dim3(128), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
     else
-      hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ, ASM_BLOCK>), grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ, ASM_BLOCK>), grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
   }
@@ -729,14 +851,16 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
   const int64_t nrows = ctx->n_owned * bs;
   const dim3 grid((unsigned)xcd_grid((nrows + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+  if (int rc = ensure_p1_coords(ctx))
+    return rc;
   if (ctx->order == 1)
   {
     if (bs == 1)
-      hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                          ctx->coeff[1].p, ctx->b.p, nrows);
     else
-      hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p,
+      hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
                          (const double*)nullptr, ctx->b.p, nrows);
   }

@@ -141,6 +141,10 @@ extern "C" int zzz_cube_generate(zzz_ctx* ctx, int problem, int order, int64_t n
   ctx->have_coeff[0] = true;
   ctx->have_coeff[1] = problem == ZZZ_FORM_POISSON;
   ctx->have_pattern = ctx->have_matrix = false;
+  ctx->xq_valid = false;
+  rc = ensure_p1_coords(ctx);
+  if (rc)
+    return rc;
 
   // forward-scatter plan (neighbours in ghost order: lower, then upper), same as host/mesh_part.cpp
   std::vector<int32_t> neigh, send_idx;

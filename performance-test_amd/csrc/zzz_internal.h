@@ -86,6 +86,11 @@ struct zzz_ctx
   // mesh
   int64_t nverts = 0, ncells = 0;
   zzz::DevBuf<double> x;         // nverts*3
+  // P1: vertex coordinates addressed by BLOCK DOF (ensure_p1_coords): the assembly kernels then read one connectivity
+  // table, not two.  Points at x when the dofmap numbers dofs as the mesh numbers vertices, else at xdof.
+  zzz::DevBuf<double> xdof;
+  const double* xq = nullptr;
+  bool xq_valid = false;
   zzz::DevBuf<int32_t> cell_verts; // ncells*4
   std::vector<int32_t> h_cell_verts;
 
@@ -234,6 +239,7 @@ int asm_tile_nnz(const zzz_ctx* ctx); // nonzeros an assembly tile may hold (LDS
 int build_adjT(zzz_ctx* ctx);
 int build_adjT_offsets(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);
+int ensure_p1_coords(zzz_ctx* ctx); // P1 only; a no-op for P2/P3
 // kernels_spmv
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
 int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec = nullptr,

@@ -61,7 +61,8 @@ def build(verbose=False):
 
 
 def hip_lib_path():
-    return os.path.join(PKG, "libzzz_hip.so")
+    # ZZZ_HIP_LIB: another build of the same library, for the A/B tools (tools/ab_lib.py); never a different backend
+    return os.environ.get("ZZZ_HIP_LIB") or os.path.join(PKG, "libzzz_hip.so")
 
 
 def host_lib_path():
