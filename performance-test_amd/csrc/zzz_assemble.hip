@@ -550,18 +550,69 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
     constexpr double mu = Ey / (2.0 * (1.0 + nu));
     constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
     const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
-    for (int a = 0; a < adj.len; ++a)
+    // Three-stage software pipeline over the row's cells, as in asm_matrix_p1: the chain adjacency -> connectivity
+    // (vertices + this lane's columns) -> coordinates and BC flags is issued one link per iteration ahead.
+    constexpr int JM = (ND + LPR - 1) / LPR; // columns of a cell this lane handles
+    struct Conn
     {
-      const int cell = adj.cell(a);
-      if (cell < 0)
-        break;
-      const int li = adj.li(a);
-      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
-      const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
+      int cell, li;
+      int4 v;
+      int dj[JM];
+    };
+    struct Data
+    {
       double p[4][3];
+      uint8_t bcj[JM * BS];
+    };
+    auto adj_at = [&](int a, int& cell, int& li) {
+      const bool in = a < adj.len;
+      cell = in ? adj.cell(a) : -1;
+      li = in ? adj.li(a) : 0;
+    };
+    auto conn_at = [&](int cell, int li, Conn& K) {
+      K.cell = cell;
+      K.li = li;
+      if (cell < 0)
+        return;
+      K.v = *reinterpret_cast<const int4*>(cell_verts + 4 * (int64_t)cell);
+      const int32_t* __restrict__ cd = cell_dofs + (int64_t)ND * cell;
+#pragma unroll
+      for (int q = 0; q < JM; ++q)
+        K.dj[q] = lane + q * LPR < ND ? cd[lane + q * LPR] : 0;
+    };
+    auto data_at = [&](const Conn& K, Data& D) {
+      if (K.cell < 0)
+        return;
+      load_cell(x, K.v, D.p);
+#pragma unroll
+      for (int q = 0; q < JM; ++q)
+#pragma unroll
+        for (int d = 0; d < BS; ++d)
+          D.bcj[q * BS + d] = bc[K.dj[q] * BS + d];
+    };
+    Conn K0, K1;
+    Data D0;
+    int c2, l2;
+    {
+      int ca, la;
+      adj_at(0, ca, la);
+      conn_at(ca, la, K0);
+      data_at(K0, D0);
+      adj_at(1, ca, la);
+      conn_at(ca, la, K1);
+      adj_at(2, c2, l2);
+    }
+    for (int a = 0; K0.cell >= 0; ++a)
+    {
+      Data D1;
+      Conn K2;
+      int c3, l3;
+      data_at(K1, D1);
+      conn_at(c2, l2, K2);
+      adj_at(a + 3, c3, l3);
+      const int li = K0.li;
       Geom G;
-      load_cell(x, v, p);
-      geometry(p, G);
+      geometry(D0.p, G);
       const double* Tl = T_s + li * ND;
       if (BS == 1)
       {
@@ -573,24 +624,32 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
         GG[3] = G.adet * (G.K[0][0] * G.K[1][0] + G.K[0][1] * G.K[1][1] + G.K[0][2] * G.K[1][2]);
         GG[4] = G.adet * (G.K[0][0] * G.K[2][0] + G.K[0][1] * G.K[2][1] + G.K[0][2] * G.K[2][2]);
         GG[5] = G.adet * (G.K[1][0] * G.K[2][0] + G.K[1][1] * G.K[2][1] + G.K[1][2] * G.K[2][2]);
-        for (int j = lane; j < ND; j += LPR)
+#pragma unroll
+        for (int q = 0; q < JM; ++q)
         {
-          const int dj = cd[j];
+          const int j = lane + q * LPR;
+          if (j >= ND)
+            break;
+          const int dj = K0.dj[q];
           const int pos = find_pos(cols_s + a0, len, dj);
           double val = 0.0;
 #pragma unroll
           for (int t = 0; t < 6; ++t)
             val += GG[t] * Tl[t * NN + j];
-          if (bcr || bc[dj])
+          if (bcr || D0.bcj[q])
             val = 0.0;
           vals_s[a0 + pos] += val;
         }
       }
       else
       {
-        for (int j = lane; j < ND; j += LPR)
+#pragma unroll
+        for (int q = 0; q < JM; ++q)
         {
-          const int dj = cd[j];
+          const int j = lane + q * LPR;
+          if (j >= ND)
+            break;
+          const int dj = K0.dj[q];
           const int pos = find_pos(cols_s + a0, len, dj * 3);
           // D[cc][d] = |detJ| sum_{al,be} K[al][cc] K[be][d] S^[al][be]_{li,j} = int d_cc phi_i d_d phi_j
           double D[3][3];
@@ -614,12 +673,17 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk(const double* __restr
           {
             const double Dcd = sel3(D[0][d], D[1][d], D[2][d], c), Ddc = sel3(D[d][0], D[d][1], D[d][2], c);
             double val = mu * ((c == d ? tr : 0.0) + Ddc) + lmbda * Dcd;
-            if (bcr || bc[dj * 3 + d])
+            if (bcr || D0.bcj[q * BS + d])
               val = 0.0;
             vals_s[a0 + pos + d] += val;
           }
         }
       }
+      K0 = K1;
+      D0 = D1;
+      K1 = K2;
+      c2 = c3;
+      l2 = l3;
     }
     if (bcr && lane == 0) // fem::set_diagonal
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
