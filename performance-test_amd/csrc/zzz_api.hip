@@ -519,7 +519,12 @@ int zzz_csr_download(zzz_ctx* ctx, int32_t* rowptr, int32_t* cols, double* vals)
   if (cols)
     ZZZ_HIP(ctx, hipMemcpy(cols, ctx->cols.p, (size_t)ctx->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (vals)
-    ZZZ_HIP(ctx, hipMemcpy(vals, ctx->vals.p, (size_t)ctx->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  {
+    if (ctx->have_matrix)
+      ZZZ_HIP(ctx, hipMemcpy(vals, ctx->vals.p, (size_t)ctx->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    else // a created, not yet assembled matrix is zero (the device array is written whole by the first assembly)
+      memset(vals, 0, (size_t)ctx->nnz * sizeof(double));
+  }
   return ZZZ_OK;
 }
 

@@ -26,17 +26,29 @@ namespace zzz
 {
 constexpr int PAT_CAP = 1024; // candidate columns per block row handled on the device
 
-__global__ void k_make_pairs(const int32_t* __restrict__ cell_dofs, int64_t n, int nd, int32_t nb,
-                             int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ cnt)
+// The (dof, cell) pairs of the dof -> cell adjacency are never materialised: the radix sort reads its keys through
+// OwnedKey (ghost rows are not assembled: parked behind the owned ones) straight from the connectivity and its values
+// from the entry's position (CellOf).  Round 1-2 wrote both arrays first (k_make_pairs, 1.7 ms at 10 M dofs, with an
+// atomic per pair for the valence); the valence now comes from the sorted keys (k_adj_bounds).
+struct OwnedKey
 {
-  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+  int32_t nb;
+  __host__ __device__ int32_t operator()(int32_t d) const { return d < nb ? d : nb; }
+};
+struct CellOf
+{
+  int32_t nd;
+  __host__ __device__ int32_t operator()(int32_t k) const { return k / nd; }
+};
+
+// adj_off[d] = first position of key d in the sorted keys (d = 0 .. nb; a dof without cells gets an empty range)
+__global__ void k_adj_bounds(const int32_t* __restrict__ keys, int64_t n, int32_t nb, int32_t* __restrict__ adj_off)
+{
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k <= n; k += (int64_t)gridDim.x * blockDim.x)
   {
-    const int32_t d = cell_dofs[k];
-    const bool owned = d < nb;
-    keys[k] = owned ? d : nb; // ghost rows are not assembled: park them behind the owned ones
-    vals[k] = (int32_t)(k / nd);
-    if (owned)
-      atomicAdd(&cnt[d], 1);
+    const int32_t cur = k < n ? keys[k] : nb + 1, prev = k ? keys[k - 1] : -1;
+    for (int32_t d = prev + 1; d <= cur && d <= nb; ++d)
+      adj_off[d] = (int32_t)k;
   }
 }
 
@@ -571,40 +583,33 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   if (N > INT32_MAX - 8)
     return fail(ctx, ZZZ_ERR_LIMIT, "dof->cell adjacency exceeds int32");
 
-  DevBuf<int32_t>&keys_in = ctx->scr_keys_in, &keys_out = ctx->scr_keys_out, &vals_in = ctx->scr_vals_in,
-  &cnt = ctx->scr_cnt;
+  DevBuf<int32_t>&keys_out = ctx->scr_keys_out, &cnt = ctx->scr_cnt;
   DevBuf<int64_t>& bptr = ctx->scr_bptr;
   DevBuf<unsigned char>& tmp = ctx->scr_tmp;
   DevBuf<int32_t> scal;
-  ZZZ_HIP(ctx, keys_in.alloc((size_t)N));
   ZZZ_HIP(ctx, keys_out.alloc((size_t)N));
-  ZZZ_HIP(ctx, vals_in.alloc((size_t)N));
   ZZZ_HIP(ctx, ctx->adj_cells.alloc((size_t)N));
   ZZZ_HIP(ctx, cnt.alloc((size_t)nb + 1));
   ZZZ_HIP(ctx, bptr.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, ctx->adj_off.alloc((size_t)nb + 1));
   ZZZ_HIP(ctx, scal.alloc(4)); // [0] max unique cols, [1] overflow
-  ZZZ_HIP(ctx, hipMemsetAsync(cnt.p, 0, ((size_t)nb + 1) * sizeof(int32_t), s));
   ZZZ_HIP(ctx, hipMemsetAsync(scal.p, 0, 4 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(cnt.p, 0, ((size_t)nb + 1) * sizeof(int32_t), s)); // cnt[nb] closes the scans
 
-  // 1. adjacency
-  hipLaunchKernelGGL(k_make_pairs, dim3(grid_for(N)), dim3(256), 0, s, ctx->cell_dofs.p, N, nd, nb, keys_in.p, vals_in.p,
-                     cnt.p);
+  // 1. adjacency: sort the (dof, cell) incidences by dof
   int end_bit = 1;
   while ((1ll << end_bit) <= (long long)nb)
     ++end_bit;
+  const auto keys_it = rocprim::make_transform_iterator(ctx->cell_dofs.p, OwnedKey{nb});
+  const auto vals_it = rocprim::make_transform_iterator(rocprim::counting_iterator<int32_t>(0), CellOf{(int32_t)nd});
   size_t tb = 0, tb2 = 0;
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p, ctx->adj_cells.p, (size_t)N, 0,
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys_it, keys_out.p, vals_it, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
-  size_t tb3 = 0;
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, ctx->adj_off.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb3, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
-  if (tb3 > tb2)
-    tb2 = tb3;
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
   ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, keys_in.p, keys_out.p, vals_in.p, ctx->adj_cells.p, (size_t)N, 0,
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, keys_it, keys_out.p, vals_it, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
-  ZZZ_HIP(ctx, ctx->adj_off.alloc((size_t)nb + 1));
-  ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb2, cnt.p, ctx->adj_off.p, 0, (size_t)nb + 1, rocprim::plus<int32_t>(), s));
+  hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for(N + 1)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
 
   // 2. pattern: count, scan, fill
   const int rgrid = grid_for((int64_t)nb, 4, 256 * 16);
@@ -669,7 +674,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   ZZZ_HIP(ctx, ctx->cols.alloc((size_t)nnz + 8));
   ZZZ_HIP(ctx, ctx->vals.alloc((size_t)nnz + 8));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->cols.p + nnz, 0, 8 * sizeof(int32_t), s));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->vals.p, 0, ((size_t)nnz + 8) * sizeof(double), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->vals.p + nnz, 0, 8 * sizeof(double), s)); // the assembly writes every entry itself
   hipLaunchKernelGGL(k_scalar_rowptr, dim3(grid_for((int64_t)nb + 1)), dim3(256), 0, s, bptr.p, cnt.p, nb, bs,
                      ctx->rowptr.p);
   if (stage)
