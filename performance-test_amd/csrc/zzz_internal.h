@@ -126,7 +126,9 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> cols;
   zzz::DevBuf<double> vals;
   // scratch of the pattern build (kept: a rebuild of the same problem reuses it)
-  zzz::DevBuf<int32_t> scr_keys_in, scr_keys_out, scr_vals_in, scr_cnt, scr_stage;
+  zzz::DevBuf<int32_t> scr_keys_out, scr_vals_in, scr_cnt, scr_stage;
+  int64_t scr_cell_of_n = -1; // scr_vals_in holds position / nd for this many connectivity entries ...
+  int scr_cell_of_nd = 0;     // ... of nd dofs per cell
   zzz::DevBuf<int64_t> scr_bptr;
   zzz::DevBuf<unsigned char> scr_tmp;
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)

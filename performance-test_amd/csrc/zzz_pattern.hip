@@ -26,20 +26,16 @@ namespace zzz
 {
 constexpr int PAT_CAP = 1024; // candidate columns per block row handled on the device
 
-// The (dof, cell) pairs of the dof -> cell adjacency are never materialised: the radix sort reads its keys through
-// OwnedKey (ghost rows are not assembled: parked behind the owned ones) straight from the connectivity and its values
-// from the entry's position (CellOf).  Round 1-2 wrote both arrays first (k_make_pairs, 1.7 ms at 10 M dofs, with an
-// atomic per pair for the valence); the valence now comes from the sorted keys (k_adj_bounds).
-struct OwnedKey
+// The (dof, cell) pairs of the dof -> cell adjacency are not written out before the sort: its keys ARE the
+// connectivity (ghost dofs are numbered behind the owned ones, so they sort behind them and k_adj_bounds ignores them)
+// and its values are the entries' cell numbers, position / nd, kept from one pattern build to the next (they depend on
+// the array's length only).  Round 1-2 wrote both arrays every time (k_make_pairs, 1.7 ms at 10 M dofs, with an atomic
+// per pair for the valence); the valence now comes from the sorted keys (k_adj_bounds).
+__global__ void k_cell_of(int64_t n, int nd, int32_t* __restrict__ out)
 {
-  int32_t nb;
-  __host__ __device__ int32_t operator()(int32_t d) const { return d < nb ? d : nb; }
-};
-struct CellOf
-{
-  int32_t nd;
-  __host__ __device__ int32_t operator()(int32_t k) const { return k / nd; }
-};
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+    out[k] = (int32_t)(k / nd);
+}
 
 // adj_off[d] = first position of key d in the sorted keys (d = 0 .. nb; a dof without cells gets an empty range)
 __global__ void k_adj_bounds(const int32_t* __restrict__ keys, int64_t n, int32_t nb, int32_t* __restrict__ adj_off)
@@ -600,14 +596,22 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   int end_bit = 1;
   while ((1ll << end_bit) <= (long long)nb)
     ++end_bit;
-  const auto keys_it = rocprim::make_transform_iterator(ctx->cell_dofs.p, OwnedKey{nb});
-  const auto vals_it = rocprim::make_transform_iterator(rocprim::counting_iterator<int32_t>(0), CellOf{(int32_t)nd});
+  while ((1ll << end_bit) <= (long long)(ctx->n_owned + ctx->n_ghost)) // ghost dofs are keys too
+    ++end_bit;
+  DevBuf<int32_t>& cell_of = ctx->scr_vals_in;
+  if (ctx->scr_cell_of_n != N || ctx->scr_cell_of_nd != nd)
+  {
+    ZZZ_HIP(ctx, cell_of.alloc((size_t)N));
+    hipLaunchKernelGGL(k_cell_of, dim3(grid_for(N)), dim3(256), 0, s, N, nd, cell_of.p);
+    ctx->scr_cell_of_n = N;
+    ctx->scr_cell_of_nd = nd;
+  }
   size_t tb = 0, tb2 = 0;
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys_it, keys_out.p, vals_it, ctx->adj_cells.p, (size_t)N, 0,
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
   ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, keys_it, keys_out.p, vals_it, ctx->adj_cells.p, (size_t)N, 0,
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
   hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for(N + 1)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
 
