@@ -37,6 +37,14 @@ __global__ void k_cell_of(int64_t n, int nd, int32_t* __restrict__ out)
     out[k] = (int32_t)(k / nd);
 }
 
+// onesweep geometry of the adjacency sort: rocPRIM's gfx950 default for (int, int) is 1024 threads x 16 items; with 8
+// items per thread the 237 M-pair sort of the 10 M-dof pattern takes 4.70 instead of 5.09 ms (tools/micro/sort_cfg.hip:
+// 4, 6, 10, 12, 16 items and 256/512 threads are all slower; wider digits do not fit the LDS)
+using AdjSortConfig
+    = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                 rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8,
+                                                                     rocprim::block_radix_rank_algorithm::match>>;
+
 // adj_off[d] = first position of key d in the sorted keys (d = 0 .. nb; a dof without cells gets an empty range)
 __global__ void k_adj_bounds(const int32_t* __restrict__ keys, int64_t n, int32_t nb, int32_t* __restrict__ adj_off)
 {
@@ -152,12 +160,14 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
 // (zzz_assemble.hip: entry a of row 64 s + lane at adjT_off[s] + 64 a + lane), which saves a separate gather pass.
 // A row with more than ROW_T_CAP unique columns or a block with more than ROW_T_ADJ adjacency entries raises
 // `overflow` and the caller uses the wavefront kernel.
-constexpr int ROW_T_BLOCK = 128, ROW_T_LD = ROW_T_BLOCK + 1, ROW_T_ADJ = 4096;
+constexpr int ROW_T_BLOCK = 128, ROW_T_LD = ROW_T_BLOCK + 1;
+// ROW_T_ADJ: adjacency entries of a block's 128 rows staged in LDS.  3200 (25 per row) leaves room for 7 workgroups of
+// the 16-register variant per CU; the second attempt takes 4096 (32 per row).
 // ROW_T_CAP: unique columns a row may have (16: the sorted list lives in 16 registers; 32: in 32).  Round 1 kept the
 // list in a private LDS column and inserted there: dependent LDS reads at 2 wavefronts per SIMD made that 5 of the
 // kernel's 7 ms at 10 M dofs; a branch-free insertion into a register array (every slot recomputed by two compares)
 // needs no memory at all.
-template <int ROW_T_CAP>
+template <int ROW_T_CAP, int ROW_T_ADJ>
 __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32_t* __restrict__ cell_dofs,
                                                                      const int32_t* __restrict__ adj_off,
                                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
@@ -607,11 +617,11 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     ctx->scr_cell_of_nd = nd;
   }
   size_t tb = 0, tb2 = 0;
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs<AdjSortConfig>(nullptr, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
   ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs<AdjSortConfig>(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
   hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for(N + 1)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
 
@@ -631,15 +641,16 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     int rc = build_adjT_offsets(ctx);
     if (rc)
       return rc;
-    const dim3 tg((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 4) + 7) / 8 * 8);
+    // 7 workgroups per CU: what the kernel's 22.6 KB of LDS allow (a cap of 4 left 40 % of that occupancy unused: 2.98 -> ~2.0 ms)
+    const dim3 tg((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 7) + 7) / 8 * 8);
     // rows of up to 16 unique columns first (the sorted list in 16 registers), then up to 32
     for (int cap = 16; cap <= 32; cap *= 2)
     {
       if (cap == 16)
-        hipLaunchKernelGGL(k_row_pattern_thread4<16>, tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
+        hipLaunchKernelGGL((k_row_pattern_thread4<16, 3200>), tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
                            ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
       else
-        hipLaunchKernelGGL(k_row_pattern_thread4<32>, tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
+        hipLaunchKernelGGL((k_row_pattern_thread4<32, 4096>), tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
                            ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
       ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
       ZZZ_HIP(ctx, hipStreamSynchronize(s));
