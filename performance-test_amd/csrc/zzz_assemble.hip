@@ -52,6 +52,29 @@ __device__ inline void load_cell(const double* __restrict__ x, const int4 v, dou
 
 // P1 through the dof-addressed coordinates (zzz_ctx::xq): dd = the cell's four block dofs
 __device__ inline void load_cell_q(const double* __restrict__ xq, const int4 dd, double p[4][3]) { load_cell(xq, dd, p); }
+// the same for a row that knows its own vertex (local index li, coordinates own[]): three gathers instead of four.  The
+// loads are predicated per lane; where the lanes of a wavefront agree on li (structured feeds) the fourth is not issued.
+__device__ inline void load_cell_q3(const double* __restrict__ xq, const int4 dd, int li, const double own[3], double p[4][3])
+{
+  const int vv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    if (k != li)
+    {
+      const double* q = xq + 3 * (int64_t)vv[k];
+      p[k][0] = q[0];
+      p[k][1] = q[1];
+      p[k][2] = q[2];
+    }
+    else
+    {
+      p[k][0] = own[0];
+      p[k][1] = own[1];
+      p[k][2] = own[2];
+    }
+  }
+}
 
 __device__ inline void geometry(const double p[4][3], Geom& G)
 {
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
     auto data_at = [&](const Conn& K, Data& D) {
       if (K.cell < 0)
         return;
-      load_cell_q(xq, K.dd, D.p);
+      load_cell_q(xq, K.dd, D.p); // (skipping the row's own vertex, as asm_vector_p1 does, made this kernel 3 % slower)
       const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -344,6 +367,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
   const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+  const double own[3] = {xq[3 * (int64_t)i], xq[3 * (int64_t)i + 1], xq[3 * (int64_t)i + 2]}; // the row's own vertex
+  const double own_f = f[r];
   // Three-stage software pipeline over the row's cells.  A cell needs a chain of three dependent loads (adjacency ->
   // connectivity -> coordinates and coefficients); each link is issued one iteration ahead of the next, so that while
   // cell a is summed the coordinates of a+1, the connectivity of a+2 and the adjacency entry a+3 are in flight and an
@@ -374,11 +399,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   auto data_at = [&](const Conn& K, Data& D) {
     if (K.cell < 0)
       return;
-    load_cell_q(xq, K.dd, D.p);
+    load_cell_q3(xq, K.dd, K.li, own, D.p);
     const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      D.fl[j] = f[(int64_t)dj[j] * BS + c];
+      D.fl[j] = j != K.li ? f[(int64_t)dj[j] * BS + c] : own_f;
   };
   Conn K0, K1;
   Data D0;
