@@ -48,11 +48,33 @@ using AdjSortConfig
 // adj_off[d] = first position of key d in the sorted keys (d = 0 .. nb; a dof without cells gets an empty range)
 __global__ void k_adj_bounds(const int32_t* __restrict__ keys, int64_t n, int32_t nb, int32_t* __restrict__ adj_off)
 {
-  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k <= n; k += (int64_t)gridDim.x * blockDim.x)
+  // four keys per thread (one 16-B load; the array is a hipMalloc allocation, so aligned)
+  const int64_t n4 = (n + 1 + 3) / 4; // positions 0 .. n
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x)
   {
-    const int32_t cur = k < n ? keys[k] : nb + 1, prev = k ? keys[k - 1] : -1;
-    for (int32_t d = prev + 1; d <= cur && d <= nb; ++d)
-      adj_off[d] = (int32_t)k;
+    const int64_t k0 = 4 * q;
+    int32_t kk[4];
+    if (k0 + 4 <= n)
+    {
+      const int4 v = *reinterpret_cast<const int4*>(keys + k0);
+      kk[0] = v.x, kk[1] = v.y, kk[2] = v.z, kk[3] = v.w;
+    }
+    else
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        kk[e] = k0 + e < n ? keys[k0 + e] : nb + 1;
+    int32_t prev = k0 ? keys[k0 - 1] : -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+    {
+      const int64_t k = k0 + e;
+      if (k > n)
+        break;
+      const int32_t cur = kk[e];
+      for (int32_t d = prev + 1; d <= cur && d <= nb; ++d)
+        adj_off[d] = (int32_t)k;
+      prev = cur;
+    }
   }
 }
 
@@ -283,7 +305,9 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
     m_s[threadIdx.x] = (r < nb && !over) ? m : 0;
     wmax = max(wmax, m);
     __syncthreads();
-    // read-out: one row per wavefront instruction, lanes = entries (contiguous in `stage`)
+    // read-out: one row per wavefront instruction, lanes = entries (contiguous in `stage`).  (Dense 64-B records per
+    // row, written four rows per instruction as whole 256-B stores, made this kernel 0.7 ms SLOWER -- 1.97 -> 2.69 ms --
+    // for 0.15 ms saved in k_row_copy; measured on one box, not understood; the sparse layout stays.)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int t = wv * 64; t < wv * 64 + 64; ++t)
     {
@@ -623,7 +647,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
   ZZZ_HIP(ctx, rocprim::radix_sort_pairs<AdjSortConfig>(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
                                          (unsigned)end_bit, s));
-  hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for(N + 1)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
+  hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for((N + 4) / 4)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
 
   // 2. pattern: count, scan, fill
   const int rgrid = grid_for((int64_t)nb, 4, 256 * 16);
