@@ -183,8 +183,7 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
 // A row with more than ROW_T_CAP unique columns or a block with more than ROW_T_ADJ adjacency entries raises
 // `overflow` and the caller uses the wavefront kernel.
 constexpr int ROW_T_BLOCK = 128, ROW_T_LD = ROW_T_BLOCK + 1;
-// ROW_T_ADJ: adjacency entries of a block's 128 rows staged in LDS.  3200 (25 per row) leaves room for 7 workgroups of
-// the 16-register variant per CU; the second attempt takes 4096 (32 per row).
+// ROW_T_ADJ: adjacency entries of a block's 128 rows staged in LDS (4096 = 32 per row on average).
 // ROW_T_CAP: unique columns a row may have (16: the sorted list lives in 16 registers; 32: in 32).  Round 1 kept the
 // list in a private LDS column and inserted there: dependent LDS reads at 2 wavefronts per SIMD made that 5 of the
 // kernel's 7 ms at 10 M dofs; a branch-free insertion into a register array (every slot recomputed by two compares)
@@ -199,8 +198,12 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
                                                                      const int32_t* __restrict__ adjT_off,
                                                                      int32_t* __restrict__ cellT, uint8_t* __restrict__ liT)
 {
-  __shared__ int32_t u[ROW_T_CAP * ROW_T_LD];
-  __shared__ int32_t adj_s[ROW_T_ADJ];
+  // the staged adjacency (read while the rows are built) and the transposed read-out buffer (written after) share
+  // their LDS: 13.8 KB per workgroup instead of 22, so that registers, not LDS, set the occupancy (8 workgroups per CU)
+  constexpr int ROW_T_SH = ROW_T_ADJ > ROW_T_CAP * ROW_T_LD ? ROW_T_ADJ : ROW_T_CAP * ROW_T_LD;
+  __shared__ int32_t sh[ROW_T_SH];
+  int32_t* const u = sh;
+  int32_t* const adj_s = sh;
   __shared__ int32_t a0_s[ROW_T_BLOCK], m_s[ROW_T_BLOCK];
   int wmax = 0;
   const int64_t nblk = ((int64_t)nb + ROW_T_BLOCK - 1) / ROW_T_BLOCK; // nb64 <= nblk * ROW_T_BLOCK
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(ROW_T_BLOCK) void k_row_pattern_thread4(const int32
     }
     if (over)
       atomicMax(overflow, 1);
+    __syncthreads(); // every row has read its adjacency: the buffer changes hands
 #pragma unroll
     for (int k = 0; k < ROW_T_CAP; ++k)
       u[k * ROW_T_LD + threadIdx.x] = cs[k]; // transposed read-out below: one row per wavefront instruction
@@ -665,13 +669,14 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     int rc = build_adjT_offsets(ctx);
     if (rc)
       return rc;
-    // 7 workgroups per CU: what the kernel's 22.6 KB of LDS allow (a cap of 4 left 40 % of that occupancy unused: 2.98 -> ~2.0 ms)
-    const dim3 tg((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 7) + 7) / 8 * 8);
+    // 8 workgroups per CU = 4 wavefronts per SIMD, what the kernel's 108 registers allow (a cap of 4 left half of that
+    // occupancy unused: 2.98 -> ~2.0 ms)
+    const dim3 tg((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 8) + 7) / 8 * 8);
     // rows of up to 16 unique columns first (the sorted list in 16 registers), then up to 32
     for (int cap = 16; cap <= 32; cap *= 2)
     {
       if (cap == 16)
-        hipLaunchKernelGGL((k_row_pattern_thread4<16, 3200>), tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
+        hipLaunchKernelGGL((k_row_pattern_thread4<16, 4096>), tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
                            ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
       else
         hipLaunchKernelGGL((k_row_pattern_thread4<32, 4096>), tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
