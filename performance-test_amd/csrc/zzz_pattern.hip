@@ -166,8 +166,16 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
   }
   // one atomic per wavefront, not per row: ~10^7 same-address atomics (or sc1 loads) serialise at
   // one L2 channel and cost ~100 ms
-  if (!FILL && lane == 0 && wmax > 0)
-    atomicMax(maxcnt, wmax);
+  if (!FILL)
+  {
+    __shared__ int32_t wmax_s[4]; // ... and one per workgroup is a quarter of that
+    if (lane == 0)
+      wmax_s[threadIdx.x >> 6] = wmax;
+    __syncthreads();
+    const int bm = max(max(wmax_s[0], wmax_s[1]), max(wmax_s[2], wmax_s[3]));
+    if (threadIdx.x == 0 && bm > 0)
+      atomicMax(maxcnt, bm);
+  }
 }
 
 // P1 (4 dofs per cell, rows of ~15 unique columns out of ~100 candidates): one THREAD per block row keeps its

@@ -293,8 +293,13 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
         ghost_flag[s] = m != 0ull;
     }
   }
-  if (lane == 0 && mine)
-    atomicAdd(bytes, mine);
+  // one atomic per workgroup (atomics on one address serialise at ~10 ns each)
+  __shared__ unsigned long long mine_s[4];
+  if (lane == 0)
+    mine_s[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0 && (mine_s[0] | mine_s[1] | mine_s[2] | mine_s[3]))
+    atomicAdd(bytes, mine_s[0] + mine_s[1] + mine_s[2] + mine_s[3]);
 }
 
 // Slice bounds from the pattern alone (once per pattern): the longest CSR range of a slice (LDS staging of
