@@ -159,6 +159,10 @@ struct zzz_ctx
   // Operator stream of the CG SpMV (zzz_sellp.hip): sliced-ELL copy in chunks of 8 entries per row, exact zeros
   // dropped, 16-bit slot-relative column codes; rebuilt from the CSR values after every assembly
   zzz::DevBuf<int32_t> sp_rownnz, sp_nch, sp_chunk_off, sp_perm, sp_codes32, sp_meta, sp_desc, sp_counter;
+  // long rows: compacted copy of the kept entries, rows starting at multiples of 8 (k_sp_compact / k_sp_fill_c)
+  zzz::DevBuf<int64_t> sp_crow;
+  zzz::DevBuf<double> sp_cvals;
+  zzz::DevBuf<int32_t> sp_ccols;
   zzz::DevBuf<uint8_t> sp_gflag;
   hipEvent_t sp_event = nullptr;
   bool sp_pending = false, sp_forced = false, sp_bounds_ok = false, sp_lds_attr = false;

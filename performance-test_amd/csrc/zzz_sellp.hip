@@ -333,6 +333,131 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
     atomicAdd(bytes, mine_s[0] + mine_s[1] + mine_s[2] + mine_s[3]);
 }
 
+// ---- long rows (P3): pack from a compacted copy.  k_sp_fill above has one lane walk one CSR row entry by entry; for
+// rows of 50-200 entries every 8-B access of a lane is its own L2 request (58 GB through L2 for a 3.6-GB job at
+// 6.2 M P3 dofs, 7.6 ms).  Instead: (1) k_sp_compact sweeps each slice's CSR range with dense loads and writes the kept
+// entries row by row into a copy whose rows start at multiples of 8 entries (crow, from a scan of the padded counts);
+// (2) k_sp_fill_c reads a lane's next eight entries as 64 + 32 contiguous, aligned bytes (four 16-B and two 16-B loads).
+struct Pad8
+{
+  __host__ __device__ int64_t operator()(int32_t n) const { return ((int64_t)n + 7) & ~(int64_t)7; }
+};
+
+__global__ __launch_bounds__(256) void k_sp_compact(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                    const double* __restrict__ vals, int nrows, int64_t nslices, int drop,
+                                                    const int64_t* __restrict__ crow, double* __restrict__ cvals,
+                                                    int32_t* __restrict__ ccols)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    const int64_t r = s * 64 + lane, rl = min(r, (int64_t)nrows - 1);
+    const int64_t S = rowptr[s * 64], E = rowptr[min(s * 64 + 64, (int64_t)nrows)];
+    const int64_t C = crow[s * 64];
+    // this lane's row relative to the slice: CSR range [a, b), start in the compacted copy, entries kept so far
+    const int a = r < nrows ? (int)(rowptr[r] - S) : (int)(E - S), b = r < nrows ? (int)(rowptr[r + 1] - S) : (int)(E - S);
+    const int cst = (int)(crow[rl] - C);
+    int kept = 0;
+    int rho = 0; // first row that may still have entries at or behind the sweep position (wave-uniform)
+    for (int64_t g = S; g < E; g += 64)
+    {
+      const int64_t k = g + lane;
+      const bool in = k < E;
+      const double v = in ? vals[k] : 0.0;
+      const int32_t c = in ? cols[k] : 0;
+      const bool keep = in && (!drop || v != 0.0);
+      const unsigned long long m = __ballot(keep);
+      const int g0 = (int)(g - S);
+      int dest = -1;
+      while (rho < 64)
+      {
+        const int ur = __builtin_amdgcn_readfirstlane(rho);
+        const int ar = __builtin_amdgcn_readlane(a, ur), br = __builtin_amdgcn_readlane(b, ur);
+        if (ar >= g0 + 64)
+          break;
+        const int lo = max(ar - g0, 0), hi = min(br - g0, 64);
+        if (hi > lo)
+        {
+          const unsigned long long below_hi = hi == 64 ? ~0ull : (1ull << hi) - 1ull;
+          const unsigned long long mask = m & below_hi & ~((1ull << lo) - 1ull);
+          const int before = __builtin_amdgcn_readlane(kept, ur), st = __builtin_amdgcn_readlane(cst, ur);
+          if (lane >= lo && lane < hi && keep)
+            dest = st + before + __popcll(mask & ((1ull << lane) - 1ull));
+          if (lane == ur)
+            kept = before + __popcll(mask);
+        }
+        if (br > g0 + 64)
+          break; // the row goes on in the next group
+        ++rho;
+      }
+      if (dest >= 0)
+      {
+        cvals[C + dest] = v;
+        ccols[C + dest] = c;
+      }
+    }
+  }
+}
+
+template <bool PERM>
+__global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ crow, const int32_t* __restrict__ rownnz,
+                                                   const double* __restrict__ cvals, const int32_t* __restrict__ ccols,
+                                                   int nrows, int64_t nslices, const int32_t* __restrict__ perm,
+                                                   const int2* __restrict__ desc, double* __restrict__ svals,
+                                                   uint16_t* __restrict__ c16, int32_t* __restrict__ c32,
+                                                   int32_t* __restrict__ meta, uint8_t* __restrict__ ghost_flag,
+                                                   unsigned long long* __restrict__ bytes, int tail_codes)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long mine = 0;
+  for (int64_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nslices; s += (int64_t)gridDim.x * 4)
+  {
+    int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
+    if (!PERM && r >= nrows)
+      r = -1;
+    const int n = r >= 0 ? rownnz[r] : 0;
+    const int64_t base = r >= 0 ? crow[r] : 0;
+    const int2 ds = desc[s];
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    bool gh = false;
+    for (int j = 0; j < nch; ++j)
+    {
+      double v[8];
+      int cl[8];
+      const int rem = n - 8 * j; // entries this row still has
+      if (rem > 0)
+      {
+        const dbl2* vp = reinterpret_cast<const dbl2*>(cvals + base + 8 * j);
+        const int4v* cp = reinterpret_cast<const int4v*>(ccols + base + 8 * j);
+        const dbl2 q0 = vp[0], q1 = vp[1], q2 = vp[2], q3 = vp[3];
+        const int4v k0 = cp[0], k1 = cp[1];
+        v[0] = q0.x, v[1] = q0.y, v[2] = q1.x, v[3] = q1.y, v[4] = q2.x, v[5] = q2.y, v[6] = q3.x, v[7] = q3.y;
+        cl[0] = k0.x, cl[1] = k0.y, cl[2] = k0.z, cl[3] = k0.w, cl[4] = k1.x, cl[5] = k1.y, cl[6] = k1.z, cl[7] = k1.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e >= rem)
+        {
+          v[e] = 0.0;
+          cl[e] = INT_MAX;
+        }
+      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tail_codes);
+    }
+    if (ghost_flag)
+    {
+      const unsigned long long m = __ballot(gh);
+      if (lane == 0)
+        ghost_flag[s] = m != 0ull;
+    }
+  }
+  __shared__ unsigned long long mine_s[4];
+  if (lane == 0)
+    mine_s[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0 && (mine_s[0] | mine_s[1] | mine_s[2] | mine_s[3]))
+    atomicAdd(bytes, mine_s[0] + mine_s[1] + mine_s[2] + mine_s[3]);
+}
+
 // Slice bounds from the pattern alone (once per pattern): the longest CSR range of a slice (LDS staging of
 // k_sp_pack) and the number of chunks the natural-order stream can need at most (no zero dropped).
 __global__ __launch_bounds__(256) void k_sp_bounds(const rp_t* __restrict__ rowptr, int nrows, int64_t nslices,
@@ -877,7 +1002,32 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
   hipLaunchKernelGGL(k_sp_desc, dim3(grid_cap(nsl, 256, 4096)), dim3(256), 0, s, ctx->sp_chunk_off.p, ctx->sp_wlast.p, nsl, desc);
   unsigned long long* bytes = reinterpret_cast<unsigned long long*>(ctx->sp_counter.p + 8);
   ZZZ_HIP(ctx, hipMemsetAsync(bytes, 0, sizeof(unsigned long long), s));
-  if (sorted)
+  if (ctx->nnz >= 16 * ctx->nrows && ctx->nnz + 8 * ctx->nrows < ((int64_t)1 << 40))
+  {
+    // long rows: through the compacted copy (crow = scan of the kept counts padded to 8)
+    const int64_t cap = ctx->nnz + 8 * ctx->nrows;
+    ZZZ_HIP(ctx, ctx->sp_crow.alloc((size_t)nrows + 1));
+    ZZZ_HIP(ctx, ctx->sp_cvals.alloc((size_t)cap));
+    ZZZ_HIP(ctx, ctx->sp_ccols.alloc((size_t)cap));
+    const auto padded = rocprim::make_transform_iterator(ctx->sp_rownnz.p, Pad8{});
+    size_t tb = 0;
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
+                                         rocprim::plus<int64_t>(), s));
+    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
+                                         rocprim::plus<int64_t>(), s));
+    hipLaunchKernelGGL(k_sp_compact, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows,
+                       nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_crow.p, ctx->sp_cvals.p, ctx->sp_ccols.p);
+    if (sorted)
+      hipLaunchKernelGGL(k_sp_fill_c<true>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
+                         ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
+                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
+    else
+      hipLaunchKernelGGL(k_sp_fill_c<false>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
+                         ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, (const int32_t*)nullptr, desc, ctx->sp_vals.p,
+                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
+  }
+  else if (sorted)
     hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
                        ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
