@@ -108,6 +108,76 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
     int P = 64;
     while (P < n)
       P <<= 1;
+    if (P <= 128)
+    {
+      // up to 128 candidates (every face and edge row of P2/P3): the keys stay in one or two registers per lane (key
+      // index = 64 kk + lane) and the bitonic network runs on cross-lane exchanges -- no LDS round trip per stage
+      // (the LDS version below spends ~6 us per row at one row per wavefront; 44 % of the P3 rows have 40 candidates)
+      int32_t x[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+      {
+        const int idx = kk * 64 + lane;
+        x[kk] = INT_MAX;
+        if (idx < n)
+        {
+          const int a = idx / nd, j = idx - a * nd;
+          x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+        }
+      }
+      for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+          if (j == 64) // partner in the other register (k == 128): ascending overall
+          {
+            const int32_t lo = min(x[0], x[1]), hi = max(x[0], x[1]);
+            x[0] = lo;
+            x[1] = hi;
+          }
+          else
+          {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+            {
+              const int idx = kk * 64 + lane;
+              const int32_t y = __shfl_xor(x[kk], j);
+              const bool up = (idx & k) == 0, lower = (lane & j) == 0;
+              x[kk] = (lower == up) ? min(x[kk], y) : max(x[kk], y);
+            }
+          }
+        }
+      // unique
+      int base = 0;
+      const int64_t rp = FILL ? bptr[r] : 0;
+      const int32_t nu = FILL ? cnt[r] : 0;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+      {
+        if (kk * 64 >= n) // wave-uniform
+          break;
+        const int idx = kk * 64 + lane;
+        int32_t prev = __shfl_up(x[kk], 1);
+        if (lane == 0)
+          prev = kk ? __builtin_amdgcn_readlane(x[0], 63) : INT_MIN;
+        const bool flag = idx < n && (idx == 0 || x[kk] != prev);
+        const unsigned long long m = __ballot(flag);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (!FILL && stage && flag)
+          stage[(int64_t)a0 * nd + pos] = x[kk];
+        if (FILL && flag)
+        {
+          const int32_t col = x[kk];
+          for (int a = 0; a < bs; ++a)
+            for (int d = 0; d < bs; ++d)
+              cols[(int64_t)bs * bs * rp + (int64_t)a * bs * nu + (int64_t)pos * bs + d] = col * bs + d;
+        }
+        base += __popcll(m);
+      }
+      if (!FILL && lane == 0)
+        cnt[r] = base;
+      wmax = max(wmax, base);
+      continue;
+    }
     for (int idx = lane; idx < P; idx += 64)
     {
       int32_t v = INT_MAX;
