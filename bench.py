@@ -497,9 +497,16 @@ def main():
                                                  else "ncclAllReduce")
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
         if not multi and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, ctx, iters)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["gpu_over_cpu_zzz_solve"] = out["cpu_baseline"]["solve_s_extrapolated"] / avg("solve")
+            if nnz > 2**31 - 1:
+                # the oracle's assembly takes the 32-bit row pointers of DOLFINx; a matrix beyond them (c5 whole: 2.4 G
+                # nonzeros, ~60 GB of host working copies) is not timed on the CPU -- said here rather than failing
+                out["cpu_baseline"] = {"value": None, "unit": "DoF/s", "cores": 0, "kind": "port",
+                                       "sample": f"not run: {nnz} nonzeros exceed the oracle's 32-bit row pointers; see "
+                                                 "--config c5_rank for the per-GPU size of the same problem"}
+            else:
+                out["cpu_baseline"] = cpu_baseline(P, ctx, iters)
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                out["gpu_over_cpu_zzz_solve"] = out["cpu_baseline"]["solve_s_extrapolated"] / avg("solve")
     ctx.close()
     if dist is not None:
         dist.barrier()
