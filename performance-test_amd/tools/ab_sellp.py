@@ -17,6 +17,7 @@ CASES = {
     "rank": ("poisson", 1, 1250000, 1),
     "c4": ("elasticity", 1, 4000000, 3),
     "c5rank": ("poisson", 3, 6250000, 1),
+    "c5": ("poisson", 3, 50000000, 1),
     "p2": ("poisson", 2, 5000000, 1),
     "e3": ("elasticity", 3, 1000000, 3),
 }
