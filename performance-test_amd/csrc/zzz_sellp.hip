@@ -952,6 +952,7 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out, bool sorted = true)
   const int64_t nsl = ctx->nslices;
   const int drop = ctx->sellp_drop ? 1 : 0;
   ZZZ_HIP(ctx, ctx->sp_rownnz.alloc((size_t)nrows + 1));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_rownnz.p + nrows, 0, sizeof(int32_t), s)); // closes the scans over nrows + 1 entries
   ZZZ_HIP(ctx, ctx->sp_nch.alloc((size_t)nsl + 1));
   ZZZ_HIP(ctx, ctx->sp_chunk_off.alloc((size_t)nsl + 1));
   ZZZ_HIP(ctx, ctx->sp_perm.alloc((size_t)nsl * 64));
