@@ -78,6 +78,70 @@ __global__ void k_adj_bounds(const int32_t* __restrict__ keys, int64_t n, int32_
   }
 }
 
+// Bitonic sort of 64 or 128 keys held one or two per lane (key index = 64 kk + lane), every stage unrolled: the
+// partner lane through ds_swizzle (lane ^ j, no address register), which of min / max a lane keeps from a compile-time
+// 64-bit lane mask fed to v_cndmask -- four instructions per stage and register instead of ten.
+template <int J>
+__device__ inline int32_t xor_lane(int32_t v)
+{
+  if constexpr (J < 32)
+    return __builtin_amdgcn_ds_swizzle(v, (J << 10) | 0x1f); // bit mode: and 0x1f, or 0, xor J
+  else
+    return __shfl_xor(v, J);
+}
+constexpr unsigned long long bitonic_min_mask(int k, int j, int kk)
+{
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+  {
+    const int idx = kk * 64 + l;
+    const bool lower = (l & j) == 0, up = (idx & k) == 0;
+    if (lower == up)
+      m |= 1ull << l;
+  }
+  return m;
+}
+__device__ inline int32_t select_by_lane_mask(unsigned long long m, int32_t if_set, int32_t if_clear)
+{
+  int32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+template <int P, int K, int J>
+__device__ inline void bitonic_stage(int32_t (&x)[2])
+{
+  if constexpr (J == 64) // partner in the other register (K == 128: ascending overall)
+  {
+    const int32_t lo = min(x[0], x[1]), hi = max(x[0], x[1]);
+    x[0] = lo;
+    x[1] = hi;
+  }
+  else
+  {
+#pragma unroll
+    for (int kk = 0; kk < (P > 64 ? 2 : 1); ++kk)
+    {
+      const int32_t y = xor_lane<J>(x[kk]);
+      const int32_t mn = min(x[kk], y), mx = max(x[kk], y);
+      x[kk] = select_by_lane_mask(kk ? bitonic_min_mask(K, J, 1) : bitonic_min_mask(K, J, 0), mn, mx);
+    }
+  }
+}
+template <int P, int K, int J>
+__device__ inline void bitonic_merge(int32_t (&x)[2])
+{
+  bitonic_stage<P, K, J>(x);
+  if constexpr (J > 1)
+    bitonic_merge<P, K, J / 2>(x);
+}
+template <int P, int K>
+__device__ inline void bitonic_sort_regs(int32_t (&x)[2])
+{
+  bitonic_merge<P, K, K / 2>(x);
+  if constexpr (K < P)
+    bitonic_sort_regs<P, K * 2>(x);
+}
+
 // One wavefront per block row: sorted unique dofs of the row's cells.
 // FILL = false: cnt[r] = number of unique columns (and the maximum over rows); when `stage` is given
 //               the sorted unique columns are also parked at stage[adj_off[r]*nd ...] so that the
@@ -125,27 +189,10 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
           x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
         }
       }
-      for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1)
-        {
-          if (j == 64) // partner in the other register (k == 128): ascending overall
-          {
-            const int32_t lo = min(x[0], x[1]), hi = max(x[0], x[1]);
-            x[0] = lo;
-            x[1] = hi;
-          }
-          else
-          {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-            {
-              const int idx = kk * 64 + lane;
-              const int32_t y = __shfl_xor(x[kk], j);
-              const bool up = (idx & k) == 0, lower = (lane & j) == 0;
-              x[kk] = (lower == up) ? min(x[kk], y) : max(x[kk], y);
-            }
-          }
-        }
+      if (P == 64)
+        bitonic_sort_regs<64, 2>(x);
+      else
+        bitonic_sort_regs<128, 2>(x);
       // unique
       int base = 0;
       const int64_t rp = FILL ? bptr[r] : 0;
