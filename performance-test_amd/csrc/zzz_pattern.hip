@@ -108,38 +108,93 @@ __device__ inline int32_t select_by_lane_mask(unsigned long long m, int32_t if_s
   return r;
 }
 template <int P, int K, int J>
-__device__ inline void bitonic_stage(int32_t (&x)[2])
+__device__ inline void bitonic_stage(int32_t (&x)[P / 64])
 {
-  if constexpr (J == 64) // partner in the other register (K == 128: ascending overall)
+  constexpr int NR = P / 64;
+  if constexpr (J >= 64) // partner in another register: kk ^ (J / 64); the direction depends on the register only
   {
-    const int32_t lo = min(x[0], x[1]), hi = max(x[0], x[1]);
-    x[0] = lo;
-    x[1] = hi;
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
+      if ((kk & (J / 64)) == 0)
+      {
+        const int hh = kk | (J / 64);
+        const int32_t lo = min(x[kk], x[hh]), hi = max(x[kk], x[hh]);
+        const bool up = ((kk * 64) & K) == 0;
+        x[kk] = up ? lo : hi;
+        x[hh] = up ? hi : lo;
+      }
   }
   else
   {
 #pragma unroll
-    for (int kk = 0; kk < (P > 64 ? 2 : 1); ++kk)
+    for (int kk = 0; kk < NR; ++kk)
     {
       const int32_t y = xor_lane<J>(x[kk]);
       const int32_t mn = min(x[kk], y), mx = max(x[kk], y);
-      x[kk] = select_by_lane_mask(kk ? bitonic_min_mask(K, J, 1) : bitonic_min_mask(K, J, 0), mn, mx);
+      x[kk] = select_by_lane_mask(bitonic_min_mask(K, J, kk), mn, mx);
     }
   }
 }
 template <int P, int K, int J>
-__device__ inline void bitonic_merge(int32_t (&x)[2])
+__device__ inline void bitonic_merge(int32_t (&x)[P / 64])
 {
   bitonic_stage<P, K, J>(x);
   if constexpr (J > 1)
     bitonic_merge<P, K, J / 2>(x);
 }
 template <int P, int K>
-__device__ inline void bitonic_sort_regs(int32_t (&x)[2])
+__device__ inline void bitonic_sort_regs(int32_t (&x)[P / 64])
 {
   bitonic_merge<P, K, K / 2>(x);
   if constexpr (K < P)
     bitonic_sort_regs<P, K * 2>(x);
+}
+
+// One row of the pattern from P / 64 keys per lane: gather the candidates, sort, emit the unique ones (see k_row_pattern)
+template <int P, bool FILL>
+__device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int nd, int bs, const int32_t* __restrict__ adj_cells,
+                                      int a0, int n, int lane, int64_t rp, int32_t nu, int32_t* __restrict__ cols,
+                                      int32_t* __restrict__ stage)
+{
+  constexpr int NR = P / 64;
+  int32_t x[NR];
+#pragma unroll
+  for (int kk = 0; kk < NR; ++kk)
+  {
+    const int idx = kk * 64 + lane;
+    x[kk] = INT_MAX;
+    if (idx < n)
+    {
+      const int a = idx / nd, j = idx - a * nd;
+      x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+    }
+  }
+  bitonic_sort_regs<P, 2>(x);
+  int base = 0;
+#pragma unroll
+  for (int kk = 0; kk < NR; ++kk)
+  {
+    if (kk * 64 >= n) // wave-uniform
+      break;
+    const int idx = kk * 64 + lane;
+    int32_t prev = __shfl_up(x[kk], 1);
+    if (lane == 0)
+      prev = kk ? __builtin_amdgcn_readlane(x[kk ? kk - 1 : 0], 63) : INT_MIN;
+    const bool flag = idx < n && (idx == 0 || x[kk] != prev);
+    const unsigned long long m = __ballot(flag);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (!FILL && stage && flag)
+      stage[(int64_t)a0 * nd + pos] = x[kk];
+    if (FILL && flag)
+    {
+      const int32_t col = x[kk];
+      for (int a = 0; a < bs; ++a)
+        for (int d = 0; d < bs; ++d)
+          cols[(int64_t)bs * bs * rp + (int64_t)a * bs * nu + (int64_t)pos * bs + d] = col * bs + d;
+    }
+    base += __popcll(m);
+  }
+  return base;
 }
 
 // One wavefront per block row: sorted unique dofs of the row's cells.
@@ -172,54 +227,22 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
     int P = 64;
     while (P < n)
       P <<= 1;
-    if (P <= 128)
+    if (P <= 512)
     {
-      // up to 128 candidates (every face and edge row of P2/P3): the keys stay in one or two registers per lane (key
-      // index = 64 kk + lane) and the bitonic network runs on cross-lane exchanges -- no LDS round trip per stage
-      // (the LDS version below spends ~6 us per row at one row per wavefront; 44 % of the P3 rows have 40 candidates)
-      int32_t x[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-      {
-        const int idx = kk * 64 + lane;
-        x[kk] = INT_MAX;
-        if (idx < n)
-        {
-          const int a = idx / nd, j = idx - a * nd;
-          x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
-        }
-      }
-      if (P == 64)
-        bitonic_sort_regs<64, 2>(x);
-      else
-        bitonic_sort_regs<128, 2>(x);
-      // unique
-      int base = 0;
+      // up to 512 candidates (every row of P2 and of P3 Poisson on the Kuhn mesh): the keys stay in P / 64 registers
+      // per lane (key index = 64 kk + lane) and the bitonic network runs on cross-lane exchanges and register swaps --
+      // no LDS round trip per stage (the LDS version below spent ~6 us per row at one row per wavefront)
       const int64_t rp = FILL ? bptr[r] : 0;
       const int32_t nu = FILL ? cnt[r] : 0;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-      {
-        if (kk * 64 >= n) // wave-uniform
-          break;
-        const int idx = kk * 64 + lane;
-        int32_t prev = __shfl_up(x[kk], 1);
-        if (lane == 0)
-          prev = kk ? __builtin_amdgcn_readlane(x[0], 63) : INT_MIN;
-        const bool flag = idx < n && (idx == 0 || x[kk] != prev);
-        const unsigned long long m = __ballot(flag);
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (!FILL && stage && flag)
-          stage[(int64_t)a0 * nd + pos] = x[kk];
-        if (FILL && flag)
-        {
-          const int32_t col = x[kk];
-          for (int a = 0; a < bs; ++a)
-            for (int d = 0; d < bs; ++d)
-              cols[(int64_t)bs * bs * rp + (int64_t)a * bs * nu + (int64_t)pos * bs + d] = col * bs + d;
-        }
-        base += __popcll(m);
-      }
+      int base;
+      if (P == 64)
+        base = row_unique_regs<64, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+      else if (P == 128)
+        base = row_unique_regs<128, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+      else if (P == 256)
+        base = row_unique_regs<256, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+      else
+        base = row_unique_regs<512, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
       if (!FILL && lane == 0)
         cnt[r] = base;
       wmax = max(wmax, base);
