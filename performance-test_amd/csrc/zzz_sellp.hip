@@ -185,8 +185,9 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
                                  double* __restrict__ svals, uint16_t* __restrict__ c16, int32_t* __restrict__ c32,
                                  int32_t* __restrict__ meta, int tail_codes)
 {
+  const bool affine_ok = (tail_codes & 2) == 0; // knob ZZZ_SELLP_AFFINE=0 sets bit 1
   int base[8];
-  bool over8 = false, over16 = false;
+  bool over8 = false, over16 = false, affine = true;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
   {
@@ -199,6 +200,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
       if (mn == INT_MAX)
         mn = 0;
       base[e] = mn;
+      affine &= has && cl[e] - mn == lane; // 64 consecutive rows reach 64 consecutive columns
       if (!has)
         cl[e] = mn; // padding: value +0.0, a column some lane reads anyway
       over8 |= cl[e] - mn > 255;
@@ -207,6 +209,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
     else
       cl[e] = 0;
   }
+  const bool all_affine = __all(affine) && affine_ok;
   const int range = __any(over16) ? 65536 : (__any(over8) ? 256 : 0);
   double* sp = svals + (size_t)c * 512;
 #pragma unroll
@@ -223,7 +226,14 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
       sp[128 * j + lane] = v[2 * j]; // odd width: the last entry alone, 8 B per lane
   }
   int mode = 0, code_bytes;
-  if (range > 65535)
+  if (all_affine)
+  {
+    // every slot: column = base + lane.  No codes at all (an interior P1 slice away from the ends of a mesh line:
+    // 56 instead of 64 B per row)
+    mode = 0x20000000;
+    code_bytes = 0;
+  }
+  else if (range > 65535)
   {
     int4v q0, q1;
     q0.x = cl[0], q0.y = cl[1], q0.z = cl[2], q0.w = cl[3];
@@ -251,7 +261,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
           | ((unsigned)(cl[3] - base[3]) << 24);
     q.y = (unsigned)(cl[4] - base[4]) | ((unsigned)(cl[5] - base[5]) << 8) | ((unsigned)(cl[6] - base[6]) << 16)
           | ((unsigned)(cl[7] - base[7]) << 24);
-    if (w <= 7 && tail_codes)
+    if (w <= 7 && (tail_codes & 1))
     {
       // the chunk's value block has a free last 512 B: codes there, and the chunk is ONE contiguous 4-KiB read
       reinterpret_cast<uint2v*>(sp + 448)[lane] = q;
@@ -670,6 +680,14 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
     const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
     cl[0] = q0.x, cl[1] = q0.y, cl[2] = q0.z, cl[3] = q0.w;
     cl[4] = q1.x, cl[5] = q1.y, cl[6] = q1.z, cl[7] = q1.w;
+  }
+  else if ((m0 & 0x60000000) == 0x20000000)
+  {
+    // affine chunk: column = slot base + lane, nothing to load
+    cl[0] = (m0 & 0x1fffffff) + lane;
+#pragma unroll
+    for (int e = 1; e < 8; ++e)
+      cl[e] = mp[e] + lane;
   }
   else if (m0 & 0x40000000)
   {
