@@ -70,12 +70,13 @@ def spmv_algorithmic_bytes(n, nnz):
     return 12 * nnz + 4 * (n + 1) + 16 * n
 
 
-def pmc_traffic(nrows, nnz):
+def pmc_traffic(nrows, nnz, streamed=None):
     """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command (they cannot share a pass and PMC
     collection cannot run inside a timed benchmark), corrected as MI355X_MICROARCH.md prescribes for
     gfx950 (FETCH_SIZE counts half of a coalesced stream: x2; KiB units).  Only reported when a
-    profile of the same matrix (rows, nonzeros) and the same SpMV kernel exists; the latest round wins."""
+    profile of the same matrix (rows, nonzeros) and the same operator stream (bytes per product) exists; the latest
+    round wins."""
     import glob
 
     best = (None, None)
@@ -85,6 +86,9 @@ def pmc_traffic(nrows, nnz):
             if d["rows"] != nrows or d["nnz"] != nnz:
                 continue
             k = d["kernels"]["spmv"]
+            # ... and of the same operator stream: a profile taken before the stream's format changed does not count
+            if streamed is not None and k.get("bytes_streamed") not in (None, streamed):
+                continue
             best = (2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024, os.path.relpath(path, ROOT))
         except Exception:
             continue
@@ -427,7 +431,6 @@ def main():
     out = None
     if rank == 0:
         alg_bytes = spmv_algorithmic_bytes(nrows, nnz) + (8 * nrows if single_reduction else 0)  # + read of r
-        traffic, traffic_src = pmc_traffic(nrows, nnz)
         achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         sinfo = ctx.spmv_info_raw()
         if sinfo[5]:
@@ -436,6 +439,7 @@ def main():
         else:
             kernel_name = "spmv_tile_kernel (CG SpMV + <p,Ap> partials)"
             streamed = (10 if sinfo[0] else 12) * nnz + 4 * (nrows + 1) + 16 * nrows + (8 * nrows if single_reduction else 0)
+        traffic, traffic_src = pmc_traffic(nrows, nnz, streamed)
         avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
         out = {
             "metric": "DoF/s for ZZZ Assemble + ZZZ Solve; CG-SpMV achieved HBM GB/s vs peak",
