@@ -1137,7 +1137,8 @@ int sell_update(zzz_ctx* ctx, bool structure)
     waves >>= 1;
   // (one wavefront per CU with up to 160 KB of staging was tried for the long rows of P3: the packing got 3 ms
   // faster, but its allocation order made the product 1.3 % slower: a net loss)
-  const bool lds_fits = lds * waves <= 160 * 1024 - 64 && (waves >= 2 || lds <= 64 * 1024);
+  // ZZZ_SELLP_SYNC=1: take the long-row path (count / compact / pack, synchronous) whatever the row lengths (tests)
+  const bool lds_fits = lds * waves <= 160 * 1024 - 64 && (waves >= 2 || lds <= 64 * 1024) && !getenv("ZZZ_SELLP_SYNC");
   if (!lds_fits || (!always && (double)ctx->sp_chunk_bound * 512.0 > 2.2 * full))
   {
     // Synchronous builds (count, scan, read-back, fill): rows too long for the LDS staging of the one-pass packer

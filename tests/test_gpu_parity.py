@@ -1276,6 +1276,75 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
                 os.environ[k] = val
 
 
+def test_affine_chunks_of_the_operator_stream_keep_every_bit():
+    """Chunks whose columns are base + lane in every slot carry no column codes (zzz_sellp.hip).  The small boxes of
+    the tests above have mesh lines shorter than a 64-row slice, so none of their chunks qualifies; a long thin box
+    (lines of 201 vertices) has many.  Same bits as the serial CSR loop, with and without the affine form, and the
+    affine stream is the smaller one."""
+    zo.set_num_threads(1)
+    rng = np.random.default_rng(77)
+    P = zzz.Part("poisson", 1, 200, 3, 3)
+    old = os.environ.get("ZZZ_SELLP_AFFINE")
+    res = {}
+    try:
+        for aff in ("0", "1"):
+            os.environ["ZZZ_SELLP_AFFINE"] = aff
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                assert c.spmv_operator_form() == 1
+                rp, cl, v = c.csr_download()
+                xv = rng.standard_normal(P.n_owned)
+                y = c.spmv(xv)
+                np.testing.assert_array_equal(y, zo.spmv(rp.astype(np.int64), cl, v, xv))
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                res[aff] = (c.spmv_info_raw()[6], it, c.vec_download(zzz.VEC_U))
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_SELLP_AFFINE", None)
+        else:
+            os.environ["ZZZ_SELLP_AFFINE"] = old
+    assert res["1"][0] < res["0"][0], (res["1"][0], res["0"][0])  # fewer bytes per product
+    assert res["1"][1] == res["0"][1]
+    np.testing.assert_array_equal(res["1"][2], res["0"][2])  # the solve does not see the encoding
+
+
+def test_long_row_packing_path_keeps_every_bit():
+    """Rows too long for the one-pass LDS packer (P3 at scale) are packed through a compacted copy (k_sp_count_sweep,
+    k_sp_compact, k_sp_fill_c).  ZZZ_SELLP_SYNC=1 sends small matrices down that path: same bits as the serial CSR
+    loop, also with whole zero rows and scattered zeros (values uploaded by the caller)."""
+    zo.set_num_threads(1)
+    rng = np.random.default_rng(78)
+    old = {k: os.environ.get(k) for k in ("ZZZ_SELLP", "ZZZ_SELLP_SYNC")}
+    os.environ["ZZZ_SELLP"], os.environ["ZZZ_SELLP_SYNC"] = "2", "1"
+    try:
+        for problem, order, dims in (("poisson", 3, (4, 5, 3)), ("elasticity", 2, (3, 4, 3)), ("elasticity", 3, (2, 3, 2)),
+                                     ("poisson", 1, (70, 3, 3))):
+            P = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                assert c.spmv_operator_form() == 1
+                rp, cl, v = c.csr_download()
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+                v2 = v.copy()
+                for r in rng.choice(rp.size - 1, size=max(1, (rp.size - 1) // 9), replace=False):
+                    v2[rp[r]:rp[r + 1]] = 0.0
+                v2[rng.random(v2.size) < 0.4] = 0.0
+                c.csr_upload_values(v2)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v2, xv))
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
 def test_fused_direction_kernel_keeps_every_bit():
     """Two kernels per iteration (the product fused with p = z + b p and the pending x update, chosen for
     cache-resident loops) against the three-kernel form: the same operations on the same operands, so the
