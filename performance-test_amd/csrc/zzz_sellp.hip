@@ -188,6 +188,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
   const bool affine_ok = (tail_codes & 2) == 0; // knob ZZZ_SELLP_AFFINE=0 sets bit 1
   int base[8];
   bool over8 = false, over16 = false, affine = true;
+  unsigned has_mask = 0; // bit e: this lane has an entry in slot e
 #pragma unroll
   for (int e = 0; e < 8; ++e)
   {
@@ -195,6 +196,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
     if (e < w) // wave-uniform
     {
       const bool has = cl[e] != INT_MAX;
+      has_mask |= has ? 1u << e : 0u;
       gh |= has && cl[e] >= nrows;
       int mn = wave_min_i(cl[e]);
       if (mn == INT_MAX)
@@ -210,6 +212,49 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
       cl[e] = 0;
   }
   const bool all_affine = __all(affine) && affine_ok;
+  // Periodic chunks (block size 3, natural row order; flags bit 2, bits 8-9 = first row mod 3): rows 3 i + k reach
+  // columns T[slot][k] + 3 i', i' = i - i0 -- three rows of a vertex share a block-column set, consecutive vertices
+  // consecutive block columns.  25 scalars instead of 512 B - 2 KB of codes.
+  bool periodic = false;
+  int T[8][3];
+  int q3 = 0;
+  if (!all_affine && (tail_codes & 4))
+  {
+    const int l = lane + ((tail_codes >> 8) & 3);
+    const int q = l / 3, k = l - 3 * q;
+    q3 = 3 * q;
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk)
+        T[e][kk] = 0;
+      if (e < w)
+      {
+        // (padding lanes carry cl == base here: they are free, so only lanes with an entry vote)
+        const bool has = ((has_mask >> e) & 1u) != 0;
+        const int d = cl[e] - q3;
+        // T[e][kk] = the (common) value of d over the lanes of class kk that have an entry; a class without entries takes
+        // another class's value: any column a lane reads anyway
+        int any_t = INT_MAX;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+        {
+          T[e][kk] = wave_min_i((has && k == kk) ? d : INT_MAX);
+          any_t = min(any_t, T[e][kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+          if (T[e][kk] == INT_MAX)
+            T[e][kk] = any_t;
+        const int mine = k == 0 ? T[e][0] : (k == 1 ? T[e][1] : T[e][2]);
+        ok &= !has || d == mine;
+        ok &= mine + q3 >= 0 && mine + q3 < nrows; // padding lanes gather too
+      }
+    }
+    periodic = __all(ok);
+  }
   const int range = __any(over16) ? 65536 : (__any(over8) ? 256 : 0);
   double* sp = svals + (size_t)c * 512;
 #pragma unroll
@@ -226,7 +271,22 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
       sp[128 * j + lane] = v[2 * j]; // odd width: the last entry alone, 8 B per lane
   }
   int mode = 0, code_bytes;
-  if (all_affine)
+  if (periodic)
+  {
+    // the chunk's code block holds the 24 column bases T[slot][row mod 3] and the phase (scalar loads in the product)
+    int32_t* tp = reinterpret_cast<int32_t*>(c16 + (size_t)c * 512);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk)
+        if (lane == 3 * e + kk)
+          tp[3 * e + kk] = T[e][kk];
+    if (lane == 24)
+      tp[24] = (tail_codes >> 8) & 3;
+    mode = (int)0xC0000000;
+    code_bytes = 128;
+  }
+  else if (all_affine)
   {
     // every slot: column = base + lane.  No codes at all (an interior P1 slice away from the ends of a mesh line:
     // 56 instead of 64 B per row)
@@ -303,6 +363,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
     const int64_t end = r >= 0 ? rowptr[r + 1] : 0;
     const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    // periodic chunks (flags bit 2) need the slice's first row mod 3 (bits 8-9); not for permuted rows
+    const int tc = PERM ? (tail_codes & ~4) : ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes);
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
@@ -325,7 +387,7 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
           }
         }
       }
-      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tail_codes);
+      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc);
     }
     if (ghost_flag)
     {
@@ -429,6 +491,7 @@ __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ c
     const int64_t base = r >= 0 ? crow[r] : 0;
     const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    const int tc = PERM ? (tail_codes & ~4) : ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes);
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
@@ -451,7 +514,7 @@ __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ c
           v[e] = 0.0;
           cl[e] = INT_MAX;
         }
-      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tail_codes);
+      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc);
     }
     if (ghost_flag)
     {
@@ -596,6 +659,7 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
     if (lane == 0)
       desc[s] = make_int2(c0, nch | (wl << 24));
     kept_w += (unsigned long long)running;
+    const int tc = (tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes;
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
@@ -609,7 +673,7 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
         v[e] = has ? lv[cstart + q] : 0.0;
         cl[e] = has ? lc[cstart + q] : INT_MAX;
       }
-      bytes_w += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tail_codes);
+      bytes_w += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc);
     }
     if (ghost_flag)
     {
@@ -674,7 +738,27 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
   }
   const int32_t* __restrict__ mp = meta + (size_t)c * 8;
   const int m0 = mp[0];
-  if (m0 < 0)
+  if (m0 < 0 && (m0 & 0x40000000))
+  {
+    // periodic chunk (block size 3): column = T[slot][row mod 3] + 3 (row div 3 - first), nothing per lane to load
+    const int32_t* __restrict__ tp = reinterpret_cast<const int32_t*>(c16 + (size_t)c * 512);
+    // the 25 words are wave-uniform: pinned into scalar registers, the selects below stay register selects.  (Left to
+    // itself the compiler folds them into a per-lane ADDRESS select, tp + 3 e + k, behind divergent branches -- and
+    // that code decoded slot 0 of the third class wrongly when the chunk sits inside the chunk loop.)
+    int t[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i)
+    {
+      t[i] = tp[i];
+      asm volatile("" : "+s"(t[i]));
+    }
+    const int l = lane + t[24];
+    const int q = l / 3, k = l - 3 * q, q3 = 3 * q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      cl[e] = (k == 0 ? t[3 * e] : (k == 1 ? t[3 * e + 1] : t[3 * e + 2])) + q3;
+  }
+  else if (m0 < 0)
   {
     const int4v* __restrict__ cp = reinterpret_cast<const int4v*>(c32 + (size_t)c * 512) + 2 * lane;
     const int4v q0 = sp_load<NT>(cp), q1 = sp_load<NT>(cp + 1);
@@ -1040,20 +1124,20 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
     if (sorted)
       hipLaunchKernelGGL(k_sp_fill_c<true>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
+                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
     else
       hipLaunchKernelGGL(k_sp_fill_c<false>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, (const int32_t*)nullptr, desc, ctx->sp_vals.p,
-                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
+                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
   }
   else if (sorted)
     hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
   else
     hipLaunchKernelGGL(k_sp_fill<false>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, (const int32_t*)nullptr, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail);
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
   ZZZ_HIP(ctx, hipGetLastError());
   unsigned long long hb = 0;
   ZZZ_HIP(ctx, hipMemcpyAsync(&hb, bytes, sizeof(hb), hipMemcpyDeviceToHost, s));
@@ -1191,7 +1275,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
   const int cap = (ctx->sp_max_range + 63) & ~63;
   hipLaunchKernelGGL(k_sp_pack, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p, ctx->cols.p,
                      ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p, reinterpret_cast<int2*>(ctx->sp_desc.p),
-                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, ctx->sellp_tail);
+                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
   ZZZ_HIP(ctx, hipGetLastError());
   if (!ctx->sp_event)
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));

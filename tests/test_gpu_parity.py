@@ -1276,19 +1276,21 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
                 os.environ[k] = val
 
 
-def test_affine_chunks_of_the_operator_stream_keep_every_bit():
-    """Chunks whose columns are base + lane in every slot carry no column codes (zzz_sellp.hip).  The small boxes of
-    the tests above have mesh lines shorter than a 64-row slice, so none of their chunks qualifies; a long thin box
-    (lines of 201 vertices) has many.  Same bits as the serial CSR loop, with and without the affine form, and the
-    affine stream is the smaller one."""
+@pytest.mark.parametrize("problem,dims,knob", [("poisson", (200, 3, 3), "ZZZ_SELLP_AFFINE"),
+                                               ("elasticity", (100, 3, 3), "ZZZ_SELLP_PERIODIC")])
+def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, knob):
+    """Chunks whose columns are base + lane in every slot (scalar rows), or T[slot][row mod 3] + 3 (row div 3) (block
+    size 3), carry no column codes (zzz_sellp.hip).  The small boxes of the tests above have mesh lines shorter than a
+    64-row slice, so none of their chunks qualifies; a long thin box has many.  Same bits as the serial CSR loop with and
+    without the code-free forms, and the code-free stream is the smaller one."""
     zo.set_num_threads(1)
     rng = np.random.default_rng(77)
-    P = zzz.Part("poisson", 1, 200, 3, 3)
-    old = os.environ.get("ZZZ_SELLP_AFFINE")
+    P = zzz.Part(problem, 1, *dims)
+    old = os.environ.get(knob)
     res = {}
     try:
-        for aff in ("0", "1"):
-            os.environ["ZZZ_SELLP_AFFINE"] = aff
+        for on in ("0", "1"):
+            os.environ[knob] = on
             with zzz.Context(0) as c:
                 c.upload_part(P)
                 c.pattern_build()
@@ -1296,16 +1298,16 @@ def test_affine_chunks_of_the_operator_stream_keep_every_bit():
                 c.assemble_vector(P.form)
                 assert c.spmv_operator_form() == 1
                 rp, cl, v = c.csr_download()
-                xv = rng.standard_normal(P.n_owned)
+                xv = rng.standard_normal(P.n_owned * P.bs)
                 y = c.spmv(xv)
                 np.testing.assert_array_equal(y, zo.spmv(rp.astype(np.int64), cl, v, xv))
                 it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
-                res[aff] = (c.spmv_info_raw()[6], it, c.vec_download(zzz.VEC_U))
+                res[on] = (c.spmv_info_raw()[6], it, c.vec_download(zzz.VEC_U))
     finally:
         if old is None:
-            os.environ.pop("ZZZ_SELLP_AFFINE", None)
+            os.environ.pop(knob, None)
         else:
-            os.environ["ZZZ_SELLP_AFFINE"] = old
+            os.environ[knob] = old
     assert res["1"][0] < res["0"][0], (res["1"][0], res["0"][0])  # fewer bytes per product
     assert res["1"][1] == res["0"][1]
     np.testing.assert_array_equal(res["1"][2], res["0"][2])  # the solve does not see the encoding
