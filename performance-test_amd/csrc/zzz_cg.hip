@@ -30,6 +30,11 @@ namespace zzz
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr int VB = 256;        // threads per workgroup of the vector kernels
 constexpr int VGRID_MAX = 2048; // 8 workgroups per CU
+// Product launches timed with HIP events when zzz_solver_opts.profile is set: every PROF_STRIDE-th iteration.  An event
+// record between two kernels costs ~3.5 us of idle GPU (rocprofv3 timeline at 1.25 M rows: 4.1-4.4 us gaps on both sides
+// of the product against 0.5-0.8 us elsewhere), i.e. 7 us per timed iteration -- 13 % of a 52-us iteration when every
+// launch was timed.
+constexpr int PROF_STRIDE = 8;
 
 // Non-temporal access for data touched once per iteration pays only when the working set of the loop exceeds the
 // 256 MiB Infinity Cache; a loop that fits (the 8-GPU per-rank size: ~100 MB of operator stream + 60 MB of vectors)
@@ -574,7 +579,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
                          ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
     int np = 0;
-    if (nprof < max_prof)
+    const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
+    if (timed)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
     {
       int rc = fused ? launch_sellp_dir(ctx, ctx->z.p, pbuf[it & 1], pbuf[(it + 1) & 1], ctx->u.p, ctx->w.p, ctx->part_a.p, &np,
@@ -583,7 +589,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       if (rc)
         return rc;
     }
-    if (nprof < max_prof)
+    if (timed)
     {
       (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
       ++nprof;
@@ -642,7 +648,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 
   ctx->prof_spmv_ms = 0.0;
   ctx->prof_spmv_n = 0;
-  const int used = nprof < its ? nprof : its; // launches past convergence return at once: not counted
+  const int used = std::min(nprof, (its + PROF_STRIDE - 1) / PROF_STRIDE); // launches past convergence return at once: not counted
   for (int i = 0; i < used; ++i)
   {
     float ms = 0;
@@ -752,14 +758,15 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
     hipLaunchKernelGGL(kern_sr_update, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p,
                        it, P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p,
                        ctx->r.p, n, 0);
-    if (nprof < max_prof)
+    const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
+    if (timed)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
     {
       int rc = apply();
       if (rc)
         return rc;
     }
-    if (nprof < max_prof)
+    if (timed)
     {
       (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
       ++nprof;
@@ -802,7 +809,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   ZZZ_HIP(ctx, hipMemcpy(ctx->history.data(), ctx->dp_hist.p, sizeof(double) * ((size_t)its + 1), hipMemcpyDeviceToHost));
   ctx->prof_spmv_ms = 0.0;
   ctx->prof_spmv_n = 0;
-  const int used = nprof < its ? nprof : its;
+  const int used = std::min(nprof, (its + PROF_STRIDE - 1) / PROF_STRIDE);
   for (int i = 0; i < used; ++i)
   {
     float ms = 0;
