@@ -141,6 +141,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   if (const char* e = getenv("ZZZ_SELLP_AFFINE")) // 0: no code-free chunks (column = slot base + lane); A/B knob
     if (atoi(e) == 0)
       ctx->sellp_tail |= 2;
+  if (const char* e = getenv("ZZZ_SELLP_ALIGN")) // 0: entries always placed by rank (no aligned one-chunk slices); A/B knob
+    ctx->sellp_align = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_PERIODIC")) // 0: no periodic chunks for block size 3 (elasticity); A/B knob
     ctx->sellp_periodic = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SPMV_LPR")) // lanes per row of the SpMV row phase: 1, 2, 4, 8, 16

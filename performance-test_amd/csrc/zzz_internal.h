@@ -175,6 +175,7 @@ struct zzz_ctx
   zzz::DevBuf<uint8_t> sp_wlast; // per slice: entries of the longest row in its last chunk (1..8)
   bool sp_sorted = false;    // rows ordered by length inside windows (SELL-C-sigma)
   int sellp_mode = 1;        // ZZZ_SELLP: 0 off, 1 automatic, 2 natural row order always, 3 sorted rows always
+  bool sellp_align = true; // scalar rows, one-chunk slices: entries placed by column so that short boundary rows fit the affine form
   bool sellp_periodic = true; // block size 3: chunks whose columns are T[slot][row mod 3] + 3 (row div 3) carry no codes
   int sellp_tail = 1;        // bit 0: 8-bit codes of a narrow chunk go into the free tail of its value block; bit 1: no affine chunks
   bool sellp_drop = true;    // ZZZ_SELLP_DROP=0: keep the exact zeros of the pattern in the stream

@@ -181,11 +181,69 @@ __global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict_
 // (7 entries) streams 3.5 KiB of values instead of 4.  Codes are as narrow as the chunk's slot ranges allow: 8-bit
 // (consecutive rows reach consecutive columns: the usual case), 16-bit, or plain int32 columns.
 // meta[c][0] carries the mode: bit 31 int32 columns, bit 30 8-bit codes.  Returns the bytes a product reads.
-__device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8], int lane, int nrows, bool& gh,
+__device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl)[8], int lane, int nrows, bool& gh,
                                  double* __restrict__ svals, uint16_t* __restrict__ c16, int32_t* __restrict__ c32,
                                  int32_t* __restrict__ meta, int tail_codes)
 {
   const bool affine_ok = (tail_codes & 2) == 0; // knob ZZZ_SELLP_AFFINE=0 sets bit 1
+  double v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    v[e] = v_in[e];
+  // Aligned slices (flags bit 3: the slice's only chunk, scalar rows in natural order).  A slice that contains the end
+  // of a mesh line has a few short rows (boundary vertices) whose entries, placed by rank, fall into other slots than
+  // the same columns of their neighbours -- and the whole chunk needs codes.  Placed by COLUMN instead, into the slot
+  // where the longest row of the slice has column - row = the same offset, every row fits the affine form
+  // column = delta[slot] + lane, with holes (value +0.0) where a row has no such entry.  A row is still summed in
+  // ascending column order; a hole adds +0.0 * x.
+  bool aligned = false;
+  int delta[8];
+  if ((tail_codes & 8) && affine_ok)
+  {
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      cnt += (e < w && cl[e] != INT_MAX) ? 1 : 0;
+    const unsigned long long full = __ballot(cnt == w); // w = the longest row's entries: never empty
+    const int ref = __builtin_amdgcn_readfirstlane(__builtin_ctzll(full));
+    bool okp = true; // uniform part: every lane's predicted column is a valid one
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+      delta[e] = e < w ? __builtin_amdgcn_readlane(cl[e], ref) - ref : 0;
+      okp &= e >= w || (delta[e] >= 0 && delta[e] + 63 < nrows);
+    }
+    double nv[8];
+    int nc[8], placed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+      nv[e] = 0.0;
+      nc[e] = INT_MAX;
+      if (e < w)
+      {
+        const int target = delta[e] + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < w && cl[q] == target)
+          {
+            nv[e] = v[q];
+            nc[e] = target;
+            ++placed;
+          }
+      }
+    }
+    aligned = okp && __all(placed == cnt);
+    if (aligned)
+    {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        v[e] = nv[e];
+        cl[e] = nc[e];
+      }
+    }
+  }
   int base[8];
   bool over8 = false, over16 = false, affine = true;
   unsigned has_mask = 0; // bit e: this lane has an entry in slot e
@@ -211,7 +269,14 @@ __device__ inline int emit_chunk(int c, int w, const double (&v)[8], int (&cl)[8
     else
       cl[e] = 0;
   }
-  const bool all_affine = __all(affine) && affine_ok;
+  bool all_affine = __all(affine) && affine_ok;
+  if (aligned)
+  {
+    all_affine = true;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      base[e] = delta[e];
+  }
   // Periodic chunks (block size 3, natural row order; flags bit 2, bits 8-9 = first row mod 3): rows 3 i + k reach
   // columns T[slot][k] + 3 i', i' = i - i0 -- three rows of a vertex share a block-column set, consecutive vertices
   // consecutive block columns.  25 scalars instead of 512 B - 2 KB of codes.
@@ -364,7 +429,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
     const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     // periodic chunks (flags bit 2) need the slice's first row mod 3 (bits 8-9); not for permuted rows
-    const int tc = PERM ? (tail_codes & ~4) : ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes);
+    // per-slice flags: bit 3 = the slice's only chunk (flags bit 4 allows the aligned placement); bits 8-9 = first row mod 3
+    const int tc = PERM ? (tail_codes & ~(4 | 16)) : (((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes) | (((tail_codes & 16) && nch == 1) ? 8 : 0));
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
@@ -491,7 +557,8 @@ __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ c
     const int64_t base = r >= 0 ? crow[r] : 0;
     const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
-    const int tc = PERM ? (tail_codes & ~4) : ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes);
+    // per-slice flags: bit 3 = the slice's only chunk (flags bit 4 allows the aligned placement); bits 8-9 = first row mod 3
+    const int tc = PERM ? (tail_codes & ~(4 | 16)) : (((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes) | (((tail_codes & 16) && nch == 1) ? 8 : 0));
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
@@ -659,7 +726,7 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
     if (lane == 0)
       desc[s] = make_int2(c0, nch | (wl << 24));
     kept_w += (unsigned long long)running;
-    const int tc = (tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes;
+    const int tc = ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes) | (((tail_codes & 16) && nch == 1) ? 8 : 0);
     bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
@@ -1124,20 +1191,20 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
     if (sorted)
       hipLaunchKernelGGL(k_sp_fill_c<true>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
+                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
     else
       hipLaunchKernelGGL(k_sp_fill_c<false>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, (const int32_t*)nullptr, desc, ctx->sp_vals.p,
-                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
+                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
   }
   else if (sorted)
     hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
   else
     hipLaunchKernelGGL(k_sp_fill<false>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, (const int32_t*)nullptr, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
   ZZZ_HIP(ctx, hipGetLastError());
   unsigned long long hb = 0;
   ZZZ_HIP(ctx, hipMemcpyAsync(&hb, bytes, sizeof(hb), hipMemcpyDeviceToHost, s));
@@ -1275,7 +1342,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
   const int cap = (ctx->sp_max_range + 63) & ~63;
   hipLaunchKernelGGL(k_sp_pack, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p, ctx->cols.p,
                      ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p, reinterpret_cast<int2*>(ctx->sp_desc.p),
-                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0));
+                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
   ZZZ_HIP(ctx, hipGetLastError());
   if (!ctx->sp_event)
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));

@@ -1277,10 +1277,13 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
 
 
 @pytest.mark.parametrize("problem,dims,knob", [("poisson", (200, 3, 3), "ZZZ_SELLP_AFFINE"),
+                                               ("poisson", (150, 4, 3), "ZZZ_SELLP_ALIGN"),
                                                ("elasticity", (100, 3, 3), "ZZZ_SELLP_PERIODIC")])
 def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, knob):
     """Chunks whose columns are base + lane in every slot (scalar rows), or T[slot][row mod 3] + 3 (row div 3) (block
-    size 3), carry no column codes (zzz_sellp.hip).  The small boxes of the tests above have mesh lines shorter than a
+    size 3), carry no column codes (zzz_sellp.hip); with ZZZ_SELLP_ALIGN the entries of a one-chunk slice are placed by
+    column, so that the short boundary rows at the end of a mesh line fit that form too (holes of value +0.0 inside a
+    row).  The small boxes of the tests above have mesh lines shorter than a
     64-row slice, so none of their chunks qualifies; a long thin box has many.  Same bits as the serial CSR loop with and
     without the code-free forms, and the code-free stream is the smaller one."""
     zo.set_num_threads(1)
