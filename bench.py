@@ -87,7 +87,7 @@ def pmc_traffic(nrows, nnz, streamed=None):
                 continue
             k = d["kernels"]["spmv"]
             # ... and of the same operator stream: a profile taken before the stream's format changed does not count
-            if streamed is not None and k.get("bytes_streamed") not in (None, streamed):
+            if streamed is not None and k.get("bytes_streamed") != streamed:
                 continue
             best = (2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024, os.path.relpath(path, ROOT))
         except Exception:
