@@ -1289,9 +1289,12 @@ def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, k
     zo.set_num_threads(1)
     rng = np.random.default_rng(77)
     P = zzz.Part(problem, 1, *dims)
-    old = os.environ.get(knob)
+    knobs = ("ZZZ_SELLP_AFFINE", "ZZZ_SELLP_ALIGN", "ZZZ_SELLP_PERIODIC")
+    saved = {k: os.environ.get(k) for k in knobs}
     res = {}
     try:
+        for k in knobs:
+            os.environ[k] = "1"  # the form under test builds on the others being at their defaults
         for on in ("0", "1"):
             os.environ[knob] = on
             with zzz.Context(0) as c:
@@ -1307,10 +1310,11 @@ def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, k
                 it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
                 res[on] = (c.spmv_info_raw()[6], it, c.vec_download(zzz.VEC_U))
     finally:
-        if old is None:
-            os.environ.pop(knob, None)
-        else:
-            os.environ[knob] = old
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
     assert res["1"][0] < res["0"][0], (res["1"][0], res["0"][0])  # fewer bytes per product
     assert res["1"][1] == res["0"][1]
     np.testing.assert_array_equal(res["1"][2], res["0"][2])  # the solve does not see the encoding
