@@ -37,12 +37,13 @@ __global__ void k_cell_of(int64_t n, int nd, int32_t* __restrict__ out)
     out[k] = (int32_t)(k / nd);
 }
 
-// onesweep geometry of the adjacency sort: rocPRIM's gfx950 default for (int, int) is 1024 threads x 16 items; with 8
-// items per thread the 237 M-pair sort of the 10 M-dof pattern takes 4.70 instead of 5.09 ms (tools/micro/sort_cfg.hip:
-// 4, 6, 10, 12, 16 items and 256/512 threads are all slower; wider digits do not fit the LDS)
+// onesweep geometry of the adjacency sort: rocPRIM's gfx950 default for (int, int) is 1024 threads x 16 items for both
+// kernels; with 8 items per thread in the SORT kernel (the histogram kernel keeps 16) the 237 M-pair sort of the 10 M-dof
+// pattern takes 4.70 instead of 5.2 ms (tools/micro/sort_cfg.hip: 4, 6, 10, 12, 16 items and 256/512 threads are slower
+// for the sort kernel, 8 items 0.28 ms slower for the histogram kernel; wider digits do not fit the LDS)
 using AdjSortConfig
     = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                 rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8,
+                                 rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 8>, 8,
                                                                      rocprim::block_radix_rank_algorithm::match>>;
 
 // adj_off[d] = first position of key d in the sorted keys (d = 0 .. nb; a dof without cells gets an empty range)

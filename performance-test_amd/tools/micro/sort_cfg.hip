@@ -55,6 +55,10 @@ using rocprim::block_radix_rank_algorithm;
 template <int BS, int IPT, int BITS, block_radix_rank_algorithm A>
 using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                        rocprim::radix_sort_onesweep_config<kernel_config<BS, IPT>, kernel_config<BS, IPT>, BITS, A>>;
+template <int HB, int HI>
+using CfgH = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                        rocprim::radix_sort_onesweep_config<kernel_config<HB, HI>, kernel_config<1024, 8>, 8,
+                                                                            block_radix_rank_algorithm::match>>;
 
 int main()
 {
@@ -68,12 +72,11 @@ int main()
   hipLaunchKernelGGL(k_keys, dim3(8192), dim3(256), 0, 0, kin, vin, (long)n, nb);
   CK(hipDeviceSynchronize());
   run<rocprim::default_config>("default (1024x16, 8 bits, match)", kin, kout, vin, vout, n, 24);
-  run<Cfg<1024, 4, 8, block_radix_rank_algorithm::match>>("1024x4 8 match", kin, kout, vin, vout, n, 24);
-  run<Cfg<1024, 6, 8, block_radix_rank_algorithm::match>>("1024x6 8 match", kin, kout, vin, vout, n, 24);
-  run<Cfg<1024, 8, 8, block_radix_rank_algorithm::match>>("1024x8 8 match", kin, kout, vin, vout, n, 24);
-  run<Cfg<1024, 10, 8, block_radix_rank_algorithm::match>>("1024x10 8 match", kin, kout, vin, vout, n, 24);
-  run<Cfg<512, 8, 8, block_radix_rank_algorithm::match>>("512x8 8 match", kin, kout, vin, vout, n, 24);
-  run<Cfg<512, 12, 8, block_radix_rank_algorithm::match>>("512x12 8 match", kin, kout, vin, vout, n, 24);
-  run<Cfg<512, 6, 8, block_radix_rank_algorithm::match>>("512x6 8 match", kin, kout, vin, vout, n, 24);
+  run<Cfg<1024, 8, 8, block_radix_rank_algorithm::match>>("H 1024x8, S 1024x8", kin, kout, vin, vout, n, 24);
+  run<CfgH<1024, 16>>("H 1024x16, S 1024x8", kin, kout, vin, vout, n, 24);
+  run<CfgH<1024, 24>>("H 1024x24, S 1024x8", kin, kout, vin, vout, n, 24);
+  run<CfgH<1024, 32>>("H 1024x32, S 1024x8", kin, kout, vin, vout, n, 24);
+  run<CfgH<1024, 12>>("H 1024x12, S 1024x8", kin, kout, vin, vout, n, 24);
+  run<CfgH<768, 16>>("H 768x16, S 1024x8", kin, kout, vin, vout, n, 24);
   return 0;
 }
