@@ -272,6 +272,7 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
+  pattern_reserve(ctx);
   return ensure_p1_coords(ctx); // function-space data (dof coordinates), not assembly work
 }
 

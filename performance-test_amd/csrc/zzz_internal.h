@@ -241,6 +241,7 @@ void set_global_error(const char* msg);
 int alloc_problem_vectors(zzz_ctx* ctx);
 // pattern (zzz_pattern.hip)
 int pattern_build_device(zzz_ctx* ctx, bool* fallback);
+void pattern_reserve(zzz_ctx* ctx); // scratch sized by the dofmap, reserved at upload time
 int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
 int ensure_cols16(zzz_ctx* ctx); // encodes the 16-bit column stream of the CSR tile kernel on first use
 int asm_tile_nnz(const zzz_ctx* ctx); // nonzeros an assembly tile may hold (LDS budget of the matrix kernels)

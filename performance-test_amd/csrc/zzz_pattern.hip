@@ -754,6 +754,49 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   return ZZZ_OK;
 }
 
+// Scratch of the pattern build whose size follows from the dofmap alone (sort buffers, the entry -> cell map, the
+// staging area): reserved when the dofmap arrives, so that a one-shot `ZZZ Assemble` (the reference driver runs every
+// phase once) does not pay ~18 ms of multi-GB hipMalloc calls inside its timer.  Failure to reserve is not an error: the
+// build allocates what it needs.
+void pattern_reserve(zzz_ctx* ctx)
+{
+  if (ctx->ncells <= 0 || ctx->nd <= 0 || ctx->n_owned <= 0)
+    return;
+  const int nd = ctx->nd;
+  const int64_t N = ctx->ncells * nd, nb = ctx->n_owned;
+  if (N > INT32_MAX - 8)
+    return;
+  hipStream_t s = ctx->stream;
+  if (ctx->scr_keys_out.alloc((size_t)N) != hipSuccess || ctx->adj_cells.alloc((size_t)N) != hipSuccess
+      || ctx->scr_cnt.alloc((size_t)nb + 1) != hipSuccess || ctx->scr_bptr.alloc((size_t)nb + 1) != hipSuccess
+      || ctx->adj_off.alloc((size_t)nb + 1) != hipSuccess || ctx->scr_vals_in.alloc((size_t)N) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  if (ctx->scr_cell_of_n != N || ctx->scr_cell_of_nd != nd)
+  {
+    hipLaunchKernelGGL(k_cell_of, dim3(grid_for(N)), dim3(256), 0, s, N, nd, ctx->scr_vals_in.p);
+    ctx->scr_cell_of_n = N;
+    ctx->scr_cell_of_nd = nd;
+  }
+  int end_bit = 1;
+  while ((1ll << end_bit) <= (long long)(ctx->n_owned + ctx->n_ghost))
+    ++end_bit;
+  size_t tb = 0, tb2 = 0;
+  if (rocprim::radix_sort_pairs<AdjSortConfig>(nullptr, tb, ctx->cell_dofs.p, ctx->scr_keys_out.p, ctx->scr_vals_in.p,
+                                               ctx->adj_cells.p, (size_t)N, 0, (unsigned)end_bit, s)
+          == hipSuccess
+      && rocprim::exclusive_scan(nullptr, tb2, ctx->scr_cnt.p, ctx->scr_bptr.p, (int64_t)0, (size_t)nb + 1,
+                                 rocprim::plus<int64_t>(), s)
+             == hipSuccess)
+    (void)ctx->scr_tmp.alloc(tb > tb2 ? tb : tb2);
+  const int64_t nstage = N * nd;
+  if (nstage < ((int64_t)3 << 30))
+    (void)ctx->scr_stage.alloc((size_t)nstage);
+  (void)hipGetLastError();
+}
+
 // returns ZZZ_OK, or ZZZ_ERR_LIMIT with *fallback = true when a row has more candidates than the
 // device kernel holds (the caller then uses the host builder)
 int pattern_build_device(zzz_ctx* ctx, bool* fallback)
