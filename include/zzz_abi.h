@@ -48,7 +48,7 @@ enum
   ZZZ_ERR_RCCL = 3,    /* RCCL error / librccl not loadable */
   ZZZ_ERR_NO_GPU = 4,  /* no usable device: the library has no CPU fallback */
   ZZZ_ERR_LIMIT = 5,   /* size exceeds an int32 index range */
-  ZZZ_ERR_DIVERGED = 6 /* Krylov breakdown (non-finite scalar) */
+  ZZZ_ERR_DIVERGED = 6 /* the solve did not converge AND zzz_solver_opts.error_if_not_converged was set */
 };
 
 /* forms: form_Poisson_{a,L,M}{1,2,3}, form_Elasticity_{a,L}{1,2,3}
@@ -108,12 +108,16 @@ typedef struct
                              * with the recurrences s = A z, w = s + b w, <p,w> by recurrence, so that one
                              * iteration needs ONE fused reduction of (<r,z>, <z,s>, norm) instead of two.
                              * ZZZ_CG_PETSC + ZZZ_OP_CSR only. */
-  int32_t reserved; /* keep 0 */
+  int32_t error_if_not_converged; /* PETSc's -ksp_error_if_not_converged: != 0 makes a solve that ends with a negative
+                                   * KSPConvergedReason (DTOL, NaN/Inf, max_it) fail with ZZZ_ERR_DIVERGED.  0 (the
+                                   * default, as in PETSc): the solve returns ZZZ_OK with its iteration count, like
+                                   * solver.solve() in solver_function (src/poisson_problem.cpp:172-178), and the
+                                   * reason is read from zzz_cg_info */
   double rtol;      /* -ksp_rtol / rtol */
   double atol;      /* -ksp_atol (PETSc default 1e-50); unused by ZZZ_CG_CGH */
   double dtol;      /* -ksp_divtol: KSPConvergedDefault stops with KSP_DIVERGED_DTOL once the norm reaches
-                     * dtol x the initial norm (the solve then fails with ZZZ_ERR_DIVERGED, where the reference's
-                     * KSPSolve returns a negative reason); <= 0 selects PETSc's default 1e4 (KSPCreate sets
+                     * dtol x the initial norm (zzz_cg_info then reports reason -4, as KSPGetConvergedReason would);
+                     * <= 0 selects PETSc's default 1e4 (KSPCreate sets
                      * divtol = 1.e4); unused by ZZZ_CG_CGH (src/cg.h has no such test) */
 } zzz_solver_opts;
 
@@ -261,7 +265,9 @@ int zzz_cg_history(zzz_ctx* ctx, int n, double* out);
 
 /* About the last zzz_cg_solve: info[0] = 1 when the iteration ran as two kernels (product fused with the
  * direction update p = z + b p, x += a p: the A/B variant ZZZ_CG_FUSED=2), 0 for the three-kernel form;
- * info[1] = its iteration count.  Same iterates, bit for bit, either way. */
+ * info[1] = its iteration count (same iterates, bit for bit, either way); info[2] = how it ended, in
+ * KSPConvergedReason's numbering: 2 KSP_CONVERGED_RTOL, 3 KSP_CONVERGED_ATOL, -3 KSP_DIVERGED_ITS (max_it / kmax
+ * reached), -4 KSP_DIVERGED_DTOL, -9 KSP_DIVERGED_NANORINF. */
 int zzz_cg_info(zzz_ctx* ctx, int64_t info[4]);
 
 /* Average duration (ms) and count of the SpMV launches event-timed during the last

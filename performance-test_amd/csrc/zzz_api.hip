@@ -747,8 +747,12 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   ZZZ_ENTER(ctx);
   if (!info || !ctx->have_pattern)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_info: no pattern");
-  if (int rc = ensure_cols16(ctx)) // the packed column stream of the tile kernel is encoded on first use
-    return rc;
+  // the packed column stream of the tile kernel is encoded on first use OF THAT KERNEL: a matrix whose product runs on
+  // the operator stream never pays for it (several hundred MB at the c4 / c5_rank sizes); info[0..2] then describe a
+  // tile kernel that was never prepared: 0 / the configured offset bits / every tile on int32 columns
+  if (!sellp_active(ctx))
+    if (int rc = ensure_cols16(ctx))
+      return rc;
   info[0] = ctx->have_cols16 ? 1 : 0;
   info[1] = ctx->cols16_offb;
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
@@ -766,7 +770,8 @@ int zzz_cg_info(zzz_ctx* ctx, int64_t info[4])
     return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_info: bad arguments");
   info[0] = ctx->last_solve_fused ? 1 : 0;
   info[1] = ctx->last_iters;
-  info[2] = info[3] = 0;
+  info[2] = ctx->last_reason;
+  info[3] = 0;
   return ZZZ_OK;
 }
 

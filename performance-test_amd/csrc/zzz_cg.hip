@@ -459,6 +459,35 @@ int vec_norm_local(zzz_ctx* ctx, const double* v, int64_t n, double* out)
 
 static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);
 
+// How the solve ended, in KSPConvergedReason's numbering [EXT: petscksp.h]: the reference's solver_function returns
+// solver.solve()'s iteration count whatever the reason (src/poisson_problem.cpp:172-178) and the driver prints its summary
+// and timings all the same, so a diverged solve is NOT an error here either -- unless the caller asks for PETSc's
+// -ksp_error_if_not_converged (zzz_solver_opts.error_if_not_converged).
+static int finish_reason(zzz_ctx* ctx, const zzz_solver_opts* o, const CgState& fin, int its)
+{
+  int reason;
+  if (fin.converged == 1)
+    reason = (o->variant == ZZZ_CG_PETSC && fin.dp < o->atol) ? 3 /* KSP_CONVERGED_ATOL */ : 2 /* KSP_CONVERGED_RTOL */;
+  else if (fin.converged == 2)
+    reason = -9; // KSP_DIVERGED_NANORINF
+  else if (fin.converged == 3)
+    reason = -4; // KSP_DIVERGED_DTOL
+  else
+    reason = -3; // KSP_DIVERGED_ITS (linalg::cg, src/cg.h:58-83, simply returns kmax)
+  ctx->last_reason = reason;
+  if (o->error_if_not_converged && reason < 0)
+  {
+    if (reason == -9)
+      return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_NANORINF: CG broke down, non-finite scalar at iteration %d", its);
+    if (reason == -4)
+      return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_DTOL: norm %g >= divtol x initial norm %g at iteration %d", fin.dp,
+                  fin.dp0, its);
+    return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_ITS: %d iterations without reaching the tolerance (norm %g)", its, fin.dp);
+  }
+  return ZZZ_OK;
+}
+
+
 int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 {
   if (o->single_reduction)
@@ -660,12 +689,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   }
   if (ctx->prof_spmv_n)
     ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
-  if (fin.converged == 2)
-    return fail(ctx, ZZZ_ERR_DIVERGED, "CG broke down: non-finite scalar at iteration %d", fin.iters);
-  if (fin.converged == 3)
-    return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_DTOL: norm %g >= divtol x initial norm %g at iteration %d", fin.dp, fin.dp0,
-                fin.iters);
-  return ZZZ_OK;
+  return finish_reason(ctx, o, fin, its);
 }
 
 // -ksp_cg_single_reduction: see k_sr_update.  Two kernels and one reduction point per iteration.
@@ -821,11 +845,6 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   }
   if (ctx->prof_spmv_n)
     ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
-  if (fin.converged == 2)
-    return fail(ctx, ZZZ_ERR_DIVERGED, "CG broke down: non-finite scalar at iteration %d", fin.iters);
-  if (fin.converged == 3)
-    return fail(ctx, ZZZ_ERR_DIVERGED, "KSP_DIVERGED_DTOL: norm %g >= divtol x initial norm %g at iteration %d", fin.dp, fin.dp0,
-                fin.iters);
-  return ZZZ_OK;
+  return finish_reason(ctx, o, fin, its);
 }
 } // namespace zzz

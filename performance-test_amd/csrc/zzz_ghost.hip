@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -24,6 +25,40 @@ namespace zzz
 int comm_exchange_bytes(zzz_ctx* ctx, const std::vector<std::vector<char>>& send, std::vector<std::vector<char>>& recv);
 int comm_size(const zzz_ctx* ctx);
 int comm_rank(const zzz_ctx* ctx);
+
+// Collective agreement on a rank-local status: every rank contributes its code (and, when it failed, its message);
+// all ranks return the same verdict -- ZZZ_OK only if every rank was fine, else the first failing rank's code with
+// its message -- so that no rank walks into the next exchange while a peer has already returned an error (with RCCL
+// the peers would block forever in the grouped send/recv, with the local backend until the barrier times out).
+static int agree(zzz_ctx* ctx, int status)
+{
+  const int nr = comm_size(ctx), me = comm_rank(ctx);
+  std::vector<std::vector<char>> out((size_t)nr), in;
+  const std::string msg = status ? ctx->err : std::string();
+  for (int r = 0; r < nr; ++r)
+  {
+    const int32_t st = status;
+    const char* p = reinterpret_cast<const char*>(&st);
+    out[(size_t)r].assign(p, p + sizeof(st));
+    out[(size_t)r].insert(out[(size_t)r].end(), msg.begin(), msg.end());
+  }
+  if (int rc = comm_exchange_bytes(ctx, out, in))
+    return rc; // the transport itself failed: nothing left to agree through
+  for (int r = 0; r < nr; ++r)
+  {
+    int32_t st = 0;
+    if (in[(size_t)r].size() >= sizeof(st))
+      memcpy(&st, in[(size_t)r].data(), sizeof(st));
+    if (st)
+    {
+      if (r == me)
+        return fail(ctx, st, "%s", msg.c_str());
+      const std::string theirs(in[(size_t)r].begin() + sizeof(st), in[(size_t)r].end());
+      return fail(ctx, st, "zzz_ghost_layer_build failed on rank %d: %s", r, theirs.c_str());
+    }
+  }
+  return ZZZ_OK;
+}
 
 template <typename T>
 static void put(std::vector<char>& b, const T* v, size_t n)
@@ -79,9 +114,18 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->comm)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_ghost_layer_build: attach a communicator first");
+  // Every rank-local failure below is made COLLECTIVE before the next exchange (agree): all ranks return an error
+  // together, none is left waiting in a send/recv for a peer that has already given up.
   const int64_t n_owned = ctx->n_owned, n_ghost = ctx->n_ghost, nloc = n_owned + n_ghost;
   const int64_t ncells = ctx->ncells, nverts = ctx->nverts;
   const int nd = ctx->nd, bs = ctx->bs, order = ctx->order;
+  const int nr = comm_size(ctx), me = comm_rank(ctx);
+  std::vector<double> x, cf, cg;
+  std::vector<int32_t> cverts, cdofs, send_idx;
+  std::vector<uint8_t> bc, fmask;
+  const bool haveF = ctx->have_coeff[ZZZ_COEFF_F], haveG = ctx->have_coeff[ZZZ_COEFF_G];
+  const int64_t nsend_old = ctx->nneigh ? ctx->send_off[(size_t)ctx->nneigh] : 0;
+  int rc = [&]() -> int {
   if (order == 0 || (int64_t)ctx->h_dof_global.size() != nloc || (int64_t)ctx->h_vert_global.size() != nverts)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_ghost_layer_build: mesh, dofmap and global indices (zzz_global_ids_upload) first");
   int64_t nrecv = 0;
@@ -89,13 +133,11 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     nrecv += ctx->recv_cnt[(size_t)k];
   if (nrecv != n_ghost)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_ghost_layer_build: upload the forward-scatter plan (zzz_halo_upload) first");
-  const int nr = comm_size(ctx), me = comm_rank(ctx);
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
   // ---- host copies of what the context holds --------------------------------------------------------------
-  std::vector<double> x, cf, cg;
-  std::vector<int32_t> cverts = ctx->h_cell_verts, cdofs = ctx->h_cell_dofs, send_idx;
-  std::vector<uint8_t> bc, fmask;
+  cverts = ctx->h_cell_verts;
+  cdofs = ctx->h_cell_dofs;
   int rc = download(ctx, ctx->x, x, (size_t)(3 * nverts));
   if (!rc && cverts.empty())
     rc = download(ctx, ctx->cell_verts, cverts, (size_t)(4 * ncells));
@@ -105,15 +147,15 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     rc = download(ctx, ctx->bc, bc, (size_t)(nloc * bs));
   if (!rc)
     rc = download(ctx, ctx->facet_mask, fmask, (size_t)ncells);
-  const bool haveF = ctx->have_coeff[ZZZ_COEFF_F], haveG = ctx->have_coeff[ZZZ_COEFF_G];
   if (!rc && haveF)
     rc = download(ctx, ctx->coeff[ZZZ_COEFF_F], cf, (size_t)(nloc * bs));
   if (!rc && haveG)
     rc = download(ctx, ctx->coeff[ZZZ_COEFF_G], cg, (size_t)nloc);
-  const int64_t nsend_old = ctx->nneigh ? ctx->send_off[(size_t)ctx->nneigh] : 0;
   if (!rc)
     rc = download(ctx, ctx->send_idx, send_idx, (size_t)nsend_old);
-  if (rc)
+  return rc;
+  }();
+  if ((rc = agree(ctx, rc)))
     return rc;
   const bool had_bc = ctx->have_bc;
   std::vector<int64_t> dof_g = ctx->h_dof_global, vert_g = ctx->h_vert_global;
@@ -216,6 +258,9 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     double f[3], gv;
   };
   std::vector<NewGhost> ng; // temporary local index nloc + position
+  std::vector<std::vector<char>> req((size_t)nr), reqin;
+  std::vector<std::vector<int32_t>> ng_of((size_t)nr); // per owner: positions in ng, in request order
+  rc = [&]() -> int {
   for (int r = 0; r < nr; ++r)
   {
     if (in[(size_t)r].size() < 2 * sizeof(int32_t))
@@ -285,11 +330,7 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
       fmask.push_back(fm);
     }
   }
-  const int64_t ncells_new = (int64_t)fmask.size();
-
   // ---- 3. ask the owners of the new ghosts for a place in the forward scatter --------------------------------
-  std::vector<std::vector<char>> req((size_t)nr), reqin;
-  std::vector<std::vector<int32_t>> ng_of((size_t)nr); // per owner: positions in ng, in request order
   for (size_t q = 0; q < ng.size(); ++q)
   {
     if (ng[q].owner < 0 || ng[q].owner >= nr || ng[q].owner == me)
@@ -297,10 +338,20 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     ng_of[(size_t)ng[q].owner].push_back((int32_t)q);
     put(req[(size_t)ng[q].owner], &ng[q].g, 1);
   }
+  return ZZZ_OK;
+  }();
+  if ((rc = agree(ctx, rc)))
+    return rc;
+  const int64_t ncells_new = (int64_t)fmask.size();
   rc = comm_exchange_bytes(ctx, req, reqin);
   if (rc)
     return rc;
   std::vector<std::vector<int32_t>> extra_send((size_t)nr);
+  std::vector<int32_t> neigh = old_neigh;
+  std::vector<int64_t> send_off, recv_cnt;
+  std::vector<int32_t> send_new;
+  int64_t n_ghost_new = 0;
+  rc = [&]() -> int {
   for (int r = 0; r < nr; ++r)
   {
     const size_t cnt = reqin[(size_t)r].size() / sizeof(int64_t);
@@ -317,14 +368,13 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
   }
 
   // ---- 4. new neighbour list, ghost numbering (grouped by neighbour: old ghosts, then new ones) --------------
-  std::vector<int32_t> neigh = old_neigh;
   for (int r = 0; r < nr; ++r)
     if ((!ng_of[(size_t)r].empty() || !extra_send[(size_t)r].empty())
         && std::find(neigh.begin(), neigh.end(), r) == neigh.end())
       neigh.push_back(r);
   const int nn = (int)neigh.size();
-  std::vector<int64_t> send_off((size_t)nn + 1, 0), recv_cnt((size_t)nn, 0);
-  std::vector<int32_t> send_new;
+  send_off.assign((size_t)nn + 1, 0);
+  recv_cnt.assign((size_t)nn, 0);
   std::vector<int32_t> remap((size_t)nloc + ng.size()); // old / temporary local block index -> new
   for (int64_t l = 0; l < n_owned; ++l)
     remap[(size_t)l] = (int32_t)l;
@@ -348,7 +398,8 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     recv_cnt[(size_t)k] += (int64_t)ng_of[(size_t)r].size();
     send_off[(size_t)k + 1] = (int64_t)send_new.size();
   }
-  const int64_t nloc_new = gpos, n_ghost_new = nloc_new - n_owned;
+  const int64_t nloc_new = gpos;
+  n_ghost_new = nloc_new - n_owned;
   if (nloc_new * bs > INT32_MAX - 8)
     return fail(ctx, ZZZ_ERR_LIMIT, "%lld local scalar dofs with the ghost layer exceed int32", (long long)(nloc_new * bs));
   for (int32_t& l : cdofs)
@@ -425,6 +476,8 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
   ctx->h_vert_global = vert_g;
   ctx->owned_cells = ncells;
   return ZZZ_OK;
+  }();
+  return agree(ctx, rc); // a rank whose re-upload failed must not leave the others believing the layer exists
 }
 
 int zzz_local_sizes(const zzz_ctx* ctx, int64_t sizes[6])

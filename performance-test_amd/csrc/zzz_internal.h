@@ -202,6 +202,7 @@ struct zzz_ctx
   zzz::CgState* h_state = nullptr; // pinned
   std::vector<double> history;
   int last_iters = 0;
+  int last_reason = 0; // KSPConvergedReason of the last solve (zzz_cg_info)
   bool last_solve_fused = false; // the last solve ran the fused product + direction kernel
 
   // profiling

@@ -112,6 +112,7 @@ struct Options
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_divtol = 1e4; // PETSc defaults (KSPCreate)
   int ksp_max_it = 10000;
   bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false, ksp_cg_single_reduction = false;
+  bool ksp_error_if_not_converged = false, ksp_converged_reason = false;
   std::vector<std::string> unused;
 };
 
@@ -134,7 +135,7 @@ void usage()
                "  --allreduce arg (=peer)         peer (xGMI peer-memory mailboxes, else falls back) | comm\n"
                "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol -ksp_divtol\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
-               "  -ksp_cg_single_reduction\n"
+               "  -ksp_cg_single_reduction -ksp_converged_reason -ksp_error_if_not_converged\n"
                "  -log_view -options_left\n"
             << std::endl;
 }
@@ -212,6 +213,10 @@ Options parse(int argc, char** argv)
         o.ksp_view = true;
       else if (key == "ksp_monitor")
         o.ksp_monitor = true;
+      else if (key == "ksp_error_if_not_converged")
+        o.ksp_error_if_not_converged = true;
+      else if (key == "ksp_converged_reason")
+        o.ksp_converged_reason = true;
       else if (key == "ksp_cg_single_reduction")
       {
         // PETSc bool option: bare flag, or followed by true/false/1/0
@@ -279,6 +284,23 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   // waiting rank gets an error and drains too); with RCCL nothing can wake them, so the process ends at once
   // with a non-zero status instead of hanging.
   bool failed = false;
+  // what a rank does once it has failed anywhere (set-up phase, ZZZ Solve, the closing norm): record, and wake or end
+  // the peers that may be waiting for it inside a collective
+  auto rank_failed = [&](const std::exception& e) {
+    failed = true;
+    S.error[rank] = e.what();
+    if (S.nranks > 1)
+    {
+      if (S.local_group)
+        zzz_local_group_abort(S.local_group);
+      else
+      {
+        std::cerr << "rank " << rank << ": " << e.what() << "\n(other ranks may be waiting in an RCCL collective: aborting)"
+                  << std::endl;
+        std::_Exit(2);
+      }
+    }
+  };
   auto phase = [&](const char* tname, auto&& body) {
     Timer t(tname ? tname : "");
     if (!failed)
@@ -291,19 +313,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
       }
       catch (const std::exception& e)
       {
-        failed = true;
-        S.error[rank] = e.what();
-        if (S.nranks > 1)
-        {
-          if (S.local_group)
-            zzz_local_group_abort(S.local_group);
-          else
-          {
-            std::cerr << "rank " << rank << ": " << e.what() << "\n(other ranks may be waiting in an RCCL collective: aborting)"
-                      << std::endl;
-            std::_Exit(2);
-          }
-        }
+        rank_failed(e);
       }
     }
     const double s = t.stop();
@@ -407,6 +417,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     so.atol = o.ksp_atol;
     so.dtol = o.ksp_divtol;
     so.single_reduction = o.ksp_cg_single_reduction ? 1 : 0;
+    so.error_if_not_converged = o.ksp_error_if_not_converged ? 1 : 0;
   }
   double solve_s = 0;
   {
@@ -423,8 +434,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
       }
       catch (const std::exception& e)
       {
-        failed = true;
-        S.error[rank] = e.what();
+        rank_failed(e);
       }
     }
     S.tmax[rank] = ts.stop();
@@ -448,11 +458,20 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     }
     catch (const std::exception& e)
     {
-      failed = true;
-      S.error[rank] = e.what();
+      rank_failed(e);
     }
   }
   bar.arrive_and_wait();
+  if (root && o.ksp_converged_reason && !failed)
+  {
+    // KSPConvergedReasonView's line; a diverged solve is reported, not fatal (src/poisson_problem.cpp:172-178)
+    std::int64_t ci[4] = {0, 0, 0, 0};
+    zzz_cg_info(ctx, ci);
+    const char* name = ci[2] == 2 ? "CONVERGED_RTOL" : ci[2] == 3 ? "CONVERGED_ATOL" : ci[2] == -3 ? "DIVERGED_ITS"
+                       : ci[2] == -4 ? "DIVERGED_DTOL" : ci[2] == -9 ? "DIVERGED_NANORINF" : "unknown";
+    std::cout << "Linear solve " << (ci[2] > 0 ? "converged" : "did not converge") << " due to " << name << " iterations "
+              << S.iters[0] << std::endl;
+  }
   if (root && o.ksp_monitor && !failed)
   {
     std::vector<double> h((size_t)S.iters[0] + 1);

@@ -71,7 +71,7 @@ def merge(pdir, tag, cfg="c2"):
                          "move 40 B/row each (k_update_p: x, p, z in, x, p out; k_update_xr: w, r, dinv in, r, z out). "
                          "Scattered-access kernels (assembly, pattern) are uncalibrated: read their numbers as relative.",
            "rows": cfg["rows_rank0"], "nnz": cfg["nnz_rank0"], "spmv_operator": cfg.get("spmv_operator"),
-           "spmv_bytes_streamed": bench["roofline"].get("bytes_streamed_per_launch"),
+           "spmv_bytes_streamed": (bench["roofline"].get("bytes_per_launch") or bench["roofline"].get("bytes_streamed_per_launch")),
            "kernels": kern}
     n = cfg["rows_rank0"]
     for k in ("k_update_p", "k_update_xr"):
@@ -82,7 +82,7 @@ def merge(pdir, tag, cfg="c2"):
         alg = 12 * cfg["nnz_rank0"] + 4 * (n + 1) + 16 * n
         kern["spmv"]["algorithmic_bytes"] = alg
         kern["spmv"]["corrected_over_algorithmic"] = kern["spmv"]["hbm_bytes_corrected"] / alg
-        st = bench["roofline"].get("bytes_streamed_per_launch")
+        st = (bench["roofline"].get("bytes_per_launch") or bench["roofline"].get("bytes_streamed_per_launch"))
         if st:
             kern["spmv"]["bytes_streamed"] = st
             kern["spmv"]["corrected_over_streamed"] = kern["spmv"]["hbm_bytes_corrected"] / st

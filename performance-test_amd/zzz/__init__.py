@@ -45,7 +45,7 @@ HOST_SYMBOLS = [
 
 class SolverOpts(C.Structure):
     _fields_ = [("variant", C.c_int32), ("pc", C.c_int32), ("norm", C.c_int32), ("op", C.c_int32),
-                ("max_it", C.c_int32), ("profile", C.c_int32), ("single_reduction", C.c_int32), ("reserved", C.c_int32),
+                ("max_it", C.c_int32), ("profile", C.c_int32), ("single_reduction", C.c_int32), ("error_if_not_converged", C.c_int32),
                 ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
 
 
@@ -406,8 +406,9 @@ class Context:
         return y
 
     def cg_solve(self, variant=CG_PETSC, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, op=OP_CSR, rtol=1e-8, atol=1e-50,
-                 max_it=10000, profile=False, single_reduction=False, dtol=0.0):
-        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0, 0, rtol, atol, dtol)
+                 max_it=10000, profile=False, single_reduction=False, dtol=0.0, error_if_not_converged=False):
+        o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0,
+                       1 if error_if_not_converged else 0, rtol, atol, dtol)
         it = C.c_int()
         rn = (C.c_double * 2)()
         self._ck(self.L.zzz_cg_solve(self.h, C.byref(o), C.byref(it), rn))
@@ -443,6 +444,12 @@ class Context:
         info = (C.c_int64 * 4)()
         self._ck(self.L.zzz_cg_info(self.h, info))
         return bool(info[0])
+
+    def cg_reason(self):
+        """KSPConvergedReason of the last solve: 2 rtol, 3 atol, -3 max_it, -4 KSP_DIVERGED_DTOL, -9 NaN/Inf"""
+        info = (C.c_int64 * 4)()
+        self._ck(self.L.zzz_cg_info(self.h, info))
+        return int(info[2])
 
     def profile(self):
         ms, n = C.c_double(), C.c_int64()

@@ -154,11 +154,20 @@ def test_solver_edge_cases(ctx):
     assert ok == 7 and np.all(np.isnan(ox))
     # KSPConvergedDefault's divergence test: norm >= divtol x initial norm -> KSP_DIVERGED_DTOL (both CG forms)
     ctx.vec_upload(zzz.VEC_B, b)
+    # As in the reference (solver_function returns solver.solve()'s count whatever the reason, src/poisson_problem.cpp:172-178)
+    # that is not an error: the solve returns its iteration count and the reason is there to be read; it only fails
+    # under -ksp_error_if_not_converged.
     for sr in (False, True):
+        it_d, _, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, dtol=0.5, single_reduction=sr)
+        assert ctx.cg_reason() == -4 and 0 <= it_d < 100
         with pytest.raises(zzz.ZzzError, match="DTOL"):
-            ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, dtol=0.5, single_reduction=sr)
+            ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, dtol=0.5, single_reduction=sr, error_if_not_converged=True)
         it, _, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=sr)  # default divtol 1e4: converges
-        assert 0 < it < 100
+        assert 0 < it < 100 and ctx.cg_reason() == 2
+        it3, _, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, max_it=3, single_reduction=sr)  # KSP_DIVERGED_ITS: no error either
+        assert it3 == 3 and ctx.cg_reason() == -3
+        with pytest.raises(zzz.ZzzError, match="KSP_DIVERGED_ITS"):
+            ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, max_it=3, single_reduction=sr, error_if_not_converged=True)
     # argument errors surface as ZzzError, not crashes
     with pytest.raises(zzz.ZzzError):
         ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_JACOBI)
@@ -1481,6 +1490,48 @@ def test_native_partition_through_ghost_layer_build(problem, order, dims, nparts
         assert abs(it - oit) <= 2
         u[lo:lo + n] = ur
     assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+
+
+def test_ghost_layer_build_fails_on_every_rank_together():
+    """A rank-local failure inside the collective zzz_ghost_layer_build (here: rank 1 never uploaded its global
+    indices) must end the call on EVERY rank with an error naming the rank at fault -- within seconds, not after the
+    peers have waited out a barrier (local backend) or for ever (RCCL send/recv)."""
+    import threading
+    import time
+
+    nparts = 2
+    grp = zzz.LocalGroup(nparts)
+    res = [None] * nparts
+
+    def run(rank):
+        try:
+            Pn = zzz.Part("poisson", 1, 4, 3, 6, nparts, rank, native=True)
+            with zzz.Context(0) as c:
+                c.comm_init_local(grp.h, rank)
+                c.upload_part(Pn)
+                c.upload_halo(Pn)
+                if rank == 0:
+                    c.upload_global_ids(Pn.global_dofs, Pn.global_verts)
+                t0 = time.perf_counter()
+                try:
+                    c.ghost_layer_build()
+                    res[rank] = ("ok", "", 0.0)
+                except zzz.ZzzError as e:
+                    res[rank] = ("error", str(e), time.perf_counter() - t0)
+        except Exception as e:  # noqa: BLE001
+            res[rank] = ("crash", repr(e), 0.0)
+            grp.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    grp.close()
+    assert all(r is not None and r[0] == "error" for r in res), res
+    assert "global indices" in res[1][1]
+    assert "rank 1" in res[0][1] and "global indices" in res[0][1]
+    assert max(r[2] for r in res) < 30.0
 
 
 def test_two_processes_real_rccl_on_one_gpu():
