@@ -245,6 +245,11 @@ def main():
                          "ndofs x processes); 0 = the number of GPUs of this run")
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none"])
     ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--numbering", default="native", choices=["native", "rcm", "random", "reverse"],
+                    help="N=1: how the CALLER numbers dofs, vertices and cells of the host feed before upload: native = "
+                         "the structured generator's own order; rcm / random / reverse = what a DOLFINx-style feed may look "
+                         "like (src/mesh.cpp:153-162,182-186).  The library renumbers internally (zzz_renumber.hip), so "
+                         "`ZZZ Solve` should not depend on this; ZZZ_RENUMBER=0 shows what the caller's order would cost")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_other_configs", action="store_true",
                     help="default run only: skip the compact records of the other BASELINE configs (c1, c4_total, c5_rank; "
@@ -314,8 +319,23 @@ def main():
     form = zzz.FORM_ELASTICITY if a.problem_type == "elasticity" else zzz.FORM_POISSON
     # host feed (C++ generator + upload) only when the CPU baseline needs the host arrays; otherwise the
     # feed is generated on the device (zzz_cube_generate) -- identical problem, no PCIe traffic
-    need_host_arrays = not multi and not a.no_cpu_baseline
+    if a.numbering != "native":
+        if multi:
+            raise SystemExit("--numbering applies to single-GPU runs (the multi-GPU feed is generated on the device)")
+        a.no_cpu_baseline = True  # the CPU port is timed on the native order only (it has no renumbering of its own)
+    need_host_arrays = not multi and (not a.no_cpu_baseline or a.numbering != "native")
     P = zzz.Part(a.problem_type, a.order, nx, ny, nz, world, rank) if need_host_arrays else None
+    if a.numbering != "native":
+        pattern = None
+        if a.numbering == "rcm":
+            # the dof graph for scipy's reverse Cuthill-McKee: the block pattern, built once on the GPU from the native feed
+            with zzz.Context(local_rank) as c0:
+                c0.upload_mesh(P.x, P.cells)
+                c0.upload_dofmap(P.order, 1, P.cell_dofs, P.n_owned, P.n_ghost)  # block graph: one dof per block
+                c0.pattern_build()
+                rp0, cl0, _ = c0.csr_download(values=False)
+            pattern = (rp0, cl0)
+        P = P.renumbered(a.numbering, seed=1, pattern=pattern)
     # ZZZ_BENCH_DEVICE: all ranks on one device (only for the two-processes-on-one-GPU probe of the RCCL path)
     ctx = zzz.Context(int(os.environ.get("ZZZ_BENCH_DEVICE", local_rank)))
     if multi:
@@ -549,8 +569,15 @@ def main():
                                               f"dropped, chunks of 8 padded), {sinfo[6]} B per product")
         else:
             out["config"]["spmv_operator"] = "CSR tile kernel"
-        out["config"]["spmv_column_stream"] = (f"16-bit band codes ({c16[1]} offset bits), {c16[2]} of {c16[3]} tiles on int32 columns"
+        out["config"]["spmv_column_stream"] = ("(CSR tile kernel not in use)" if sinfo[5] else
+                                               f"16-bit band codes ({c16[1]} offset bits), {c16[2]} of {c16[3]} tiles on int32 columns"
                                                if c16[0] else "int32")
+        iperm, ikind = ctx.internal_order()
+        out["config"]["numbering"] = {
+            "caller": a.numbering,
+            "internal": {0: "the caller's order kept", 1: "lattice order computed by the library (zzz_renumber.hip)",
+                         2: "coordinate-bin order computed by the library"}[ikind],
+            "dofs_moved": int(np.count_nonzero(iperm != np.arange(iperm.size)))}
         if rank_info:
             out["config"]["ranks"] = rank_info
         if tuning:

@@ -252,6 +252,18 @@ int zzz_ghost_layer_build(zzz_ctx* ctx);
 /* sizes = {vertices, cells, owned block dofs, ghost block dofs, cells the caller uploaded, neighbours} */
 int zzz_local_sizes(const zzz_ctx* ctx, int64_t sizes[6]);
 
+/* The library keeps the owned dofs in an INTERNAL locality order of its own (computed from geometry when the dofmap
+ * is uploaded: lexicographic by lattice cell, entity type by entity type -- csrc/zzz_renumber.hip), so that its speed does
+ * not depend on the numbering DOLFINx's partitioner and reordering happened to produce (src/mesh.cpp:153-162,182-186).
+ * Every index and vector of this ABI is in the CALLER's numbering; the translation is the library's business.  Two
+ * things are visible all the same: (1) MatMult sums a row in ascending INTERNAL column order, so zzz_spmv (and the CG
+ * iterates) equal the serial CSR loop bit for bit on the internally ordered system P A P^T, and the caller-ordered loop
+ * only to round-off -- exactly as PETSc's result depends on the local numbering of the run; (2) this function, which
+ * returns P: perm[i] = caller index of internal owned block dof i (the identity when the caller's order was kept:
+ * structured feeds of this repository, meshes that are not a lattice, ZZZ_RENUMBER=0).  kind (optional): 0 caller's
+ * order kept, 1 lattice order, 2 coordinate-bin order (ZZZ_RENUMBER=2 only).  No reference counterpart. */
+int zzz_internal_order_download(zzz_ctx* ctx, int32_t* perm /* n_owned */, int32_t* kind);
+
 /* ---- solve ----------------------------------------------------------------------------- */
 
 /* solver_function(u, b) (src/poisson_problem.cpp:164-179; src/cgpoisson_problem.cpp:178-244;

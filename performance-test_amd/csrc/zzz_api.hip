@@ -272,6 +272,11 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
+  // the library's own locality order of the owned dofs (zzz_renumber.hip): from here on the device connectivity is in
+  // internal numbering and every entry point below translates at the boundary
+  rc = renumber_build(ctx);
+  if (rc)
+    return rc;
   pattern_reserve(ctx);
   return ensure_p1_coords(ctx); // function-space data (dof coordinates), not assembly work
 }
@@ -288,7 +293,10 @@ int zzz_bc_upload(zzz_ctx* ctx, int64_t nbc, const int32_t* bc_dofs)
   {
     if (bc_dofs[i] < 0 || bc_dofs[i] >= ctx->nloc())
       return fail(ctx, ZZZ_ERR_ARG, "bc_dofs[%lld] = %d out of range", (long long)i, bc_dofs[i]);
-    m[bc_dofs[i]] = 1;
+    int64_t d = bc_dofs[i];
+    if (ctx->renumbered && d / ctx->bs < ctx->n_owned)
+      d = (int64_t)ctx->h_iperm[(size_t)(d / ctx->bs)] * ctx->bs + d % ctx->bs;
+    m[(size_t)d] = 1;
   }
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->bc.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -324,6 +332,15 @@ int zzz_coeff_upload(zzz_ctx* ctx, int which, const double* values)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_coeff_upload before zzz_dofmap_upload");
   if ((which != ZZZ_COEFF_F && which != ZZZ_COEFF_G) || !values)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_coeff_upload: bad arguments");
+  std::vector<double> tmp;
+  if (ctx->renumbered)
+  {
+    // coefficient G is scalar-valued whatever the block size of the space (src/poisson_problem.cpp:96-106): both are
+    // stored with nloc * bs entries and Poisson has bs = 1, so one layout serves
+    tmp.resize((size_t)ctx->nloc());
+    to_internal(ctx, values, tmp.data(), false);
+    values = tmp.data();
+  }
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->coeff[which].p, values, (size_t)ctx->nloc() * sizeof(double), hipMemcpyHostToDevice,
                               ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -382,7 +399,15 @@ static int pattern_build_host(zzz_ctx* ctx)
   }
   const int nd = ctx->nd, bs = ctx->bs;
   const int64_t nb = ctx->n_owned, nc = ctx->ncells;
-  const int32_t* cd = ctx->h_cell_dofs.data();
+  std::vector<int32_t> cd_internal;
+  if (ctx->renumbered) // the host copy keeps the caller's numbering (zzz_ghost_layer_build reads it)
+  {
+    cd_internal = ctx->h_cell_dofs;
+    for (int32_t& d : cd_internal)
+      if (d < nb)
+        d = ctx->h_iperm[(size_t)d];
+  }
+  const int32_t* cd = ctx->renumbered ? cd_internal.data() : ctx->h_cell_dofs.data();
   // owned block dof -> incident cells, ascending (counting sort over cells)
   std::vector<int32_t> off((size_t)nb + 1, 0);
   for (int64_t c = 0; c < nc; ++c)
@@ -512,6 +537,19 @@ int zzz_csr_download(zzz_ctx* ctx, int32_t* rowptr, int32_t* cols, double* vals)
   if (!ctx->have_pattern)
     return fail(ctx, ZZZ_ERR_ARG, "no sparsity pattern yet");
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->renumbered)
+  {
+    if (rowptr && ctx->nnz > INT32_MAX)
+      return fail(ctx, ZZZ_ERR_LIMIT, "%lld nonzeros do not fit 32-bit row pointers: use zzz_csr_rowptr64_download",
+                  (long long)ctx->nnz);
+    std::vector<rp_t> rpc;
+    if (int rc = csr_to_caller(ctx, rpc, cols, vals, cols != nullptr))
+      return rc;
+    if (rowptr)
+      for (size_t i = 0; i < rpc.size(); ++i)
+        rowptr[i] = (int32_t)rpc[i];
+    return ZZZ_OK;
+  }
   if (rowptr)
   {
     // the matrix of record keeps 64-bit row pointers; this entry point serves the 32-bit form of DOLFINx / the parity
@@ -542,6 +580,14 @@ int zzz_csr_rowptr64_download(zzz_ctx* ctx, int64_t* rowptr)
   if (!ctx->have_pattern || !rowptr)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_rowptr64_download: no sparsity pattern yet / NULL array");
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->renumbered)
+  {
+    std::vector<rp_t> rpc;
+    if (int rc = csr_to_caller(ctx, rpc, nullptr, nullptr, false))
+      return rc;
+    std::copy(rpc.begin(), rpc.end(), rowptr);
+    return ZZZ_OK;
+  }
   ZZZ_HIP(ctx, hipMemcpy(rowptr, ctx->rowptr.p, ((size_t)ctx->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
   return ZZZ_OK;
 }
@@ -551,7 +597,16 @@ int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals)
   ZZZ_ENTER(ctx);
   if (!ctx->have_pattern || !vals)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_upload_values: no pattern or NULL values");
+  std::vector<double> vi;
+  if (ctx->renumbered)
+  {
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = csr_values_to_internal(ctx, vals, vi))
+      return rc;
+    vals = vi.data();
+  }
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->vals.p, vals, (size_t)ctx->nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the staging copy above may be a local
   int rc = sell_update(ctx, false);
   if (rc)
     return rc;
@@ -599,6 +654,13 @@ int zzz_vec_download(zzz_ctx* ctx, int which, double* out)
   if (!v || !v->p || !out)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_vec_download: bad vector / not allocated");
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->renumbered)
+  {
+    std::vector<double> tmp((size_t)(ctx->n_owned * ctx->bs));
+    ZZZ_HIP(ctx, hipMemcpy(tmp.data(), v->p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    to_caller(ctx, tmp.data(), out, true);
+    return ZZZ_OK;
+  }
   ZZZ_HIP(ctx, hipMemcpy(out, v->p, (size_t)(ctx->n_owned * ctx->bs) * sizeof(double), hipMemcpyDeviceToHost));
   return ZZZ_OK;
 }
@@ -609,6 +671,13 @@ int zzz_vec_upload(zzz_ctx* ctx, int which, const double* in)
   DevBuf<double>* v = pick_vec(ctx, which);
   if (!v || !v->p || !in)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_vec_upload: bad vector / not allocated");
+  std::vector<double> tmp;
+  if (ctx->renumbered)
+  {
+    tmp.resize((size_t)(ctx->n_owned * ctx->bs));
+    to_internal(ctx, in, tmp.data(), true);
+    in = tmp.data();
+  }
   ZZZ_HIP(ctx, hipMemcpyAsync(v->p, in, (size_t)(ctx->n_owned * ctx->bs) * sizeof(double), hipMemcpyHostToDevice,
                               ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -630,8 +699,16 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
   if (!ctx->have_matrix || !x || !y)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv: no matrix or NULL vector");
   const size_t n = (size_t)(ctx->n_owned * ctx->bs);
+  std::vector<double> xin;
+  if (ctx->renumbered)
+  {
+    xin.resize(n);
+    to_internal(ctx, x, xin.data(), true);
+    x = xin.data();
+  }
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, ctx->p.n * sizeof(double), ctx->stream));
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->p.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int rc;
   if (ctx->comm && ctx->overlap && ctx->have_tile_split)
     rc = launch_spmv_overlapped(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
@@ -647,6 +724,13 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
   }
   if (rc)
     return rc;
+  if (ctx->renumbered)
+  {
+    ZZZ_HIP(ctx, hipMemcpyAsync(xin.data(), ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    to_caller(ctx, xin.data(), y, true);
+    return ZZZ_OK;
+  }
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
@@ -691,8 +775,16 @@ int zzz_action(zzz_ctx* ctx, const double* x, double* y)
   if (!ctx->have_pattern || !x || !y)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_action: no pattern/adjacency or NULL vector");
   const size_t n = (size_t)(ctx->n_owned * ctx->bs);
+  std::vector<double> xin;
+  if (ctx->renumbered)
+  {
+    xin.resize(n);
+    to_internal(ctx, x, xin.data(), true);
+    x = xin.data();
+  }
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, ctx->p.n * sizeof(double), ctx->stream));
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->p.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm)
   {
     int rc = comm_halo_forward(ctx, ctx->p.p);
@@ -702,6 +794,13 @@ int zzz_action(zzz_ctx* ctx, const double* x, double* y)
   int rc = launch_matfree_action(ctx, ctx->p.p, ctx->w.p, nullptr, nullptr);
   if (rc)
     return rc;
+  if (ctx->renumbered)
+  {
+    ZZZ_HIP(ctx, hipMemcpyAsync(xin.data(), ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    to_caller(ctx, xin.data(), y, true);
+    return ZZZ_OK;
+  }
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZZZ_OK;
@@ -761,6 +860,18 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   info[5] = sellp_active(ctx) ? (ctx->sp_sorted ? 2 : 1) : 0;
   info[6] = sellp_active(ctx) ? sellp_stream_bytes(ctx) : 0; // bytes of the operator stream read per product
   info[7] = sellp_active(ctx) ? ctx->sp_chunks * 512 : 0;     // its entries, padding included
+  return ZZZ_OK;
+}
+
+int zzz_internal_order_download(zzz_ctx* ctx, int32_t* perm, int32_t* kind)
+{
+  if (!ctx || ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_internal_order_download: no dofmap yet");
+  if (perm)
+    for (int64_t i = 0; i < ctx->n_owned; ++i)
+      perm[i] = ctx->renumbered ? ctx->h_perm[(size_t)i] : (int32_t)i;
+  if (kind)
+    *kind = ctx->renumbered ? ctx->renumber_kind : 0;
   return ZZZ_OK;
 }
 

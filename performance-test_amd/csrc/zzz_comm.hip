@@ -1041,6 +1041,14 @@ int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const i
   for (int64_t i = 0; i < nsend; ++i)
     if (send_idx[i] < 0 || send_idx[i] >= ctx->n_owned)
       return fail(ctx, ZZZ_ERR_ARG, "send_idx[%lld] = %d is not an owned block dof", (long long)i, send_idx[i]);
+  std::vector<int32_t> send_internal;
+  if (ctx->renumbered && nsend)
+  {
+    send_internal.assign(send_idx, send_idx + nsend);
+    for (int32_t& d : send_internal)
+      d = ctx->h_iperm[(size_t)d];
+    send_idx = send_internal.data();
+  }
   ctx->nneigh = nneigh;
   ctx->neigh_rank.assign(neigh_rank, neigh_rank + nneigh);
   ctx->send_off.assign(send_off, send_off + nneigh + 1);

@@ -120,6 +120,7 @@ extern "C" int zzz_cube_generate(zzz_ctx* ctx, int problem, int order, int64_t n
   ctx->n_ghost = S.n_lower + S.n_upper;
   ctx->h_cell_verts.clear();
   ctx->h_cell_dofs.clear();
+  renumber_clear(ctx); // this feed is generated in the internal order (host/cube_layout.h)
   ZZZ_HIP(ctx, ctx->x.alloc((size_t)(3 * S.nverts)));
   ZZZ_HIP(ctx, ctx->cell_verts.alloc((size_t)(4 * S.ncells)));
   ZZZ_HIP(ctx, ctx->cell_dofs.alloc((size_t)(S.nd * S.ncells)));

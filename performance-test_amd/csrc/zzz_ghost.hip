@@ -153,6 +153,35 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     rc = download(ctx, ctx->coeff[ZZZ_COEFF_G], cg, (size_t)nloc);
   if (!rc)
     rc = download(ctx, ctx->send_idx, send_idx, (size_t)nsend_old);
+  if (!rc && ctx->renumbered)
+  {
+    // the device holds the library's internal numbering of the owned dofs; this function works in the caller's
+    // (h_cell_dofs, h_dof_global) and re-uploads through the translating entry points
+    const int32_t* perm = ctx->h_perm.data();
+    for (int32_t& d : send_idx)
+      d = perm[(size_t)d];
+    std::vector<uint8_t> bc2(bc.size());
+    for (int64_t i = 0; i < nloc; ++i)
+    {
+      const int64_t dst = i < n_owned ? perm[(size_t)i] : i;
+      for (int k = 0; k < bs; ++k)
+        bc2[(size_t)(dst * bs + k)] = bc[(size_t)(i * bs + k)];
+    }
+    bc.swap(bc2);
+    std::vector<double> t;
+    if (haveF)
+    {
+      t.resize(cf.size());
+      to_caller(ctx, cf.data(), t.data(), false);
+      cf.swap(t);
+    }
+    if (haveG)
+    {
+      t.resize(cg.size());
+      to_caller(ctx, cg.data(), t.data(), false);
+      cg.swap(t);
+    }
+  }
   return rc;
   }();
   if ((rc = agree(ctx, rc)))

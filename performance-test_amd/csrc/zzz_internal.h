@@ -102,6 +102,14 @@ struct zzz_ctx
   // global indices of the local block dofs / vertices (zzz_global_ids_upload): only the ghost-layer build needs them
   std::vector<int64_t> h_dof_global, h_vert_global;
   int64_t owned_cells = 0; // cells the caller uploaded, when zzz_ghost_layer_build has appended ghost cells
+  // Internal locality numbering of the owned block dofs (zzz_renumber.hip): perm[internal] = caller index,
+  // iperm[caller] = internal index; ghosts keep their places.  Everything on the device (cell_dofs, pattern, CSR,
+  // vectors) is in internal order when `renumbered`; h_cell_dofs, h_dof_global stay in the caller's.
+  bool renumbered = false;
+  int renumber_kind = 0; // 0: not examined / left alone, 1: lattice key, 2: coordinate bins
+  zzz::DevBuf<int32_t> perm, iperm;
+  std::vector<int32_t> h_perm, h_iperm;
+  std::vector<uint16_t> csr_slot; // caller CSR entry -> position inside its internal row (built on first CSR download)
 
   // bc marker per local scalar dof (owned + ghost)
   zzz::DevBuf<uint8_t> bc;
@@ -250,6 +258,13 @@ int build_adjT(zzz_ctx* ctx);
 int build_adjT_offsets(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);
 int ensure_p1_coords(zzz_ctx* ctx); // P1 only; a no-op for P2/P3
+// internal numbering (zzz_renumber.hip)
+int renumber_build(zzz_ctx* ctx);
+void renumber_clear(zzz_ctx* ctx);
+void to_internal(const zzz_ctx* ctx, const double* in, double* out, bool owned_only);
+void to_caller(const zzz_ctx* ctx, const double* in, double* out, bool owned_only);
+int csr_to_caller(zzz_ctx* ctx, std::vector<zzz::rp_t>& rowptr_c, int32_t* cols_c, double* vals_c, bool need_cols);
+int csr_values_to_internal(zzz_ctx* ctx, const double* vals_c, std::vector<double>& vals_i);
 // kernels_spmv
 // y = A x (x has ncols entries), optionally per-block partials of <x_owned, y>
 int launch_spmv(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec = nullptr,

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
-    "zzz_profile_get", "zzz_cg_info", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
+    "zzz_profile_get", "zzz_cg_info", "zzz_internal_order_download", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
 ]
 HOST_SYMBOLS = [
@@ -114,6 +114,7 @@ def hip():
         L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.zzz_spmv_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.zzz_internal_order_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.zzz_comm_unique_id.argtypes = [C.c_void_p]
         L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.zzz_local_group_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -241,6 +242,82 @@ class Part:
         m = np.zeros(self.nloc * self.bs, np.uint8)
         m[self.bc_dofs] = 1
         return m
+
+    def renumbered(self, kind, seed=0, pattern=None):
+        """The same partition as a caller with ANOTHER numbering would feed it (what DOLFINx's partitioner and graph
+        reordering leave, src/mesh.cpp:153-162,182-186): owned block dofs, mesh vertices and cells renumbered.
+          "random": three independent random permutations (the worst case);
+          "rcm":    dofs in reverse Cuthill-McKee order of the dof graph (pattern = (rowptr, cols) of the BLOCK graph,
+                    or None to build it from the connectivity), vertices in the order of their P1 dofs' new numbers
+                    where that applies, cells sorted by their lowest new dof (what a graph reordering of both gives);
+          "reverse": every numbering reversed (a cheap deterministic case).
+        Ghost dofs keep their places (the forward scatter defines them).  Q.dof_new_of_old maps old -> new owned dofs."""
+        import copy
+
+        rng = np.random.default_rng(seed)
+        n, nv, nc = self.n_owned, self.nverts, self.ncells
+        if kind == "random":
+            new_of_old, v_new_of_old, c_order = rng.permutation(n), rng.permutation(nv), rng.permutation(nc)
+        elif kind == "reverse":
+            new_of_old, v_new_of_old, c_order = np.arange(n)[::-1].copy(), np.arange(nv)[::-1].copy(), np.arange(nc)[::-1].copy()
+        elif kind == "rcm":
+            import scipy.sparse as sp
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+            if pattern is None:
+                cd = self.cell_dofs
+                own = cd < n
+                rows = np.repeat(cd, self.nd, axis=1).reshape(-1)
+                cols = np.tile(cd, (1, self.nd)).reshape(-1)
+                keep = (rows < n) & (cols < n)
+                G = sp.csr_matrix((np.ones(int(keep.sum()), np.int8), (rows[keep], cols[keep])), shape=(n, n))
+                del own
+            else:
+                rp, cl = pattern
+                keep = cl < n
+                rows = np.repeat(np.arange(n), np.diff(rp))
+                G = sp.csr_matrix((np.ones(int(keep.sum()), np.int8), (rows[keep], cl[keep])), shape=(n, n))
+            order = reverse_cuthill_mckee(G, symmetric_mode=True).astype(np.int64)  # order[new] = old
+            new_of_old = np.empty(n, np.int64)
+            new_of_old[order] = np.arange(n)
+            # vertices: by the lowest new dof of the cells' vertex dofs (P1: the vertex's own dof); cells: by lowest new dof
+            full0 = np.concatenate([new_of_old, np.arange(n, self.nloc)])
+            vkey = np.full(nv, np.iinfo(np.int64).max)
+            np.minimum.at(vkey, self.cells.reshape(-1), full0[self.cell_dofs[:, :4]].reshape(-1))
+            v_order = np.argsort(vkey, kind="stable")
+            v_new_of_old = np.empty(nv, np.int64)
+            v_new_of_old[v_order] = np.arange(nv)
+            c_order = np.argsort(full0[self.cell_dofs].min(axis=1), kind="stable")
+        else:
+            raise ValueError(kind)
+        full = np.concatenate([new_of_old, np.arange(n, self.nloc)]).astype(np.int64)
+        Q = copy.copy(self)
+        Q.dof_new_of_old = new_of_old.astype(np.int64)
+        bs = self.bs
+
+        def blocks(v, width):
+            out = np.empty_like(v)
+            out.reshape(self.nloc, width)[full] = v.reshape(self.nloc, width)
+            return out
+
+        Q.cell_dofs = full[self.cell_dofs][c_order].astype(np.int32)
+        Q.cells = v_new_of_old[self.cells][c_order].astype(np.int32)
+        Q.x = np.empty_like(self.x)
+        Q.x[v_new_of_old] = self.x
+        Q.global_verts = np.empty_like(self.global_verts)
+        Q.global_verts[v_new_of_old] = self.global_verts
+        c_new_of_old = np.empty(nc, np.int64)
+        c_new_of_old[c_order] = np.arange(nc)
+        Q.facets = self.facets.copy()
+        if Q.facets.size:
+            Q.facets[:, 0] = c_new_of_old[self.facets[:, 0]]
+        Q.bc_dofs = np.sort(full[self.bc_dofs // bs] * bs + self.bc_dofs % bs).astype(np.int32)
+        Q.f = blocks(self.f, bs)
+        Q.g = blocks(self.g, 1) if self.g is not None else None
+        Q.dof_x = blocks(self.dof_x.reshape(-1), 3).reshape(-1, 3)
+        Q.global_dofs = blocks(self.global_dofs, 1)
+        Q.send_idx = full[self.send_idx].astype(np.int32)
+        return Q
 
 
 # ------------------------------------------------------------------------------------------------
@@ -444,6 +521,14 @@ class Context:
         info = (C.c_int64 * 4)()
         self._ck(self.L.zzz_cg_info(self.h, info))
         return bool(info[0])
+
+    def internal_order(self):
+        """(perm, kind): perm[i] = caller index of the library's internal owned block dof i (identity when the caller's
+        order was kept); kind 0 kept, 1 lattice order, 2 coordinate bins"""
+        perm = np.zeros(self.n_owned, np.int32)
+        kind = C.c_int32()
+        self._ck(self.L.zzz_internal_order_download(self.h, perm.ctypes.data_as(C.c_void_p), C.byref(kind)))
+        return perm, int(kind.value)
 
     def cg_reason(self):
         """KSPConvergedReason of the last solve: 2 rtol, 3 atol, -3 max_it, -4 KSP_DIVERGED_DTOL, -9 NaN/Inf"""

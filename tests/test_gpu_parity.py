@@ -406,6 +406,116 @@ def test_unsorted_cells_and_foreign_numbering(ctx, problem, order):
     assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
 
 
+def _internal_system(rp, cl, v, perm, bs):
+    """P A P^T: the caller-ordered CSR (rp, cl, v) in the library's internal order (perm[i] = caller block index of
+    internal block i; ghost columns, if any, keep their places), columns ascending within a row"""
+    import scipy.sparse as sp
+
+    n = rp.shape[0] - 1
+    ncol = max(n, int(cl.max()) + 1)
+    sperm = (perm.astype(np.int64)[:, None] * bs + np.arange(bs)).reshape(-1)  # scalar internal -> caller
+    inv = np.arange(ncol, dtype=np.int64)
+    inv[sperm] = np.arange(n)
+    # keep structural zeros: carry the entries as (value, position) through scipy by their indices
+    A = sp.csr_matrix((np.arange(1, v.size + 1, dtype=np.float64), cl, rp), shape=(n, ncol))
+    B = sp.csr_matrix(A[sperm])  # rows in internal order
+    B = sp.csr_matrix((B.data, inv[B.indices], B.indptr), shape=(n, ncol))
+    B.sort_indices()
+    return B.indptr.astype(np.int64), B.indices.astype(np.int32), v[(B.data - 1).astype(np.int64)], sperm
+
+
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (70, 5, 4)), ("poisson", 1, (9, 7, 8)), ("elasticity", 1, (6, 5, 7)),
+                                                ("poisson", 2, (5, 4, 6)), ("poisson", 3, (4, 3, 5)), ("elasticity", 3, (2, 3, 2))])
+@pytest.mark.parametrize("kind", ["random", "rcm", "reverse"])
+def test_library_is_independent_of_the_callers_numbering(problem, order, dims, kind):
+    """A feed numbered as DOLFINx would number it -- partitioner- and reordering-dependent (src/mesh.cpp:153-162,
+    182-186), here random / reverse Cuthill-McKee / reversed dofs, vertices AND cells -- is put into the library's own
+    lattice order behind the ABI.  At the ABI nothing changes: CSR indices bit-exact in the CALLER's numbering, A and b
+    to 1e-12, solution to 1e-6.  Inside, the numbering is the one the structured feed has natively, so the operator
+    stream is byte for byte as large (the same speed by construction), and the product is bit-identical to the serial
+    CSR loop on the internally ordered system P A P^T (zzz_internal_order_download gives P)."""
+    zo.set_num_threads(1)
+    P = zzz.Part(problem, order, *dims)
+    Q = P.renumbered(kind, seed=5)
+    bs = P.bs
+    rng = np.random.default_rng(9)
+    with zzz.Context(0) as c0, zzz.Context(0) as c:
+        c0.upload_part(P)
+        perm0, kind0 = c0.internal_order()
+        assert kind0 == 0 and np.array_equal(perm0, np.arange(P.n_owned))  # the structured feed IS in internal order
+        c0.pattern_build()
+        c0.assemble_matrix(P.form)
+        c0.assemble_vector(P.form)
+        c.upload_part(Q)
+        perm, k = c.internal_order()
+        assert k == 1
+        # internal block i is the structured feed's dof i, whose number at the caller is new_of_old[i]
+        np.testing.assert_array_equal(perm, Q.dof_new_of_old)
+        c.pattern_build()
+        c.assemble_matrix(Q.form)
+        c.assemble_vector(Q.form)
+        assert c.spmv_info_raw()[5:8] == c0.spmv_info_raw()[5:8]  # same operator form, same stream bytes, same entries
+        rp, cl, v = c.csr_download()
+        orp, ocl = zo.pattern(Q.n_owned, Q.cell_dofs, bs)
+        np.testing.assert_array_equal(rp, orp)
+        np.testing.assert_array_equal(cl, ocl)
+        ov = zo.assemble_matrix(Q.form, order, Q.x, Q.cells, Q.cell_dofs, Q.bc_marker(), orp, ocl)
+        ob = zo.assemble_vector(Q.form, order, Q.x, Q.cells, Q.cell_dofs, Q.f, Q.g, Q.facets if Q.form == 0 else None,
+                                Q.bc_marker())
+        assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+        b = c.vec_download(zzz.VEC_B)
+        assert np.abs(b - ob).max() <= 1e-12 * np.abs(ob).max()
+        # the product: bit-exact on the internally ordered system, round-off close to the caller-ordered loop
+        xv = rng.standard_normal(Q.n_owned * bs)
+        y = c.spmv(xv)
+        irp, icl, iv, sperm = _internal_system(rp.astype(np.int64), cl, v, perm, bs)
+        yi = zo.spmv(irp, icl, iv, xv[sperm])
+        np.testing.assert_array_equal(y[sperm], yi)
+        yc = zo.spmv(rp.astype(np.int64), cl, v, xv)
+        assert np.abs(y - yc).max() <= 1e-13 * np.abs(yc).max()
+        # ... and it is the structured feed's product (same internal pattern and stream; the values differ in their last
+        # bits only because the caller's CELL order, in which an entry's contributions are added, is another one)
+        s_new = (Q.dof_new_of_old[:, None] * bs + np.arange(bs)).reshape(-1)
+        y0 = c0.spmv(xv[s_new])
+        assert np.abs(y[s_new] - y0).max() <= 1e-12 * np.abs(y0).max()
+        # values uploaded in the caller's CSR order land where they belong
+        v2 = v * rng.uniform(0.5, 1.5, v.size)
+        c.csr_upload_values(v2)
+        np.testing.assert_array_equal(c.csr_download()[2], v2)
+        irp, icl, iv2, _ = _internal_system(rp.astype(np.int64), cl, v2, perm, bs)
+        np.testing.assert_array_equal(c.spmv(xv)[sperm], zo.spmv(irp, icl, iv2, xv[sperm]))
+        c.csr_upload_values(v)
+        # solve: same iteration count as the structured feed (identical internal systems), solution in caller order
+        it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        it0, _, _ = c0.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        assert abs(it - it0) <= 1
+        u = c.vec_download(zzz.VEC_U)
+        u0 = c0.vec_download(zzz.VEC_U)
+        assert np.linalg.norm(u[s_new] - u0) <= 1e-7 * np.linalg.norm(u0)
+        oit, ou, _, _ = zo.pcg(orp, ocl, ov, ob, rtol=1e-8)
+        assert abs(it - oit) <= 2
+        assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+        if problem == "poisson":
+            ya = c.action(xv)
+            assert np.abs(ya - zo.action_poisson(order, Q.x, Q.cells, Q.cell_dofs, Q.bc_marker(), xv)).max() <= 1e-11 * np.abs(ov).max()
+        # vectors cross the ABI in caller order both ways
+        c.vec_upload(zzz.VEC_B, xv)
+        np.testing.assert_array_equal(c.vec_download(zzz.VEC_B), xv)
+    # ZZZ_RENUMBER=0: the caller's order is kept, and the product is then the caller-ordered CSR loop bit for bit
+    os.environ["ZZZ_RENUMBER"] = "0"
+    try:
+        with zzz.Context(0) as c:
+            c.upload_part(Q)
+            assert c.internal_order()[1] == 0
+            c.pattern_build()
+            c.assemble_matrix(Q.form)
+            rp, cl, v = c.csr_download()
+            np.testing.assert_array_equal(cl, ocl)
+            np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+    finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
+
+
 def test_size_limits_are_errors_not_crashes():
     """Maximum sizes: local indices are int32; a partition beyond that range is refused up front
     (before anything is allocated) with ZZZ_ERR_LIMIT and a message that says what to do."""
@@ -776,6 +886,9 @@ def test_packed_column_stream(cols16):
         os.environ.pop("ZZZ_COLS16", None)
     else:
         os.environ["ZZZ_COLS16"] = cols16
+    # the packed columns belong to the CSR tile kernel: keep the product off the operator stream, or nothing here would
+    # run through them (and zzz_spmv_info would, rightly, not even encode them)
+    os.environ["ZZZ_SELLP"] = "0"
     try:
         zo.set_num_threads(4)
         rng = np.random.default_rng(3)
@@ -795,7 +908,9 @@ def test_packed_column_stream(cols16):
                 rp, cl, v = c.csr_download()
                 xv = rng.standard_normal(P.n_owned * P.bs)
                 np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
-            # random global numbering of a 97 k-dof P1 problem
+            # random global numbering of a 97 k-dof P1 problem, KEPT by the library (ZZZ_RENUMBER=0: without it the dofs
+            # would be put back into lattice order behind the ABI and no tile would need int32 columns)
+            os.environ["ZZZ_RENUMBER"] = "0"
             O = zo.Problem("poisson", 1, 45, 45, 45)
             perm = rng.permutation(O.n).astype(np.int32)
             cell_dofs = np.ascontiguousarray(perm[O.cell_dofs])
@@ -829,6 +944,8 @@ def test_packed_column_stream(cols16):
             assert abs(it - oit) <= 2
             assert np.linalg.norm(u[perm] - ou) <= 1e-6 * np.linalg.norm(ou)
     finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
+        os.environ.pop("ZZZ_SELLP", None)
         if old is None:
             os.environ.pop("ZZZ_COLS16", None)
         else:
@@ -1261,7 +1378,9 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
                 v2[rng.random(v2.size) < 0.3] = 0.0
                 c.csr_upload_values(v2)
                 np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v2, xv))
-        # random global numbering of a 97 k-dof P1 problem: the columns of a slot span more than 16 bits
+        # random global numbering of a 97 k-dof P1 problem, kept by the library (ZZZ_RENUMBER=0): the columns of a slot
+        # span more than 16 bits
+        os.environ["ZZZ_RENUMBER"] = "0"
         O = zo.Problem("poisson", 1, 45, 45, 45)
         perm = rng.permutation(O.n).astype(np.int32)
         cell_dofs = np.ascontiguousarray(perm[O.cell_dofs])
@@ -1278,6 +1397,7 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
             xv = rng.standard_normal(O.n)
             np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
     finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
         for k, val in old.items():
             if val is None:
                 os.environ.pop(k, None)
