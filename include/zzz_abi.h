@@ -216,7 +216,16 @@ int zzz_vec_upload(zzz_ctx* ctx, int which, const double* in);
 int zzz_vec_norm(zzz_ctx* ctx, int which, double* out);
 
 /* y = A x on host vectors of the owned size (ghost values of x are exchanged first when a
- * communicator is attached).  MatMult; for parity checks of the SpMV kernel alone. */
+ * communicator is attached).  MatMult; for parity checks of the SpMV kernel alone.
+ * Non-finite x: the product runs on an operator stream that leaves out the entries whose assembled value is exactly
+ * zero (what MAT_IGNORE_ZERO_ENTRIES does to an AIJ matrix [EXT]) and pads aligned slices with +0.0 entries pointing
+ * at a neighbouring column of the same slice.  For finite x that changes no bit of y.  For x with Inf/NaN it does:
+ * PETSc's MatMult on the full pattern yields NaN in every row that has a STRUCTURAL entry in such a column (0 * NaN);
+ * this product yields NaN in every row with a NONZERO entry there, may miss rows whose only coupling to that column
+ * is an exact zero, and may add rows of the same 64-row slice through a padding entry.  The CG iterations see a
+ * non-finite vector only after they have broken down (reported as KSP_DIVERGED_NANORINF either way).  ZZZ_SELLP_DROP=0
+ * with ZZZ_SELLP_ALIGN=0 keeps every structural entry and no padding on a real column: NaN then propagates exactly
+ * as in the serial CSR loop (tested). */
 int zzz_spmv(zzz_ctx* ctx, const double* x, double* y);
 
 /* Measurement aid: HIP-event time of `reps` back-to-back launches of the CG SpMV kernel

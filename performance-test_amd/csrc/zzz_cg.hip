@@ -189,7 +189,8 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
                                                   const double* __restrict__ pw_parts, int npw,
                                                   const double* __restrict__ w, const double* __restrict__ dinv,
                                                   double* __restrict__ r, double* __restrict__ z, int64_t n, int norm,
-                                                  double* __restrict__ pa, double* __restrict__ pb, int variant)
+                                                  double* __restrict__ pa, double* __restrict__ pb, int variant,
+                                                  TailArgs tail)
 {
   if (block_converged(st))
     return;
@@ -251,6 +252,11 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   }
   const double ta = block_reduce_sum(sa, sh);
   const double tb = block_reduce_sum(sb, sh);
+  if (tail.parts) // multi-GPU: <r,z> and the norm are all-reduced in the tail of this launch (zzz_tail.h)
+  {
+    tail_arrive(tail, ta, tb, 0.0);
+    return;
+  }
   if (threadIdx.x == 0)
   {
     pa[blockIdx.x] = ta;
@@ -511,6 +517,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     fused_mode = atoi(e);
   const bool fused = o->op == ZZZ_OP_CSR && fused_mode == 2 && sellp_active(ctx);
   ctx->last_solve_fused = fused;
+  // multi-GPU: the scalar all-reduce rides in the tail of the product launch when that launch is the operator stream's
+  const bool fold_product = multi && !fused && o->op == ZZZ_OP_CSR && sellp_active(ctx);
   if (fused)
     ZZZ_HIP(ctx, ctx->p_alt.alloc((size_t)ctx->nloc()));
   double* pbuf[2] = {ctx->p.p, fused ? ctx->p_alt.p : ctx->p.p};
@@ -611,10 +619,18 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
     if (timed)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
+    bool folded = false;
+    if (fold_product && comm_tail_args(ctx, ctx->tail, 1, ctx->red.p + 2))
+    {
+      ctx->tail_armed = true; // <p,w> is all-reduced in the tail of the product launch
+      ctx->tail_used = false;
+    }
     {
       int rc = fused ? launch_sellp_dir(ctx, ctx->z.p, pbuf[it & 1], pbuf[(it + 1) & 1], ctx->u.p, ctx->w.p, ctx->part_a.p, &np,
                                         it, P, rz_src, nn_src, n_rz, multi && ctx->overlap)
                      : apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+      folded = ctx->tail_used;
+      ctx->tail_armed = ctx->tail_used = false;
       if (rc)
         return rc;
     }
@@ -625,13 +641,24 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     }
     if (multi)
     {
-      int rc = comm_reduce_allreduce(ctx, stop_flag, ctx->part_a.p, nullptr, nullptr, np, 1, ctx->red.p + 2);
-      if (rc)
-        return rc;
+      if (!folded)
+      {
+        int rc = comm_reduce_allreduce(ctx, stop_flag, ctx->part_a.p, nullptr, nullptr, np, 1, ctx->red.p + 2);
+        if (rc)
+          return rc;
+      }
       np = 1;
     }
+    TailArgs Txr;
+    const bool folded_xr = multi && comm_tail_args(ctx, Txr, 2, ctx->red.p);
+    if (folded_xr)
+    {
+      Txr.expected = g;
+      Txr.base = 0;
+    }
     hipLaunchKernelGGL(kern_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->alpha_hist.p, it, pw_src,
-                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb, P.variant);
+                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb, P.variant, Txr);
+    if (!folded_xr)
     {
       int rc = allreduce_beta();
       if (rc)
@@ -730,8 +757,15 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   }
   int np = 0;
   // s = A z with the three partial dot products; then (multi) one all-reduce of three doubles
+  const bool fold_product = multi && sellp_active(ctx);
   auto apply = [&]() -> int {
     int rc;
+    bool folded = false;
+    if (fold_product && comm_tail_args(ctx, ctx->tail, 3, ctx->red.p))
+    {
+      ctx->tail_armed = true; // (<r,z>, norm, <z,s>) all-reduced in the tail of the product launch
+      ctx->tail_used = false;
+    }
     if (multi && ctx->overlap && ctx->have_tile_split)
       rc = launch_spmv_overlapped(ctx, ctx->z.p, ctx->sr_s.p, parts, &np, ctx->r.p, nn_is_rr);
     else
@@ -744,14 +778,19 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
       }
       rc = launch_spmv(ctx, ctx->z.p, ctx->sr_s.p, parts, &np, ctx->r.p, nn_is_rr);
     }
+    folded = ctx->tail_used;
+    ctx->tail_armed = ctx->tail_used = false;
     if (rc)
       return rc;
     if (multi)
     {
-      rc = comm_reduce_allreduce(ctx, reinterpret_cast<const int*>(ctx->state.p), parts + SPMV_PSTRIDE,
-                                 parts + 2 * SPMV_PSTRIDE, parts, np, 3, ctx->red.p);
-      if (rc)
-        return rc;
+      if (!folded)
+      {
+        rc = comm_reduce_allreduce(ctx, reinterpret_cast<const int*>(ctx->state.p), parts + SPMV_PSTRIDE,
+                                   parts + 2 * SPMV_PSTRIDE, parts, np, 3, ctx->red.p);
+        if (rc)
+          return rc;
+      }
       np = 1;
     }
     return ZZZ_OK;

@@ -234,6 +234,7 @@ struct P2P
   std::vector<bool> ipc_opened;         // peer[r] came from hipIpcOpenMemHandle
   zzz::DevBuf<double*> peer_dev;        // the same pointers for the kernel
   zzz::DevBuf<int32_t> fail;            // device flag: a poll timed out
+  double* tail_mem = nullptr;           // uncached: partial arrays + ticket of the folded all-reduce (zzz_tail.h)
   int64_t seq = 0;                      // round counter = tag; identical call sequence on every rank
   bool enabled = false;
   bool verified = false;                // attach passed on every rank: may be switched on and off
@@ -442,6 +443,30 @@ int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const
   return comm_allreduce_sum(ctx, out, nv);
 }
 
+bool comm_tail_args(zzz_ctx* ctx, TailArgs& T, int nv, double* out)
+{
+  // A/B knob ZZZ_TAIL=1: fold the all-reduce into the producer's tail.  Measured slower than the kernel of its own
+  // (zzz_tail.h has the numbers), so off unless asked for; read per call so that one process can compare both.
+  const char* e = getenv("ZZZ_TAIL");
+  const bool off = !(e && atoi(e) == 1);
+  if (off || !comm_p2p_enabled(ctx) || !ctx->comm->p2p->tail_mem)
+    return false;
+  P2P* P = ctx->comm->p2p;
+  T = TailArgs();
+  T.parts = P->tail_mem;
+  T.ticket = reinterpret_cast<int*>(P->tail_mem + (size_t)TAIL_PART_DOUBLES);
+  T.nv = nv;
+  T.out = out;
+  T.peers = P->peer_dev.p;
+  T.box = P->box;
+  T.nranks = P->nranks;
+  T.rank = P->rank;
+  T.seq = ++P->seq;
+  T.fail = P->fail.p;
+  T.timeout = P2P_TIMEOUT_TICKS;
+  return true;
+}
+
 // did a peer all-reduce time out since the last call?  (checked at the end of a solve)
 int comm_p2p_check(zzz_ctx* ctx)
 {
@@ -468,6 +493,8 @@ static void p2p_destroy(P2P* P)
       (void)hipIpcCloseMemHandle(P->peer[r]);
   if (P->box)
     (void)hipFree(P->box);
+  if (P->tail_mem)
+    (void)hipFree(P->tail_mem);
   delete P;
 }
 
@@ -817,6 +844,21 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
   }
   if (e == hipSuccess)
     e = hipMemset(P->box, 0xff, bytes < 4096 ? 4096 : bytes); // tags = -1: no round has that number
+  if (e == hipSuccess)
+  {
+    // partial arrays + tickets of the folded all-reduce (producers on all eight XCDs, one reader)
+    const size_t tb = sizeof(double) * (size_t)TAIL_PART_DOUBLES + sizeof(int) * (size_t)TAIL_TICKET_INTS;
+    // ordinary device memory: the producers store write-through (sc1), the reader acquires at agent scope (zzz_tail.h).
+    // (Uncached memory was tried first: its stores alone stretched a 20-us product of 2048 workgroups to 40 us.)
+    hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&P->tail_mem), tb);
+    if (e2 == hipSuccess)
+      e2 = hipMemset(P->tail_mem, 0, tb);
+    if (e2 != hipSuccess)
+    {
+      (void)hipGetLastError();
+      P->tail_mem = nullptr; // the separate all-reduce kernel stays in use
+    }
+  }
   if (e == hipSuccess)
   {
     h.ok = 1;

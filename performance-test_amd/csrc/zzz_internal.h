@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/zzz_abi.h"
+#include "zzz_tail.h"
 
 namespace zzz
 {
@@ -218,6 +219,10 @@ struct zzz_ctx
   double prof_spmv_ms = 0.0;
   int64_t prof_spmv_n = 0;
 
+  // the scalar all-reduce folded into the tail of the producing kernel (zzz_tail.h): armed by the CG loop before a
+  // product whose partials it wants all-reduced, consumed by the operator-stream launcher (tail_used tells the loop)
+  zzz::TailArgs tail;
+  bool tail_armed = false, tail_used = false;
   // multi-GPU
   zzz::Comm* comm = nullptr;
   int nneigh = 0;
@@ -297,6 +302,9 @@ int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n);
 int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const double* pb, const double* pc, int np, int nv,
                           double* out);
 bool comm_p2p_enabled(const zzz_ctx* ctx);
+// fills T for one folded all-reduce of nv values into out (takes the next mailbox round number); false when the
+// mailboxes are not in use or ZZZ_TAIL=0: the caller then launches the separate reduce / all-reduce kernel
+bool comm_tail_args(zzz_ctx* ctx, zzz::TailArgs& T, int nv, double* out);
 int comm_p2p_check(zzz_ctx* ctx);
 int comm_halo_forward(zzz_ctx* ctx, double* vec);
 int comm_halo_begin(zzz_ctx* ctx, double* vec); // on the comm stream, after the work enqueued so far

@@ -897,7 +897,8 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
                                                               int nrows, int64_t nslices, double* __restrict__ partials,
                                                               const int* __restrict__ stop_flag,
                                                               const int32_t* __restrict__ group_list, int64_t nlist,
-                                                              const double* __restrict__ rvec, int pstride, int nn_is_rr)
+                                                              const double* __restrict__ rvec, int pstride, int nn_is_rr,
+                                                              TailArgs tail)
 {
   // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
   // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
@@ -951,13 +952,26 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
   if (DOT)
   {
     const double sres = block_reduce_sum(dot, red);
-    if (threadIdx.x == 0)
-      partials[blockIdx.x] = sres;
+    double s1 = 0.0, s2 = 0.0;
     if (rvec)
     {
-      const double s1 = block_reduce_sum(dot_rx, red);
-      const double s2 = block_reduce_sum(dot_nn, red);
-      if (threadIdx.x == 0)
+      s1 = block_reduce_sum(dot_rx, red);
+      s2 = block_reduce_sum(dot_nn, red);
+    }
+    if (tail.parts)
+    {
+      // multi-GPU: the all-reduce of these sums happens in the tail of this launch (zzz_tail.h); output order
+      // (<r,x>, norm, <x,y>) for the single-reduction form, <x,y> alone otherwise
+      if (rvec)
+        tail_arrive(tail, s1, s2, sres);
+      else
+        tail_arrive(tail, sres, 0.0, 0.0);
+      return;
+    }
+    if (threadIdx.x == 0)
+    {
+      partials[blockIdx.x] = sres;
+      if (rvec)
       {
         partials[pstride + blockIdx.x] = s1;
         partials[2 * pstride + blockIdx.x] = s2;
@@ -1424,7 +1438,8 @@ static int sp_grid(int64_t ngroups)
 
 template <bool DOT>
 static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
-                       const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr)
+                       const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr,
+                       const TailArgs& tail = TailArgs())
 {
   // load policy by stream size, as for the tile kernel: a stream that stays in the 256 MiB Infinity Cache from
   // one CG iteration to the next is read with plain loads, a larger one with non-temporal loads
@@ -1435,7 +1450,7 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
 #define ZZZ_SP_GO(NT, PERM)                                                                                            \
   hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off, ctx->sp_vals.p,     \
                      ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y, (int)ctx->nrows,          \
-                     ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr)
+                     ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr, tail)
   if (ctx->sp_sorted)
   {
     if (nt)
@@ -1459,7 +1474,16 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
   const int gs = sp_grid((ctx->nslices + 3) / 4);
   if (partials)
   {
-    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr);
+    TailArgs T;
+    if (ctx->tail_armed)
+    {
+      T = ctx->tail;
+      T.expected = gs;
+      T.base = 0;
+      ctx->tail_armed = false;
+      ctx->tail_used = true;
+    }
+    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr, T);
     if (npartials)
       *npartials = gs;
   }
@@ -1482,13 +1506,26 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   const int g_bd = gb ? sp_grid(gb) : 0;
   if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
     return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
+  TailArgs Ti, Tb;
+  if (partials && ctx->tail_armed)
+  {
+    // one ticket over both launches: the workgroup that arrives last (in the boundary launch, or in the interior
+    // one when no group touches a ghost column) finishes the reduction
+    Ti = ctx->tail;
+    Ti.expected = g_in + g_bd;
+    Ti.base = 0;
+    Tb = Ti;
+    Tb.base = g_in;
+    ctx->tail_armed = false;
+    ctx->tail_used = true;
+  }
   int rc = comm_halo_begin(ctx, x);
   if (rc)
     return rc;
   if (gi)
   {
     if (partials)
-      launch_one<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr);
+      launch_one<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr, Ti);
     else
       launch_one<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi, nullptr, 0);
   }
@@ -1498,7 +1535,7 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   if (gb)
   {
     if (partials)
-      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr);
+      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr, Tb);
     else
       launch_one<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb, nullptr, 0);
   }

@@ -316,6 +316,36 @@ def test_rccl_path_single_rank(ctx):
         assert it3 == it0 and rn3 == rn0
 
 
+def test_allreduce_folded_into_the_producers_tail_keeps_every_bit():
+    """ZZZ_TAIL=1 (csrc/zzz_tail.h): the scalar all-reduce of a multi-GPU iteration done by the last-arriving workgroup of
+    the product / of k_update_xr instead of a kernel of its own -- same summation tree, same mailbox protocol: identical
+    iteration counts, norm histories and solutions, in both CG forms, with more partials than one pass of the tree
+    (> 512 workgroups).  An A/B variant, off by default (measured 1 us slower per iteration at the 8-GPU per-rank size)."""
+    P = zzz.Part("poisson", 1, 60, 60, 61)
+    res = {}
+    try:
+        for tail in ("0", "1"):
+            os.environ["ZZZ_TAIL"] = tail
+            with zzz.Context(0) as c:
+                c.comm_init(1, 0, zzz.comm_unique_id())
+                c.upload_part(P)
+                c.upload_halo(P)
+                assert c.comm_p2p_attach(c.comm_p2p_export())
+                c.pattern_build()
+                c.assemble_matrix(zzz.FORM_POISSON)
+                c.assemble_vector(zzz.FORM_POISSON)
+                for sr in (False, True):
+                    it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=sr)
+                    res[(tail, sr)] = (it, rn, r0, c.cg_history(it + 1), c.vec_download(zzz.VEC_U))
+    finally:
+        os.environ.pop("ZZZ_TAIL", None)
+    for sr in (False, True):
+        a, b = res[("0", sr)], res[("1", sr)]
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[0] > 50
+        np.testing.assert_array_equal(a[3], b[3])
+        np.testing.assert_array_equal(a[4], b[4])
+
+
 def test_driver_binary_surface():
     """dolfinx-scaling-test keeps the reference's CLI, timer names and stdout lines
     (src/main.cpp:57-74,186-205,232-233; src/mesh.cpp:192-193; README.md:148-161)."""
@@ -514,6 +544,53 @@ def test_library_is_independent_of_the_callers_numbering(problem, order, dims, k
             np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
     finally:
         os.environ.pop("ZZZ_RENUMBER", None)
+
+
+def test_non_finite_vector_through_the_product():
+    """Inf/NaN in x (include/zzz_abi.h, zzz_spmv): the operator stream drops exact zeros and pads aligned slices, so
+    NaN propagates through NONZERO couplings always, through exact-zero couplings only with ZZZ_SELLP_DROP=0 +
+    ZZZ_SELLP_ALIGN=0 -- and then exactly as in the serial CSR loop."""
+    zo.set_num_threads(1)
+    P = zzz.Part("poisson", 1, 150, 4, 3)
+    rng = np.random.default_rng(21)
+    xv = rng.standard_normal(P.n_owned)
+    bad = rng.choice(P.n_owned, size=25, replace=False)
+    xv[bad[:15]] = np.nan
+    xv[bad[15:]] = np.inf
+    saved = {k: os.environ.get(k) for k in ("ZZZ_SELLP_DROP", "ZZZ_SELLP_ALIGN")}
+    try:
+        for exact in (False, True):
+            for k in saved:
+                if exact:
+                    os.environ[k] = "0"
+                else:
+                    os.environ.pop(k, None)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                rp, cl, v = c.csr_download()
+                y = c.spmv(xv)
+                yo = zo.spmv(rp.astype(np.int64), cl, v, xv)
+                # rows that meet a non-finite x through a nonzero value
+                nz = v != 0.0
+                hit = np.zeros(P.n_owned, bool)
+                rows = np.repeat(np.arange(P.n_owned), np.diff(rp))
+                hit[rows[nz & ~np.isfinite(xv[cl])]] = True
+                assert np.all(~np.isfinite(y[hit]))
+                fin = np.isfinite(yo)
+                assert np.array_equal(y[fin & np.isfinite(y)], yo[fin & np.isfinite(y)])
+                if exact:
+                    np.testing.assert_array_equal(np.isnan(y), np.isnan(yo))
+                    np.testing.assert_array_equal(y[fin], yo[fin])
+                else:
+                    assert np.count_nonzero(~np.isfinite(y)) >= np.count_nonzero(hit)
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
 
 
 def test_size_limits_are_errors_not_crashes():

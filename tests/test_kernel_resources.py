@@ -61,6 +61,9 @@ def test_operator_stream_kernel_keeps_full_occupancy(tmp_path):
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
-        assert vgprs <= 64 and occ == 8 and scratch <= 64 and lds <= 64, (name, vgprs, occ, scratch, lds)
+        sgprs = int(re.search(r"TotalSGPRs: (\d+)", b).group(1))
+        # LDS: the cross-wavefront sums and the folded all-reduce's tail (zzz_tail.h), a few hundred bytes per workgroup;
+        # SGPRs <= 80 keeps eight 256-thread workgroups per CU admissible (MI355X_MICROARCH.md, Residency)
+        assert vgprs <= 64 and occ == 8 and scratch <= 64 and lds <= 512 and sgprs <= 80, (name, vgprs, occ, scratch, lds, sgprs)
         seen += 1
     assert seen == 8
