@@ -112,13 +112,14 @@ __global__ __launch_bounds__(VB) void k_init_residual(const double* __restrict__
   }
 }
 
-// The convergence flag can be set by workgroup 0 of the SAME launch while other workgroups start:
-// read it once per workgroup and broadcast, so all threads of a workgroup take the same branch.
-__device__ inline int block_converged(const CgState* st)
+// The convergence flag can be set by workgroup 0 of the SAME launch while other workgroups start: one value per
+// workgroup (thread 0's, loaded by the caller ahead of its other requests), so all threads of a workgroup take the same
+// branch -- the reductions behind it need every wavefront.
+__device__ inline int block_flag(int f)
 {
   __shared__ int flag;
   if (threadIdx.x == 0)
-    flag = st->converged;
+    flag = f;
   __syncthreads();
   return flag;
 }
@@ -137,6 +138,24 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
                                                  int update_dir)
 {
   __shared__ double sh[VB / 64];
+  // The first entries of this thread are requested BEFORE the scalar prologue (flag, partial sums, convergence logic: a
+  // chain of dependent loads and barriers of 3-5 us that every workgroup walks): at the 8-GPU per-rank size a thread
+  // has one or two entries in all, so the kernel was prologue + one memory round trip in sequence (11-12 us for 50 MB
+  // that stream in 7).  Clamped index: the loads are unconditional, a thread without entries drops them.
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * VB;
+  const int64_t i0 = blockIdx.x * (int64_t)VB + threadIdx.x;
+  dbl2* __restrict__ p2 = reinterpret_cast<dbl2*>(p);
+  dbl2* __restrict__ x2 = reinterpret_cast<dbl2*>(x);
+  const dbl2* __restrict__ z2 = reinterpret_cast<const dbl2*>(z);
+  const int64_t c0 = (i0 < n2) ? i0 : 0;
+  dbl2 pi0 = {0, 0}, xi0 = {0, 0}, zi0 = {0, 0};
+  if (n2 > 0)
+  {
+    pi0 = p2[c0];
+    xi0 = vload<NT>(x2 + c0);
+    zi0 = vload<NT>(z2 + c0);
+  }
+  const double alpha_h = it > 0 ? alpha_hist[it - 1] : 0.0; // requested with the rest of the prologue's inputs
   DirScalars S;
   if (!cg_direction_scalars(st, beta_hist, dp_hist, it, P, pa, pb, np, sh, S))
     return;
@@ -150,23 +169,29 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
         p[i] = z[i];
     return;
   }
-  const double alpha = alpha_hist[it - 1];
+  const double alpha = alpha_h;
   const double bcoef = rz / bprev;
   // two entries per lane and load (16-B accesses); the arithmetic per entry is unchanged
-  const int64_t n2 = n >> 1;
-  dbl2* __restrict__ p2 = reinterpret_cast<dbl2*>(p);
-  dbl2* __restrict__ x2 = reinterpret_cast<dbl2*>(x);
-  const dbl2* __restrict__ z2 = reinterpret_cast<const dbl2*>(z);
-  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
+  for (int64_t i = i0; i < n2; i += stride)
   {
-    const dbl2 pi = p2[i];
-    dbl2 xi = vload<NT>(x2 + i); // x is touched once per iteration: keep the cache for p, z, w
+    dbl2 pi, xi, zi;
+    if (i == i0)
+    {
+      pi = pi0;
+      xi = xi0; // x is touched once per iteration: keep the cache for p, z, w
+      zi = zi0; // last use of z
+    }
+    else
+    {
+      pi = p2[i];
+      xi = vload<NT>(x2 + i);
+      zi = vload<NT>(z2 + i);
+    }
     xi.x = alpha * pi.x + xi.x; // src/cg.h:68, one kernel late
     xi.y = alpha * pi.y + xi.y;
     vstore<NT>(xi, x2 + i);
     if (dir)
     {
-      const dbl2 zi = vload<NT>(z2 + i); // last use of z
       dbl2 pn;
       pn.x = bcoef * pi.x + zi.x;
       pn.y = bcoef * pi.y + zi.y;
@@ -192,11 +217,30 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
                                                   double* __restrict__ pa, double* __restrict__ pb, int variant,
                                                   TailArgs tail)
 {
-  if (block_converged(st))
+  // first entries requested before the scalar prologue (see k_update_p)
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * VB;
+  const int64_t i0 = blockIdx.x * (int64_t)VB + threadIdx.x;
+  const dbl2* __restrict__ w2 = reinterpret_cast<const dbl2*>(w);
+  const dbl2* __restrict__ d2 = reinterpret_cast<const dbl2*>(dinv);
+  dbl2* __restrict__ r2 = reinterpret_cast<dbl2*>(r);
+  dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
+  const int64_t c0 = (i0 < n2) ? i0 : 0;
+  dbl2 wi0 = {0, 0}, di0 = {0, 0}, ri0 = {0, 0};
+  // (the scalar inputs of the prologue are requested in the same breath, below: flag, beta, <p,w>)
+  if (n2 > 0)
+  {
+    wi0 = vload<NT>(w2 + c0); // last use of w
+    di0 = vload<NT>(d2 + c0);
+    ri0 = vload<NT>(r2 + c0); // r and D^-1 are touched once per iteration
+  }
+  const int f0 = st->converged;
+  const double beta_it = beta_hist[it];
+  const double pw1 = pw_parts[0]; // the all-reduced value itself when a communicator is attached (npw == 1)
+  if (block_flag(f0))
     return;
   __shared__ double sh[VB / 64];
-  const double pw = reduce_parts_bcast(pw_parts, npw, sh);
-  const double alpha = beta_hist[it] / pw; // src/cg.h:65
+  const double pw = npw == 1 ? pw1 : reduce_parts_bcast(pw_parts, npw, sh);
+  const double alpha = beta_it / pw; // src/cg.h:65
   // KSPCG stops on a non-finite scalar (KSP_DIVERGED_NANORINF / _BREAKDOWN); linalg::cg has no such guard: with
   // rnorm0 == 0 its alpha is 0/0, every comparison with NaN is false and the loop runs kmax times (src/cg.h:58-83)
   if (variant != ZZZ_CG_CGH && !isfinite(alpha))
@@ -212,15 +256,21 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   if (blockIdx.x == 0 && threadIdx.x == 0)
     alpha_hist[it] = alpha; // x += alpha p: applied by k_update_p(it + 1)
   double sa = 0, sb = 0;
-  const int64_t n2 = n >> 1;
-  const dbl2* __restrict__ w2 = reinterpret_cast<const dbl2*>(w);
-  const dbl2* __restrict__ d2 = reinterpret_cast<const dbl2*>(dinv);
-  dbl2* __restrict__ r2 = reinterpret_cast<dbl2*>(r);
-  dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
-  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
+  for (int64_t i = i0; i < n2; i += stride)
   {
-    const dbl2 wi = vload<NT>(w2 + i) /* last use of w */, di = vload<NT>(d2 + i);
-    dbl2 ri = vload<NT>(r2 + i), zi; // r and D^-1 are touched once per iteration
+    dbl2 wi, di, ri, zi;
+    if (i == i0)
+    {
+      wi = wi0;
+      di = di0;
+      ri = ri0;
+    }
+    else
+    {
+      wi = vload<NT>(w2 + i);
+      di = vload<NT>(d2 + i);
+      ri = vload<NT>(r2 + i);
+    }
     ri.x = -alpha * wi.x + ri.x; // src/cg.h:71
     ri.y = -alpha * wi.y + ri.y;
     zi.x = di.x * ri.x;
@@ -279,14 +329,48 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
                                                   double* __restrict__ w, double* __restrict__ x, double* __restrict__ r,
                                                   int64_t n, int scalars_only)
 {
-  if (block_converged(st))
-    return;
-  __shared__ double sh[VB / 64];
-  const double rz = reduce_parts_bcast(pa, np, sh);
-  const double nn = reduce_parts_bcast(pb, np, sh);
-  const double zs = reduce_parts_bcast(pc, np, sh);
+  // first entries requested before the scalar prologue (see k_update_p): seven 16-B loads in flight per thread while
+  // the workgroup walks the flag, the three partial sums and the convergence logic
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * VB;
+  const int64_t i0 = blockIdx.x * (int64_t)VB + threadIdx.x;
+  const dbl2* __restrict__ s2 = reinterpret_cast<const dbl2*>(s);
+  const dbl2* __restrict__ d2 = reinterpret_cast<const dbl2*>(dinv);
+  dbl2 *__restrict__ z2 = reinterpret_cast<dbl2*>(z), *__restrict__ p2 = reinterpret_cast<dbl2*>(p),
+                     *__restrict__ w2 = reinterpret_cast<dbl2*>(w), *__restrict__ x2 = reinterpret_cast<dbl2*>(x),
+                     *__restrict__ r2 = reinterpret_cast<dbl2*>(r);
+  const int64_t c0 = (i0 < n2) ? i0 : 0;
+  dbl2 zi0 = {0, 0}, si0 = {0, 0}, di0 = {0, 0}, xi0 = {0, 0}, ri0 = {0, 0}, po0 = {0, 0}, wo0 = {0, 0};
+  if (n2 > 0 && !scalars_only)
+  {
+    zi0 = z2[c0];
+    si0 = vload<NT>(s2 + c0);
+    di0 = vload<NT>(d2 + c0);
+    xi0 = vload<NT>(x2 + c0);
+    ri0 = vload<NT>(r2 + c0);
+    po0 = vload<NT>(p2 + c0); // zero before the first iteration (cg_solve_single_reduction clears p and w)
+    wo0 = vload<NT>(w2 + c0);
+  }
+  // ... and so are the scalar inputs: flag, tolerances, last iteration's coefficients, and (communicator attached:
+  // np == 1) the three all-reduced sums themselves -- that prologue then has no barrier and one memory round trip
+  const int f0 = st->converged;
+  const double ttol_st = st->ttol, dp0_st = st->dp0;
+  const double bo_h = it > 0 ? beta_hist[it - 1] : 1.0, dpi_h = it > 0 ? dpi_hist[it - 1] : 0.0;
+  double rz = pa[0], nn = pb[0], zs = pc[0];
+  if (np == 1)
+  {
+    // every thread holds the same flag unless workgroup 0 of THIS launch is just setting it -- and then every
+    // workgroup reaches the same verdict from the same scalars and leaves below: no wavefront updates a vector
+    if (f0)
+      return;
+  }
+  else
+  {
+    if (block_flag(f0))
+      return;
+    reduce_parts3_bcast(pa, pb, pc, np, rz, nn, zs);
+  }
   const double dp = (P.norm == ZZZ_NORM_NATURAL) ? sqrt(fabs(rz)) : sqrt(nn);
-  double ttol = st->ttol;
+  double ttol = ttol_st;
   if (it == 0)
     ttol = fmax(P.rtol * dp, P.atol);
   int conv = 0;
@@ -294,14 +378,14 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     conv = 2;
   else if (dp <= ttol) // KSPConvergedDefault
     conv = 1;
-  else if (dp >= P.dtol * (it == 0 ? dp : st->dp0)) // ... KSP_DIVERGED_DTOL
+  else if (dp >= P.dtol * (it == 0 ? dp : dp0_st)) // ... KSP_DIVERGED_DTOL
     conv = 3;
   double b = 0.0, dpi = zs;
   if (it > 0)
   {
-    const double bo = beta_hist[it - 1];
+    const double bo = bo_h;
     b = rz / bo;
-    dpi = zs - rz * rz * dpi_hist[it - 1] / (bo * bo);
+    dpi = zs - rz * rz * dpi_h / (bo * bo);
   }
   const double a = rz / dpi;
   if (!conv && !scalars_only && !isfinite(a))
@@ -335,21 +419,24 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     r[i] = ri;
     z[i] = dinv[i] * ri;
   };
-  const int64_t n2 = n >> 1;
-  const dbl2* __restrict__ s2 = reinterpret_cast<const dbl2*>(s);
-  const dbl2* __restrict__ d2 = reinterpret_cast<const dbl2*>(dinv);
-  dbl2 *__restrict__ z2 = reinterpret_cast<dbl2*>(z), *__restrict__ p2 = reinterpret_cast<dbl2*>(p),
-                     *__restrict__ w2 = reinterpret_cast<dbl2*>(w), *__restrict__ x2 = reinterpret_cast<dbl2*>(x),
-                     *__restrict__ r2 = reinterpret_cast<dbl2*>(r);
-  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * VB)
+  for (int64_t i = i0; i < n2; i += stride)
   {
     // cache policy: only z (gathered by the next SpMV) and s (its output) are worth keeping; p, w, x, r, D^-1
     // are touched by this kernel alone, once per iteration
-    const dbl2 zi = z2[i], si = vload<NT>(s2 + i), di = vload<NT>(d2 + i);
-    dbl2 pn = zi, wn = si, xi = vload<NT>(x2 + i), ri = vload<NT>(r2 + i), zn;
+    dbl2 zi, si, di, xi, ri, po, wo;
+    if (i == i0)
+    {
+      zi = zi0, si = si0, di = di0, xi = xi0, ri = ri0, po = po0, wo = wo0;
+    }
+    else
+    {
+      zi = z2[i], si = vload<NT>(s2 + i), di = vload<NT>(d2 + i), xi = vload<NT>(x2 + i), ri = vload<NT>(r2 + i);
+      if (it != 0)
+        po = vload<NT>(p2 + i), wo = vload<NT>(w2 + i);
+    }
+    dbl2 pn = zi, wn = si, zn;
     if (it != 0)
     {
-      const dbl2 po = vload<NT>(p2 + i), wo = vload<NT>(w2 + i);
       pn.x = b * po.x + zi.x;
       pn.y = b * po.y + zi.y;
       wn.x = b * wo.x + si.x;
@@ -433,7 +520,11 @@ static int vgrid(int64_t n)
   // at least 8 entries per thread: every workgroup starts by summing the producer's per-workgroup partials, so for
   // small vectors fewer, longer workgroups are faster (1.25 M rows: 57.8 -> 52.9 us per iteration with 610 instead of
   // 2048 workgroups, 0.5 M rows 40.8 -> 37.0 us; 16 per thread the same, 32 slower); large vectors keep 8 per CU
-  constexpr int per = 8;
+  static const int per = [] {
+    const char* e = getenv("ZZZ_VGRID_PER"); // measurement knob (entries per thread)
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 64 ? v : 8;
+  }();
   int64_t g = (n + VB * per - 1) / (VB * per);
   if (g > VGRID_MAX)
     g = VGRID_MAX;

@@ -21,6 +21,46 @@ __device__ inline double reduce_parts_bcast(const double* __restrict__ parts, in
 }
 
 
+// The same for up to three partial arrays in ONE pass and one barrier pair (same tree per array as reduce_parts_bcast:
+// strided per-thread sums, shuffles inside a wavefront, the per-wavefront sums added in order -- here by every thread
+// from LDS instead of by thread 0 plus a broadcast).  pc may be null.
+__device__ inline void reduce_parts3_bcast(const double* __restrict__ pa, const double* __restrict__ pb,
+                                           const double* __restrict__ pc, int np, double& ra, double& rb, double& rc)
+{
+  __shared__ double sh[3 * 16];
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x)
+  {
+    s0 += pa[i];
+    s1 += pb[i];
+    if (pc)
+      s2 += pc[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    s0 += __shfl_down(s0, o, 64);
+    s1 += __shfl_down(s1, o, 64);
+    s2 += __shfl_down(s2, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0)
+  {
+    sh[wv] = s0;
+    sh[nw + wv] = s1;
+    sh[2 * nw + wv] = s2;
+  }
+  __syncthreads();
+  ra = rb = rc = 0.0;
+  for (int i = 0; i < nw; ++i)
+  {
+    ra += sh[i];
+    rb += sh[nw + i];
+    rc += sh[2 * nw + i];
+  }
+}
+
 // The scalar logic at the head of iteration `it` (convergence test of the completed iterations and the new
 // direction's coefficient), identical in every workgroup; workgroup 0 records it.  pa/pb: partials (or the single
 // all-reduced values) of <r,z> and of the test norm.  Returns false when an EARLIER launch has stopped the solve
@@ -35,21 +75,20 @@ __device__ inline bool cg_direction_scalars(CgState* __restrict__ st, double* __
                                             const double* __restrict__ pa, const double* __restrict__ pb, int np, double* sh,
                                             DirScalars& S)
 {
-  {
-    __shared__ int flag;
-    if (threadIdx.x == 0)
-    {
-      const int c = __atomic_load_n(&st->conv_it1, __ATOMIC_RELAXED);
-      flag = c != 0 && c - 1 < it;
-    }
-    __syncthreads();
-    if (flag)
-      return false;
-  }
-  const double rz = reduce_parts_bcast(pa, np, sh);
-  const double nn = reduce_parts_bcast(pb, np, sh);
+  // every input of the scalar logic is requested up-front (uniform loads, one round trip): the stop word, the state,
+  // last iteration's <r,z>, and -- communicator attached, np == 1 -- the two all-reduced sums themselves
+  const int c = __atomic_load_n(&st->conv_it1, __ATOMIC_RELAXED);
+  const double dp0_st = st->dp0, ttol_st = st->ttol;
+  const double bprev_h = (it == 0) ? 1.0 : beta_hist[it - 1];
+  double rz = pa[0], nn = pb[0], unused;
+  // stopped by an EARLIER launch (c - 1 < it): that word was written before this launch began, so every wavefront
+  // reads the same value and the branch is uniform without a broadcast
+  if (c != 0 && c - 1 < it)
+    return false;
+  if (np != 1)
+    reduce_parts3_bcast(pa, pb, nullptr, np, rz, nn, unused);
   // scalar logic, identical in every workgroup; workgroup 0 records it
-  double dp, dp0 = st->dp0, ttol = st->ttol;
+  double dp, dp0 = dp0_st, ttol = ttol_st;
   int conv = 0;
   if (P.variant == ZZZ_CG_CGH)
   {
@@ -78,7 +117,7 @@ __device__ inline bool cg_direction_scalars(CgState* __restrict__ st, double* __
     else if (dp >= P.dtol * dp0) // ... KSP_DIVERGED_DTOL
       conv = 3;
   }
-  const double bprev = (it == 0) ? 1.0 : beta_hist[it - 1];
+  const double bprev = bprev_h;
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     beta_hist[it] = rz;

@@ -361,13 +361,16 @@ __global__ __launch_bounds__(1024) void k_allreduce_p2p(const int* __restrict__ 
                                                         double* box, int nranks, int rank, long long seq,
                                                         int* __restrict__ fail, long long timeout)
 {
-  if (stop && *stop) // CG already converged (the same on every rank: identical scalars everywhere)
-    return;
+  // the stop word is requested together with the partials (one memory round trip instead of two on the critical path
+  // of every iteration); a stopped solve then sums stale partials for nothing and leaves
+  const int stopv = stop ? *stop : 0; // CG already converged (the same on every rank: identical scalars everywhere)
   __shared__ double val[3];
   __shared__ int timed_out;
   if (threadIdx.x == 0)
     timed_out = 0;
   reduce3(pa, pb, pc, np, nv, val);
+  if (stopv)
+    return;
   const int par = (int)(seq & 1);
   if ((int)threadIdx.x < nranks)
   {
