@@ -179,6 +179,8 @@ void zzz_ctx_destroy(zzz_ctx* ctx)
     (void)hipEventDestroy(ctx->sp_event);
   if (ctx->h_state)
     (void)hipHostFree(ctx->h_state);
+  if (ctx->adj_flag_host)
+    (void)hipHostFree(ctx->adj_flag_host);
   if (ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -277,6 +279,7 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   rc = renumber_build(ctx);
   if (rc)
     return rc;
+  ctx->adj_runs_n = -1;
   pattern_reserve(ctx);
   return ensure_p1_coords(ctx); // function-space data (dof coordinates), not assembly work
 }

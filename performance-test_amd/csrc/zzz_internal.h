@@ -139,6 +139,11 @@ struct zzz_ctx
   int64_t scr_cell_of_n = -1; // scr_vals_in holds position / nd for this many connectivity entries ...
   int scr_cell_of_nd = 0;     // ... of nd dofs per cell
   zzz::DevBuf<int64_t> scr_bptr;
+  // monotone runs of the connectivity (zzz_pattern.hip, adjacency without a sort): per run {local dof index k, first
+  // cell, end cell}; found once per dofmap (adj_runs_n: -1 not examined, 0 none usable / too many, else the count)
+  zzz::DevBuf<int32_t> adj_runs, adj_run_lo, adj_win_base;
+  int adj_runs_n = -1;
+  int32_t* adj_flag_host = nullptr; // pinned: "a window did not fit" travels here behind the build's kernels
   zzz::DevBuf<unsigned char> scr_tmp;
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
   zzz::DevBuf<int32_t> adjT_off, adjT_cells; // the same lists transposed in 64-row slices (dense wave reads)

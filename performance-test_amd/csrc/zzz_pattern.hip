@@ -754,6 +754,305 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols)
   return ZZZ_OK;
 }
 
+// ---- dof -> cell adjacency WITHOUT a sort, for connectivities made of few monotone runs ---------------------------
+// create_matrix needs, for every owned dof, the ascending list of its cells.  Sorting the (dof, cell) incidences costs
+// three radix passes over 237 M pairs at the headline size (rocPRIM onesweep: 4.9 of create_matrix's 7.7 ms).  But the
+// connectivity of a structured feed -- native, or put into lattice order by zzz_renumber.hip -- is a handful of
+// MONOTONE RUNS: inside a block of cells (one simplex type of one slab, typically) the dof number at a fixed local
+// index k grows strictly with the cell number.  The incidences of a WINDOW of 256 consecutive dofs are then, in every
+// run, one contiguous range of at most 256 cells, found by binary search; one workgroup (one thread per cell of a
+// range) counts the window's incidences per dof in LDS, scans, places them, orders each dof's cells, and writes its part
+// of adj_off / adj_cells with dense stores.  No global atomics, no library sort.  (Reading whole connectivity records over
+// the hull of the ranges of all k was tried: the ranges of different k lie a mesh plane apart -- 28 ms.)  Connectivities
+// with more runs than ADJ_MAX_RUNS (a caller's arbitrary cell order) or a window beyond the LDS budget take the radix
+// sort as before.
+constexpr int ADJ_W = 256;          // dofs per window = threads per workgroup
+constexpr int ADJ_CAP = 7168;       // incidences a window may hold in LDS
+constexpr int ADJ_MAX_RUNS = 512;   // (block, local index) pairs
+constexpr int ADJ_BREAK_CAP = 4096; // break records collected before giving up
+
+// cells c where some sequence k stops growing (cd[c][k] <= cd[c-1][k]); out: the cells, count in nbreaks[0]
+__global__ void k_run_breaks(const int32_t* __restrict__ cd, int64_t ncells, int nd, int cap, int32_t* __restrict__ nbreaks,
+                             int32_t* __restrict__ out)
+{
+  const int64_t total = (ncells - 1) * nd;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t c = 1 + t / nd;
+    const int k = (int)(t % nd);
+    if (cd[c * nd + k] <= cd[(c - 1) * nd + k])
+    {
+      const int slot = atomicAdd(nbreaks, 1);
+      if (slot < cap)
+        out[slot] = (int32_t)c;
+    }
+  }
+}
+
+// lo[r][w] = first cell of run r = {k, first cell, end cell} whose key is >= w * ADJ_W   (w = 0 .. nwin)
+__global__ void k_run_window_bounds(const int32_t* __restrict__ cd, int nd, const int32_t* __restrict__ runs, int nruns,
+                                    int nwin, int32_t* __restrict__ lo)
+{
+  const int64_t total = (int64_t)nruns * (nwin + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int r = (int)(t / (nwin + 1)), w = (int)(t % (nwin + 1));
+    const int k = runs[3 * r];
+    int a = runs[3 * r + 1], b = runs[3 * r + 2];
+    const int64_t key = (int64_t)w * ADJ_W;
+    while (a < b)
+    {
+      const int m = (a + b) >> 1;
+      if (cd[(int64_t)m * nd + k] < key)
+        a = m + 1;
+      else
+        b = m;
+    }
+    lo[t] = a;
+  }
+}
+
+// tot[w] = incidences of window w (one thread per window; lo[r][.] is contiguous in w: dense reads)
+__global__ void k_window_tot(const int32_t* __restrict__ lo, int nruns, int nwin, int32_t* __restrict__ tot)
+{
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += gridDim.x * blockDim.x)
+  {
+    int t = 0;
+    for (int r = 0; r < nruns; ++r)
+      t += lo[(int64_t)r * (nwin + 1) + w + 1] - lo[(int64_t)r * (nwin + 1) + w];
+    tot[w] = t;
+  }
+}
+
+// base = exclusive scan of tot, in place (one workgroup: a few tens of values per thread); flag[0] |= a window does
+// not fit the LDS of k_adj_window
+__global__ __launch_bounds__(1024) void k_window_base(int nwin, int32_t* __restrict__ base, int32_t* __restrict__ flag)
+{
+  __shared__ int64_t part[1024];
+  const int per = (nwin + 1023) / 1024;
+  const int w0 = min(nwin, (int)threadIdx.x * per), w1 = min(nwin, w0 + per);
+  int64_t sum = 0;
+  bool over = false;
+  for (int w = w0; w < w1; ++w)
+  {
+    sum += base[w];
+    over |= base[w] > ADJ_CAP;
+  }
+  if (over)
+    flag[0] = 1;
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    int64_t acc = 0;
+    for (int i = 0; i < 1024; ++i)
+    {
+      const int64_t v = part[i];
+      part[i] = acc;
+      acc += v;
+    }
+    if (acc > INT32_MAX)
+      flag[0] = 1;
+    base[nwin] = (int32_t)acc;
+  }
+  __syncthreads();
+  int64_t acc = part[threadIdx.x];
+  for (int w = w0; w < w1; ++w)
+  {
+    const int32_t v = base[w];
+    base[w] = (int32_t)acc;
+    acc += v;
+  }
+}
+
+__global__ __launch_bounds__(ADJ_W) void k_adj_window(const int32_t* __restrict__ cd, int nd, const int32_t* __restrict__ runs,
+                                                      int nruns, const int32_t* __restrict__ lo, int nwin,
+                                                      const int32_t* __restrict__ base, int32_t nb,
+                                                      int32_t* __restrict__ adj_off, int32_t* __restrict__ adj_cells)
+{
+  __shared__ int32_t seg0[ADJ_MAX_RUNS], segn[ADJ_MAX_RUNS], segk[ADJ_MAX_RUNS];
+  __shared__ int32_t out_s[ADJ_CAP];
+  __shared__ int32_t cnt[ADJ_W], off[ADJ_W + 1], cur[ADJ_W];
+  __shared__ int wsum[ADJ_W / 64];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  if (base[w + 1] - base[w] > ADJ_CAP)
+  {
+    // k_window_base has raised the flag and the host will build again with the sort; until it looks, the kernels behind
+    // this one must find something harmless here: all the window's entries, valid cell numbers, on its first dof
+    const int32_t gb = base[w], ge = base[w + 1];
+    if (w * ADJ_W + tid <= nb)
+      adj_off[w * ADJ_W + tid] = tid == 0 ? gb : ge;
+    for (int t = gb + tid; t < ge; t += ADJ_W)
+      adj_cells[t] = 0;
+    return;
+  }
+  for (int r = tid; r < nruns; r += ADJ_W)
+  {
+    const int a = lo[(int64_t)r * (nwin + 1) + w], b = lo[(int64_t)r * (nwin + 1) + w + 1];
+    seg0[r] = a;
+    segn[r] = b - a; // <= 256: the keys of a run grow strictly
+    segk[r] = runs[3 * r];
+  }
+  cnt[tid] = 0;
+  cur[tid] = 0;
+  __syncthreads();
+  const int32_t key0 = w * ADJ_W;
+  // Thread tid owns the tid-th cell of every run's range.  Two sweeps (count, place); eight runs' loads are requested
+  // together (unconditional, clamped), then used; the second sweep's reads come from L2.
+  auto sweep = [&](auto&& hit) {
+    for (int r0 = 0; r0 < nruns; r0 += 8)
+    {
+      int key[8], cell[8];
+      bool in[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+      {
+        const int r = min(r0 + u, nruns - 1);
+        in[u] = r0 + u < nruns && tid < segn[r];
+        cell[u] = seg0[r] + (in[u] ? tid : 0);
+        key[u] = cd[(int64_t)cell[u] * nd + segk[r]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (in[u])
+          hit(key[u] - key0, cell[u]);
+    }
+  };
+  sweep([&](int key, int) { atomicAdd(&cnt[key], 1); });
+  __syncthreads();
+  // exclusive scan of the counts (256 values: wavefront scans + carry)
+  {
+    int v = cnt[tid];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+    {
+      const int u = __shfl_up(v, o, 64);
+      if ((tid & 63) >= o)
+        v += u;
+    }
+    if ((tid & 63) == 63)
+      wsum[tid >> 6] = v;
+    __syncthreads();
+    int carry = 0;
+    for (int q = 0; q < (tid >> 6); ++q)
+      carry += wsum[q];
+    off[tid] = carry + v - cnt[tid];
+    if (tid == ADJ_W - 1)
+      off[ADJ_W] = carry + v;
+  }
+  __syncthreads();
+  const int T = off[ADJ_W];
+  // place (arrival order), then order each dof's cells ascending = the serial assembly order
+  sweep([&](int key, int c) { out_s[off[key] + atomicAdd(&cur[key], 1)] = c; });
+  __syncthreads();
+  {
+    const int a = off[tid], n = cnt[tid];
+    for (int i = 1; i < n; ++i)
+    {
+      const int32_t v = out_s[a + i];
+      int j = i - 1;
+      while (j >= 0 && out_s[a + j] > v)
+      {
+        out_s[a + j + 1] = out_s[a + j];
+        --j;
+      }
+      out_s[a + j + 1] = v;
+    }
+  }
+  __syncthreads();
+  // the window's part of the adjacency, dense stores
+  const int32_t gb = base[w];
+  if (key0 + tid <= nb)
+    adj_off[key0 + tid] = gb + off[tid];
+  if (w == nwin - 1 && tid == 0 && nb == nwin * ADJ_W) // (otherwise written above: the last window also holds ghost keys)
+    adj_off[nb] = gb + T;
+  for (int t = tid; t < T; t += ADJ_W)
+    adj_cells[gb + t] = out_s[t];
+}
+
+// finds the monotone runs of the current connectivity (once per dofmap): ctx->adj_runs_n > 0 when the sort-free
+// path applies
+static void adjacency_find_runs(zzz_ctx* ctx)
+{
+  ctx->adj_runs_n = 0;
+  if (getenv("ZZZ_ADJ_SORT")) // A/B knob: always the radix sort
+    return;
+  const int nd = ctx->nd;
+  const int64_t nc = ctx->ncells;
+  if (nc >= INT32_MAX)
+    return;
+  hipStream_t s = ctx->stream;
+  DevBuf<int32_t> nbr, brk;
+  if (nbr.alloc(1) != hipSuccess || brk.alloc((size_t)ADJ_BREAK_CAP) != hipSuccess
+      || hipMemsetAsync(nbr.p, 0, sizeof(int32_t), s) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  if (nc > 1)
+    hipLaunchKernelGGL(k_run_breaks, dim3(grid_for((nc - 1) * nd)), dim3(256), 0, s, ctx->cell_dofs.p, nc, nd, ADJ_BREAK_CAP,
+                       nbr.p, brk.p);
+  int32_t n = 0;
+  if (hipMemcpyAsync(&n, nbr.p, sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  if (n > ADJ_BREAK_CAP)
+    return; // not a connectivity of few monotone runs
+  std::vector<int32_t> cuts((size_t)n);
+  if (n && hipMemcpy(cuts.data(), brk.p, cuts.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  // blocks between ALL break cells (whatever k broke): inside a block every local index grows strictly
+  cuts.push_back(0);
+  cuts.push_back((int32_t)nc);
+  std::sort(cuts.begin(), cuts.end());
+  cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+  const int nblocks = (int)cuts.size() - 1;
+  if (nblocks < 1 || (int64_t)nblocks * nd > ADJ_MAX_RUNS)
+    return;
+  std::vector<int32_t> runs;
+  for (int j = 0; j < nblocks; ++j)
+    for (int k = 0; k < nd; ++k)
+      runs.insert(runs.end(), {k, cuts[(size_t)j], cuts[(size_t)j + 1]});
+  const int nruns = nblocks * nd;
+  const int nwin = (int)((ctx->n_owned + ADJ_W - 1) / ADJ_W);
+  if (ctx->adj_runs.alloc(runs.size()) != hipSuccess
+      || hipMemcpy(ctx->adj_runs.p, runs.data(), runs.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess
+      || ctx->adj_run_lo.alloc((size_t)nruns * (nwin + 1)) != hipSuccess || ctx->adj_win_base.alloc((size_t)nwin + 2) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  ctx->adj_runs_n = nruns;
+}
+
+// adjacency through the runs, enqueued without a host wait: whether every window fitted arrives in
+// ctx->adj_flag_host behind these kernels and is looked at the next time the build waits for the device anyway
+static int adjacency_by_runs(zzz_ctx* ctx)
+{
+  const int nruns = ctx->adj_runs_n, nd = ctx->nd;
+  const int32_t nb = (int32_t)ctx->n_owned;
+  const int nwin = (nb + ADJ_W - 1) / ADJ_W;
+  hipStream_t s = ctx->stream;
+  if (!ctx->adj_flag_host)
+    ZZZ_HIP(ctx, hipHostMalloc((void**)&ctx->adj_flag_host, sizeof(int32_t), hipHostMallocDefault));
+  int32_t* flag = ctx->adj_win_base.p + nwin + 1;
+  ZZZ_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_run_window_bounds, dim3(grid_for((int64_t)nruns * (nwin + 1), 256, 16384)), dim3(256), 0, s,
+                     ctx->cell_dofs.p, nd, ctx->adj_runs.p, nruns, nwin, ctx->adj_run_lo.p);
+  hipLaunchKernelGGL(k_window_tot, dim3(grid_for(nwin)), dim3(256), 0, s, ctx->adj_run_lo.p, nruns, nwin, ctx->adj_win_base.p);
+  hipLaunchKernelGGL(k_window_base, dim3(1), dim3(1024), 0, s, nwin, ctx->adj_win_base.p, flag);
+  hipLaunchKernelGGL(k_adj_window, dim3(nwin), dim3(ADJ_W), 0, s, ctx->cell_dofs.p, nd, ctx->adj_runs.p, nruns, ctx->adj_run_lo.p,
+                     nwin, ctx->adj_win_base.p, nb, ctx->adj_off.p, ctx->adj_cells.p);
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->adj_flag_host, flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+
 // Scratch of the pattern build whose size follows from the dofmap alone (sort buffers, the entry -> cell map, the
 // staging area): reserved when the dofmap arrives, so that a one-shot `ZZZ Assemble` (the reference driver runs every
 // phase once) does not pay ~18 ms of multi-GB hipMalloc calls inside its timer.  Failure to reserve is not an error: the
@@ -795,6 +1094,7 @@ void pattern_reserve(zzz_ctx* ctx)
   if (nstage < ((int64_t)3 << 30))
     (void)ctx->scr_stage.alloc((size_t)nstage);
   (void)hipGetLastError();
+  adjacency_find_runs(ctx); // a property of the dofmap, like the sizes above
 }
 
 // returns ZZZ_OK, or ZZZ_ERR_LIMIT with *fallback = true when a row has more candidates than the
@@ -841,9 +1141,20 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
                                          (unsigned)end_bit, s));
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, cnt.p, bptr.p, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s));
   ZZZ_HIP(ctx, tmp.alloc(tb > tb2 ? tb : tb2));
-  ZZZ_HIP(ctx, rocprim::radix_sort_pairs<AdjSortConfig>(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N, 0,
-                                         (unsigned)end_bit, s));
-  hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for((N + 4) / 4)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
+  if (ctx->adj_runs_n < 0)
+    adjacency_find_runs(ctx);
+  const bool by_runs = ctx->adj_runs_n > 0;
+  if (by_runs)
+  {
+    if (int rc = adjacency_by_runs(ctx))
+      return rc;
+  }
+  else
+  {
+    ZZZ_HIP(ctx, rocprim::radix_sort_pairs<AdjSortConfig>(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N,
+                                           0, (unsigned)end_bit, s));
+    hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for((N + 4) / 4)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
+  }
 
   // 2. pattern: count, scan, fill
   const int rgrid = grid_for((int64_t)nb, 4, 256 * 16);
@@ -855,6 +1166,8 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     stage = ctx->scr_stage.p;
   int32_t h[4] = {0, 0, 0, 0};
   bool counted = false;
+  // (called after a device wait) a window of the sort-free adjacency did not fit: build again, sorting
+  auto adjacency_overflowed = [&]() { return by_runs && ctx->adj_flag_host && *ctx->adj_flag_host != 0; };
   if (nd == 4 && stage && !getenv("ZZZ_PATTERN_WAVE"))
   {
     // P1: one thread per row; scal[2] = "a row has more than ROW_T_CAP unique columns"
@@ -875,6 +1188,11 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
                            ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
       ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
       ZZZ_HIP(ctx, hipStreamSynchronize(s));
+      if (adjacency_overflowed())
+      {
+        ctx->adj_runs_n = 0;
+        return pattern_build_device(ctx, fallback);
+      }
       if (h[2] == 0 || cap == 32)
         break;
       ZZZ_HIP(ctx, hipMemsetAsync(scal.p, 0, 4 * sizeof(int32_t), s));
@@ -890,6 +1208,11 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
                        ctx->adj_cells.p, nb, cnt.p, scal.p, (const int64_t*)nullptr, (int32_t*)nullptr, scal.p + 1, stage);
     ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    if (adjacency_overflowed())
+    {
+      ctx->adj_runs_n = 0;
+      return pattern_build_device(ctx, fallback);
+    }
   }
   if (h[1] > 0)
   {

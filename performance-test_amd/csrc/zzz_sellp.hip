@@ -903,22 +903,38 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
   // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
   // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
   // spmv_tile_kernel
-  if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
-    return;
   __shared__ double red[SP_BLOCK / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ngroups = group_list ? nlist : (nslices + 3) / 4; // a workgroup takes 4 consecutive slices
   double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
-  for (int i = 0;; ++i)
-  {
+  // A slice is a chain of dependent round trips: (group list ->) descriptor -> values / codes / bases -> gathers.  At the
+  // 8-GPU per-rank size a wavefront has two or three slices in all, so the kernel's length is that chain times three;
+  // the slice number and descriptor of the NEXT slice are therefore requested (scalar loads) before the current slice's
+  // chunks, and those of the first slice before the stop word is looked at.
+  auto next_slice = [&](int i, int& s_out, int2& ds_out) -> int { // 1 valid, 0 no slice for this wavefront, -1 done
     const int64_t gi = sp_xcd_item(ngroups, blockIdx.x, gridDim.x, i);
     if (gi < 0)
-      break;
+      return -1;
     const int64_t g = group_list ? group_list[gi] : gi;
     const int s = __builtin_amdgcn_readfirstlane((int)(4 * g + wv));
+    s_out = s;
     if (s >= nslices)
+      return 0;
+    ds_out = desc[s];
+    return 1;
+  };
+  int s_n = 0;
+  int2 ds_n = make_int2(0, 0);
+  int st_n = next_slice(0, s_n, ds_n);
+  if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
+    return;
+  for (int i = 0; st_n >= 0; ++i)
+  {
+    const int st = st_n, s = s_n;
+    const int2 ds = ds_n;
+    st_n = next_slice(i + 1, s_n, ds_n);
+    if (st == 0)
       continue;
-    const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
     if (!PERM && r >= nrows)
