@@ -269,8 +269,11 @@ int zzz_local_sizes(const zzz_ctx* ctx, int64_t sizes[6]);
  * iterates) equal the serial CSR loop bit for bit on the internally ordered system P A P^T, and the caller-ordered loop
  * only to round-off -- exactly as PETSc's result depends on the local numbering of the run; (2) this function, which
  * returns P: perm[i] = caller index of internal owned block dof i (the identity when the caller's order was kept:
- * structured feeds of this repository, meshes that are not a lattice, ZZZ_RENUMBER=0).  kind (optional): 0 caller's
- * order kept, 1 lattice order, 2 coordinate-bin order (ZZZ_RENUMBER=2 only).  No reference counterpart. */
+ * structured feeds of this repository, meshes that are not a lattice, ZZZ_RENUMBER=0).  kind (optional): low bits 0 caller's
+ * dof order kept, 1 lattice order, 2 coordinate-bin order (ZZZ_RENUMBER=2 only); bit 4 (16): the CELLS are kept in an
+ * internal order as well (simplex type by simplex type, lattice cube by lattice cube) -- invisible at this ABI except
+ * that an entry of A or b is then the sum of its cells' contributions in that order instead of the caller's cell
+ * order (the same terms; differences of the last bits).  No reference counterpart. */
 int zzz_internal_order_download(zzz_ctx* ctx, int32_t* perm /* n_owned */, int32_t* kind);
 
 /* ---- solve ----------------------------------------------------------------------------- */

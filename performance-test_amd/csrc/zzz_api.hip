@@ -322,6 +322,13 @@ int zzz_facets_upload(zzz_ctx* ctx, int64_t nfacets, const int32_t* pairs)
       return fail(ctx, ZZZ_ERR_ARG, "facet %lld = (%d, %d) out of range", (long long)i, c, f);
     m[c] |= (uint8_t)(1u << f);
   }
+  if (ctx->cells_renumbered) // the device holds the cells in the library's order: mask of internal cell i = caller's cperm[i]
+  {
+    std::vector<uint8_t> mi(m.size());
+    for (size_t i = 0; i < m.size(); ++i)
+      mi[i] = m[(size_t)ctx->h_cperm[i]];
+    m.swap(mi);
+  }
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->facet_mask.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->nfacets = nfacets;
@@ -403,14 +410,13 @@ static int pattern_build_host(zzz_ctx* ctx)
   const int nd = ctx->nd, bs = ctx->bs;
   const int64_t nb = ctx->n_owned, nc = ctx->ncells;
   std::vector<int32_t> cd_internal;
-  if (ctx->renumbered) // the host copy keeps the caller's numbering (zzz_ghost_layer_build reads it)
+  const bool internal = ctx->renumbered || ctx->cells_renumbered;
+  if (internal) // the host copy keeps the caller's dof numbering and cell order (zzz_ghost_layer_build reads it)
   {
-    cd_internal = ctx->h_cell_dofs;
-    for (int32_t& d : cd_internal)
-      if (d < nb)
-        d = ctx->h_iperm[(size_t)d];
+    cd_internal.resize((size_t)(nc * nd));
+    ZZZ_HIP(ctx, hipMemcpy(cd_internal.data(), ctx->cell_dofs.p, cd_internal.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
   }
-  const int32_t* cd = ctx->renumbered ? cd_internal.data() : ctx->h_cell_dofs.data();
+  const int32_t* cd = internal ? cd_internal.data() : ctx->h_cell_dofs.data();
   // owned block dof -> incident cells, ascending (counting sort over cells)
   std::vector<int32_t> off((size_t)nb + 1, 0);
   for (int64_t c = 0; c < nc; ++c)
@@ -874,7 +880,7 @@ int zzz_internal_order_download(zzz_ctx* ctx, int32_t* perm, int32_t* kind)
     for (int64_t i = 0; i < ctx->n_owned; ++i)
       perm[i] = ctx->renumbered ? ctx->h_perm[(size_t)i] : (int32_t)i;
   if (kind)
-    *kind = ctx->renumbered ? ctx->renumber_kind : 0;
+    *kind = (ctx->renumbered ? ctx->renumber_kind : 0) | (ctx->cells_renumbered ? 16 : 0);
   return ZZZ_OK;
 }
 

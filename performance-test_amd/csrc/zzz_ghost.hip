@@ -139,6 +139,7 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
   cverts = ctx->h_cell_verts;
   cdofs = ctx->h_cell_dofs;
   int rc = download(ctx, ctx->x, x, (size_t)(3 * nverts));
+  // (the host copies are the caller's; only a device-generated feed has none, and that one is in internal order anyway)
   if (!rc && cverts.empty())
     rc = download(ctx, ctx->cell_verts, cverts, (size_t)(4 * ncells));
   if (!rc && cdofs.empty())
@@ -153,6 +154,13 @@ int zzz_ghost_layer_build(zzz_ctx* ctx)
     rc = download(ctx, ctx->coeff[ZZZ_COEFF_G], cg, (size_t)nloc);
   if (!rc)
     rc = download(ctx, ctx->send_idx, send_idx, (size_t)nsend_old);
+  if (!rc && ctx->cells_renumbered)
+  {
+    std::vector<uint8_t> fm2(fmask.size());
+    for (int64_t i = 0; i < ncells; ++i)
+      fm2[(size_t)ctx->h_cperm[(size_t)i]] = fmask[(size_t)i];
+    fmask.swap(fm2);
+  }
   if (!rc && ctx->renumbered)
   {
     // the device holds the library's internal numbering of the owned dofs; this function works in the caller's

@@ -111,6 +111,10 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> perm, iperm;
   std::vector<int32_t> h_perm, h_iperm;
   std::vector<uint16_t> csr_slot; // caller CSR entry -> position inside its internal row (built on first CSR download)
+  // ... and of the cells (simplex type by simplex type, lattice cube by lattice cube): h_cperm[internal] = caller cell.
+  // cell_verts, cell_dofs and facet_mask on the device are in internal cell order when cells_renumbered.
+  bool cells_renumbered = false;
+  std::vector<int32_t> h_cperm;
 
   // bc marker per local scalar dof (owned + ghost)
   zzz::DevBuf<uint8_t> bc;

@@ -186,6 +186,82 @@ __global__ void k_dof_keys(const double* __restrict__ x, const int32_t* __restri
   }
 }
 
+// Key of a cell on the vertex lattice: (simplex type, z, y, x of its lattice cube).  The type is read off the geometry: the
+// four corners of the cube the vertices sit on, as 3-bit codes (x = 1, y = 2, z = 4) in ascending order -- for the six
+// Kuhn simplices of create_box that is the order (0,1,3,7) (0,1,5,7) (0,2,3,7) (0,2,6,7) (0,4,5,7) (0,4,6,7), the
+// structured feed's own.  A cell that is not inside one lattice cube gets no key (flag).
+__global__ void k_cell_keys(const double* __restrict__ x, const int32_t* __restrict__ cell_verts, int64_t ncells, Lattice L,
+                            unsigned long long* __restrict__ keys, int32_t* __restrict__ flag)
+{
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * blockDim.x)
+  {
+    int idx[4][3];
+    bool off_lattice = false;
+    for (int v = 0; v < 4; ++v)
+    {
+      const int32_t gv = cell_verts[4 * c + v];
+      for (int a = 0; a < 3; ++a)
+      {
+        double f;
+        locate(L, a, x[3 * (int64_t)gv + a], idx[v][a], f);
+        off_lattice |= f != 0.0;
+      }
+    }
+    int lo[3];
+    for (int a = 0; a < 3; ++a)
+      lo[a] = min(min(idx[0][a], idx[1][a]), min(idx[2][a], idx[3][a]));
+    int code[4];
+    for (int v = 0; v < 4; ++v)
+    {
+      code[v] = 0;
+      for (int a = 0; a < 3; ++a)
+      {
+        const int d = idx[v][a] - lo[a];
+        off_lattice |= d > 1;
+        code[v] |= (d & 1) << a;
+      }
+    }
+    // four values: a sorting network
+    auto cswap = [](int& p, int& q) {
+      const int mn = min(p, q), mx = max(p, q);
+      p = mn;
+      q = mx;
+    };
+    cswap(code[0], code[1]);
+    cswap(code[2], code[3]);
+    cswap(code[0], code[2]);
+    cswap(code[1], code[3]);
+    cswap(code[1], code[2]);
+    if (off_lattice || lo[0] >= (1 << 17) || lo[1] >= (1 << 17) || lo[2] >= (1 << 17))
+    {
+      flag[0] = 1;
+      keys[c] = ~0ull;
+      continue;
+    }
+    const unsigned long long type = (unsigned long long)((code[0] << 9) | (code[1] << 6) | (code[2] << 3) | code[3]);
+    keys[c] = (type << 51) | ((unsigned long long)lo[2] << 34) | ((unsigned long long)lo[1] << 17) | (unsigned long long)lo[0];
+  }
+}
+
+// out[i][0..w) = in[perm[i]][0..w)
+__global__ void k_gather_rows(const int32_t* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, int w,
+                              int32_t* __restrict__ out)
+{
+  const int64_t total = n * w;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t i = t / w;
+    out[t] = in[(int64_t)perm[i] * w + (t - i * w)];
+  }
+}
+
+__global__ void k_not_identity(const int32_t* __restrict__ perm, int64_t n, int32_t* __restrict__ flag)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (perm[i] != (int32_t)i)
+      flag[0] = 1;
+}
+
 __global__ void k_iota(int32_t* __restrict__ v, int64_t n)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -220,6 +296,20 @@ __global__ void k_translate(int32_t* __restrict__ cell_dofs, int64_t n, const in
 int grid_of(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 16384); }
 } // namespace
 
+static int renumber_cells(zzz_ctx* ctx, const Lattice& L);
+
+// forgets the dof order only (the cells may already have been put into theirs)
+static void renumber_clear_dofs(zzz_ctx* ctx)
+{
+  ctx->renumbered = false;
+  ctx->perm.release();
+  ctx->iperm.release();
+  ctx->h_perm.clear();
+  ctx->h_iperm.clear();
+  ctx->csr_slot.clear();
+  ctx->csr_slot.shrink_to_fit();
+}
+
 void renumber_clear(zzz_ctx* ctx)
 {
   ctx->renumbered = false;
@@ -230,6 +320,9 @@ void renumber_clear(zzz_ctx* ctx)
   ctx->csr_slot.clear();
   ctx->csr_slot.shrink_to_fit();
   ctx->renumber_kind = 0;
+  ctx->cells_renumbered = false;
+  ctx->h_cperm.clear();
+  ctx->h_cperm.shrink_to_fit();
 }
 
 // Called by zzz_dofmap_upload with the caller's connectivity on the device: decides on the internal order, and when
@@ -287,6 +380,9 @@ int renumber_build(zzz_ctx* ctx)
   // a lattice holds (nearly) all of its points: an unstructured cloud has as many distinct values per axis as points
   if (lattice && (double)L.m[0] * (double)L.m[1] * (double)L.m[2] > 8.0 * (double)nv)
     lattice = false;
+  if (lattice)
+    if (int rc = renumber_cells(ctx, L))
+      return rc;
   if (!lattice)
   {
     if (mode < 2)
@@ -333,12 +429,12 @@ int renumber_build(zzz_ctx* ctx)
   // the sub-cubes, a curved geometry): leave the caller's order alone rather than guess
   if (lattice && hflag[1] && mode < 2)
   {
-    renumber_clear(ctx);
+    renumber_clear_dofs(ctx);
     return ZZZ_OK;
   }
   if (!hflag[0])
   {
-    renumber_clear(ctx); // the caller's numbering IS the internal order
+    renumber_clear_dofs(ctx); // the caller's numbering IS the internal order
     ctx->renumber_kind = lattice ? 1 : 2;
     return ZZZ_OK;
   }
@@ -350,6 +446,53 @@ int renumber_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   ctx->renumbered = true;
   ctx->renumber_kind = lattice ? 1 : 2;
+  return ZZZ_OK;
+}
+
+// The cells in the library's own order (lattice meshes only; called by renumber_build with the vertex lattice in hand).
+// The assembly walks "the a-th cell of my dof" for 64 neighbouring rows at a time and the adjacency build looks for
+// monotone runs (zzz_pattern.hip): both want the cells simplex type by simplex type, cube by cube -- whatever order the
+// caller's mesh library left them in.  An entry of A or b is then summed in ascending INTERNAL cell order: the same
+// sum as the reference's cell loop up to the order of its terms.
+static int renumber_cells(zzz_ctx* ctx, const Lattice& L)
+{
+  hipStream_t s = ctx->stream;
+  const int64_t nc = ctx->ncells;
+  if (nc < 2)
+    return ZZZ_OK;
+  DevBuf<unsigned long long> keys, skeys;
+  DevBuf<int32_t> ident, cperm, flag, tmpi;
+  DevBuf<unsigned char> tmp;
+  ZZZ_HIP(ctx, keys.alloc((size_t)nc));
+  ZZZ_HIP(ctx, skeys.alloc((size_t)nc));
+  ZZZ_HIP(ctx, ident.alloc((size_t)nc));
+  ZZZ_HIP(ctx, cperm.alloc((size_t)nc));
+  ZZZ_HIP(ctx, flag.alloc(2));
+  ZZZ_HIP(ctx, hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_cell_keys, dim3(grid_of(nc)), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, nc, L, keys.p, flag.p);
+  hipLaunchKernelGGL(k_iota, dim3(grid_of(nc)), dim3(256), 0, s, ident.p, nc);
+  size_t tb = 0;
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys.p, skeys.p, ident.p, cperm.p, (size_t)nc, 0, 64, s));
+  ZZZ_HIP(ctx, tmp.alloc(tb));
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, keys.p, skeys.p, ident.p, cperm.p, (size_t)nc, 0, 64, s)); // stable
+  hipLaunchKernelGGL(k_not_identity, dim3(grid_of(nc)), dim3(256), 0, s, cperm.p, nc, flag.p + 1);
+  int32_t hf[2] = {0, 0};
+  ZZZ_HIP(ctx, hipMemcpyAsync(hf, flag.p, sizeof(hf), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  ZZZ_HIP(ctx, hipGetLastError());
+  if (hf[0] || !hf[1])
+    return ZZZ_OK; // a cell that is no lattice simplex (keep the caller's order), or the order is already this one
+  const int nd = ctx->nd;
+  ZZZ_HIP(ctx, tmpi.alloc((size_t)(nc * std::max(nd, 4))));
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_of(nc * 4)), dim3(256), 0, s, ctx->cell_verts.p, cperm.p, nc, 4, tmpi.p);
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->cell_verts.p, tmpi.p, (size_t)(4 * nc) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_of(nc * nd)), dim3(256), 0, s, ctx->cell_dofs.p, cperm.p, nc, nd, tmpi.p);
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->cell_dofs.p, tmpi.p, (size_t)(nd * nc) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  ctx->h_cperm.resize((size_t)nc);
+  ZZZ_HIP(ctx, hipMemcpyAsync(ctx->h_cperm.data(), cperm.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  ZZZ_HIP(ctx, hipGetLastError());
+  ctx->cells_renumbered = true;
   return ZZZ_OK;
 }
 

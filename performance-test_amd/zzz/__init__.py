@@ -528,7 +528,12 @@ class Context:
         perm = np.zeros(self.n_owned, np.int32)
         kind = C.c_int32()
         self._ck(self.L.zzz_internal_order_download(self.h, perm.ctypes.data_as(C.c_void_p), C.byref(kind)))
-        return perm, int(kind.value)
+        return perm, int(kind.value) & 15
+
+    def cells_renumbered(self):
+        kind = C.c_int32()
+        self._ck(self.L.zzz_internal_order_download(self.h, None, C.byref(kind)))
+        return bool(int(kind.value) & 16)
 
     def cg_reason(self):
         """KSPConvergedReason of the last solve: 2 rtol, 3 atol, -3 max_it, -4 KSP_DIVERGED_DTOL, -9 NaN/Inf"""

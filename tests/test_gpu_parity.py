@@ -485,6 +485,8 @@ def test_library_is_independent_of_the_callers_numbering(problem, order, dims, k
         c.assemble_matrix(Q.form)
         c.assemble_vector(Q.form)
         assert c.spmv_info_raw()[5:8] == c0.spmv_info_raw()[5:8]  # same operator form, same stream bytes, same entries
+        # the cells are in the library's order too (simplex type by simplex type, cube by cube: the structured feed's)
+        assert c.cells_renumbered() and not c0.cells_renumbered()
         rp, cl, v = c.csr_download()
         orp, ocl = zo.pattern(Q.n_owned, Q.cell_dofs, bs)
         np.testing.assert_array_equal(rp, orp)
@@ -591,6 +593,46 @@ def test_non_finite_vector_through_the_product():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
+
+
+def test_adjacency_without_sort_and_its_fallbacks(ctx):
+    """create_matrix builds the dof -> cell adjacency without a sort when the connectivity consists of few monotone runs
+    (csrc/zzz_pattern.hip).  Three feeds must give the oracle's pattern and values: (i) the structured one (sort-free
+    path), (ii) the same cells listed TWICE -- twice the valence: a window of 256 dofs no longer fits the LDS budget, found
+    on the device, and the build is repeated with the radix sort --, (iii) the cells in random order (thousands of runs:
+    the sort from the start)."""
+    zo.set_num_threads(2)
+    P = zzz.Part("poisson", 1, 9, 8, 40)
+    rng = np.random.default_rng(4)
+    order = rng.permutation(P.ncells)
+    feeds = {"structured": (P.cells, P.cell_dofs, P.facets),
+             "every cell twice": (np.concatenate([P.cells, P.cells]), np.concatenate([P.cell_dofs, P.cell_dofs]), P.facets),
+             "random cell order": (P.cells[order], P.cell_dofs[order],
+                                   np.column_stack([np.argsort(order)[P.facets[:, 0]], P.facets[:, 1]]).astype(np.int32))}
+    os.environ["ZZZ_RENUMBER"] = "0"  # keep the feeds exactly as given
+    try:
+        for name, (cells, cd, facets) in feeds.items():
+            cells, cd = np.ascontiguousarray(cells), np.ascontiguousarray(cd)
+            ctx.upload_mesh(P.x, cells)
+            ctx.upload_dofmap(1, 1, cd, P.n_owned, 0)
+            ctx.upload_bc(P.bc_dofs)
+            ctx.upload_facets(facets)
+            ctx.upload_coeff(zzz.COEFF_F, P.f)
+            ctx.upload_coeff(zzz.COEFF_G, P.g)
+            for _ in range(2):  # the second build reuses what the first one learnt about the connectivity
+                ctx.pattern_build()
+                ctx.assemble_matrix(zzz.FORM_POISSON)
+                ctx.assemble_vector(zzz.FORM_POISSON)
+                rp, cl, v = ctx.csr_download()
+                orp, ocl = zo.pattern(P.n_owned, cd, 1)
+                np.testing.assert_array_equal(rp, orp, err_msg=name)
+                np.testing.assert_array_equal(cl, ocl, err_msg=name)
+                ov = zo.assemble_matrix(0, 1, P.x, cells, cd, P.bc_marker(), orp, ocl)
+                ob = zo.assemble_vector(0, 1, P.x, cells, cd, P.f, P.g, facets, P.bc_marker())
+                assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max(), name
+                assert np.abs(ctx.vec_download(zzz.VEC_B) - ob).max() <= 1e-12 * np.abs(ob).max(), name
+    finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
 
 
 def test_size_limits_are_errors_not_crashes():
