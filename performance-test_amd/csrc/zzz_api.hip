@@ -367,6 +367,7 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_pattern_build before zzz_dofmap_upload");
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->have_adj_li = false;
+  ctx->have_asm_pos = false;
   const char* mode = getenv("ZZZ_PATTERN"); // "host": the C++ host builder (kept for meshes whose
                                             // vertex valence exceeds the device kernel's LDS budget)
   int rc;

@@ -865,7 +865,301 @@ int asm_tile_nnz(const zzz_ctx* ctx)
 {
   if (ctx->bs == 1 && ctx->order == 1)
     return ASM_NNZ_P1;
+  if (const char* e = getenv("ZZZ_ASM_CAP")) // measurement knob
+    if (atoi(e) >= 1024 && atoi(e) <= 8192)
+      return atoi(e);
+  if (ctx->have_asm_pos)
+  {
+    // position-based kernel (asm_matrix_pk_pos: no columns in LDS, persistent workgroups): smaller tiles = more
+    // workgroups per CU.  Measured (tools/ab_asm.sh): Poisson P3 6.2 M dofs 2.80 ms at 2048 against 4.79 at 4096 and 3.30
+    // at 1536; elasticity P2 2 M 2.23 ms at 3072 (2.45 at 4096, 3.79 at 2048); elasticity P3 keeps 4096 (a block row of a
+    // vertex has ~2000 entries)
+    if (ctx->bs == 1)
+      return ASM_NNZ_SMALL;
+    return ctx->order == 2 ? 3072 : ASM_NNZ;
+  }
   return (ctx->bs == 1 && ctx->order == 2) ? ASM_NNZ_SMALL : ASM_NNZ;
+}
+
+// Geometry factors of every cell, once per assembly (one thread per cell, dense): BS = 1: |detJ| (K K^T), the six
+// numbers 00 11 22 01 02 12 that Poisson's element tensor is contracted with; BS = 3: |detJ| and K (ten numbers).
+// The row-gather kernel below then fetches 48 (80) bytes per (row, cell) pair -- all lanes of a row the same address,
+// neighbouring rows mostly the same cell -- instead of the cell's vertices, their coordinates and ~150 flops.
+template <int BS>
+__global__ void k_cell_geom(const double* __restrict__ x, const int32_t* __restrict__ cell_verts, int64_t ncells,
+                            double* __restrict__ out)
+{
+  constexpr int NG = BS == 1 ? 6 : 10;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * blockDim.x)
+  {
+    double p[4][3];
+    load_cell(x, *reinterpret_cast<const int4*>(cell_verts + 4 * c), p);
+    Geom G;
+    geometry(p, G);
+    double* o = out + c * NG;
+    if (BS == 1)
+    {
+      o[0] = G.adet * (G.K[0][0] * G.K[0][0] + G.K[0][1] * G.K[0][1] + G.K[0][2] * G.K[0][2]);
+      o[1] = G.adet * (G.K[1][0] * G.K[1][0] + G.K[1][1] * G.K[1][1] + G.K[1][2] * G.K[1][2]);
+      o[2] = G.adet * (G.K[2][0] * G.K[2][0] + G.K[2][1] * G.K[2][1] + G.K[2][2] * G.K[2][2]);
+      o[3] = G.adet * (G.K[0][0] * G.K[1][0] + G.K[0][1] * G.K[1][1] + G.K[0][2] * G.K[1][2]);
+      o[4] = G.adet * (G.K[0][0] * G.K[2][0] + G.K[0][1] * G.K[2][1] + G.K[0][2] * G.K[2][2]);
+      o[5] = G.adet * (G.K[1][0] * G.K[2][0] + G.K[1][1] * G.K[2][1] + G.K[1][2] * G.K[2][2]);
+    }
+    else
+    {
+      o[0] = G.adet;
+#pragma unroll
+      for (int al = 0; al < 3; ++al)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          o[1 + 3 * al + d] = G.K[al][d];
+    }
+  }
+}
+
+// The same assembly with (i) the POSITIONS of the element-matrix entries handed over by the pattern build
+// (zzz_ctx::asm_pos: for the a-th cell of block row i and local column j, the rank of dof j among the row's sorted
+// columns -- a by-product of the sort that found those columns) and (ii) the cells' geometry factors evaluated once
+// (k_cell_geom).  No column search (it was 7-8 dependent LDS reads per entry, 545 M entries per assembly of the
+// 6.2 M-dof P3 problem), no columns in LDS (a third of the tile's footprint), no connectivity, vertex or coordinate
+// read in the row walk: a (row, cell) pair is its adjacency entry, 2 B per column and one 48-B geometry record.
+// Constrained COLUMNS are zeroed in one dense pass over the tile's CSR segment at the end (columns and flags read
+// once per nonzero, not once per contribution); constrained rows contribute zeros and get their diagonal
+// (fem::set_diagonal) after that pass.  Same sums in the same order as asm_matrix_pk.
+template <int ND, int BS, int LPR>
+__global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __restrict__ geom,
+                                                               const int32_t* __restrict__ adjT_off,
+                                                               const int32_t* __restrict__ adjT_cells,
+                                                               const uint8_t* __restrict__ adj_li,
+                                                               const int32_t* __restrict__ adj_off,
+                                                               const uint16_t* __restrict__ pos,
+                                                               const uint8_t* __restrict__ bc,
+                                                               const rp_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ cols, double* __restrict__ vals,
+                                                               const int32_t* __restrict__ tiles, int64_t ntiles,
+                                                               const double* __restrict__ tab, int cap)
+{
+  constexpr int NT = (BS == 1) ? 6 : 9;
+  constexpr int NN = ND * ND;
+  constexpr int NG = BS == 1 ? 6 : 10;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* vals_s = reinterpret_cast<double*>(lds_raw);
+  double* T_s = vals_s + cap; // cap = nonzeros a tile may hold (asm_tile_nnz)
+  for (int k = threadIdx.x; k < NT * NN; k += ASM_BLOCK)
+  {
+    if (BS == 1)
+    {
+      // symmetrised pieces: G is symmetric, so S^{ab} + S^{ba} is all a < b needs
+      const int t = k / NN, ij = k % NN;
+      const int a = t < 3 ? t : (t == 3 ? 0 : (t == 4 ? 0 : 1)), b = t < 3 ? t : (t == 3 ? 1 : 2);
+      T_s[k] = (t < 3) ? tab[(a * 3 + a) * NN + ij] : tab[(a * 3 + b) * NN + ij] + tab[(b * 3 + a) * NN + ij];
+    }
+    else
+      T_s[k] = tab[k];
+  }
+  // persistent workgroups: the reference tensors above are staged once per workgroup, not once per tile (at 2048
+  // nonzeros per tile the 6.2 M-dof P3 matrix has 146 k tiles: 2.8 GB of table reads otherwise); XCD x walks the x-th
+  // eighth of the tiles
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, n_in_xcd = (gridDim.x + 7 - xcd) >> 3;
+  const int64_t t_lo = ntiles * xcd / 8, t_hi = ntiles * (xcd + 1) / 8;
+  for (int64_t tile = t_lo + wg_in_xcd; tile < t_hi; tile += n_in_xcd)
+  {
+  const int d0 = tiles[tile], d1 = tiles[tile + 1];
+  const int row0 = d0 * BS, row1 = d1 * BS;
+  const int64_t s = rowptr[row0];
+  const int e = (int)(rowptr[row1] - s); // entries of the tile's CSR segment (fits LDS)
+  for (int k = threadIdx.x; k < e; k += ASM_BLOCK)
+    vals_s[k] = 0.0;
+  // block dofs of the tile in order of descending cell count, as in asm_matrix_pk
+  __shared__ int ord_s[ASM_ORD_CAP];
+  __shared__ int hist_s[34];
+  const int nt = d1 - d0;
+  const bool sorted = nt <= ASM_ORD_CAP;
+  if (sorted)
+  {
+    if (threadIdx.x < 34)
+      hist_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += ASM_BLOCK)
+      atomicAdd(&hist_s[32 - min(adj_off[d0 + k + 1] - adj_off[d0 + k], 32)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int acc = 0;
+      for (int b = 0; b < 33; ++b)
+      {
+        const int h = hist_s[b];
+        hist_s[b] = acc;
+        acc += h;
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += ASM_BLOCK)
+      ord_s[atomicAdd(&hist_s[32 - min(adj_off[d0 + k + 1] - adj_off[d0 + k], 32)], 1)] = k;
+  }
+  __syncthreads();
+  const int lane = (int)threadIdx.x % LPR;
+  constexpr int JM = (ND + LPR - 1) / LPR; // columns of a cell this lane handles
+  constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
+  constexpr double mu = Ey / (2.0 * (1.0 + nu));
+  constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+  for (int q = (int)threadIdx.x / LPR; q < nt * BS; q += ASM_BLOCK / LPR)
+  {
+    const int i = d0 + (sorted ? ord_s[q / BS] : q / BS), c = q % BS;
+    const int r = i * BS + c;
+    const int a0 = (int)(rowptr[r] - s);
+    const bool bcr = bc[r] != 0;
+    const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+    const uint16_t* __restrict__ prow = pos + (int64_t)adj_off[i] * ND; // positions of the row's (cell, column) pairs
+    // software pipeline over the row's cells: the adjacency entry of cell a + 2 and the geometry record and positions of
+    // cell a + 1 are in flight while cell a is evaluated
+    struct Item
+    {
+      int cell, li;
+      double g[NG];
+      int pj[JM];
+    };
+    auto adj_at = [&](int a, int& cell, int& li) {
+      const bool in = a < adj.len;
+      cell = in ? adj.cell(a) : -1;
+      li = in ? adj.li(a) : 0;
+    };
+    auto item_at = [&](int a, int cell, int li, Item& K) {
+      K.cell = cell;
+      K.li = li;
+      if (cell < 0)
+        return;
+      const double* __restrict__ gp = geom + (int64_t)cell * NG;
+#pragma unroll
+      for (int t = 0; t < NG; ++t)
+        K.g[t] = gp[t];
+#pragma unroll
+      for (int qq = 0; qq < JM; ++qq)
+        K.pj[qq] = lane + qq * LPR < ND ? prow[a * ND + lane + qq * LPR] : 0;
+    };
+    Item K0;
+    int c1, l1;
+    {
+      int ca, la;
+      adj_at(0, ca, la);
+      item_at(0, ca, la, K0);
+      adj_at(1, c1, l1);
+    }
+    for (int a = 0; K0.cell >= 0; ++a)
+    {
+      Item K1;
+      int c2, l2;
+      item_at(a + 1, c1, l1, K1);
+      adj_at(a + 2, c2, l2);
+      const double* Tl = T_s + K0.li * ND;
+      if (BS == 1)
+      {
+#pragma unroll
+        for (int qq = 0; qq < JM; ++qq)
+        {
+          const int j = lane + qq * LPR;
+          if (j >= ND)
+            break;
+          double val = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            val += K0.g[t] * Tl[t * NN + j];
+          if (bcr)
+            val = 0.0;
+          vals_s[a0 + K0.pj[qq]] += val;
+        }
+      }
+      else
+      {
+        const double adet = K0.g[0];
+        const double* Kf = K0.g + 1; // K[al][d] at Kf[3 al + d]
+#pragma unroll
+        for (int qq = 0; qq < JM; ++qq)
+        {
+          const int j = lane + qq * LPR;
+          if (j >= ND)
+            break;
+          // D[cc][d] = |detJ| sum_{al,be} K[al][cc] K[be][d] S^[al][be]_{li,j} = int d_cc phi_i d_d phi_j
+          double D[3][3];
+          {
+            double tmp[3][3];
+#pragma unroll
+            for (int al = 0; al < 3; ++al)
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                tmp[al][d] = Tl[(al * 3 + 0) * NN + j] * Kf[0 + d] + Tl[(al * 3 + 1) * NN + j] * Kf[3 + d]
+                             + Tl[(al * 3 + 2) * NN + j] * Kf[6 + d];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                D[cc][d] = adet * (Kf[0 + cc] * tmp[0][d] + Kf[3 + cc] * tmp[1][d] + Kf[6 + cc] * tmp[2][d]);
+          }
+          const double tr = D[0][0] + D[1][1] + D[2][2];
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+          {
+            const double Dcd = sel3(D[0][d], D[1][d], D[2][d], c), Ddc = sel3(D[d][0], D[d][1], D[d][2], c);
+            double val = mu * ((c == d ? tr : 0.0) + Ddc) + lmbda * Dcd;
+            if (bcr)
+              val = 0.0;
+            vals_s[a0 + K0.pj[qq] * 3 + d] += val;
+          }
+        }
+      }
+      K0 = K1;
+      c1 = c2;
+      l1 = l2;
+    }
+  }
+  __syncthreads();
+  // constrained columns: one dense pass over the tile's entries (column index and flag once per nonzero)
+  for (int k = threadIdx.x; k < e; k += ASM_BLOCK)
+    if (bc[cols[s + k]])
+      vals_s[k] = 0.0;
+  __syncthreads();
+  // fem::set_diagonal on constrained rows (their diagonal was zeroed with the rest of the constrained columns)
+  for (int q = threadIdx.x; q < nt * BS; q += ASM_BLOCK)
+  {
+    const int r = row0 + q;
+    if (bc[r])
+    {
+      const int64_t g0 = rowptr[r];
+      vals_s[(int)(g0 - s) + find_pos(cols + g0, (int)(rowptr[r + 1] - g0), r)] = 1.0;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < e; k += ASM_BLOCK)
+    vals[s + k] = vals_s[k];
+  __syncthreads(); // the next tile reuses vals_s, ord_s, hist_s
+  }
+}
+
+template <int ND, int BS, int LPR>
+static int launch_matrix_pk_pos(zzz_ctx* ctx)
+{
+  constexpr int NT = (BS == 1) ? 6 : 9;
+  constexpr int NG = BS == 1 ? 6 : 10;
+  const int cap = asm_tile_nnz(ctx);
+  const size_t lds = (size_t)cap * 8 + (size_t)NT * ND * ND * 8;
+  auto kern = asm_matrix_pk_pos<ND, BS, LPR>;
+  const unsigned bit = (16u << ((ND == 10 ? 0 : 2) + (BS == 1 ? 0 : 1))) << (LPR == 8 ? 0 : (LPR == 4 ? 4 : 8));
+  if (!(ctx->lds_attr_set & bit))
+  {
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->lds_attr_set |= bit;
+  }
+  ZZZ_HIP(ctx, ctx->cell_geom.alloc((size_t)(ctx->ncells * NG)));
+  hipLaunchKernelGGL(k_cell_geom<BS>, dim3((unsigned)std::min<int64_t>((ctx->ncells + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
+                     ctx->x.p, ctx->cell_verts.p, ctx->ncells, ctx->cell_geom.p);
+  int per_cu = (int)(160 * 1024 / (lds + 2560)); // workgroups a CU holds (LDS-bound; ord_s / hist_s on top)
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  const int64_t grid = std::min<int64_t>(xcd_grid(ctx->n_asm_tiles), 256 * (int64_t)per_cu);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ASM_BLOCK), lds, ctx->stream, ctx->cell_geom.p,
+                     ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->adj_off.p, ctx->asm_pos.p, ctx->bc.p,
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p, cap);
+  return ZZZ_OK;
 }
 
 template <int ND, int BS, int LPR>
@@ -922,7 +1216,20 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
     int rc = ensure_tables(ctx);
     if (rc)
       return rc;
-    if (ctx->order == 2)
+    if (ctx->have_asm_pos) // positions from the pattern build: no column search (asm_matrix_pk_pos)
+    {
+      const char* e = getenv("ZZZ_ASM_LPR"); // measurement knob
+      const int lpr = e ? atoi(e) : 0;
+      if (ctx->order == 2)
+        rc = bs == 1 ? (lpr == 2 ? launch_matrix_pk_pos<10, 1, 2>(ctx) : launch_matrix_pk_pos<10, 1, 4>(ctx))
+                     : launch_matrix_pk_pos<10, 3, 4>(ctx);
+      else
+        // lanes per row: Poisson P3 four (five columns each, no idle lane: 2.80 against 2.92 ms), elasticity P3 eight
+        rc = bs == 1 ? (lpr == 8 ? launch_matrix_pk_pos<20, 1, 8>(ctx) : lpr == 2 ? launch_matrix_pk_pos<20, 1, 2>(ctx)
+                                                                        : launch_matrix_pk_pos<20, 1, 4>(ctx))
+                     : (lpr == 4 ? launch_matrix_pk_pos<20, 3, 4>(ctx) : launch_matrix_pk_pos<20, 3, 8>(ctx));
+    }
+    else if (ctx->order == 2)
       rc = bs == 1 ? launch_matrix_pk<10, 1, 4>(ctx) : launch_matrix_pk<10, 3, 4>(ctx);
     else
       rc = bs == 1 ? launch_matrix_pk<20, 1, 8>(ctx) : launch_matrix_pk<20, 3, 8>(ctx);

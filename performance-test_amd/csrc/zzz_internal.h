@@ -154,6 +154,11 @@ struct zzz_ctx
   zzz::DevBuf<uint8_t> adj_li;             // local index of the dof in each of those cells, same layout
   zzz::DevBuf<double> cell_w;              // matrix-free: Ae_c u_c per cell, component-major
   bool have_adj_li = false;
+  // P2/P3: position inside its CSR row of every (adjacency entry, local column) pair -- a by-product of the pattern
+  // build's sort (the candidates carry their origin through it), so that the matrix assembly adds without searching
+  zzz::DevBuf<uint16_t> asm_pos;
+  bool have_asm_pos = false;
+  zzz::DevBuf<double> cell_geom; // P2/P3 matrix assembly: per cell |detJ| K K^T (6 doubles) or |detJ|, K (10), evaluated once per assembly
   int max_row_nnz = 0;
   // SpMV tiling (row-aligned tiles of the nonzero stream)
   zzz::DevBuf<double> alpha_hist; // step lengths: x += alpha_k p_k is applied by the NEXT direction update

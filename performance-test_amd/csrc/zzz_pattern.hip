@@ -151,11 +151,17 @@ __device__ inline void bitonic_sort_regs(int32_t (&x)[P / 64])
     bitonic_sort_regs<P, K * 2>(x);
 }
 
-// One row of the pattern from P / 64 keys per lane: gather the candidates, sort, emit the unique ones (see k_row_pattern)
-template <int P, bool FILL>
+// One row of the pattern from P / 64 keys per lane: gather the candidates, sort, emit the unique ones (see k_row_pattern).
+// POS: every candidate carries its origin (a * nd + j: which cell of the row, which local dof) through the sort in the
+// low 9 bits of its key -- key = (dof << 9 | origin) with the sign bit flipped, so that the network's signed compares
+// order it as an unsigned number: needs dof < 2^23 and at most 512 candidates -- and its rank among the unique columns,
+// which the scan of the "new column" flags yields anyway, is written to pos[adj entry * nd + j]: the position of that
+// element-matrix entry inside the row, which the matrix assembly would otherwise find by binary search, 545 M times
+// per assembly of the 6.2 M-dof P3 problem.
+template <int P, bool FILL, bool POS>
 __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int nd, int bs, const int32_t* __restrict__ adj_cells,
                                       int a0, int n, int lane, int64_t rp, int32_t nu, int32_t* __restrict__ cols,
-                                      int32_t* __restrict__ stage)
+                                      int32_t* __restrict__ stage, uint16_t* __restrict__ pos_out)
 {
   constexpr int NR = P / 64;
   int32_t x[NR];
@@ -167,7 +173,8 @@ __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int
     if (idx < n)
     {
       const int a = idx / nd, j = idx - a * nd;
-      x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+      const int32_t d = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+      x[kk] = POS ? (int32_t)((((uint32_t)d << 9) | (uint32_t)idx) ^ 0x80000000u) : d;
     }
   }
   bitonic_sort_regs<P, 2>(x);
@@ -178,17 +185,23 @@ __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int
     if (kk * 64 >= n) // wave-uniform
       break;
     const int idx = kk * 64 + lane;
-    int32_t prev = __shfl_up(x[kk], 1);
+    const int32_t cur = POS ? (int32_t)(((uint32_t)x[kk] ^ 0x80000000u) >> 9) : x[kk]; // (the padding keys are never looked at)
+    int32_t prev = __shfl_up(cur, 1);
     if (lane == 0)
-      prev = kk ? __builtin_amdgcn_readlane(x[kk ? kk - 1 : 0], 63) : INT_MIN;
-    const bool flag = idx < n && (idx == 0 || x[kk] != prev);
+    {
+      const int32_t last = __builtin_amdgcn_readlane(x[kk ? kk - 1 : 0], 63);
+      prev = kk ? (POS ? (int32_t)(((uint32_t)last ^ 0x80000000u) >> 9) : last) : INT_MIN;
+    }
+    const bool flag = idx < n && (idx == 0 || cur != prev);
     const unsigned long long m = __ballot(flag);
     const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (POS && idx < n) // rank of this candidate's column: heads up to and including this lane, minus one
+      pos_out[(int64_t)a0 * nd + (int)(((uint32_t)x[kk] ^ 0x80000000u) & 511u)] = (uint16_t)(pos - (flag ? 0 : 1));
     if (!FILL && stage && flag)
-      stage[(int64_t)a0 * nd + pos] = x[kk];
+      stage[(int64_t)a0 * nd + pos] = cur;
     if (FILL && flag)
     {
-      const int32_t col = x[kk];
+      const int32_t col = cur;
       for (int a = 0; a < bs; ++a)
         for (int d = 0; d < bs; ++d)
           cols[(int64_t)bs * bs * rp + (int64_t)a * bs * nu + (int64_t)pos * bs + d] = col * bs + d;
@@ -209,7 +222,8 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
                                                      const int32_t* __restrict__ adj_cells, int32_t nb,
                                                      int32_t* __restrict__ cnt, int32_t* __restrict__ maxcnt,
                                                      const int64_t* __restrict__ bptr, int32_t* __restrict__ cols,
-                                                     int32_t* __restrict__ overflow, int32_t* __restrict__ stage)
+                                                     int32_t* __restrict__ overflow, int32_t* __restrict__ stage,
+                                                     uint16_t* __restrict__ pos_out, int32_t* __restrict__ pos_missed)
 {
   __shared__ int32_t lds[4][PAT_CAP];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -236,19 +250,25 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
       const int64_t rp = FILL ? bptr[r] : 0;
       const int32_t nu = FILL ? cnt[r] : 0;
       int base;
+#define ZZZ_ROW_REGS(PP)                                                                                                       \
+  base = (!FILL && pos_out) ? row_unique_regs<PP, FILL, true>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage, pos_out) \
+                            : row_unique_regs<PP, FILL, false>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage, nullptr)
       if (P == 64)
-        base = row_unique_regs<64, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+        ZZZ_ROW_REGS(64);
       else if (P == 128)
-        base = row_unique_regs<128, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+        ZZZ_ROW_REGS(128);
       else if (P == 256)
-        base = row_unique_regs<256, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+        ZZZ_ROW_REGS(256);
       else
-        base = row_unique_regs<512, FILL>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage);
+        ZZZ_ROW_REGS(512);
+#undef ZZZ_ROW_REGS
       if (!FILL && lane == 0)
         cnt[r] = base;
       wmax = max(wmax, base);
       continue;
     }
+    if (!FILL && pos_out && lane == 0)
+      *pos_missed = 1; // a row of more than 512 candidates: no positions, the assembly searches
     for (int idx = lane; idx < P; idx += 64)
     {
       int32_t v = INT_MAX;
@@ -1092,7 +1112,11 @@ void pattern_reserve(zzz_ctx* ctx)
     (void)ctx->scr_tmp.alloc(tb > tb2 ? tb : tb2);
   const int64_t nstage = N * nd;
   if (nstage < ((int64_t)3 << 30))
+  {
     (void)ctx->scr_stage.alloc((size_t)nstage);
+    if (nd > 4 && ctx->n_owned + ctx->n_ghost < ((int64_t)1 << 23))
+      (void)ctx->asm_pos.alloc((size_t)nstage);
+  }
   (void)hipGetLastError();
   adjacency_find_runs(ctx); // a property of the dofmap, like the sizes above
 }
@@ -1204,10 +1228,19 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   }
   if (!counted)
   {
+    // P2/P3: the positions of the element-matrix entries inside their rows, for the assembly (row_unique_regs)
+    uint16_t* pos_out = nullptr;
+    ctx->have_asm_pos = false;
+    if (nd > 4 && stage && ctx->n_owned + ctx->n_ghost < ((int64_t)1 << 23) && !getenv("ZZZ_ASM_SEARCH")
+        && ctx->asm_pos.alloc((size_t)nstage) == hipSuccess)
+      pos_out = ctx->asm_pos.p;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_row_pattern<false>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
-                       ctx->adj_cells.p, nb, cnt.p, scal.p, (const int64_t*)nullptr, (int32_t*)nullptr, scal.p + 1, stage);
+                       ctx->adj_cells.p, nb, cnt.p, scal.p, (const int64_t*)nullptr, (int32_t*)nullptr, scal.p + 1, stage, pos_out,
+                       scal.p + 3);
     ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    ctx->have_asm_pos = pos_out != nullptr && h[3] == 0;
     if (adjacency_overflowed())
     {
       ctx->adj_runs_n = 0;
@@ -1241,7 +1274,8 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
                        nb, cnt.p, bptr.p, ctx->cols.p);
   else
     hipLaunchKernelGGL(k_row_pattern<true>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,
-                       ctx->adj_cells.p, nb, cnt.p, scal.p, bptr.p, ctx->cols.p, scal.p + 1, (int32_t*)nullptr);
+                       ctx->adj_cells.p, nb, cnt.p, scal.p, bptr.p, ctx->cols.p, scal.p + 1, (int32_t*)nullptr, (uint16_t*)nullptr,
+                       (int32_t*)nullptr);
   ZZZ_HIP(ctx, hipGetLastError());
   // 3. tiles
   int rc = build_tiles_device(ctx, h[0]);

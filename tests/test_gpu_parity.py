@@ -635,6 +635,39 @@ def test_adjacency_without_sort_and_its_fallbacks(ctx):
         os.environ.pop("ZZZ_RENUMBER", None)
 
 
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 2, (9, 8, 7)), ("poisson", 3, (6, 5, 7)), ("elasticity", 2, (5, 4, 6)),
+                                                ("elasticity", 3, (3, 4, 3))])
+def test_position_based_assembly_keeps_every_bit(problem, order, dims):
+    """P2/P3 matrix assembly with the entries' positions handed over by the pattern build and the cells' geometry
+    evaluated once (asm_matrix_pk_pos, the default) against the kernel that searches the columns and recomputes the
+    geometry per (row, cell) pair (ZZZ_ASM_SEARCH=1): the same contributions added in the same order -- identical bits,
+    Dirichlet rows and columns included; and the oracle's values to 1e-12."""
+    zo.set_num_threads(2)
+    P = zzz.Part(problem, order, *dims)
+    out = {}
+    try:
+        for search in ("0", "1"):
+            if search == "1":
+                os.environ["ZZZ_ASM_SEARCH"] = "1"
+            else:
+                os.environ.pop("ZZZ_ASM_SEARCH", None)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_matrix(P.form)  # idempotent
+                out[search] = c.csr_download()
+    finally:
+        os.environ.pop("ZZZ_ASM_SEARCH", None)
+    for a, b in zip(out["0"], out["1"]):
+        np.testing.assert_array_equal(a, b)
+    rp, cl, v = out["0"]
+    orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, P.bs)
+    np.testing.assert_array_equal(cl, ocl)
+    ov = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, P.bc_marker(), orp, ocl)
+    assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+
+
 def test_size_limits_are_errors_not_crashes():
     """Maximum sizes: local indices are int32; a partition beyond that range is refused up front
     (before anything is allocated) with ZZZ_ERR_LIMIT and a message that says what to do."""
