@@ -153,15 +153,15 @@ __device__ inline void bitonic_sort_regs(int32_t (&x)[P / 64])
 
 // One row of the pattern from P / 64 keys per lane: gather the candidates, sort, emit the unique ones (see k_row_pattern).
 // POS: every candidate carries its origin (a * nd + j: which cell of the row, which local dof) through the sort in the
-// low 9 bits of its key -- key = (dof << 9 | origin) with the sign bit flipped, so that the network's signed compares
-// order it as an unsigned number: needs dof < 2^23 and at most 512 candidates -- and its rank among the unique columns,
+// low 9 bits of its key -- key = ((dof - lowest dof of the row) << 9 | origin) with the sign bit flipped, so that the
+// network's signed compares order it as an unsigned number: at most 512 candidates -- and its rank among the unique columns,
 // which the scan of the "new column" flags yields anyway, is written to pos[adj entry * nd + j]: the position of that
 // element-matrix entry inside the row, which the matrix assembly would otherwise find by binary search, 545 M times
 // per assembly of the 6.2 M-dof P3 problem.
 template <int P, bool FILL, bool POS>
 __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int nd, int bs, const int32_t* __restrict__ adj_cells,
                                       int a0, int n, int lane, int64_t rp, int32_t nu, int32_t* __restrict__ cols,
-                                      int32_t* __restrict__ stage, uint16_t* __restrict__ pos_out)
+                                      int32_t* __restrict__ stage, uint16_t* __restrict__ pos_out, int32_t* __restrict__ pos_missed)
 {
   constexpr int NR = P / 64;
   int32_t x[NR];
@@ -173,8 +173,35 @@ __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int
     if (idx < n)
     {
       const int a = idx / nd, j = idx - a * nd;
-      const int32_t d = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
-      x[kk] = POS ? (int32_t)((((uint32_t)d << 9) | (uint32_t)idx) ^ 0x80000000u) : d;
+      x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+    }
+  }
+  int32_t dmin = 0;
+  if (POS)
+  {
+    // the key holds the dof RELATIVE to the row's lowest column, so that 23 bits suffice at any problem size as long
+    // as a row's columns lie within 8 M dofs of each other (a row that does not: *pos_missed, the assembly searches)
+    int32_t mn = INT_MAX, mx = 0;
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
+    {
+      mn = min(mn, x[kk]);
+      mx = max(mx, x[kk] == INT_MAX ? 0 : x[kk]);
+    }
+    dmin = wave_min_i(mn);
+    const int32_t dmax = wave_max_i(mx);
+    if (dmax - dmin >= (1 << 23))
+    {
+      if (lane == 0)
+        *pos_missed = 1;
+      dmin = dmax - ((1 << 23) - 1); // keys stay in range; the ranks of this row are not used
+    }
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
+    {
+      const int idx = kk * 64 + lane;
+      if (idx < n)
+        x[kk] = (int32_t)(((((uint32_t)max(x[kk] - dmin, 0)) << 9) | (uint32_t)idx) ^ 0x80000000u);
     }
   }
   bitonic_sort_regs<P, 2>(x);
@@ -185,12 +212,12 @@ __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int
     if (kk * 64 >= n) // wave-uniform
       break;
     const int idx = kk * 64 + lane;
-    const int32_t cur = POS ? (int32_t)(((uint32_t)x[kk] ^ 0x80000000u) >> 9) : x[kk]; // (the padding keys are never looked at)
+    const int32_t cur = POS ? (int32_t)(((uint32_t)x[kk] ^ 0x80000000u) >> 9) + dmin : x[kk]; // (the padding keys are never looked at)
     int32_t prev = __shfl_up(cur, 1);
     if (lane == 0)
     {
       const int32_t last = __builtin_amdgcn_readlane(x[kk ? kk - 1 : 0], 63);
-      prev = kk ? (POS ? (int32_t)(((uint32_t)last ^ 0x80000000u) >> 9) : last) : INT_MIN;
+      prev = kk ? (POS ? (int32_t)(((uint32_t)last ^ 0x80000000u) >> 9) + dmin : last) : INT_MIN;
     }
     const bool flag = idx < n && (idx == 0 || cur != prev);
     const unsigned long long m = __ballot(flag);
@@ -251,8 +278,9 @@ __global__ __launch_bounds__(256) void k_row_pattern(const int32_t* __restrict__
       const int32_t nu = FILL ? cnt[r] : 0;
       int base;
 #define ZZZ_ROW_REGS(PP)                                                                                                       \
-  base = (!FILL && pos_out) ? row_unique_regs<PP, FILL, true>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage, pos_out) \
-                            : row_unique_regs<PP, FILL, false>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage, nullptr)
+  base = (!FILL && pos_out)                                                                                                    \
+             ? row_unique_regs<PP, FILL, true>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage, pos_out, pos_missed) \
+             : row_unique_regs<PP, FILL, false>(cell_dofs, nd, bs, adj_cells, a0, n, lane, rp, nu, cols, stage, nullptr, nullptr)
       if (P == 64)
         ZZZ_ROW_REGS(64);
       else if (P == 128)
@@ -1073,6 +1101,21 @@ static int adjacency_by_runs(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
+// The staging area of the sorted unique columns (4 B per candidate: 17 GB for Poisson P3 at 50 M dofs) is worth a
+// quarter of whatever memory is free: without it the fill pass sorts every row a second time (30 of 75 ms there).
+static bool stage_fits(const zzz_ctx* ctx, int64_t nstage)
+{
+  if (ctx->scr_stage.p && (int64_t)ctx->scr_stage.cap >= nstage)
+    return true;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return nstage < ((int64_t)3 << 30);
+  }
+  return nstage < ((int64_t)3 << 30) || (double)nstage * 4.0 < 0.25 * (double)fr;
+}
+
 // Scratch of the pattern build whose size follows from the dofmap alone (sort buffers, the entry -> cell map, the
 // staging area): reserved when the dofmap arrives, so that a one-shot `ZZZ Assemble` (the reference driver runs every
 // phase once) does not pay ~18 ms of multi-GB hipMalloc calls inside its timer.  Failure to reserve is not an error: the
@@ -1111,12 +1154,10 @@ void pattern_reserve(zzz_ctx* ctx)
              == hipSuccess)
     (void)ctx->scr_tmp.alloc(tb > tb2 ? tb : tb2);
   const int64_t nstage = N * nd;
-  if (nstage < ((int64_t)3 << 30))
-  {
+  if (stage_fits(ctx, nstage))
     (void)ctx->scr_stage.alloc((size_t)nstage);
-    if (nd > 4 && ctx->n_owned + ctx->n_ghost < ((int64_t)1 << 23))
-      (void)ctx->asm_pos.alloc((size_t)nstage);
-  }
+  if (nd > 4)
+    (void)ctx->asm_pos.alloc((size_t)nstage);
   (void)hipGetLastError();
   adjacency_find_runs(ctx); // a property of the dofmap, like the sizes above
 }
@@ -1186,7 +1227,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   // it would not fit comfortably -- then the fill pass sorts again
   const int64_t nstage = N * nd;
   int32_t* stage = nullptr;
-  if (nstage < ((int64_t)3 << 30) && ctx->scr_stage.alloc((size_t)nstage) == hipSuccess)
+  if (stage_fits(ctx, nstage) && ctx->scr_stage.alloc((size_t)nstage) == hipSuccess)
     stage = ctx->scr_stage.p;
   int32_t h[4] = {0, 0, 0, 0};
   bool counted = false;
@@ -1231,8 +1272,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     // P2/P3: the positions of the element-matrix entries inside their rows, for the assembly (row_unique_regs)
     uint16_t* pos_out = nullptr;
     ctx->have_asm_pos = false;
-    if (nd > 4 && stage && ctx->n_owned + ctx->n_ghost < ((int64_t)1 << 23) && !getenv("ZZZ_ASM_SEARCH")
-        && ctx->asm_pos.alloc((size_t)nstage) == hipSuccess)
+    if (nd > 4 && !getenv("ZZZ_ASM_SEARCH") && ctx->asm_pos.alloc((size_t)nstage) == hipSuccess)
       pos_out = ctx->asm_pos.p;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_row_pattern<false>, dim3(rgrid), dim3(256), 0, s, ctx->cell_dofs.p, nd, bs, ctx->adj_off.p,

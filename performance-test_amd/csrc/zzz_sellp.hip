@@ -53,20 +53,6 @@ __device__ inline int64_t sp_xcd_item(int64_t n, int b, int nb, int i)
   return t < hi ? t : -1;
 }
 
-// wave-wide minimum in every lane's hands (a scalar): an inclusive min-scan inside the rows of 16 lanes with DPP
-// row shifts, two row broadcasts, then lane 63 read out -- thirteen vector instructions, no LDS crossbar
-__device__ inline int wave_min_i(int v)
-{
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x111, 0xf, 0xf, false)); // row_shr:1
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x112, 0xf, 0xf, false)); // row_shr:2
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x114, 0xf, 0xf, false)); // row_shr:4
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false)); // row_shr:8
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1, 3
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2, 3
-  return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ inline int wave_max_i(int v) { return -wave_min_i(-v); } // |v| < 2^31 - 1 here
-
 // ---- build ------------------------------------------------------------------------------------------
 // entries of each row that the stream keeps
 // The same counts with dense loads: one wavefront sweeps the CSR range of its 64 rows 64 entries at a time; every lane

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/stats_pattern_$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o t -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no_cpu_baseline --no_other_configs > $OUT/bench.json 2> $OUT/bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o t -- python3 $R/bench.py --config $CFG --steps ${STEPS:-3} --warmup 1 --no_cpu_baseline --no_other_configs > $OUT/bench.json 2> $OUT/bench.log
 python3 - <<PY
 import csv,glob
 f=glob.glob("$OUT/p/**/*kernel_stats.csv",recursive=True)[0]
