@@ -30,6 +30,7 @@ constexpr int ASM_NNZ_P1 = 1920;    // scalar P1: ~126 rows per tile for a 128-t
 constexpr int ASM_NNZ_SMALL = 2048; // ... or half of that for scalar P1/P2 (short rows): twice the workgroups per CU
                                     // (measured: Poisson P1 6.6 -> 5.6 ms, P2 6.4 -> 4.5 ms; elasticity and P3 lose)
 constexpr int ASM_ORD_CAP = 512; // block dofs of a tile that the high-order kernel sorts by cell count
+constexpr int ASM_RP_CAP = 255;  // scalar rows of a tile whose offsets the position-based kernel keeps in LDS
 
 struct Geom
 {
@@ -938,7 +939,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
                                                                const rp_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ cols, double* __restrict__ vals,
                                                                const int32_t* __restrict__ tiles, int64_t ntiles,
-                                                               const double* __restrict__ tab, int cap)
+                                                               const double* __restrict__ tab, int cap,
+                                                               int32_t* __restrict__ rownnz)
 {
   constexpr int NT = (BS == 1) ? 6 : 9;
   constexpr int NN = ND * ND;
@@ -974,7 +976,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
   // block dofs of the tile in order of descending cell count, as in asm_matrix_pk
   __shared__ int ord_s[ASM_ORD_CAP];
   __shared__ int hist_s[34];
+  __shared__ int rp_s[ASM_RP_CAP + 1]; // the tile's row offsets relative to s: every later phase reads them here
   const int nt = d1 - d0;
+  const bool rp_in_lds = nt * BS <= ASM_RP_CAP;
+  if (rp_in_lds)
+    for (int k = threadIdx.x; k <= nt * BS; k += ASM_BLOCK)
+      rp_s[k] = (int)(rowptr[row0 + k] - s);
+  auto row_begin = [&](int q) { return rp_in_lds ? rp_s[q] : (int)(rowptr[row0 + q] - s); }; // q = scalar row - row0
   const bool sorted = nt <= ASM_ORD_CAP;
   if (sorted)
   {
@@ -1008,7 +1016,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
   {
     const int i = d0 + (sorted ? ord_s[q / BS] : q / BS), c = q % BS;
     const int r = i * BS + c;
-    const int a0 = (int)(rowptr[r] - s);
+    const int a0 = row_begin(r - row0);
     const bool bcr = bc[r] != 0;
     const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
     const uint16_t* __restrict__ prow = pos + (int64_t)adj_off[i] * ND; // positions of the row's (cell, column) pairs
@@ -1125,13 +1133,28 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
     const int r = row0 + q;
     if (bc[r])
     {
-      const int64_t g0 = rowptr[r];
-      vals_s[(int)(g0 - s) + find_pos(cols + g0, (int)(rowptr[r + 1] - g0), r)] = 1.0;
+      const int b0 = row_begin(q);
+      vals_s[b0 + find_pos(cols + s + b0, row_begin(q + 1) - b0, r)] = 1.0;
     }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < e; k += ASM_BLOCK)
     vals[s + k] = vals_s[k];
+  // the operator stream of the CG product keeps the non-zero entries only: how many each row has is counted here, where
+  // the finished values still sit in LDS (the packer's own dense count sweep re-read all of them: 4.5 ms at 2.4 G entries)
+  if (rownnz)
+    for (int q = (int)threadIdx.x >> 3; q < nt * BS; q += ASM_BLOCK / 8) // eight lanes per row
+    {
+      const int b0 = row_begin(q), len = row_begin(q + 1) - b0;
+      int n = 0;
+      for (int k = threadIdx.x & 7; k < len; k += 8)
+        n += vals_s[b0 + k] != 0.0 ? 1 : 0;
+      n += __shfl_down(n, 4, 8);
+      n += __shfl_down(n, 2, 8);
+      n += __shfl_down(n, 1, 8);
+      if ((threadIdx.x & 7) == 0)
+        rownnz[row0 + q] = n;
+    }
   __syncthreads(); // the next tile reuses vals_s, ord_s, hist_s
   }
 }
@@ -1153,12 +1176,18 @@ static int launch_matrix_pk_pos(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->cell_geom.alloc((size_t)(ctx->ncells * NG)));
   hipLaunchKernelGGL(k_cell_geom<BS>, dim3((unsigned)std::min<int64_t>((ctx->ncells + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
                      ctx->x.p, ctx->cell_verts.p, ctx->ncells, ctx->cell_geom.p);
-  int per_cu = (int)(160 * 1024 / (lds + 2560)); // workgroups a CU holds (LDS-bound; ord_s / hist_s on top)
+  int per_cu = (int)(160 * 1024 / (lds + 3400)); // workgroups a CU holds (LDS-bound; ord_s, rp_s, hist_s on top)
   per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   const int64_t grid = std::min<int64_t>(xcd_grid(ctx->n_asm_tiles), 256 * (int64_t)per_cu);
+  // the non-zero count per row, for the packer of the operator stream (zzz_sellp.hip: sp_build_sorted)
+  int32_t* rownnz = nullptr;
+  if (ctx->sellp_mode != 0 && ctx->sellp_drop && ctx->sp_rownnz.alloc((size_t)ctx->nrows + 1) == hipSuccess)
+    rownnz = ctx->sp_rownnz.p;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ASM_BLOCK), lds, ctx->stream, ctx->cell_geom.p,
                      ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->adj_off.p, ctx->asm_pos.p, ctx->bc.p,
-                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p, cap);
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p, cap, rownnz);
+  ctx->sp_rownnz_fresh = rownnz != nullptr;
   return ZZZ_OK;
 }
 
@@ -1193,6 +1222,7 @@ static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
 
 int launch_assemble_matrix(zzz_ctx* ctx, int form)
 {
+  ctx->sp_rownnz_fresh = false;
   const int bs = form == ZZZ_FORM_ELASTICITY ? 3 : 1;
   if (bs != ctx->bs)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);

@@ -189,6 +189,7 @@ struct zzz_ctx
   zzz::DevBuf<uint8_t> sp_gflag;
   hipEvent_t sp_event = nullptr;
   bool sp_pending = false, sp_forced = false, sp_bounds_ok = false, sp_lds_attr = false;
+  bool sp_rownnz_fresh = false; // sp_rownnz holds the non-zero counts of the CURRENT values (left by the matrix assembly)
   int sp_max_range = 0;       // longest CSR range of a 64-row slice
   int64_t sp_chunk_bound = 0; // chunks of the natural-order stream if no entry were zero
   zzz::DevBuf<uint16_t> sp_codes16;

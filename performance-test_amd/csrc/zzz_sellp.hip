@@ -1142,7 +1142,11 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out, bool sorted = true)
   ZZZ_HIP(ctx, ctx->sp_chunk_off.alloc((size_t)nsl + 1));
   ZZZ_HIP(ctx, ctx->sp_perm.alloc((size_t)nsl * 64));
   ZZZ_HIP(ctx, ctx->sp_wlast.alloc((size_t)nsl + 1));
-  if (drop && ctx->nnz >= 16 * ctx->nrows) // long rows: dense sweep (short rows: a lane's row is one or two cache lines)
+  const bool counted = drop && ctx->sp_rownnz_fresh; // the matrix assembly has left the counts (asm_matrix_pk_pos)
+  ctx->sp_rownnz_fresh = false;
+  if (counted)
+    ;
+  else if (drop && ctx->nnz >= 16 * ctx->nrows) // long rows: dense sweep (short rows: a lane's row is one or two cache lines)
     hipLaunchKernelGGL(k_sp_count_sweep, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, nsl,
                        ctx->sp_rownnz.p);
   else
