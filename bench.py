@@ -607,6 +607,11 @@ def main():
         if multi or a.force_comm:
             out["config"]["scalar_allreduce"] = ("peer-memory mailboxes over xGMI (one kernel: reduce + exchange)" if p2p
                                                  else "ncclAllReduce")
+            # the combination the timed steps ran, and how it was chosen: --cg given = taken as asked, no tuning solves
+            out["config"]["cg_form"] = {"form": "single_reduction" if single_reduction else "classical",
+                                        "scalar_allreduce": "peer_memory" if p2p else "ncclAllReduce",
+                                        "chosen_by": ("--cg " + a.cg) if a.cg != "auto" else
+                                                     ("warm-up tuning (fastest of %d combinations)" % len(tuning) if tuning else "default")}
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
         if not multi and not a.no_cpu_baseline:
             if nnz > 2**31 - 1:

@@ -324,7 +324,8 @@ const char* zzz_comm_library_path(void);
 /* What the multi-GPU path of this context does, for diagnostics (bench.py prints it per rank): info = {ranks,
  * rank, neighbours, bytes sent per forward scatter, bytes received, 1 = halo on its own communicator + stream
  * (ncclCommSplit), 1 = CG scalars through the peer-memory mailboxes, 1 = halo overlapped with the interior rows,
- * interior / boundary work items (groups of 256 rows or tiles) of the product, 1 = host-mediated local backend, 0}. */
+ * interior / boundary work items (groups of 256 rows or tiles) of the product, 1 = host-mediated local backend, mean exposed
+ * halo wait per product of the last profiled solve in ns (main stream idle between its interior rows and the halo's arrival)}. */
 int zzz_comm_info(zzz_ctx* ctx, int64_t info[12]);
 
 /* ncclGetUniqueId on the root; ship the bytes to the other ranks out of band (the driver's

@@ -175,6 +175,8 @@ void zzz_ctx_destroy(zzz_ctx* ctx)
   comm_destroy(ctx);
   for (hipEvent_t ev : ctx->ev)
     (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_halo)
+    (void)hipEventDestroy(ev);
   if (ctx->sp_event)
     (void)hipEventDestroy(ctx->sp_event);
   if (ctx->h_state)

@@ -691,6 +691,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       ZZZ_HIP(ctx, hipEventCreate(&ctx->ev[i]));
   }
   int nprof = 0;
+  ctx->prof_halo_n = 0;
+  ctx->prof_halo_wait_ms = 0.0;
 
   // host polling: copy the state every CHECK iterations, look at it NSLOT-1 batches later
   constexpr int CHECK = 8, NSLOT = 4;
@@ -708,6 +710,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
                          ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
     int np = 0;
     const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
+    ctx->prof_now = timed;
     if (timed)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
     bool folded = false;
@@ -725,6 +728,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       if (rc)
         return rc;
     }
+    ctx->prof_now = false;
     if (timed)
     {
       (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
@@ -807,6 +811,21 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   }
   if (ctx->prof_spmv_n)
     ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
+  {
+    int cnt = 0;
+    for (int i = 0; i < ctx->prof_halo_n; ++i)
+    {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ctx->ev_halo[(size_t)(2 * i)], ctx->ev_halo[(size_t)(2 * i + 1)]) == hipSuccess)
+      {
+        ctx->prof_halo_wait_ms += ms;
+        ++cnt;
+      }
+    }
+    if (cnt)
+      ctx->prof_halo_wait_ms /= cnt;
+    (void)hipGetLastError();
+  }
   return finish_reason(ctx, o, fin, its);
 }
 
@@ -896,6 +915,8 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
       ZZZ_HIP(ctx, hipEventCreate(&ctx->ev[i]));
   }
   int nprof = 0;
+  ctx->prof_halo_n = 0;
+  ctx->prof_halo_wait_ms = 0.0;
   {
     int rc = apply();
     if (rc)
@@ -913,6 +934,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
                        it, P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p,
                        ctx->r.p, n, 0);
     const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
+    ctx->prof_now = timed;
     if (timed)
       (void)hipEventRecord(ctx->ev[2 * nprof], s);
     {
@@ -920,6 +942,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
       if (rc)
         return rc;
     }
+    ctx->prof_now = false;
     if (timed)
     {
       (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
@@ -975,6 +998,21 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   }
   if (ctx->prof_spmv_n)
     ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
+  {
+    int cnt = 0;
+    for (int i = 0; i < ctx->prof_halo_n; ++i)
+    {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ctx->ev_halo[(size_t)(2 * i)], ctx->ev_halo[(size_t)(2 * i + 1)]) == hipSuccess)
+      {
+        ctx->prof_halo_wait_ms += ms;
+        ++cnt;
+      }
+    }
+    if (cnt)
+      ctx->prof_halo_wait_ms /= cnt;
+    (void)hipGetLastError();
+  }
   return finish_reason(ctx, o, fin, its);
 }
 } // namespace zzz

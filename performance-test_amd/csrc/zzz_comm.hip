@@ -546,7 +546,24 @@ int comm_halo_end(zzz_ctx* ctx)
 {
   if (!ctx->comm || ctx->comm->local || !ctx->comm->comm_halo || ctx->nneigh == 0 || !ctx->comm_stream)
     return ZZZ_OK;
+  // timed iteration: how long the main stream sits between the interior rows and the halo's arrival
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof_now && ctx->prof_halo_n < 256)
+  {
+    while ((int)ctx->ev_halo.size() < 2 * (ctx->prof_halo_n + 1))
+    {
+      hipEvent_t e;
+      ZZZ_HIP(ctx, hipEventCreate(&e));
+      ctx->ev_halo.push_back(e);
+    }
+    e0 = ctx->ev_halo[(size_t)(2 * ctx->prof_halo_n)];
+    e1 = ctx->ev_halo[(size_t)(2 * ctx->prof_halo_n + 1)];
+    ++ctx->prof_halo_n;
+    ZZZ_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  }
   ZZZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done, 0));
+  if (e1)
+    ZZZ_HIP(ctx, hipEventRecord(e1, ctx->stream));
   return ZZZ_OK;
 }
 
@@ -754,6 +771,7 @@ int zzz_comm_info(zzz_ctx* ctx, int64_t info[12])
   info[8] = stream_split ? ctx->n_groups_interior : ctx->n_tiles_interior;
   info[9] = stream_split ? ctx->n_groups_boundary : ctx->n_tiles_boundary;
   info[10] = ctx->comm && ctx->comm->local ? 1 : 0;
+  info[11] = (int64_t)(ctx->prof_halo_wait_ms * 1.0e6); // ns: mean exposed halo wait per product of the last profiled solve
   return ZZZ_OK;
 }
 

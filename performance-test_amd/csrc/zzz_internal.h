@@ -233,6 +233,12 @@ struct zzz_ctx
   std::vector<hipEvent_t> ev;
   double prof_spmv_ms = 0.0;
   int64_t prof_spmv_n = 0;
+  // exposed halo wait of the overlapped product (time between the end of the interior launch and the arrival of the
+  // halo, on the main stream), sampled on the iterations whose product is timed
+  std::vector<hipEvent_t> ev_halo;
+  bool prof_now = false; // set by the CG loop around a timed product launch
+  int prof_halo_n = 0;
+  double prof_halo_wait_ms = 0.0;
 
   // the scalar all-reduce folded into the tail of the producing kernel (zzz_tail.h): armed by the CG loop before a
   // product whose partials it wants all-reduced, consumed by the operator-stream launcher (tail_used tells the loop)

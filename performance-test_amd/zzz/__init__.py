@@ -550,7 +550,8 @@ class Context:
         info = (C.c_int64 * 12)()
         self._ck(self.L.zzz_comm_info(self.h, info))
         keys = ("ranks", "rank", "neighbours", "halo_bytes_sent", "halo_bytes_received", "halo_own_communicator",
-                "peer_memory_allreduce", "halo_overlapped", "interior_items", "boundary_items", "local_backend")
+                "peer_memory_allreduce", "halo_overlapped", "interior_items", "boundary_items", "local_backend",
+                "halo_wait_ns_per_product")
         return {k: int(v) for k, v in zip(keys, info)}
 
     def comm_init(self, nranks, rank, uid_bytes):

@@ -1474,6 +1474,37 @@ def test_bench_multi_gpu_process_layout_on_one_gpu():
     assert abs(cfg["krylov_iterations"] - 306) <= 40 and cfg["relative_residual"] <= 1e-8
 
 
+@pytest.mark.parametrize("cg", ["classical", "single_reduction"])
+@pytest.mark.parametrize("p2p", ["0", "1"])
+def test_bench_multi_gpu_branches_on_one_gpu(cg, p2p):
+    """Every branch the N > 1 tuning of bench.py can select -- {classical, single_reduction} x {ncclAllReduce, peer-memory
+    mailboxes} -- runs under test on one GPU, launched the way the driver launches N > 1 (torch.distributed.run, env://
+    on 127.0.0.1, gloo group, unique-id broadcast, 1-rank RCCL communicator): `--cg` given explicitly means NO tuning
+    solves, the JSON line says which combination ran and why, carries the per-rank halo wait, and the solve is the
+    single-GPU one (975-iteration problem scaled down: same count in every branch)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(zzz.PKG)
+    env = dict(os.environ, ZZZ_P2P=p2p, MASTER_ADDR="127.0.0.1")
+    port = 29600 + (0 if cg == "classical" else 2) + int(p2p)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--force_dist", "--ndofs", "200000",
+           "--steps", "1", "--warmup", "1", "--cg", cg]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    cfg = d["config"]
+    assert cfg["cg_form"]["form"] == cg and cfg["cg_form"]["chosen_by"] == "--cg " + cg
+    assert cfg["cg_form"]["scalar_allreduce"] == ("peer_memory" if p2p == "1" else "ncclAllReduce")
+    assert "cg_form_tuning_s" not in cfg  # explicit --cg: no warm-up solves of other combinations
+    assert ("-ksp_cg_single_reduction" in cfg["workload"]) == (cg == "single_reduction")
+    rk = cfg["ranks"][0]
+    assert rk["ranks"] == 1 and rk["peer_memory_allreduce"] == int(p2p) and "halo_wait_ns_per_product" in rk
+    assert 250 <= cfg["krylov_iterations"] <= 330 and cfg["relative_residual"] <= 1e-8
+
+
 def test_spmv_kernel_selection(ctx):
     """Matrices whose rows have similar lengths run on the sliced-ELL operator stream (exact zeros dropped, natural
     row order), very long rows of mixed lengths on its length-sorted form, the rest on the CSR tile kernel -- and

@@ -211,3 +211,30 @@ def test_native_partition_feed(problem, order):
             np.testing.assert_array_equal(sent, up.global_dofs[up.n_owned:])
             assert up.recv_cnt[list(up.neigh).index(r)] == sent.size
     assert seen_cells == parts[0].global_cells
+
+
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (5, 4, 6)), ("poisson", 3, (2, 3, 2)), ("elasticity", 2, (2, 2, 3))])
+@pytest.mark.parametrize("kind", ["random", "rcm", "reverse"])
+def test_renumbered_feed_is_the_same_problem(problem, order, dims, kind):
+    """zzz.Part.renumbered (what bench.py --numbering and the GPU tests feed: dofs, vertices and cells renumbered the way a
+    DOLFINx-style mesh library might leave them, src/mesh.cpp:153-162,182-186) describes the SAME discrete problem: the
+    oracle's matrix and right-hand side of the renumbered feed are the permuted ones of the original."""
+    P = zzz.Part(problem, order, *dims)
+    Q = P.renumbered(kind, seed=1)
+    bs, N = P.bs, P.n_owned * P.bs
+    assert sorted(Q.dof_new_of_old) == list(range(P.n_owned))
+    fac = P.facets if P.form == 0 else None
+    rp, cl = zo.pattern(P.n_owned, P.cell_dofs, bs)
+    v = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, P.bc_marker(), rp, cl)
+    b = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, fac, P.bc_marker())
+    rq, cq = zo.pattern(Q.n_owned, Q.cell_dofs, bs)
+    vq = zo.assemble_matrix(Q.form, order, Q.x, Q.cells, Q.cell_dofs, Q.bc_marker(), rq, cq)
+    bq = zo.assemble_vector(Q.form, order, Q.x, Q.cells, Q.cell_dofs, Q.f, Q.g, Q.facets if Q.form == 0 else None, Q.bc_marker())
+    A = sp.csr_matrix((v, cl, rp), shape=(N, N))
+    Aq = sp.csr_matrix((vq, cq, rq), shape=(N, N))
+    s = (Q.dof_new_of_old[:, None] * bs + np.arange(bs)).reshape(-1)  # scalar old -> new
+    Pm = sp.csr_matrix((np.ones(N), (s, np.arange(N))), shape=(N, N))
+    D = (Pm @ A @ Pm.T - Aq).tocoo()
+    assert A.nnz == Aq.nnz
+    assert D.nnz == 0 or np.abs(D.data).max() <= 1e-12 * np.abs(v).max()
+    assert np.abs(bq[s] - b).max() <= 1e-12 * np.abs(b).max()
