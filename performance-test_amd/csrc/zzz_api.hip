@@ -619,7 +619,7 @@ int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals)
   }
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->vals.p, vals, (size_t)ctx->nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the staging copy above may be a local
-  ctx->sp_rownnz_fresh = false; // counts left by an assembly belong to the values just replaced
+  ctx->sp_rownnz_fresh = ctx->sp_compact_fresh = false; // what an assembly left belongs to the values just replaced
   int rc = sell_update(ctx, false);
   if (rc)
     return rc;
@@ -638,7 +638,7 @@ int zzz_assemble_matrix(zzz_ctx* ctx, int form)
   int rc = launch_assemble_matrix(ctx, form);
   if (!rc)
     rc = sell_update(ctx, false); // MatAssemblyEnd-like finalisation: refresh the SpMV copy
-  ctx->sp_rownnz_fresh = false;   // (whether or not this packing path had a use for the counts)
+  ctx->sp_rownnz_fresh = ctx->sp_compact_fresh = false; // (whether or not this packing path had a use for them)
   if (!rc)
     ctx->have_matrix = true;
   return rc;

@@ -940,7 +940,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
                                                                const int32_t* __restrict__ cols, double* __restrict__ vals,
                                                                const int32_t* __restrict__ tiles, int64_t ntiles,
                                                                const double* __restrict__ tab, int cap,
-                                                               int32_t* __restrict__ rownnz)
+                                                               int32_t* __restrict__ rownnz, const int64_t* __restrict__ crow,
+                                                               double* __restrict__ cvals, int32_t* __restrict__ ccols)
 {
   constexpr int NT = (BS == 1) ? 6 : 9;
   constexpr int NN = ND * ND;
@@ -1142,17 +1143,31 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
     vals[s + k] = vals_s[k];
   // the operator stream of the CG product keeps the non-zero entries only: how many each row has is counted here, where
   // the finished values still sit in LDS (the packer's own dense count sweep re-read all of them: 4.5 ms at 2.4 G entries)
+  // ... and, with `crow` (capacity-based row starts, zzz_sellp.hip: sellp_capacity_rows), the kept entries themselves go
+  // into the packer's compacted copy from here: its own compaction sweep re-read values and columns of the whole matrix
+  // (2.2 ms at 6.2 M P3 dofs, 17 ms at 49.8 M)
   if (rownnz)
     for (int q = (int)threadIdx.x >> 3; q < nt * BS; q += ASM_BLOCK / 8) // eight lanes per row
     {
       const int b0 = row_begin(q), len = row_begin(q + 1) - b0;
+      const int sub = threadIdx.x & 7, grp = (threadIdx.x & 63) >> 3;
+      const int64_t cb = crow ? crow[row0 + q] : 0;
       int n = 0;
-      for (int k = threadIdx.x & 7; k < len; k += 8)
-        n += vals_s[b0 + k] != 0.0 ? 1 : 0;
-      n += __shfl_down(n, 4, 8);
-      n += __shfl_down(n, 2, 8);
-      n += __shfl_down(n, 1, 8);
-      if ((threadIdx.x & 7) == 0)
+      for (int k0 = 0; k0 < len; k0 += 8)
+      {
+        const int k = k0 + sub;
+        const double v = k < len ? vals_s[b0 + k] : 0.0;
+        const bool keep = k < len && v != 0.0;
+        const unsigned m8 = (unsigned)(__ballot(keep) >> (8 * grp)) & 0xffu;
+        if (crow && keep)
+        {
+          const int at = n + __popc(m8 & ((1u << sub) - 1u));
+          cvals[cb + at] = v;
+          ccols[cb + at] = cols[s + b0 + k];
+        }
+        n += __popc(m8);
+      }
+      if (sub == 0)
         rownnz[row0 + q] = n;
     }
   __syncthreads(); // the next tile reuses vals_s, ord_s, hist_s
@@ -1184,10 +1199,20 @@ static int launch_matrix_pk_pos(zzz_ctx* ctx)
   if (ctx->sellp_mode != 0 && ctx->sellp_drop && ctx->sp_rownnz.alloc((size_t)ctx->nrows + 1) == hipSuccess)
     rownnz = ctx->sp_rownnz.p;
   (void)hipGetLastError();
+  // long rows (the packer's synchronous path): the compacted copy of the kept entries is written from here as well
+  const int64_t* crow = nullptr;
+  if (rownnz && ctx->nnz >= 16 * ctx->nrows && ctx->nnz + 8 * ctx->nrows < ((int64_t)1 << 40) && !getenv("ZZZ_ASM_NO_COMPACT"))
+  {
+    if (int rc = sellp_capacity_rows(ctx))
+      return rc;
+    crow = ctx->sp_crow.p;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ASM_BLOCK), lds, ctx->stream, ctx->cell_geom.p,
                      ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->adj_off.p, ctx->asm_pos.p, ctx->bc.p,
-                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p, cap, rownnz);
+                     ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->asm_tile.p, ctx->n_asm_tiles, ctx->tables.p, cap, rownnz, crow,
+                     ctx->sp_cvals.p, ctx->sp_ccols.p);
   ctx->sp_rownnz_fresh = rownnz != nullptr;
+  ctx->sp_compact_fresh = crow != nullptr;
   return ZZZ_OK;
 }
 
@@ -1222,7 +1247,7 @@ static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
 
 int launch_assemble_matrix(zzz_ctx* ctx, int form)
 {
-  ctx->sp_rownnz_fresh = false;
+  ctx->sp_rownnz_fresh = ctx->sp_compact_fresh = false;
   const int bs = form == ZZZ_FORM_ELASTICITY ? 3 : 1;
   if (bs != ctx->bs)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);

@@ -190,6 +190,8 @@ struct zzz_ctx
   hipEvent_t sp_event = nullptr;
   bool sp_pending = false, sp_forced = false, sp_bounds_ok = false, sp_lds_attr = false;
   bool sp_rownnz_fresh = false; // sp_rownnz holds the non-zero counts of the CURRENT values (left by the matrix assembly)
+  bool sp_compact_fresh = false; // ... and sp_cvals / sp_ccols the kept entries, rows at sp_crow (capacity-based starts)
+  bool sp_crow_is_cap = false;   // sp_crow = scan of the FULL row lengths padded to 8 (pattern-only; valid until the pattern changes)
   int sp_max_range = 0;       // longest CSR range of a 64-row slice
   int64_t sp_chunk_bound = 0; // chunks of the natural-order stream if no entry were zero
   zzz::DevBuf<uint16_t> sp_codes16;
@@ -300,6 +302,7 @@ int sell_update(zzz_ctx* ctx, bool structure);
 bool sellp_active(zzz_ctx* ctx);
 int sellp_resolve(zzz_ctx* ctx);
 int sellp_pattern_bounds(zzz_ctx* ctx);
+int sellp_capacity_rows(zzz_ctx* ctx); // sp_crow := capacity-based row starts of the compacted copy (+ its allocation)
 int64_t sellp_stream_bytes(const zzz_ctx* ctx);
 int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr);
 int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,

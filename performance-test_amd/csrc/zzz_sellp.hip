@@ -1196,18 +1196,24 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
   {
     // long rows: through the compacted copy (crow = scan of the kept counts padded to 8)
     const int64_t cap = ctx->nnz + 8 * ctx->nrows;
-    ZZZ_HIP(ctx, ctx->sp_crow.alloc((size_t)nrows + 1));
-    ZZZ_HIP(ctx, ctx->sp_cvals.alloc((size_t)cap));
-    ZZZ_HIP(ctx, ctx->sp_ccols.alloc((size_t)cap));
-    const auto padded = rocprim::make_transform_iterator(ctx->sp_rownnz.p, Pad8{});
-    size_t tb = 0;
-    ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
-                                         rocprim::plus<int64_t>(), s));
-    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
-    ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
-                                         rocprim::plus<int64_t>(), s));
-    hipLaunchKernelGGL(k_sp_compact, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows,
-                       nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_crow.p, ctx->sp_cvals.p, ctx->sp_ccols.p);
+    const bool compacted = ctx->sp_compact_fresh && ctx->sp_crow_is_cap; // the matrix assembly has written the copy already
+    ctx->sp_compact_fresh = false;
+    if (!compacted)
+    {
+      ZZZ_HIP(ctx, ctx->sp_crow.alloc((size_t)nrows + 1));
+      ZZZ_HIP(ctx, ctx->sp_cvals.alloc((size_t)cap));
+      ZZZ_HIP(ctx, ctx->sp_ccols.alloc((size_t)cap));
+      ctx->sp_crow_is_cap = false;
+      const auto padded = rocprim::make_transform_iterator(ctx->sp_rownnz.p, Pad8{});
+      size_t tb = 0;
+      ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
+                                           rocprim::plus<int64_t>(), s));
+      ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+      ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
+                                           rocprim::plus<int64_t>(), s));
+      hipLaunchKernelGGL(k_sp_compact, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows,
+                         nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_crow.p, ctx->sp_cvals.p, ctx->sp_ccols.p);
+    }
     if (sorted)
       hipLaunchKernelGGL(k_sp_fill_c<true>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
@@ -1235,10 +1241,44 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
   return sp_group_split(ctx, gflag);
 }
 
+__global__ void k_sp_cap_len(const rp_t* __restrict__ rowptr, int nrows, int64_t* __restrict__ out)
+{
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= nrows; r += (int64_t)gridDim.x * blockDim.x)
+    out[r] = r < nrows ? ((rowptr[r + 1] - rowptr[r] + 7) & ~(int64_t)7) : 0;
+}
+
+// Row starts of the compacted copy by CAPACITY (every row has room for its whole pattern row, padded to 8): a
+// function of the pattern alone, so that the matrix assembly can write the kept entries of a row where the packer
+// will look for them without knowing how many the rows before it keep (asm_matrix_pk_pos; k_sp_fill_c reads
+// crow[r] and rownnz[r] only).
+int sellp_capacity_rows(zzz_ctx* ctx)
+{
+  if (ctx->sp_crow_is_cap)
+    return ZZZ_OK;
+  hipStream_t s = ctx->stream;
+  const int nrows = (int)ctx->nrows;
+  const int64_t cap = ctx->nnz + 8 * ctx->nrows;
+  ZZZ_HIP(ctx, ctx->sp_crow.alloc((size_t)nrows + 1));
+  ZZZ_HIP(ctx, ctx->sp_cvals.alloc((size_t)cap));
+  ZZZ_HIP(ctx, ctx->sp_ccols.alloc((size_t)cap));
+  hipLaunchKernelGGL(k_sp_cap_len, dim3(grid_cap((int64_t)nrows + 1, 256, 4096)), dim3(256), 0, s, ctx->rowptr.p, nrows, ctx->sp_crow.p);
+  size_t tb = 0;
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->sp_crow.p, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
+                                       rocprim::plus<int64_t>(), s));
+  ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->sp_crow.p, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
+                                       rocprim::plus<int64_t>(), s));
+  ZZZ_HIP(ctx, hipGetLastError());
+  ctx->sp_crow_is_cap = true;
+  return ZZZ_OK;
+}
+
 // Pattern-only bounds of the natural-order stream (once per pattern; one small read-back).
 int sellp_pattern_bounds(zzz_ctx* ctx)
 {
   ctx->sp_bounds_ok = false;
+  ctx->sp_crow_is_cap = false;
+  ctx->sp_compact_fresh = ctx->sp_rownnz_fresh = false;
   ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
   if (ctx->nrows <= 0)
     return ZZZ_OK;
