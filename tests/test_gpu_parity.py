@@ -393,10 +393,12 @@ def test_driver_binary_surface():
 
 @pytest.mark.parametrize("problem,order", [("poisson", 1), ("poisson", 2), ("poisson", 3), ("elasticity", 1),
                                            ("elasticity", 3)])
-def test_unsorted_cells_and_foreign_numbering(ctx, problem, order):
+def test_unsorted_cells_and_foreign_numbering(ctx, problem, order, renumber=None):
     """A mesh the structured feed never produces: the oracle's create_box-style cells (vertices NOT
     sorted, both orientations of det J, edge sub-dofs permuted by the dofmap) with its entity-blocked
     dof numbering, cells shuffled, on a stretched and sheared geometry."""
+    if renumber is not None:
+        os.environ["ZZZ_RENUMBER"] = renumber
     O = zo.Problem(problem, order, 3, 2, 3)
     rng = np.random.default_rng(11 + order)
     perm = rng.permutation(O.cells.shape[0])
@@ -409,8 +411,13 @@ def test_unsorted_cells_and_foreign_numbering(ctx, problem, order):
     x = np.ascontiguousarray((O.x + jitter) @ M.T + np.array([0.3, -0.1, 0.2]))
     facets = zo.exterior_facets(cells) if problem == "poisson" else None
     bs = O.bs
-    ctx.upload_mesh(x, cells)
-    ctx.upload_dofmap(order, bs, cell_dofs, O.nblock, 0)
+    try:
+        ctx.upload_mesh(x, cells)
+        ctx.upload_dofmap(order, bs, cell_dofs, O.nblock, 0)
+    finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
+    # a jittered, sheared mesh is no lattice: the caller's order stays unless the coordinate-bin order is asked for
+    assert ctx.internal_order()[1] == (2 if renumber == "2" else 0) and not ctx.cells_renumbered()
     ctx.upload_bc(np.nonzero(O.bc)[0].astype(np.int32))
     ctx.upload_coeff(zzz.COEFF_F, O.f)
     if problem == "poisson":
@@ -666,6 +673,14 @@ def test_position_based_assembly_keeps_every_bit(problem, order, dims):
     np.testing.assert_array_equal(cl, ocl)
     ov = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, P.bc_marker(), orp, ocl)
     assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+
+
+@pytest.mark.parametrize("problem,order", [("poisson", 1), ("poisson", 3), ("elasticity", 2)])
+def test_coordinate_bin_order_on_a_mesh_that_is_no_lattice(ctx, problem, order):
+    """ZZZ_RENUMBER=2: also a mesh that is no lattice (jittered, sheared, cells shuffled) is put into an internal order
+    (dofs by coordinate bins); at the ABI nothing may change: the oracle's pattern in the caller's numbering, A, b, the
+    matrix-free action and the solve."""
+    test_unsorted_cells_and_foreign_numbering(ctx, problem, order, renumber="2")
 
 
 def test_size_limits_are_errors_not_crashes():
