@@ -504,7 +504,6 @@ void to_internal(const zzz_ctx* ctx, const double* in, double* out, bool owned_o
   const int bs = ctx->bs;
   const int64_t nb = ctx->n_owned, nall = owned_only ? nb : nb + ctx->n_ghost;
   const int32_t* perm = ctx->h_perm.data();
-#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < nall; ++i)
   {
     const int64_t src = i < nb ? perm[i] : i;
@@ -518,7 +517,6 @@ void to_caller(const zzz_ctx* ctx, const double* in, double* out, bool owned_onl
   const int bs = ctx->bs;
   const int64_t nb = ctx->n_owned, nall = owned_only ? nb : nb + ctx->n_ghost;
   const int32_t* perm = ctx->h_perm.data();
-#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < nall; ++i)
   {
     const int64_t dst = i < nb ? perm[i] : i;
@@ -564,17 +562,16 @@ int csr_to_caller(zzz_ctx* ctx, std::vector<rp_t>& rowptr_c, int32_t* cols_c, do
   if (!have_slot)
     ctx->csr_slot.resize((size_t)nnz);
   int bad = 0;
-#pragma omp parallel
+  // (serial on purpose: these are inspection / set-up calls, and a process that also holds the CPU oracle would otherwise
+  // run two OpenMP runtimes -- clang's here, gcc's there -- side by side)
   {
     std::vector<std::pair<int32_t, int32_t>> tmp;
-#pragma omp for schedule(dynamic, 1024)
     for (int64_t r = 0; r < nrows; ++r)
     {
       const int64_t ri = (int64_t)iperm[r / bs] * bs + r % bs;
       const rp_t a = rp[(size_t)ri], len = rp[(size_t)ri + 1] - a, o = rowptr_c[(size_t)r];
       if (len > 65535)
       {
-#pragma omp atomic write
         bad = 1;
         continue;
       }
@@ -636,7 +633,6 @@ int csr_values_to_internal(zzz_ctx* ctx, const double* vals_c, std::vector<doubl
     }
   }
   vals_i.resize((size_t)ctx->nnz);
-#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < nrows; ++r)
   {
     const int64_t ri = (int64_t)ctx->h_iperm[(size_t)(r / bs)] * bs + r % bs;

@@ -1,19 +1,19 @@
 #!/bin/bash
 # Derived-metric probe of the CG kernels (one rocprofv3 --pmc pass per metric group; kernel trace only).
-# Usage: bash performance-test_amd/tools/pmc_probe.sh "MemUnitBusy MemUnitStalled" "L2CacheHit" ...
+# Usage: CFG=c5_rank bash performance-test_amd/tools/pmc_probe.sh "MemUnitBusy MemUnitStalled" "L2CacheHit" ...
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmcp_$i -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline > /dev/null 2> $R/gpurun_out/pmcp_$i.log
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmcp_$i -o p -- python3 $R/bench.py --config ${CFG:-c2} --steps 1 --warmup 0 --no_cpu_baseline --no_other_configs > /dev/null 2> $R/gpurun_out/pmcp_$i.log
   python3 - "$R/gpurun_out/pmcp_$i" <<'PY'
 import csv,glob,sys,collections,re
 acc=collections.defaultdict(lambda: collections.defaultdict(lambda:[0.0,0]))
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
-        k="spmv" if "spmv_tile" in n else "update_p" if "k_update_p" in n else "update_xr" if "k_update_xr" in n else None
+        k="spmv" if ("spmv_tile" in n or "spmv_sellp" in n) else "update_p" if "k_update_p" in n else "update_xr" if "k_update_xr" in n else None
         if not k: continue
         if int(r["End_Timestamp"])-int(r["Start_Timestamp"])<30000: continue
         a=acc[k][r["Counter_Name"]]; a[0]+=float(r["Counter_Value"]); a[1]+=1
