@@ -112,6 +112,11 @@ def merge(pdir, tag, cfg="c2"):
         kern["asm_matrix"]["algorithmic_bytes"] = alg
         kern["asm_matrix"]["corrected_over_algorithmic"] = kern["asm_matrix"]["hbm_bytes_corrected"] / alg
         kern["asm_matrix"]["values_only_bytes"] = 8 * nnz
+        # long rows: the kernel's epilogue also writes the stream packer's compacted copy (value + column of every kept
+        # entry: at most 12 B per nonzero), work the packer's own sweeps did before
+        if nnz >= 16 * n:
+            kern["asm_matrix"]["with_compacted_copy_bytes"] = alg + 12 * nnz
+            kern["asm_matrix"]["corrected_over_algorithmic_with_compacted_copy"] = kern["asm_matrix"]["hbm_bytes_corrected"] / (alg + 12 * nnz)
     json.dump(doc, open(os.path.join(out, f"{tag}_pmc_{cfg_name}.json"), "w"), indent=1)
     print(json.dumps({k: {"GB": round(v["hbm_bytes_corrected"] / 1e9, 3),
                           "ratio": round(v.get("corrected_over_algorithmic", 0), 3)} for k, v in kern.items()}, indent=1))
