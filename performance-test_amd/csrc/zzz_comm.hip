@@ -234,7 +234,8 @@ struct P2P
   std::vector<bool> ipc_opened;         // peer[r] came from hipIpcOpenMemHandle
   zzz::DevBuf<double*> peer_dev;        // the same pointers for the kernel
   zzz::DevBuf<int32_t> fail;            // device flag: a poll timed out
-  double* tail_mem = nullptr;           // uncached: partial arrays + ticket of the folded all-reduce (zzz_tail.h)
+  double* tail_mem = nullptr;           // partial arrays + tickets of the folded all-reduce (zzz_tail.h)
+  bool tail_on = false;                 // ZZZ_TAIL=1 when the mailbox was created (A/B variant, off by default)
   int64_t seq = 0;                      // round counter = tag; identical call sequence on every rank
   bool enabled = false;
   bool verified = false;                // attach passed on every rank: may be switched on and off
@@ -448,10 +449,9 @@ int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const
 
 bool comm_tail_args(zzz_ctx* ctx, TailArgs& T, int nv, double* out)
 {
-  // A/B knob ZZZ_TAIL=1: fold the all-reduce into the producer's tail.  Measured slower than the kernel of its own
-  // (zzz_tail.h has the numbers), so off unless asked for; read per call so that one process can compare both.
-  const char* e = getenv("ZZZ_TAIL");
-  const bool off = !(e && atoi(e) == 1);
+  // A/B knob ZZZ_TAIL=1 (read when the mailbox is created): fold the all-reduce into the producer's tail.  Measured
+  // slower than the kernel of its own (zzz_tail.h has the numbers), so off unless asked for.
+  const bool off = !(ctx->comm && ctx->comm->p2p && ctx->comm->p2p->tail_on);
   if (off || !comm_p2p_enabled(ctx) || !ctx->comm->p2p->tail_mem)
     return false;
   P2P* P = ctx->comm->p2p;
@@ -855,6 +855,8 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
   P2P* P = new P2P();
   P->nranks = ctx->comm->nranks;
   P->rank = ctx->comm->rank;
+  if (const char* e = getenv("ZZZ_TAIL"))
+    P->tail_on = atoi(e) == 1;
   const size_t bytes = sizeof(double) * 2 * (size_t)P->nranks * P2P_SLOT;
   // uncached: remote stores must be visible to the local poll without a kernel boundary
   hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes < 4096 ? 4096 : bytes, hipDeviceMallocUncached);
