@@ -243,7 +243,11 @@ def main():
     ap.add_argument("--mesh_nproc", type=int, default=0,
                     help="number of processes the mesh-size search is run for (src/mesh.cpp:87-90; weak scaling: "
                          "ndofs x processes); 0 = the number of GPUs of this run")
-    ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none"])
+    ap.add_argument("--pc", default="jacobi", choices=["jacobi", "none", "chebyshev_jacobi"],
+                    help="BASELINE's metric is quoted with jacobi; chebyshev_jacobi is the library's polynomial "
+                         "preconditioner (fewer iterations and all-reduces, more products), an A/B line only")
+    ap.add_argument("--pc_degree", type=int, default=0)
+    ap.add_argument("--pc_ratio", type=float, default=0.0)
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--numbering", default="native", choices=["native", "rcm", "random", "reverse"],
                     help="N=1: how the CALLER numbers dofs, vertices and cells of the host feed before upload: native = "
@@ -251,6 +255,7 @@ def main():
                          "like (src/mesh.cpp:153-162,182-186).  The library renumbers internally (zzz_renumber.hip), so "
                          "`ZZZ Solve` should not depend on this; ZZZ_RENUMBER=0 shows what the caller's order would cost")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_alt_pc", action="store_true", help="skip the Chebyshev-Jacobi solve beside the measurement")
     ap.add_argument("--no_other_configs", action="store_true",
                     help="default run only: skip the compact records of the other BASELINE configs (c1, c4_total, c5_rank; "
                          "3 steps each, after and outside the headline's timed region)")
@@ -389,8 +394,11 @@ def main():
     cold["ZZZ Assemble vector"] = (time.perf_counter() - t0) * 1e3
     cold["ZZZ Assemble (pattern + matrix + vector)"] = sum(cold.values())
     nrows, ncols, nnz = ctx.csr_sizes()
-    pc = zzz.PC_JACOBI if a.pc == "jacobi" else zzz.PC_NONE
+    pc = {"jacobi": zzz.PC_JACOBI, "none": zzz.PC_NONE, "chebyshev_jacobi": zzz.PC_CHEBYSHEV_JACOBI}[a.pc]
+    pc_kw = dict(pc_degree=a.pc_degree, pc_ratio=a.pc_ratio) if pc == zzz.PC_CHEBYSHEV_JACOBI else {}
     single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and (multi or a.force_comm))
+    if pc == zzz.PC_CHEBYSHEV_JACOBI:
+        single_reduction = False  # the polynomial preconditioner runs in the classical KSPCG form
 
     def step(profile=False):
         t = {}
@@ -409,7 +417,7 @@ def main():
         t["assemble_vector"] = time.perf_counter() - t1
         t2 = time.perf_counter()
         it, rn, r0 = ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, profile=profile,
-                                  single_reduction=single_reduction)
+                                  single_reduction=single_reduction, **pc_kw)
         ctx.sync()
         t["solve"] = time.perf_counter() - t2
         t["iters"] = it
@@ -441,7 +449,8 @@ def main():
             # N > 1: which CG form and which all-reduce transport are faster depends on the all-reduce latency
             # of this node, which only a run on it can tell: time one solve of each combination on the
             # assembled warm-up system (untimed region), MAX over ranks, and keep the fastest for the timed steps.
-            combos = [(sr, pm) for pm in ((True, False) if p2p else (False,)) for sr in (True, False)]
+            forms = (False,) if pc == zzz.PC_CHEBYSHEV_JACOBI else (True, False)
+            combos = [(sr, pm) for pm in ((True, False) if p2p else (False,)) for sr in forms]
             tuning = {}
             for sr, pm in combos:
                 if p2p:
@@ -450,7 +459,7 @@ def main():
                 ctx.sync()
                 t0 = time.perf_counter()
                 try:
-                    ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, single_reduction=sr)
+                    ctx.cg_solve(variant=zzz.CG_PETSC, pc=pc, rtol=a.rtol, max_it=10000, single_reduction=sr, **pc_kw)
                     ctx.sync()
                     dt = time.perf_counter() - t0
                 except zzz.ZzzError:
@@ -524,6 +533,30 @@ def main():
             rank_info = [None] * world
             with deadline(300, "all_gather of the per-rank diagnostics"):
                 dist.all_gather_object(rank_info, mine)
+    # beside the measurement (after it, untimed): the same assembled system solved once with the library's polynomial
+    # preconditioner -- fewer iterations and all-reduces for more products, i.e. what the N > 1 runs are bound by
+    alt_pc = None
+    if pc == zzz.PC_JACOBI and not a.no_alt_pc:
+        try:
+            with deadline(600, "Chebyshev-Jacobi solve beside the measurement"):
+                ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
+                barrier()
+                ctx.sync()
+                t0 = time.perf_counter()
+                ita, rna, r0a = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                if dist is not None:
+                    tt = torch.tensor([dt], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt[0])
+                alt_pc = {"pc_type": "chebyshev_jacobi (degree 3, ratio 60: the library's defaults)", "ZZZ Solve ms": dt * 1e3,
+                          "krylov_iterations": ita, "relative_residual": rna / r0a if r0a else 0.0,
+                          "products_per_iteration": 3, "allreduces_per_iteration": 2,
+                          "jacobi ZZZ Solve ms": float(np.mean([p["solve"] for p in phases])) * 1e3,
+                          "note": "one solve of the timed steps' system, outside the timed region; not part of value"}
+        except zzz.ZzzError as e:
+            alt_pc = {"error": repr(e)}
     ms_per_step = elapsed / a.steps * 1e3
     iters = phases[-1]["iters"]
 
@@ -612,6 +645,8 @@ def main():
                                         "scalar_allreduce": "peer_memory" if p2p else "ncclAllReduce",
                                         "chosen_by": ("--cg " + a.cg) if a.cg != "auto" else
                                                      ("warm-up tuning (fastest of %d combinations)" % len(tuning) if tuning else "default")}
+        if alt_pc is not None:
+            out["alt_preconditioner"] = alt_pc
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
         if not multi and not a.no_cpu_baseline:
             if nnz > 2**31 - 1:

@@ -77,7 +77,13 @@ enum
 enum
 {
   ZZZ_PC_NONE = 0,
-  ZZZ_PC_JACOBI = 1
+  ZZZ_PC_JACOBI = 1,
+  /* polynomial preconditioner: z = p_k(D^-1 A) D^-1 r, k steps of the Chebyshev iteration for D^-1 A started from zero
+   * (PETSc: -pc_type ksp -ksp_ksp_type chebyshev -ksp_ksp_max_it k -ksp_pc_type jacobi [EXT]).  The "stronger
+   * preconditioner" of README.md:61-62,108-110 that needs only the product and no reduction inside its application:
+   * fewer CG iterations, i.e. fewer all-reduces per solve, for more products -- for multi-GPU runs.  Spectrum
+   * bounds [hi / pc_ratio, hi] with hi = Gershgorin's bound of D^-1 A.  ZZZ_CG_PETSC + ZZZ_OP_CSR only. */
+  ZZZ_PC_CHEBYSHEV_JACOBI = 2
 };
 enum
 {
@@ -119,6 +125,10 @@ typedef struct
                      * dtol x the initial norm (zzz_cg_info then reports reason -4, as KSPGetConvergedReason would);
                      * <= 0 selects PETSc's default 1e4 (KSPCreate sets
                      * divtol = 1.e4); unused by ZZZ_CG_CGH (src/cg.h has no such test) */
+  /* (added in round 3 behind the fields above, whose layout is unchanged) */
+  int32_t pc_degree; /* ZZZ_PC_CHEBYSHEV_JACOBI: Chebyshev steps per application (0 selects 3) */
+  int32_t pc_pad;    /* keep 0 */
+  double pc_ratio;   /* ZZZ_PC_CHEBYSHEV_JACOBI: upper / lower bound of the targeted spectrum (<= 1 selects 60) */
 } zzz_solver_opts;
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -291,7 +301,8 @@ int zzz_cg_history(zzz_ctx* ctx, int n, double* out);
  * direction update p = z + b p, x += a p: the A/B variant ZZZ_CG_FUSED=2), 0 for the three-kernel form;
  * info[1] = its iteration count (same iterates, bit for bit, either way); info[2] = how it ended, in
  * KSPConvergedReason's numbering: 2 KSP_CONVERGED_RTOL, 3 KSP_CONVERGED_ATOL, -3 KSP_DIVERGED_ITS (max_it / kmax
- * reached), -4 KSP_DIVERGED_DTOL, -9 KSP_DIVERGED_NANORINF. */
+ * reached), -4 KSP_DIVERGED_DTOL, -9 KSP_DIVERGED_NANORINF; info[3] = with ZZZ_PC_CHEBYSHEV_JACOBI the upper bound of
+ * the spectrum of D^-1 A the polynomial was built on, x 1e6 (0 otherwise). */
 int zzz_cg_info(zzz_ctx* ctx, int64_t info[4]);
 
 /* Average duration (ms) and count of the SpMV launches event-timed during the last

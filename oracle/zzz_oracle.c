@@ -1351,6 +1351,125 @@ int zo_pcg(i64 n, const i64* rowptr_in, const i32* cols_in, const double* vals_i
   return it;
 }
 
+/* KSPCG with a POLYNOMIAL preconditioner: z = p_k(D^-1 A) D^-1 r, k steps of the Chebyshev iteration for D^-1 A
+ * started from zero -- what PETSc selects with "-pc_type ksp -ksp_ksp_type chebyshev -ksp_ksp_max_it k -ksp_pc_type
+ * jacobi" [EXT]; the README's answer to Jacobi's iteration counts is a stronger preconditioner (README.md:61-62,108-110;
+ * BoomerAMG / GAMG there, which are out of scope) and this is the one that needs no more than the product and no
+ * reduction inside its application.  Spectrum bounds as KSPChebyshevEstEigSet's defaults [EXT]: [0.1, 1.1] x an estimate
+ * of the largest eigenvalue of D^-1 A, here from `power_its` steps of the power method started from the vector of ones
+ * (deterministic and independent of the numbering).  The Chebyshev recurrence is Saad, Iterative Methods, Alg. 12.1:
+ *   theta = (hi + lo)/2, delta = (hi - lo)/2, sigma = theta/delta, rho_0 = 1/sigma, d_0 = g/theta (g = D^-1 r), z_0 = 0
+ *   z_{i+1} = z_i + d_i;  g_{i+1} = g_i - D^-1 A d_i;  rho_{i+1} = 1/(2 sigma - rho_i);
+ *   d_{i+1} = rho_{i+1} rho_i d_i + (2 rho_{i+1}/delta) g_{i+1}
+ * Preconditioned-norm test as KSPCG's default.  rnorm_out = {final norm, initial norm, eigenvalue estimate}. */
+int zo_pcg_cheb(i64 n, const i64* rowptr, const i32* cols, const double* vals, const double* b, double* x, int degree,
+                int power_its, double ratio, double rtol, double atol, int max_it, double* rnorm_out)
+{
+  double* r = malloc(sizeof(double) * (size_t)n);
+  double* z = malloc(sizeof(double) * (size_t)n);
+  double* p = malloc(sizeof(double) * (size_t)n);
+  double* w = malloc(sizeof(double) * (size_t)n);
+  double* g = malloc(sizeof(double) * (size_t)n);
+  double* d = malloc(sizeof(double) * (size_t)n);
+  double* dinv = malloc(sizeof(double) * (size_t)n);
+  for (i64 i = 0; i < n; ++i)
+  {
+    i64 q = find_col(rowptr, cols, i, (i32)i);
+    double dd = q >= 0 ? vals[q] : 0.0;
+    if (dd == 0.0)
+      dd = 1.0;
+    dinv[i] = 1.0 / dd;
+    x[i] = 0.0;
+    r[i] = b[i];
+    p[i] = 0.0;
+  }
+  /* upper bound of the spectrum of D^-1 A: Gershgorin's, the largest row sum of |D^-1 A| (rigorous, so the polynomial is
+   * positive on the whole spectrum and the preconditioner stays SPD; independent of numbering and partition) */
+  double est = 0.0;
+  for (i64 i = 0; i < n; ++i)
+  {
+    double sum = 0.0;
+    for (i64 k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      sum += fabs(vals[k]);
+    sum *= fabs(dinv[i]);
+    if (sum > est)
+      est = sum;
+  }
+  (void)power_its;
+  const double hi = est, lo = est / ratio;
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+#define ZO_CHEB_APPLY()                                                                        \
+  do                                                                                           \
+  {                                                                                            \
+    double rho = 1.0 / sigma;                                                                  \
+    for (i64 i = 0; i < n; ++i)                                                                \
+    {                                                                                          \
+      g[i] = dinv[i] * r[i];                                                                   \
+      d[i] = g[i] / theta;                                                                     \
+      z[i] = 0.0;                                                                              \
+    }                                                                                          \
+    for (int s = 0; s < degree; ++s)                                                           \
+    {                                                                                          \
+      zo_spmv(n, rowptr, cols, vals, d, w);                                                    \
+      const double rhon = 1.0 / (2.0 * sigma - rho);                                           \
+      const double c1 = rhon * rho, c2 = 2.0 * rhon / delta;                                   \
+      for (i64 i = 0; i < n; ++i)                                                              \
+      {                                                                                        \
+        z[i] = z[i] + d[i];                                                                    \
+        g[i] = -1.0 * (dinv[i] * w[i]) + g[i];                                                 \
+        d[i] = c1 * d[i] + c2 * g[i];                                                          \
+      }                                                                                        \
+      rho = rhon;                                                                              \
+    }                                                                                          \
+    if (degree == 0)                                                                           \
+      for (i64 i = 0; i < n; ++i)                                                              \
+        z[i] = g[i];                                                                           \
+  } while (0)
+  ZO_CHEB_APPLY();
+  double beta = dot(n, r, z), betaold = 1.0;
+  double dp = sqrt(dot(n, z, z));
+  const double dp0 = dp;
+  const double ttol = fmax(rtol * dp0, atol);
+  int it = 0;
+  if (!(dp <= ttol))
+  {
+    while (it < max_it)
+    {
+      if (it == 0)
+        axpy(n, p, 0.0, p, z);
+      else
+        axpy(n, p, beta / betaold, p, z);
+      zo_spmv(n, rowptr, cols, vals, p, w);
+      const double dpi = dot(n, p, w);
+      const double a = beta / dpi;
+      axpy(n, x, a, p, x);
+      axpy(n, r, -a, w, r);
+      ZO_CHEB_APPLY();
+      betaold = beta;
+      beta = dot(n, r, z);
+      dp = sqrt(dot(n, z, z));
+      ++it;
+      if (dp <= ttol)
+        break;
+    }
+  }
+#undef ZO_CHEB_APPLY
+  if (rnorm_out)
+  {
+    rnorm_out[0] = dp;
+    rnorm_out[1] = dp0;
+    rnorm_out[2] = est;
+  }
+  free(r);
+  free(z);
+  free(p);
+  free(w);
+  free(g);
+  free(d);
+  free(dinv);
+  return it;
+}
+
 /* y = A x with the summation order of the GPU row phase for long rows (csrc/zzz_spmv.hip, lpr_shift > 0):
  * `lanes` (a power of two) partial sums over contiguous chunks of ceil(len/lanes) products, each in column
  * order, combined by a butterfly: ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)).  lanes == 1 is zo_spmv.  No

@@ -64,6 +64,8 @@ def lib():
         L.zo_pcg.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_double,
                              C.c_int, f64p]
         L.zo_pcg_sr.argtypes = L.zo_pcg.argtypes
+        L.zo_pcg_cheb.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  C.c_double, C.c_int, f64p]
         L.zo_spmv_chunked.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int]
         L.zo_norm2.restype = C.c_double
         L.zo_norm2.argtypes = [C.c_int64, f64p]
@@ -269,6 +271,15 @@ def pcg_single_reduction(rowptr, cols, vals, b, pc=PC_JACOBI, norm_type=NORM_PRE
     rn = np.zeros(3)
     it = lib().zo_pcg_sr(b.shape[0], rowptr, cols, vals, b, x, pc, norm_type, rtol, atol, max_it, rn)
     return int(it), x, float(rn[0]), float(rn[1])
+
+
+def pcg_chebyshev(rowptr, cols, vals, b, degree=2, ratio=10.0, rtol=1e-8, atol=1e-50, max_it=10000):
+    """KSPCG with the Chebyshev-Jacobi polynomial preconditioner restated; returns (iterations, x, final_norm,
+    initial_norm, eigenvalue estimate)"""
+    x = np.zeros_like(b)
+    rn = np.zeros(3)
+    it = lib().zo_pcg_cheb(b.shape[0], rowptr, cols, vals, b, x, degree, 0, ratio, rtol, atol, max_it, rn)
+    return int(it), x, float(rn[0]), float(rn[1]), float(rn[2])
 
 
 def norm2(x):

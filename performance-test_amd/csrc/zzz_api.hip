@@ -833,10 +833,12 @@ int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rno
     return fail(ctx, ZZZ_ERR_ARG, "unknown CG variant %d", o->variant);
   if (o->variant == ZZZ_CG_CGH && o->pc != ZZZ_PC_NONE)
     return fail(ctx, ZZZ_ERR_ARG, "src/cg.h has no preconditioner: use pc = ZZZ_PC_NONE");
-  if (o->pc != ZZZ_PC_NONE && o->pc != ZZZ_PC_JACOBI)
-    return fail(ctx, ZZZ_ERR_ARG, "unsupported preconditioner %d (none, jacobi)", o->pc);
-  if (o->pc == ZZZ_PC_JACOBI && o->op != ZZZ_OP_CSR)
+  if (o->pc != ZZZ_PC_NONE && o->pc != ZZZ_PC_JACOBI && o->pc != ZZZ_PC_CHEBYSHEV_JACOBI)
+    return fail(ctx, ZZZ_ERR_ARG, "unsupported preconditioner %d (none, jacobi, chebyshev-jacobi)", o->pc);
+  if (o->pc != ZZZ_PC_NONE && o->op != ZZZ_OP_CSR)
     return fail(ctx, ZZZ_ERR_ARG, "Jacobi needs the assembled operator");
+  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI && (o->variant != ZZZ_CG_PETSC || o->single_reduction || o->pc_degree < 0 || o->pc_degree > 64))
+    return fail(ctx, ZZZ_ERR_ARG, "the Chebyshev-Jacobi preconditioner applies to the classical KSPCG form, degree 1..64");
   if (o->norm < 0 || o->norm > 2)
     return fail(ctx, ZZZ_ERR_ARG, "unknown norm type %d", o->norm);
   if (o->single_reduction && (o->variant != ZZZ_CG_PETSC || o->op != ZZZ_OP_CSR))
@@ -896,7 +898,7 @@ int zzz_cg_info(zzz_ctx* ctx, int64_t info[4])
   info[0] = ctx->last_solve_fused ? 1 : 0;
   info[1] = ctx->last_iters;
   info[2] = ctx->last_reason;
-  info[3] = 0;
+  info[3] = (int64_t)(ctx->last_pc_bound * 1.0e6); // Chebyshev-Jacobi: spectrum bound x 1e6
   return ZZZ_OK;
 }
 

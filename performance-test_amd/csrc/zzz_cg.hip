@@ -585,8 +585,13 @@ static int finish_reason(zzz_ctx* ctx, const zzz_solver_opts* o, const CgState& 
 }
 
 
+static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);
+
 int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 {
+  ctx->last_pc_bound = 0.0;
+  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI)
+    return cg_solve_chebyshev(ctx, o, iters, rnorm);
   if (o->single_reduction)
     return cg_solve_single_reduction(ctx, o, iters, rnorm);
   const int64_t n = ctx->n_owned * ctx->bs; // owned scalar rows
@@ -826,6 +831,341 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       ctx->prof_halo_wait_ms /= cnt;
     (void)hipGetLastError();
   }
+  return finish_reason(ctx, o, fin, its);
+}
+
+// ---- KSPCG with the Chebyshev-Jacobi polynomial preconditioner (ZZZ_PC_CHEBYSHEV_JACOBI; oracle: zo_pcg_cheb) -------
+// z = p_k(D^-1 A) D^-1 r by k steps of the Chebyshev iteration for D^-1 A on [hi / ratio, hi], hi = Gershgorin's bound:
+// no reduction inside the application, k more products per CG iteration, roughly k + 1 times fewer CG iterations and
+// all-reduces.  The rest of the iteration is the classical loop's: k_update_p (test, x and p), the product, then k_cheb_xr
+// (k_update_xr's r -= alpha w with the polynomial's first term) and one product + k_cheb_step per further term; the last
+// k_cheb_step sums <r,z> and the norm.
+__global__ __launch_bounds__(VB) void k_row_abs_max(const rp_t* __restrict__ rowptr, const double* __restrict__ vals,
+                                                    const double* __restrict__ dinv, int64_t n, double* __restrict__ parts)
+{
+  __shared__ double sh[VB / 64];
+  double m = 0.0;
+  for (int64_t r = blockIdx.x * (int64_t)VB + threadIdx.x; r < n; r += (int64_t)gridDim.x * VB)
+  {
+    double sum = 0.0;
+    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+      sum += fabs(vals[k]);
+    m = fmax(m, sum * fabs(dinv[r]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    m = fmax(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0)
+    sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int i = 1; i < VB / 64; ++i)
+      m = fmax(m, sh[i]);
+    parts[blockIdx.x] = m;
+  }
+}
+// g = D^-1 r; d = g / theta; z = d (the polynomial's first term: z_1 = 0 + d_0)
+__global__ __launch_bounds__(VB) void k_cheb_init(const int* __restrict__ stop, const double* __restrict__ r,
+                                                  const double* __restrict__ dinv, double theta, double* __restrict__ gv,
+                                                  double* __restrict__ d, double* __restrict__ z, int64_t n)
+{
+  if (*stop)
+    return;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    const double gi = dinv[i] * r[i];
+    const double di = gi / theta;
+    gv[i] = gi;
+    d[i] = di;
+    z[i] = di;
+  }
+}
+// k_update_xr and k_cheb_init in one pass: alpha = beta / <p,w>; r -= alpha w; g = D^-1 r; d = g / theta; z = d
+__global__ __launch_bounds__(VB) void k_cheb_xr(CgState* __restrict__ st, const double* __restrict__ beta_hist,
+                                                double* __restrict__ alpha_hist, int it, const double* __restrict__ pw_parts,
+                                                int npw, const double* __restrict__ w, const double* __restrict__ dinv,
+                                                double theta, double* __restrict__ r, double* __restrict__ gv,
+                                                double* __restrict__ d, double* __restrict__ z, int64_t n)
+{
+  const int f0 = st->converged;
+  const double beta_it = beta_hist[it];
+  const double pw1 = pw_parts[0];
+  if (block_flag(f0))
+    return;
+  __shared__ double sh[VB / 64];
+  const double pw = npw == 1 ? pw1 : reduce_parts_bcast(pw_parts, npw, sh);
+  const double alpha = beta_it / pw;
+  if (!isfinite(alpha)) // KSP_DIVERGED_NANORINF, as in k_update_xr
+  {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      st->iters = it;
+      st->converged = 2;
+      __atomic_store_n(&st->conv_it1, it + 1, __ATOMIC_RELAXED);
+    }
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    alpha_hist[it] = alpha;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    const double ri = -alpha * w[i] + r[i];
+    const double gi = dinv[i] * ri;
+    const double di = gi / theta;
+    r[i] = ri;
+    gv[i] = gi;
+    d[i] = di;
+    z[i] = di;
+  }
+}
+// one term of the polynomial, w = A d_(j-1) given: g -= D^-1 w; d_j = c1 d_(j-1) + c2 g; z += d_j.  The last term leaves
+// g and d alone and sums the partials of <r,z> and of the test norm (the arrays k_update_p reads).
+__global__ __launch_bounds__(VB) void k_cheb_step(const int* __restrict__ stop, const double* __restrict__ w,
+                                                  const double* __restrict__ dinv, double c1, double c2, int last,
+                                                  double* __restrict__ gv, double* __restrict__ d, double* __restrict__ z,
+                                                  const double* __restrict__ r, int norm, double* __restrict__ pa,
+                                                  double* __restrict__ pb, int64_t n)
+{
+  if (*stop)
+    return;
+  __shared__ double sh[VB / 64];
+  double sa = 0, sb = 0;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    const double gi = -1.0 * (dinv[i] * w[i]) + gv[i];
+    const double dn = c1 * d[i] + c2 * gi;
+    const double zi = z[i] + dn;
+    z[i] = zi;
+    if (!last)
+    {
+      gv[i] = gi;
+      d[i] = dn;
+    }
+    else
+    {
+      const double ri = r[i];
+      sa += ri * zi;
+      sb += (norm == ZZZ_NORM_UNPRECONDITIONED) ? ri * ri : zi * zi;
+    }
+  }
+  if (last)
+  {
+    const double ta = block_reduce_sum(sa, sh);
+    const double tb = block_reduce_sum(sb, sh);
+    if (threadIdx.x == 0)
+    {
+      pa[blockIdx.x] = ta;
+      pb[blockIdx.x] = tb;
+    }
+  }
+}
+// partials of <r,z> and of the test norm (the arrays k_update_p reads)
+__global__ __launch_bounds__(VB) void k_dots_rz(const int* __restrict__ stop, const double* __restrict__ r,
+                                                const double* __restrict__ z, int64_t n, int norm, double* __restrict__ pa,
+                                                double* __restrict__ pb)
+{
+  if (*stop)
+    return;
+  __shared__ double sh[VB / 64];
+  double sa = 0, sb = 0;
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    const double ri = r[i], zi = z[i];
+    sa += ri * zi;
+    sb += (norm == ZZZ_NORM_UNPRECONDITIONED) ? ri * ri : zi * zi;
+  }
+  const double ta = block_reduce_sum(sa, sh);
+  const double tb = block_reduce_sum(sb, sh);
+  if (threadIdx.x == 0)
+  {
+    pa[blockIdx.x] = ta;
+    pb[blockIdx.x] = tb;
+  }
+}
+
+int comm_allgather_max(zzz_ctx* ctx, double* v); // zzz_comm.hip: maximum of one double over the ranks (set-up exchange)
+
+static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
+{
+  const int64_t n = ctx->n_owned * ctx->bs;
+  const int max_it = o->max_it;
+  // the scalar logic is KSPCG's with a preconditioner: k_update_p / k_update_xr take pc = Jacobi semantics for alpha, beta
+  CgParams P{o->variant, ZZZ_PC_JACOBI, o->norm, o->rtol, o->atol, o->dtol > 0.0 ? o->dtol : 1.0e4};
+  const bool multi = ctx->comm != nullptr;
+  const int g = vgrid(n);
+  hipStream_t s = ctx->stream;
+  const int degree = o->pc_degree > 0 ? o->pc_degree : 3;
+  const double ratio = o->pc_ratio > 1.0 ? o->pc_ratio : 60.0;
+  ctx->last_solve_fused = false;
+  ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->alpha_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->sr_s.alloc((size_t)ctx->nloc())); // Chebyshev direction d (ghost entries: the product gathers it)
+  ZZZ_HIP(ctx, ctx->p_alt.alloc((size_t)ctx->nloc())); // Chebyshev residual g
+  double *chd = ctx->sr_s.p, *chg = ctx->p_alt.p;
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(chd, 0, sizeof(double) * (size_t)ctx->nloc(), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
+  hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n, 1);
+  // spectrum bound: Gershgorin's for D^-1 A, maximum over the ranks
+  hipLaunchKernelGGL(k_row_abs_max, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->vals.p, ctx->dinv.p, n, ctx->part_b.p);
+  std::vector<double> hp((size_t)g);
+  ZZZ_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->part_b.p, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  double hi = 0.0;
+  for (double v : hp)
+    hi = std::max(hi, v);
+  if (multi)
+    if (int rc = comm_allgather_max(ctx, &hi))
+      return rc;
+  if (!(hi > 0.0) || !std::isfinite(hi))
+    hi = 1.0;
+  const double lo = hi / ratio;
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+
+  const int* stop_flag = reinterpret_cast<const int*>(ctx->state.p);
+  auto apply = [&](double* x, double* y, double* parts, int* np) -> int {
+    if (multi && ctx->overlap && ctx->have_tile_split)
+      return launch_spmv_overlapped(ctx, x, y, parts, np);
+    if (multi)
+      if (int rc = comm_halo_forward(ctx, x))
+        return rc;
+    return launch_spmv(ctx, x, y, parts, np);
+  };
+  double* pa = ctx->part_b.p;
+  double* pb = ctx->part_b.p + VGRID_MAX;
+  // the terms after the first of z = p_k(D^-1 A) D^-1 r (g, d and z hold the first), then the partials of <r,z> and the
+  // norm (all-reduced when a communicator is attached)
+  auto polynomial = [&]() -> int {
+    double rho = 1.0 / sigma;
+    for (int st = 1; st < degree; ++st)
+    {
+      if (int rc = apply(chd, ctx->w.p, nullptr, nullptr))
+        return rc;
+      const double rhon = 1.0 / (2.0 * sigma - rho);
+      hipLaunchKernelGGL(k_cheb_step, dim3(g), dim3(VB), 0, s, stop_flag, ctx->w.p, ctx->dinv.p, rhon * rho, 2.0 * rhon / delta,
+                         st + 1 == degree ? 1 : 0, chg, chd, ctx->z.p, ctx->r.p, P.norm, pa, pb, n);
+      rho = rhon;
+    }
+    if (degree == 1)
+      hipLaunchKernelGGL(k_dots_rz, dim3(g), dim3(VB), 0, s, stop_flag, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
+    if (multi)
+      return comm_reduce_allreduce(ctx, stop_flag, pa, pb, nullptr, g, 2, ctx->red.p);
+    return ZZZ_OK;
+  };
+  // r = b
+  hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(VB), 0, s, ctx->b.p, (const double*)nullptr, ctx->dinv.p, ctx->r.p, ctx->z.p, n,
+                     P.norm, pa, pb);
+  hipLaunchKernelGGL(k_cheb_init, dim3(g), dim3(VB), 0, s, stop_flag, ctx->r.p, ctx->dinv.p, theta, chg, chd, ctx->z.p, n);
+  if (int rc = polynomial())
+    return rc;
+  const double *rz_src = pa, *nn_src = pb, *pw_src = ctx->part_a.p;
+  int n_rz = g;
+  if (multi)
+  {
+    rz_src = ctx->red.p;
+    nn_src = ctx->red.p + 1;
+    pw_src = ctx->red.p + 2;
+    n_rz = 1;
+  }
+  const int max_prof = o->profile ? 512 : 0;
+  if ((int)ctx->ev.size() < 2 * max_prof)
+  {
+    size_t old = ctx->ev.size();
+    ctx->ev.resize(2 * max_prof);
+    for (size_t i = old; i < ctx->ev.size(); ++i)
+      ZZZ_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+  }
+  int nprof = 0;
+  ctx->prof_halo_n = 0;
+  ctx->prof_halo_wait_ms = 0.0;
+  constexpr int CHECK = 8, NSLOT = 4;
+  EventRing<NSLOT> chk_ev;
+  ZZZ_HIP(ctx, chk_ev.create());
+  int nchk = 0;
+  bool stop = false;
+  int it = 0;
+  for (; it < max_it && !stop; ++it)
+  {
+    hipLaunchKernelGGL(k_update_p<false>, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p, ctx->alpha_hist.p,
+                       it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
+    int np = 0;
+    const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
+    ctx->prof_now = timed;
+    if (timed)
+      (void)hipEventRecord(ctx->ev[2 * nprof], s);
+    {
+      int rc = apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+      ctx->prof_now = false;
+      if (rc)
+        return rc;
+    }
+    if (timed)
+    {
+      (void)hipEventRecord(ctx->ev[2 * nprof + 1], s);
+      ++nprof;
+    }
+    if (multi)
+    {
+      if (int rc = comm_reduce_allreduce(ctx, stop_flag, ctx->part_a.p, nullptr, nullptr, np, 1, ctx->red.p + 2))
+        return rc;
+      np = 1;
+    }
+    hipLaunchKernelGGL(k_cheb_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->alpha_hist.p, it, pw_src, np,
+                       ctx->w.p, ctx->dinv.p, theta, ctx->r.p, chg, chd, ctx->z.p, n);
+    if (int rc = polynomial())
+      return rc;
+    if ((it + 1) % CHECK == 0)
+    {
+      const int slot = nchk % NSLOT;
+      if (nchk >= NSLOT - 1)
+      {
+        const int old = (nchk - (NSLOT - 1)) % NSLOT;
+        ZZZ_HIP(ctx, hipEventSynchronize(chk_ev[old]));
+        if (ctx->h_state[old].converged)
+          stop = true;
+      }
+      ZZZ_HIP(ctx, hipMemcpyAsync(&ctx->h_state[slot], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+      ZZZ_HIP(ctx, hipEventRecord(chk_ev[slot], s));
+      ++nchk;
+    }
+  }
+  hipLaunchKernelGGL(k_update_p<false>, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p, ctx->alpha_hist.p, it,
+                     P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 0);
+  ZZZ_HIP(ctx, hipGetLastError());
+  CgState fin;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (int rc = comm_p2p_check(ctx))
+    return rc;
+  const int its = fin.converged ? fin.iters : max_it;
+  ctx->last_iters = its;
+  if (iters)
+    *iters = its;
+  if (rnorm)
+  {
+    rnorm[0] = fin.dp;
+    rnorm[1] = fin.dp0;
+  }
+  ctx->history.resize((size_t)its + 1);
+  ZZZ_HIP(ctx, hipMemcpy(ctx->history.data(), ctx->dp_hist.p, sizeof(double) * ((size_t)its + 1), hipMemcpyDeviceToHost));
+  ctx->prof_spmv_ms = 0.0;
+  ctx->prof_spmv_n = 0;
+  const int used = std::min(nprof, (its + PROF_STRIDE - 1) / PROF_STRIDE);
+  for (int i = 0; i < used; ++i)
+  {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess)
+    {
+      ctx->prof_spmv_ms += ms;
+      ctx->prof_spmv_n++;
+    }
+  }
+  if (ctx->prof_spmv_n)
+    ctx->prof_spmv_ms /= (double)ctx->prof_spmv_n;
+  ctx->last_pc_bound = hi;
   return finish_reason(ctx, o, fin, its);
 }
 

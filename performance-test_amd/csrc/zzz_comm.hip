@@ -715,6 +715,37 @@ int comm_exchange_bytes(zzz_ctx* ctx, const std::vector<std::vector<char>>& send
   return ZZZ_OK;
 }
 
+// maximum of one double over the ranks, through the all-reduce the CG scalars take (peer-memory mailboxes or the
+// communicator's all-reduce): rank r's value travels in slot r of a sum of otherwise-zero slots, three slots per round
+int comm_allgather_max(zzz_ctx* ctx, double* v)
+{
+  if (!ctx->comm || ctx->comm->nranks == 1)
+    return ZZZ_OK;
+  const int n = ctx->comm->nranks, me = ctx->comm->rank;
+  hipStream_t s = ctx->stream;
+  double best = *v;
+  for (int q = 0; q < n; q += 3)
+  {
+    double slot[3] = {0.0, 0.0, 0.0}, got[3] = {0.0, 0.0, 0.0};
+    if (me >= q && me < q + 3)
+      slot[me - q] = *v;
+    double* in = ctx->part_a.p; // three one-entry "partial arrays"
+    ZZZ_HIP(ctx, hipMemcpyAsync(in, slot, sizeof(slot), hipMemcpyHostToDevice, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s)); // slot[] leaves scope
+    if (int rc = comm_reduce_allreduce(ctx, nullptr, in, in + 1, in + 2, 1, 3, ctx->red.p + 4))
+      return rc;
+    ZZZ_HIP(ctx, hipMemcpyAsync(got, ctx->red.p + 4, sizeof(got), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    for (int k = 0; k < 3 && q + k < n; ++k)
+      if (got[k] > best)
+        best = got[k];
+  }
+  if (int rc = comm_p2p_check(ctx))
+    return rc;
+  *v = best;
+  return ZZZ_OK;
+}
+
 void comm_destroy(zzz_ctx* ctx)
 {
   if (ctx->comm_stream)

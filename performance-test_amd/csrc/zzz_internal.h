@@ -229,6 +229,7 @@ struct zzz_ctx
   std::vector<double> history;
   int last_iters = 0;
   int last_reason = 0; // KSPConvergedReason of the last solve (zzz_cg_info)
+  double last_pc_bound = 0.0; // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound the last solve used
   bool last_solve_fused = false; // the last solve ran the fused product + direction kernel
 
   // profiling

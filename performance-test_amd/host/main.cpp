@@ -111,6 +111,8 @@ struct Options
   std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_divtol = 1e4; // PETSc defaults (KSPCreate)
   int ksp_max_it = 10000;
+  int pc_degree = 0;      // -pc_chebyshev_jacobi_degree (0: the library's default, 3)
+  double pc_ratio = 0.0;  // -pc_chebyshev_jacobi_ratio  (0: the library's default, 60)
   bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false, ksp_cg_single_reduction = false;
   bool ksp_error_if_not_converged = false, ksp_converged_reason = false;
   std::vector<std::string> unused;
@@ -133,7 +135,8 @@ void usage()
                "  --ngpus arg (=1)                number of GPUs (takes the place of mpirun -np)\n"
                "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
                "  --allreduce arg (=peer)         peer (xGMI peer-memory mailboxes, else falls back) | comm\n"
-               "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none} -ksp_rtol -ksp_atol -ksp_divtol\n"
+               "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none,chebyshev_jacobi} -ksp_rtol -ksp_atol\n"
+               "  -ksp_divtol -pc_chebyshev_jacobi_degree (=3) -pc_chebyshev_jacobi_ratio (=60)\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
                "  -ksp_cg_single_reduction -ksp_converged_reason -ksp_error_if_not_converged\n"
                "  -log_view -options_left\n"
@@ -199,6 +202,10 @@ Options parse(int argc, char** argv)
         o.ksp_type = next();
       else if (key == "pc_type")
         o.pc_type = next();
+      else if (key == "pc_chebyshev_jacobi_degree")
+        o.pc_degree = std::stoi(next());
+      else if (key == "pc_chebyshev_jacobi_ratio")
+        o.pc_ratio = std::stod(next());
       else if (key == "ksp_rtol")
         o.ksp_rtol = std::stod(next());
       else if (key == "ksp_atol")
@@ -407,7 +414,9 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   else
   {
     so.variant = ZZZ_CG_PETSC;
-    so.pc = o.pc_type == "none" ? ZZZ_PC_NONE : ZZZ_PC_JACOBI;
+    so.pc = o.pc_type == "none" ? ZZZ_PC_NONE : o.pc_type == "chebyshev_jacobi" ? ZZZ_PC_CHEBYSHEV_JACOBI : ZZZ_PC_JACOBI;
+    so.pc_degree = o.pc_degree;
+    so.pc_ratio = o.pc_ratio;
     so.norm = o.ksp_norm_type == "unpreconditioned" ? ZZZ_NORM_UNPRECONDITIONED
               : o.ksp_norm_type == "natural"        ? ZZZ_NORM_NATURAL
                                                     : ZZZ_NORM_PRECONDITIONED;
@@ -508,8 +517,9 @@ void solve(int argc, char** argv)
     std::cerr << "warning: --output (XDMF, src/main.cpp:213-223) is outside the hot-path scope; ignored\n";
   if (o.ksp_type != "cg")
     throw std::runtime_error("-ksp_type " + o.ksp_type + ": only cg is built");
-  if (o.pc_type != "jacobi" && o.pc_type != "none")
-    throw std::runtime_error("-pc_type " + o.pc_type + ": only jacobi and none are built (hypre/gamg are out of scope)");
+  if (o.pc_type != "jacobi" && o.pc_type != "none" && o.pc_type != "chebyshev_jacobi")
+    throw std::runtime_error("-pc_type " + o.pc_type +
+                             ": only jacobi, none and chebyshev_jacobi are built (hypre/gamg are out of scope)");
   if (o.order < 1 || o.order > 3)
     throw std::out_of_range("vector::_M_range_check: order must be 1..3"); // form_*.at(order - 1)
   const int ndev = zzz_device_count();

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(PKG)
 FORM_POISSON, FORM_ELASTICITY = 0, 1
 COEFF_F, COEFF_G = 0, 1
 VEC_B, VEC_U = 0, 1
-PC_NONE, PC_JACOBI = 0, 1
+PC_NONE, PC_JACOBI, PC_CHEBYSHEV_JACOBI = 0, 1, 2
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL = 0, 1, 2
 CG_PETSC, CG_CGH = 0, 1
 OP_CSR, OP_MATFREE = 0, 1
@@ -46,7 +46,8 @@ HOST_SYMBOLS = [
 class SolverOpts(C.Structure):
     _fields_ = [("variant", C.c_int32), ("pc", C.c_int32), ("norm", C.c_int32), ("op", C.c_int32),
                 ("max_it", C.c_int32), ("profile", C.c_int32), ("single_reduction", C.c_int32), ("error_if_not_converged", C.c_int32),
-                ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
+                ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
+                ("pc_degree", C.c_int32), ("pc_pad", C.c_int32), ("pc_ratio", C.c_double)]
 
 
 class ZzzError(RuntimeError):
@@ -483,9 +484,10 @@ class Context:
         return y
 
     def cg_solve(self, variant=CG_PETSC, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, op=OP_CSR, rtol=1e-8, atol=1e-50,
-                 max_it=10000, profile=False, single_reduction=False, dtol=0.0, error_if_not_converged=False):
+                 max_it=10000, profile=False, single_reduction=False, dtol=0.0, error_if_not_converged=False,
+                 pc_degree=0, pc_ratio=0.0):
         o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0,
-                       1 if error_if_not_converged else 0, rtol, atol, dtol)
+                       1 if error_if_not_converged else 0, rtol, atol, dtol, pc_degree, 0, pc_ratio)
         it = C.c_int()
         rn = (C.c_double * 2)()
         self._ck(self.L.zzz_cg_solve(self.h, C.byref(o), C.byref(it), rn))
@@ -540,6 +542,11 @@ class Context:
         info = (C.c_int64 * 4)()
         self._ck(self.L.zzz_cg_info(self.h, info))
         return int(info[2])
+
+    def cg_info(self):
+        info = (C.c_int64 * 4)()
+        self._ck(self.L.zzz_cg_info(self.h, info))
+        return {"fused": bool(info[0]), "reason": int(info[2]), "pc_spectrum_bound": info[3] * 1.0e-6}
 
     def profile(self):
         ms, n = C.c_double(), C.c_int64()

@@ -1026,6 +1026,106 @@ def test_single_reduction_cg(ctx, problem, order, dims, norm):
         ctx.cg_solve(op=zzz.OP_MATFREE, pc=zzz.PC_NONE, single_reduction=True)
 
 
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (24, 22, 23)), ("poisson", 2, (8, 7, 9)),
+                                                ("poisson", 3, (5, 4, 6)), ("elasticity", 1, (8, 8, 9)),
+                                                ("elasticity", 2, (4, 3, 5))])
+@pytest.mark.parametrize("degree,ratio", [(1, 30.0), (2, 10.0), (3, 30.0), (5, 60.0)])
+def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, ratio):
+    """ZZZ_PC_CHEBYSHEV_JACOBI (fewer all-reduces per solve) against its oracle restatement
+    zo.pcg_chebyshev: same spectrum bound, iteration count +-2, solution 1e-6, residual within rtol; degree 1 is
+    Jacobi scaled by a constant (the same iteration as PC_JACOBI); degree >= 2 takes fewer iterations than Jacobi."""
+    P = zo.Problem(problem, order, *dims)
+    G = zzz.Part(problem, order, *dims)
+    ctx.upload_part(G)
+    ctx.pattern_build()
+    ctx.assemble_matrix(G.form)
+    ctx.assemble_vector(G.form)
+    rowptr, cols, vals = ctx.csr_download()
+    b = ctx.vec_download(zzz.VEC_B)
+    ito, uo, rno, r0o, est = zo.pcg_chebyshev(rowptr.astype(np.int64), cols, vals, b, degree=degree, ratio=ratio, rtol=1e-9)
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+    u = ctx.vec_download(zzz.VEC_U)
+    assert ctx.cg_reason() == 2
+    assert abs(ctx.cg_info()["pc_spectrum_bound"] - est) <= 2e-6 * est
+    assert abs(it - ito) <= 2
+    assert abs(r0 - r0o) <= 1e-11 * r0o and rn <= 1e-9 * r0
+    assert np.linalg.norm(u - uo) <= 1e-6 * np.linalg.norm(uo)
+    r = b - zo.spmv(rowptr.astype(np.int64), cols, vals, u)
+    assert np.linalg.norm(r) <= 1e-6 * np.linalg.norm(b)
+    itj, _, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+    uj = ctx.vec_download(zzz.VEC_U)
+    assert np.linalg.norm(u - uj) <= 1e-6 * np.linalg.norm(uj)
+    if degree == 1:
+        assert abs(it - itj) <= 1
+    else:
+        assert it < itj
+    # run-to-run: every bit
+    it2, rn2, _ = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+    assert it2 == it and rn2 == rn and np.array_equal(ctx.vec_download(zzz.VEC_U), u)
+    # KSPCG with the assembled operator only
+    for kw in (dict(variant=zzz.CG_CGH), dict(op=zzz.OP_MATFREE), dict(single_reduction=True), dict(pc_degree=-1)):
+        with pytest.raises(zzz.ZzzError):
+            ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, **kw)
+
+
+@pytest.mark.parametrize("p2p", [False, True], ids=["allreduce-comm", "allreduce-peer-memory"])
+@pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (10, 9, 12), 2), ("poisson", 2, (5, 4, 9), 3),
+                                                       ("elasticity", 1, (5, 5, 8), 2)])
+def test_chebyshev_jacobi_partitioned_on_one_gpu(problem, order, dims, nparts, p2p):
+    """The polynomial's products exchange the halo of its direction vector and the spectrum bound is the maximum over
+    the ranks: the partitioned solve reproduces the single-rank one (iterations +-1, solution 1e-9)."""
+    import threading
+
+    if p2p and nparts > 2:
+        pytest.skip("peer-memory all-reduce between > 2 contexts of one process on one GPU")
+    G = zzz.Part(problem, order, *dims)
+    with zzz.Context(0) as c0:
+        c0.upload_part(G)
+        c0.pattern_build()
+        c0.assemble_matrix(G.form)
+        c0.assemble_vector(G.form)
+        it0, rn0, r00 = c0.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-8)
+        u0 = c0.vec_download(zzz.VEC_U)
+        bound0 = c0.cg_info()["pc_spectrum_bound"]
+    grp = zzz.LocalGroup(nparts)
+    out = [None] * nparts
+    err = []
+    handles = [None] * nparts
+    bar = threading.Barrier(nparts)
+
+    def run(rank):
+        try:
+            P = zzz.Part(problem, order, *dims, nparts, rank)
+            with zzz.Context(0) as c:
+                c.comm_init_local(grp.h, rank)
+                if p2p:
+                    handles[rank] = c.comm_p2p_export()
+                    bar.wait()
+                    assert c.comm_p2p_attach(b"".join(handles)), "peer-memory all-reduce refused on one GPU"
+                c.cube_generate(problem, order, *dims, nparts, rank)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-8)
+                out[rank] = (it, rn, r0, c.vec_download(zzz.VEC_U), c.cg_info()["pc_spectrum_bound"])
+        except Exception as e:  # noqa: BLE001
+            err.append((rank, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    grp.close()
+    assert not err, err
+    assert all(o is not None for o in out)
+    assert {o[0] for o in out} <= {it0 - 1, it0, it0 + 1} and len({o[0] for o in out}) == 1
+    assert len({o[4] for o in out}) == 1 and abs(out[0][4] - bound0) <= 1e-5 * bound0
+    u = np.concatenate([o[3] for o in out])
+    assert np.linalg.norm(u - u0) <= 1e-9 * np.linalg.norm(u0)
+    assert all(o[1] == out[0][1] and o[2] == out[0][2] and o[1] <= 1e-8 * o[2] for o in out)
+
+
 def test_single_reduction_cg_breakdown_and_limits(ctx):
     """max_it reached, zero right-hand side and immediate convergence behave as in the classical path"""
     G = zzz.Part("poisson", 1, 6, 6, 6)
