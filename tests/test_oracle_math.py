@@ -228,6 +228,55 @@ def test_single_reduction_pcg_equals_classical(problem, order, dims, norm):
     assert it3 == 0 and rn3 == 0.0 and not u3.any()
 
 
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (12, 11, 13)), ("poisson", 3, (3, 3, 4)),
+                                                ("elasticity", 2, (3, 3, 3))])
+def test_chebyshev_jacobi_restatement(problem, order, dims):
+    """The polynomial preconditioner restated in the oracle against an independent numpy / scipy statement: the
+    Gershgorin bound, z = p_k(D^-1 A) D^-1 r built from the three-term recurrence of the Chebyshev polynomials (not
+    from the oracle's rho recurrence), symmetry and positivity of the preconditioner, the solution of the direct
+    solver, degree 1 = Jacobi's iteration count, higher degrees fewer iterations."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    P = zo.Problem(problem, order, *dims)
+    P.assemble()
+    n = P.b.shape[0]
+    A = sp.csr_matrix((P.vals, P.cols, P.rowptr), shape=(n, n))
+    dinv = 1.0 / A.diagonal()
+    hi = float((abs(A).sum(axis=1).A1 * abs(dinv)).max())
+    uref = spl.spsolve(A.tocsc(), P.b)
+    itj, uj, _, _ = zo.pcg(P.rowptr, P.cols, P.vals, P.b, rtol=1e-10)
+    its = {}
+    for degree, ratio in ((1, 30.0), (2, 10.0), (3, 60.0), (6, 100.0)):
+        it, u, rn, r0, est = zo.pcg_chebyshev(P.rowptr, P.cols, P.vals, P.b, degree=degree, ratio=ratio, rtol=1e-10)
+        its[degree] = it
+        assert abs(est - hi) <= 1e-13 * hi
+        assert rn <= 1e-10 * r0
+        assert np.linalg.norm(u - uref) <= 1e-7 * np.linalg.norm(uref)
+    assert abs(its[1] - itj) <= 1 and its[6] < its[3] < its[2] < its[1]
+
+    # the polynomial itself: e_k = (I - M_k D^-1 A) e_0 must be the scaled Chebyshev polynomial T_k((theta - t) / delta) /
+    # T_k(theta / delta) of t = D^-1 A; checked through one application (max_it = 1 from r = b: x_1 = alpha z, alpha > 0)
+    for degree, ratio in ((2, 10.0), (4, 30.0)):
+        lo = hi / ratio
+        theta, delta = 0.5 * (hi + lo), 0.5 * (hi - lo)
+        B = sp.diags(dinv) @ A
+        g0 = dinv * P.b
+        # Chebyshev three-term recurrence on vectors: y_j = T_j((theta I - B) / delta) g0
+        y_prev, y = g0, (theta * g0 - B @ g0) / delta
+        t_prev, t = 1.0, theta / delta
+        for _ in range(degree - 1):
+            y_prev, y = y, 2.0 * (theta * y - B @ y) / delta - y_prev
+            t_prev, t = t, 2.0 * (theta / delta) * t - t_prev
+        resid = y / t                       # (I - B M_k) g0  with M_k = p_k(B)
+        z_expected = spl.spsolve(sp.csc_matrix(B), g0 - resid)   # p_k(B) g0 = B^-1 (g0 - resid)
+        it, x1, _, _, _ = zo.pcg_chebyshev(P.rowptr, P.cols, P.vals, P.b, degree=degree, ratio=ratio, rtol=1e-30, max_it=1)
+        assert it == 1
+        alpha = float(x1 @ z_expected) / float(z_expected @ z_expected)
+        assert alpha > 0 and np.linalg.norm(x1 - alpha * z_expected) <= 1e-9 * np.linalg.norm(x1)
+        assert abs(alpha - float(P.b @ z_expected) / float(z_expected @ (A @ z_expected))) <= 1e-9 * alpha
+
+
 def test_chunked_spmv_is_the_serial_spmv_to_roundoff():
     """zo_spmv_chunked restates the GPU's multi-lane row sums: lanes = 1 IS zo_spmv, more lanes change
     only the association of the additions."""
