@@ -934,7 +934,7 @@ __global__ __launch_bounds__(VB) void k_cheb_step(const int* __restrict__ stop, 
   for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
   {
     const double gi = -1.0 * (dinv[i] * w[i]) + gv[i];
-    const double dn = c1 * d[i] + c2 * gi;
+    const double dn = c1 * d[i] + c2 * gi; // (built with -ffp-contract=off: rounded as written, here, in the product's epilogue and in the oracle)
     const double zi = z[i] + dn;
     z[i] = zi;
     if (!last)
@@ -1037,22 +1037,73 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
   double* pa = ctx->part_b.p;
   double* pb = ctx->part_b.p + VGRID_MAX;
   // the terms after the first of z = p_k(D^-1 A) D^-1 r (g, d and z hold the first), then the partials of <r,z> and the
-  // norm (all-reduced when a communicator is attached)
+  // norm (all-reduced when a communicator is attached).  On the operator stream a term is the EPILOGUE of its product
+  // (ChebEpi, zzz_sellp.hip): w = A d never travels through memory and the term costs no launch of its own; d then
+  // alternates between two buffers (other lanes still gather the old one).  A/B knob ZZZ_CHEB_FUSED=0: product and
+  // k_cheb_step as two launches (the tile kernel's form) -- same bits.
+  bool fused = sellp_active(ctx);
+  if (const char* e = getenv("ZZZ_CHEB_FUSED"))
+    fused = fused && atoi(e) != 0;
+  const bool split = multi && ctx->overlap && ctx->have_tile_split;
+  if (split && !ctx->have_group_split)
+    fused = false;
+  double* chd2 = nullptr;
+  if (fused && degree > 2)
+  {
+    ZZZ_HIP(ctx, ctx->cheb_d2.alloc((size_t)ctx->nloc()));
+    chd2 = ctx->cheb_d2.p;
+    ZZZ_HIP(ctx, hipMemsetAsync(chd2, 0, sizeof(double) * (size_t)ctx->nloc(), s));
+  }
+  const int nn_is_rr = P.norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
+  int np_last = g;
   auto polynomial = [&]() -> int {
     double rho = 1.0 / sigma;
+    double *dcur = chd, *dalt = chd2;
     for (int st = 1; st < degree; ++st)
     {
-      if (int rc = apply(chd, ctx->w.p, nullptr, nullptr))
-        return rc;
+      const bool last = st + 1 == degree;
       const double rhon = 1.0 / (2.0 * sigma - rho);
-      hipLaunchKernelGGL(k_cheb_step, dim3(g), dim3(VB), 0, s, stop_flag, ctx->w.p, ctx->dinv.p, rhon * rho, 2.0 * rhon / delta,
-                         st + 1 == degree ? 1 : 0, chg, chd, ctx->z.p, ctx->r.p, P.norm, pa, pb, n);
+      const double c1 = rhon * rho, c2 = 2.0 * rhon / delta;
       rho = rhon;
+      if (fused)
+      {
+        ChebEpi E;
+        E.dinv = ctx->dinv.p;
+        E.g = chg;
+        E.z = ctx->z.p;
+        E.r = ctx->r.p;
+        E.c1 = c1;
+        E.c2 = c2;
+        double* parts = last ? ctx->part_a.p : nullptr;
+        int rc;
+        if (split)
+          rc = launch_sellp_overlapped(ctx, dcur, dalt, parts, last ? &np_last : nullptr, nullptr, nn_is_rr, &E);
+        else
+        {
+          if (multi)
+            if (int rh = comm_halo_forward(ctx, dcur))
+              return rh;
+          rc = launch_sellp(ctx, dcur, dalt, parts, last ? &np_last : nullptr, nullptr, nn_is_rr, &E);
+        }
+        if (rc)
+          return rc;
+        std::swap(dcur, dalt);
+        continue;
+      }
+      if (int rc = apply(dcur, ctx->w.p, nullptr, nullptr))
+        return rc;
+      hipLaunchKernelGGL(k_cheb_step, dim3(g), dim3(VB), 0, s, stop_flag, ctx->w.p, ctx->dinv.p, c1, c2, last ? 1 : 0, chg, dcur,
+                         ctx->z.p, ctx->r.p, P.norm, pa, pb, n);
     }
     if (degree == 1)
       hipLaunchKernelGGL(k_dots_rz, dim3(g), dim3(VB), 0, s, stop_flag, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
     if (multi)
+    {
+      if (fused && degree > 1)
+        return comm_reduce_allreduce(ctx, stop_flag, ctx->part_a.p + SPMV_PSTRIDE, ctx->part_a.p + 2 * SPMV_PSTRIDE, nullptr,
+                                     np_last, 2, ctx->red.p);
       return comm_reduce_allreduce(ctx, stop_flag, pa, pb, nullptr, g, 2, ctx->red.p);
+    }
     return ZZZ_OK;
   };
   // r = b
@@ -1063,6 +1114,13 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
     return rc;
   const double *rz_src = pa, *nn_src = pb, *pw_src = ctx->part_a.p;
   int n_rz = g;
+  if (fused && degree > 1)
+  {
+    // the last term's partials sit behind the product's own (strides 1 and 2 of its partial array)
+    rz_src = ctx->part_a.p + SPMV_PSTRIDE;
+    nn_src = ctx->part_a.p + 2 * SPMV_PSTRIDE;
+    n_rz = np_last;
+  }
   if (multi)
   {
     rz_src = ctx->red.p;

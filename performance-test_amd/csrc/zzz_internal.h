@@ -12,6 +12,19 @@
 #include "../../include/zzz_abi.h"
 #include "zzz_tail.h"
 
+// One term of the Chebyshev-Jacobi polynomial (cg_solve_chebyshev) as the epilogue of the product of d: with
+// w_i = (A d)_i in the lane that owns row i,  g_i -= D^-1_ii w_i;  d'_i = c1 d_i + c2 g_i (written to the product's
+// output vector);  z_i += d'_i.  The last term leaves g and d alone and sums <r,z> and the test norm into the
+// partial arrays at strides 1 and 2.  dinv == null: the plain product.
+struct ChebEpi
+{
+  const double* dinv = nullptr;
+  double* g = nullptr;
+  double* z = nullptr;
+  const double* r = nullptr;
+  double c1 = 0.0, c2 = 0.0;
+};
+
 namespace zzz
 {
 // ---- device buffer -------------------------------------------------------------------------
@@ -224,6 +237,7 @@ struct zzz_ctx
   zzz::DevBuf<double> part_a, part_b, red; // block partials; reduced scalars
   zzz::DevBuf<double> beta_hist, dp_hist, dpi_hist;
   zzz::DevBuf<double> sr_s; // single-reduction CG: s = A z
+  zzz::DevBuf<double> cheb_d2; // Chebyshev-Jacobi: second direction buffer of the polynomial's fused terms
   zzz::DevBuf<zzz::CgState> state;
   zzz::CgState* h_state = nullptr; // pinned
   std::vector<double> history;
@@ -305,9 +319,10 @@ int sellp_resolve(zzz_ctx* ctx);
 int sellp_pattern_bounds(zzz_ctx* ctx);
 int sellp_capacity_rows(zzz_ctx* ctx); // sp_crow := capacity-based row starts of the compacted copy (+ its allocation)
 int64_t sellp_stream_bytes(const zzz_ctx* ctx);
-int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr);
+int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr,
+                 const ChebEpi* epi = nullptr);
 int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,
-                            int nn_is_rr);
+                            int nn_is_rr, const ChebEpi* epi = nullptr);
 int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new, double* xsol, double* y, double* partials,
                      int* npartials, int it, const zzz::CgParams& P, const double* pa, const double* pb, int np, bool overlap);
 

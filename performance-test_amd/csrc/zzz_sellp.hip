@@ -872,7 +872,7 @@ __device__ inline void chunk_product(int c, int w, int lane, const double* __res
       sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * xv[e];
 }
 
-template <bool DOT, bool NT, bool PERM>
+template <bool DOT, bool NT, bool PERM, bool CHEB = false>
 __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __restrict__ desc,
                                                               const double* __restrict__ svals,
                                                               const uint16_t* __restrict__ c16,
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
                                                               const int* __restrict__ stop_flag,
                                                               const int32_t* __restrict__ group_list, int64_t nlist,
                                                               const double* __restrict__ rvec, int pstride, int nn_is_rr,
-                                                              TailArgs tail)
+                                                              TailArgs tail, ChebEpi epi)
 {
   // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
   // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
     if (!PERM && r >= nrows)
       r = -1;
-    const double xr = (DOT && r >= 0) ? x[r] : 0.0;
+    const double xr = ((DOT || CHEB) && r >= 0) ? x[r] : 0.0;
     double sum = 0.0;
     for (int j = 0; j + 1 < nch; ++j)
       chunk_product<NT, true>(c0 + j, 8, lane, svals, c16, c32, meta, x, sum);
@@ -936,7 +936,29 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
       else
         chunk_product<NT, false>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, x, sum);
     }
-    if (r >= 0)
+    if (CHEB)
+    {
+      // a term of the Chebyshev-Jacobi polynomial (ChebEpi): x is d, y the next d; DOT marks the last term
+      if (r >= 0)
+      {
+        const double gi = -1.0 * (epi.dinv[r] * sum) + epi.g[r];
+        const double dn = epi.c1 * xr + epi.c2 * gi;
+        const double zi = epi.z[r] + dn;
+        epi.z[r] = zi;
+        if (DOT)
+        {
+          const double ri = epi.r[r];
+          dot_rx += ri * zi;
+          dot_nn += nn_is_rr ? ri * ri : zi * zi;
+        }
+        else
+        {
+          epi.g[r] = gi;
+          y[r] = dn;
+        }
+      }
+    }
+    else if (r >= 0)
     {
       y[r] = sum;
       if (DOT)
@@ -953,14 +975,14 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
   }
   if (DOT)
   {
-    const double sres = block_reduce_sum(dot, red);
+    const double sres = CHEB ? 0.0 : block_reduce_sum(dot, red);
     double s1 = 0.0, s2 = 0.0;
-    if (rvec)
+    if (rvec || CHEB)
     {
       s1 = block_reduce_sum(dot_rx, red);
       s2 = block_reduce_sum(dot_nn, red);
     }
-    if (tail.parts)
+    if (!CHEB && tail.parts)
     {
       // multi-GPU: the all-reduce of these sums happens in the tail of this launch (zzz_tail.h); output order
       // (<r,x>, norm, <x,y>) for the single-reduction form, <x,y> alone otherwise
@@ -972,8 +994,9 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     }
     if (threadIdx.x == 0)
     {
-      partials[blockIdx.x] = sres;
-      if (rvec)
+      if (!CHEB)
+        partials[blockIdx.x] = sres;
+      if (rvec || CHEB)
       {
         partials[pstride + blockIdx.x] = s1;
         partials[2 * pstride + blockIdx.x] = s2;
@@ -1485,7 +1508,7 @@ static int sp_grid(int64_t ngroups)
 template <bool DOT>
 static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
                        const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr,
-                       const TailArgs& tail = TailArgs())
+                       const TailArgs& tail = TailArgs(), const ChebEpi* epi = nullptr)
 {
   // load policy by stream size, as for the tile kernel: a stream that stays in the 256 MiB Infinity Cache from
   // one CG iteration to the next is read with plain loads, a larger one with non-temporal loads
@@ -1494,9 +1517,19 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
     nt = (ctx->spmv_variant & 1) != 0;
   const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
 #define ZZZ_SP_GO(NT, PERM)                                                                                            \
-  hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off, ctx->sp_vals.p,     \
-                     ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y, (int)ctx->nrows,          \
-                     ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr, tail)
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (epi)                                                                                                           \
+      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, true>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off,       \
+                         ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,       \
+                         (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr,   \
+                         TailArgs(), *epi);                                                                            \
+    else                                                                                                               \
+      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off,             \
+                         ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,       \
+                         (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr,   \
+                         tail, ChebEpi());                                                                             \
+  } while (0)
   if (ctx->sp_sorted)
   {
     if (nt)
@@ -1514,7 +1547,8 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
 #undef ZZZ_SP_GO
 }
 
-int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr)
+int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr,
+                 const ChebEpi* epi)
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   const int gs = sp_grid((ctx->nslices + 3) / 4);
@@ -1529,12 +1563,12 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
       ctx->tail_armed = false;
       ctx->tail_used = true;
     }
-    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr, T);
+    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr, T, epi);
     if (npartials)
       *npartials = gs;
   }
   else
-    launch_one<false>(ctx, gs, x, y, nullptr, stop, nullptr, 0, nullptr, 0);
+    launch_one<false>(ctx, gs, x, y, nullptr, stop, nullptr, 0, nullptr, 0, TailArgs(), epi);
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
@@ -1542,7 +1576,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
 // Partitioned matrix: forward halo of x overlapped with the groups that reference no ghost column
 // (scheme and the 7-of-8 workgroup slots: launch_spmv_overlapped in zzz_spmv.hip)
 int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,
-                            int nn_is_rr)
+                            int nn_is_rr, const ChebEpi* epi)
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
@@ -1571,9 +1605,9 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   if (gi)
   {
     if (partials)
-      launch_one<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr, Ti);
+      launch_one<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr, Ti, epi);
     else
-      launch_one<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi, nullptr, 0);
+      launch_one<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi, nullptr, 0, TailArgs(), epi);
   }
   rc = comm_halo_end(ctx);
   if (rc)
@@ -1581,9 +1615,9 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   if (gb)
   {
     if (partials)
-      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr, Tb);
+      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr, Tb, epi);
     else
-      launch_one<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb, nullptr, 0);
+      launch_one<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb, nullptr, 0, TailArgs(), epi);
   }
   if (npartials)
     *npartials = g_in + g_bd;

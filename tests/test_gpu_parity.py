@@ -1062,6 +1062,28 @@ def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, rati
     # run-to-run: every bit
     it2, rn2, _ = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
     assert it2 == it and rn2 == rn and np.array_equal(ctx.vec_download(zzz.VEC_U), u)
+    # the polynomial's terms as launches of their own (the tile kernel's form) instead of the product's epilogue: the
+    # same iteration up to the grouping of the partial sums of <r,z>
+    os.environ["ZZZ_CHEB_FUSED"] = "0"
+    try:
+        it3, rn3, r03 = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+        u3 = ctx.vec_download(zzz.VEC_U)
+    finally:
+        del os.environ["ZZZ_CHEB_FUSED"]
+    assert abs(it3 - it) <= 1 and abs(r03 - r0) <= 1e-13 * r0 and np.linalg.norm(u3 - u) <= 1e-8 * np.linalg.norm(u)
+    os.environ["ZZZ_SELLP"] = "0"   # and on the CSR tile kernel (the knob is read when a context is created)
+    try:
+        with zzz.Context(0) as c:
+            c.upload_part(G)
+            c.pattern_build()
+            c.assemble_matrix(G.form)
+            c.assemble_vector(G.form)
+            it4, rn4, r04 = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+            u4 = c.vec_download(zzz.VEC_U)
+            assert c.spmv_operator_form() == 0
+    finally:
+        del os.environ["ZZZ_SELLP"]
+    assert abs(it4 - it) <= 1 and np.linalg.norm(u4 - u) <= 1e-8 * np.linalg.norm(u)
     # KSPCG with the assembled operator only
     for kw in (dict(variant=zzz.CG_CGH), dict(op=zzz.OP_MATFREE), dict(single_reduction=True), dict(pc_degree=-1)):
         with pytest.raises(zzz.ZzzError):
