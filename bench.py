@@ -43,10 +43,10 @@ class deadline:
     region whose collectives could block on a rank that has died): when it does not finish in time the process
     prints why and ends with a NON-ZERO status by a plain exit -- never a hang, never a re-exec."""
 
-    def __init__(self, seconds, what):
+    def __init__(self, seconds, what, last_words=None):
         import threading
 
-        self.what, self.seconds = what, seconds
+        self.what, self.seconds, self.last_words = what, seconds, last_words
         self.t = threading.Timer(seconds, self._fire)
         self.t.daemon = True
 
@@ -54,6 +54,11 @@ class deadline:
         sys.stderr.write(f"bench.py: '{self.what}' did not finish within {self.seconds} s "
                          f"(rank {os.environ.get('RANK', '0')}); giving up\n")
         sys.stderr.flush()
+        if self.last_words is not None:
+            # an extra beside a measurement that is already complete: its line is printed, not lost
+            self.last_words()
+            sys.stdout.flush()
+            os._exit(0)
         os._exit(3)
 
     def __enter__(self):
@@ -533,30 +538,6 @@ def main():
             rank_info = [None] * world
             with deadline(300, "all_gather of the per-rank diagnostics"):
                 dist.all_gather_object(rank_info, mine)
-    # beside the measurement (after it, untimed): the same assembled system solved once with the library's polynomial
-    # preconditioner -- fewer iterations and all-reduces for more products, i.e. what the N > 1 runs are bound by
-    alt_pc = None
-    if pc == zzz.PC_JACOBI and not a.no_alt_pc:
-        try:
-            with deadline(600, "Chebyshev-Jacobi solve beside the measurement"):
-                ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
-                barrier()
-                ctx.sync()
-                t0 = time.perf_counter()
-                ita, rna, r0a = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
-                ctx.sync()
-                dt = time.perf_counter() - t0
-                if dist is not None:
-                    tt = torch.tensor([dt], dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dt = float(tt[0])
-                alt_pc = {"pc_type": "chebyshev_jacobi (degree 3, ratio 60: the library's defaults)", "ZZZ Solve ms": dt * 1e3,
-                          "krylov_iterations": ita, "relative_residual": rna / r0a if r0a else 0.0,
-                          "products_per_iteration": 3, "allreduces_per_iteration": 2,
-                          "jacobi ZZZ Solve ms": float(np.mean([p["solve"] for p in phases])) * 1e3,
-                          "note": "one solve of the timed steps' system, outside the timed region; not part of value"}
-        except zzz.ZzzError as e:
-            alt_pc = {"error": repr(e)}
     ms_per_step = elapsed / a.steps * 1e3
     iters = phases[-1]["iters"]
 
@@ -645,8 +626,6 @@ def main():
                                         "scalar_allreduce": "peer_memory" if p2p else "ncclAllReduce",
                                         "chosen_by": ("--cg " + a.cg) if a.cg != "auto" else
                                                      ("warm-up tuning (fastest of %d combinations)" % len(tuning) if tuning else "default")}
-        if alt_pc is not None:
-            out["alt_preconditioner"] = alt_pc
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"
         if not multi and not a.no_cpu_baseline:
             if nnz > 2**31 - 1:
@@ -659,6 +638,37 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(P, ctx, iters)
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
                 out["gpu_over_cpu_zzz_solve"] = out["cpu_baseline"]["solve_s_extrapolated"] / avg("solve")
+    # beside the measurement (after it, untimed): the same assembled system solved once with the library's polynomial
+    # preconditioner -- fewer iterations and all-reduces for more products, i.e. what the N > 1 runs are bound by
+    alt_pc = None
+    if pc == zzz.PC_JACOBI and not a.no_alt_pc:
+        try:
+            def line_without_it():
+                if rank == 0:
+                    out["alt_preconditioner"] = {"error": "did not finish within 600 s"}
+                    print(json.dumps(out))
+
+            with deadline(600, "Chebyshev-Jacobi solve beside the measurement", last_words=line_without_it):
+                ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
+                barrier()
+                ctx.sync()
+                t0 = time.perf_counter()
+                ita, rna, r0a = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                if dist is not None:
+                    tt = torch.tensor([dt], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt[0])
+                alt_pc = {"pc_type": "chebyshev_jacobi (degree 3, ratio 60: the library's defaults)", "ZZZ Solve ms": dt * 1e3,
+                          "krylov_iterations": ita, "relative_residual": rna / r0a if r0a else 0.0,
+                          "products_per_iteration": 3, "allreduces_per_iteration": 2,
+                          "jacobi ZZZ Solve ms": float(np.mean([p["solve"] for p in phases])) * 1e3,
+                          "note": "one solve of the timed steps' system, outside the timed region; not part of value"}
+        except zzz.ZzzError as e:
+            alt_pc = {"error": repr(e)}
+        if rank == 0:
+            out["alt_preconditioner"] = alt_pc
     ctx.close()
     if rank == 0 and not multi and not a.force_comm and a.config is None and not a.no_other_configs \
             and (a.problem_type, a.order, a.ndofs) == ("poisson", 1, 10000000):
