@@ -253,6 +253,7 @@ def main():
                          "preconditioner (fewer iterations and all-reduces, more products), an A/B line only")
     ap.add_argument("--pc_degree", type=int, default=0)
     ap.add_argument("--pc_ratio", type=float, default=0.0)
+    ap.add_argument("--pc_esteig", type=int, default=0, help="Lanczos steps of the spectrum estimate (0: 10, < 0: Gershgorin alone)")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--numbering", default="native", choices=["native", "rcm", "random", "reverse"],
                     help="N=1: how the CALLER numbers dofs, vertices and cells of the host feed before upload: native = "
@@ -400,7 +401,7 @@ def main():
     cold["ZZZ Assemble (pattern + matrix + vector)"] = sum(cold.values())
     nrows, ncols, nnz = ctx.csr_sizes()
     pc = {"jacobi": zzz.PC_JACOBI, "none": zzz.PC_NONE, "chebyshev_jacobi": zzz.PC_CHEBYSHEV_JACOBI}[a.pc]
-    pc_kw = dict(pc_degree=a.pc_degree, pc_ratio=a.pc_ratio) if pc == zzz.PC_CHEBYSHEV_JACOBI else {}
+    pc_kw = dict(pc_degree=a.pc_degree, pc_ratio=a.pc_ratio, pc_esteig_its=a.pc_esteig) if pc == zzz.PC_CHEBYSHEV_JACOBI else {}
     single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and (multi or a.force_comm))
     if pc == zzz.PC_CHEBYSHEV_JACOBI:
         single_reduction = False  # the polynomial preconditioner runs in the classical KSPCG form

@@ -82,7 +82,8 @@ enum
    * (PETSc: -pc_type ksp -ksp_ksp_type chebyshev -ksp_ksp_max_it k -ksp_pc_type jacobi [EXT]).  The "stronger
    * preconditioner" of README.md:61-62,108-110 that needs only the product and no reduction inside its application:
    * fewer CG iterations, i.e. fewer all-reduces per solve, for more products -- for multi-GPU runs.  Spectrum
-   * bounds [hi / pc_ratio, hi] with hi = Gershgorin's bound of D^-1 A.  ZZZ_CG_PETSC + ZZZ_OP_CSR only. */
+   * bounds [hi / pc_ratio, hi] with hi = min(Gershgorin's bound of D^-1 A, 1.1 x a Lanczos estimate: pc_esteig_its).
+   * ZZZ_CG_PETSC + ZZZ_OP_CSR only. */
   ZZZ_PC_CHEBYSHEV_JACOBI = 2
 };
 enum
@@ -127,7 +128,9 @@ typedef struct
                      * divtol = 1.e4); unused by ZZZ_CG_CGH (src/cg.h has no such test) */
   /* (added in round 3 behind the fields above, whose layout is unchanged) */
   int32_t pc_degree; /* ZZZ_PC_CHEBYSHEV_JACOBI: Chebyshev steps per application (0 selects 3) */
-  int32_t pc_pad;    /* keep 0 */
+  int32_t pc_esteig_its; /* ZZZ_PC_CHEBYSHEV_JACOBI: Jacobi-PCG iterations on a noise vector whose Lanczos coefficients give
+                          * the estimate of the largest eigenvalue of D^-1 A (PETSc's -ksp_chebyshev_esteig, safety factor
+                          * 1.1); the bound used is min(Gershgorin's, 1.1 x estimate).  0 selects 10, < 0 Gershgorin alone */
   double pc_ratio;   /* ZZZ_PC_CHEBYSHEV_JACOBI: upper / lower bound of the targeted spectrum (<= 1 selects 60) */
 } zzz_solver_opts;
 

@@ -66,6 +66,10 @@ def lib():
         L.zo_pcg_sr.argtypes = L.zo_pcg.argtypes
         L.zo_pcg_cheb.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_int, f64p]
+        L.zo_esteig.restype = C.c_double
+        L.zo_esteig.argtypes = [C.c_int64, i64p, i32p, f64p, C.c_int, C.c_int64]
+        L.zo_noise.restype = C.c_double
+        L.zo_noise.argtypes = [C.c_int64]
         L.zo_spmv_chunked.argtypes = [C.c_int64, i64p, i32p, f64p, f64p, f64p, C.c_int]
         L.zo_norm2.restype = C.c_double
         L.zo_norm2.argtypes = [C.c_int64, f64p]
@@ -273,13 +277,19 @@ def pcg_single_reduction(rowptr, cols, vals, b, pc=PC_JACOBI, norm_type=NORM_PRE
     return int(it), x, float(rn[0]), float(rn[1])
 
 
-def pcg_chebyshev(rowptr, cols, vals, b, degree=2, ratio=10.0, rtol=1e-8, atol=1e-50, max_it=10000):
+def pcg_chebyshev(rowptr, cols, vals, b, degree=2, ratio=10.0, rtol=1e-8, atol=1e-50, max_it=10000, est_its=0):
     """KSPCG with the Chebyshev-Jacobi polynomial preconditioner restated; returns (iterations, x, final_norm,
-    initial_norm, eigenvalue estimate)"""
+    initial_norm, spectrum bound).  est_its = 0: Gershgorin's bound; > 0: min(Gershgorin, 1.1 x the Lanczos estimate of
+    est_its Jacobi-PCG iterations on the noise vector)"""
     x = np.zeros_like(b)
     rn = np.zeros(3)
-    it = lib().zo_pcg_cheb(b.shape[0], rowptr, cols, vals, b, x, degree, 0, ratio, rtol, atol, max_it, rn)
+    it = lib().zo_pcg_cheb(b.shape[0], rowptr, cols, vals, b, x, degree, est_its, ratio, rtol, atol, max_it, rn)
     return int(it), x, float(rn[0]), float(rn[1]), float(rn[2])
+
+
+def esteig(rowptr, cols, vals, est_its=10, offset=0):
+    """largest Ritz value of D^-1 A after est_its Jacobi-PCG iterations on the noise vector (zo_esteig)"""
+    return float(lib().zo_esteig(rowptr.shape[0] - 1, rowptr, cols, vals, est_its, offset))
 
 
 def norm2(x):

@@ -985,6 +985,121 @@ __global__ __launch_bounds__(VB) void k_dots_rz(const int* __restrict__ stop, co
 }
 
 int comm_allgather_max(zzz_ctx* ctx, double* v); // zzz_comm.hip: maximum of one double over the ranks (set-up exchange)
+int comm_allgather_double(zzz_ctx* ctx, double v, double* all);
+int comm_rank_of(const zzz_ctx* ctx, int* nranks);
+
+// the noise vector of the spectrum estimate (oracle: zo_noise): a fixed hash of the GLOBAL row number in the caller's
+// numbering, so that neither the library's internal order nor the partition changes the estimate
+__global__ __launch_bounds__(VB) void k_noise(const int32_t* __restrict__ perm, int bs, int64_t offset, int64_t n,
+                                              double* __restrict__ v)
+{
+  for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+  {
+    int64_t row = i;
+    if (perm)
+      row = (int64_t)perm[i / bs] * bs + i % bs;
+    unsigned int h = (unsigned int)((unsigned long long)(offset + row) * 2654435761ull + 12345ull);
+    h ^= h >> 16;
+    h *= 0x45d9f3bu;
+    h ^= h >> 16;
+    v[i] = (double)h / 4294967296.0 - 0.5;
+  }
+}
+
+// largest eigenvalue of the k x k symmetric tridiagonal (diagonal t, off-diagonal e): bisection on the Sturm count
+static double tridiag_lmax(int k, const double* t, const double* e)
+{
+  double lo = t[0], hi = t[0];
+  for (int j = 0; j < k; ++j)
+  {
+    const double rad = (j > 0 ? std::fabs(e[j - 1]) : 0.0) + (j + 1 < k ? std::fabs(e[j]) : 0.0);
+    lo = std::min(lo, t[j] - rad);
+    hi = std::max(hi, t[j] + rad);
+  }
+  for (int itb = 0; itb < 200 && hi - lo > 4.0e-16 * std::fabs(hi); ++itb)
+  {
+    const double mid = 0.5 * (lo + hi);
+    int above = 0;
+    double q = 1.0;
+    for (int j = 0; j < k; ++j)
+    {
+      const double off2 = j > 0 ? e[j - 1] * e[j - 1] : 0.0;
+      q = (t[j] - mid) - (j > 0 ? off2 / q : 0.0);
+      if (q == 0.0)
+        q = 1.0e-300;
+      if (q > 0.0)
+        ++above;
+    }
+    if (above > 0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+// PETSc's -ksp_chebyshev_esteig: `its` iterations of Jacobi-PCG (the classical loop above, communicator and all) on the
+// noise vector; the Lanczos tridiagonal of its step lengths and <r,z> values gives the largest Ritz value of D^-1 A
+// (from below: 0.97-0.98 of the eigenvalue after 10 iterations).  0 when it could not be formed.
+static int chebyshev_esteig(zzz_ctx* ctx, const zzz_solver_opts* o, int its, double* ritz)
+{
+  *ritz = 0.0;
+  its = std::min(its, 64);
+  const int64_t n = ctx->n_owned * ctx->bs;
+  int nranks = 1;
+  const int me = comm_rank_of(ctx, &nranks);
+  std::vector<double> sizes((size_t)nranks);
+  if (int rc = comm_allgather_double(ctx, (double)n, sizes.data()))
+    return rc;
+  int64_t offset = 0;
+  for (int r = 0; r < me; ++r)
+    offset += (int64_t)sizes[(size_t)r];
+  ZZZ_HIP(ctx, ctx->cheb_noise.alloc(ctx->b.n));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->cheb_noise.p, 0, sizeof(double) * ctx->cheb_noise.n, ctx->stream));
+  hipLaunchKernelGGL(k_noise, dim3(vgrid(n)), dim3(VB), 0, ctx->stream, ctx->renumbered ? ctx->perm.p : (const int32_t*)nullptr,
+                     ctx->bs, offset, n, ctx->cheb_noise.p);
+  zzz_solver_opts o2 = *o;
+  o2.pc = ZZZ_PC_JACOBI;
+  o2.norm = ZZZ_NORM_PRECONDITIONED;
+  o2.max_it = its;
+  o2.rtol = 0.0;
+  o2.atol = 0.0;
+  o2.dtol = 1.0e300;
+  o2.profile = 0;
+  o2.single_reduction = 0;
+  o2.error_if_not_converged = 0;
+  auto swap_b = [&]() {
+    std::swap(ctx->b.p, ctx->cheb_noise.p);
+    std::swap(ctx->b.n, ctx->cheb_noise.n);
+    std::swap(ctx->b.cap, ctx->cheb_noise.cap);
+  };
+  swap_b();
+  int ran = 0;
+  double rn[2];
+  const int rc = cg_solve(ctx, &o2, &ran, rn);
+  swap_b();
+  if (rc)
+    return rc;
+  if (ran < 2)
+    return ZZZ_OK;
+  std::vector<double> alpha((size_t)ran), rho((size_t)ran + 1);
+  ZZZ_HIP(ctx, hipMemcpy(alpha.data(), ctx->alpha_hist.p, sizeof(double) * (size_t)ran, hipMemcpyDeviceToHost));
+  ZZZ_HIP(ctx, hipMemcpy(rho.data(), ctx->beta_hist.p, sizeof(double) * ((size_t)ran + 1), hipMemcpyDeviceToHost));
+  std::vector<double> t((size_t)ran), e((size_t)ran);
+  for (int j = 0; j < ran; ++j)
+  {
+    if (!(alpha[(size_t)j] > 0.0) || !std::isfinite(alpha[(size_t)j]) || !(rho[(size_t)j] > 0.0) || !std::isfinite(rho[(size_t)j]))
+      return ZZZ_OK;
+    t[(size_t)j] = 1.0 / alpha[(size_t)j] + (j > 0 ? (rho[(size_t)j] / rho[(size_t)j - 1]) / alpha[(size_t)j - 1] : 0.0);
+    if (j + 1 < ran)
+      e[(size_t)j] = std::sqrt(rho[(size_t)j + 1] / rho[(size_t)j]) / alpha[(size_t)j];
+  }
+  for (int j = 0; j + 1 < ran; ++j)
+    if (!std::isfinite(e[(size_t)j]))
+      return ZZZ_OK;
+  *ritz = tridiag_lmax(ran, t.data(), e.data());
+  return ZZZ_OK;
+}
 
 static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 {
@@ -1022,6 +1137,25 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
       return rc;
   if (!(hi > 0.0) || !std::isfinite(hi))
     hi = 1.0;
+  // ... tightened by the Lanczos estimate where that is lower (Gershgorin's bound is exact for P1 Laplacians, 2, and up to
+  // 2.7 x too high for P2 / P3 / elasticity, which costs 1.6 x the products); safety factor 1.1 as in PETSc
+  const int est_its = o->pc_esteig_its == 0 ? 10 : o->pc_esteig_its;
+  if (est_its > 0)
+  {
+    double ritz = 0.0;
+    if (int rc = chebyshev_esteig(ctx, o, est_its, &ritz))
+      return rc;
+    if (ritz > 0.0 && std::isfinite(ritz) && 1.1 * ritz < hi)
+      hi = 1.1 * ritz;
+    // the estimate ran through the classical loop: its state is this solve's to reset
+    ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
+    ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
+    ZZZ_HIP(ctx, ctx->alpha_hist.alloc((size_t)max_it + 2));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s));
+    hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n, 1);
+  }
   const double lo = hi / ratio;
   const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 

@@ -715,20 +715,23 @@ int comm_exchange_bytes(zzz_ctx* ctx, const std::vector<std::vector<char>>& send
   return ZZZ_OK;
 }
 
-// maximum of one double over the ranks, through the all-reduce the CG scalars take (peer-memory mailboxes or the
-// communicator's all-reduce): rank r's value travels in slot r of a sum of otherwise-zero slots, three slots per round
-int comm_allgather_max(zzz_ctx* ctx, double* v)
+// One double of every rank to every rank, through the all-reduce the CG scalars take (peer-memory mailboxes or the
+// communicator's all-reduce): rank r's value travels in slot r of a sum of otherwise-zero slots, three slots per round.
+// all: nranks values (all[0] = v without a communicator).
+int comm_allgather_double(zzz_ctx* ctx, double v, double* all)
 {
   if (!ctx->comm || ctx->comm->nranks == 1)
+  {
+    all[0] = v;
     return ZZZ_OK;
+  }
   const int n = ctx->comm->nranks, me = ctx->comm->rank;
   hipStream_t s = ctx->stream;
-  double best = *v;
   for (int q = 0; q < n; q += 3)
   {
     double slot[3] = {0.0, 0.0, 0.0}, got[3] = {0.0, 0.0, 0.0};
     if (me >= q && me < q + 3)
-      slot[me - q] = *v;
+      slot[me - q] = v;
     double* in = ctx->part_a.p; // three one-entry "partial arrays"
     ZZZ_HIP(ctx, hipMemcpyAsync(in, slot, sizeof(slot), hipMemcpyHostToDevice, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s)); // slot[] leaves scope
@@ -737,13 +740,29 @@ int comm_allgather_max(zzz_ctx* ctx, double* v)
     ZZZ_HIP(ctx, hipMemcpyAsync(got, ctx->red.p + 4, sizeof(got), hipMemcpyDeviceToHost, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
     for (int k = 0; k < 3 && q + k < n; ++k)
-      if (got[k] > best)
-        best = got[k];
+      all[q + k] = got[k];
   }
-  if (int rc = comm_p2p_check(ctx))
+  return comm_p2p_check(ctx);
+}
+
+int comm_allgather_max(zzz_ctx* ctx, double* v)
+{
+  if (!ctx->comm || ctx->comm->nranks == 1)
+    return ZZZ_OK;
+  std::vector<double> all((size_t)ctx->comm->nranks);
+  if (int rc = comm_allgather_double(ctx, *v, all.data()))
     return rc;
-  *v = best;
+  for (double w : all)
+    if (w > *v)
+      *v = w;
   return ZZZ_OK;
+}
+
+int comm_rank_of(const zzz_ctx* ctx, int* nranks)
+{
+  if (nranks)
+    *nranks = ctx->comm ? ctx->comm->nranks : 1;
+  return ctx->comm ? ctx->comm->rank : 0;
 }
 
 void comm_destroy(zzz_ctx* ctx)

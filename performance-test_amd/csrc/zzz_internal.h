@@ -238,6 +238,7 @@ struct zzz_ctx
   zzz::DevBuf<double> beta_hist, dp_hist, dpi_hist;
   zzz::DevBuf<double> sr_s; // single-reduction CG: s = A z
   zzz::DevBuf<double> cheb_d2; // Chebyshev-Jacobi: second direction buffer of the polynomial's fused terms
+  zzz::DevBuf<double> cheb_noise; // ... and the right-hand side of its spectrum estimate
   zzz::DevBuf<zzz::CgState> state;
   zzz::CgState* h_state = nullptr; // pinned
   std::vector<double> history;

@@ -113,6 +113,7 @@ struct Options
   int ksp_max_it = 10000;
   int pc_degree = 0;      // -pc_chebyshev_jacobi_degree (0: the library's default, 3)
   double pc_ratio = 0.0;  // -pc_chebyshev_jacobi_ratio  (0: the library's default, 60)
+  int pc_esteig = 0;      // -pc_chebyshev_jacobi_esteig (0: the library's default, 10 Lanczos steps; < 0: Gershgorin alone)
   bool ksp_view = false, log_view = false, options_left = false, ksp_monitor = false, ksp_cg_single_reduction = false;
   bool ksp_error_if_not_converged = false, ksp_converged_reason = false;
   std::vector<std::string> unused;
@@ -136,7 +137,7 @@ void usage()
                "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
                "  --allreduce arg (=peer)         peer (xGMI peer-memory mailboxes, else falls back) | comm\n"
                "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none,chebyshev_jacobi} -ksp_rtol -ksp_atol\n"
-               "  -ksp_divtol -pc_chebyshev_jacobi_degree (=3) -pc_chebyshev_jacobi_ratio (=60)\n"
+               "  -ksp_divtol -pc_chebyshev_jacobi_degree (=3) -pc_chebyshev_jacobi_ratio (=60) -pc_chebyshev_jacobi_esteig (=10)\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
                "  -ksp_cg_single_reduction -ksp_converged_reason -ksp_error_if_not_converged\n"
                "  -log_view -options_left\n"
@@ -206,6 +207,8 @@ Options parse(int argc, char** argv)
         o.pc_degree = std::stoi(next());
       else if (key == "pc_chebyshev_jacobi_ratio")
         o.pc_ratio = std::stod(next());
+      else if (key == "pc_chebyshev_jacobi_esteig")
+        o.pc_esteig = std::stoi(next());
       else if (key == "ksp_rtol")
         o.ksp_rtol = std::stod(next());
       else if (key == "ksp_atol")
@@ -417,6 +420,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     so.pc = o.pc_type == "none" ? ZZZ_PC_NONE : o.pc_type == "chebyshev_jacobi" ? ZZZ_PC_CHEBYSHEV_JACOBI : ZZZ_PC_JACOBI;
     so.pc_degree = o.pc_degree;
     so.pc_ratio = o.pc_ratio;
+    so.pc_esteig_its = o.pc_esteig;
     so.norm = o.ksp_norm_type == "unpreconditioned" ? ZZZ_NORM_UNPRECONDITIONED
               : o.ksp_norm_type == "natural"        ? ZZZ_NORM_NATURAL
                                                     : ZZZ_NORM_PRECONDITIONED;

@@ -47,7 +47,7 @@ class SolverOpts(C.Structure):
     _fields_ = [("variant", C.c_int32), ("pc", C.c_int32), ("norm", C.c_int32), ("op", C.c_int32),
                 ("max_it", C.c_int32), ("profile", C.c_int32), ("single_reduction", C.c_int32), ("error_if_not_converged", C.c_int32),
                 ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
-                ("pc_degree", C.c_int32), ("pc_pad", C.c_int32), ("pc_ratio", C.c_double)]
+                ("pc_degree", C.c_int32), ("pc_esteig_its", C.c_int32), ("pc_ratio", C.c_double)]
 
 
 class ZzzError(RuntimeError):
@@ -485,9 +485,9 @@ class Context:
 
     def cg_solve(self, variant=CG_PETSC, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, op=OP_CSR, rtol=1e-8, atol=1e-50,
                  max_it=10000, profile=False, single_reduction=False, dtol=0.0, error_if_not_converged=False,
-                 pc_degree=0, pc_ratio=0.0):
+                 pc_degree=0, pc_ratio=0.0, pc_esteig_its=0):
         o = SolverOpts(variant, pc, norm, op, max_it, 1 if profile else 0, 1 if single_reduction else 0,
-                       1 if error_if_not_converged else 0, rtol, atol, dtol, pc_degree, 0, pc_ratio)
+                       1 if error_if_not_converged else 0, rtol, atol, dtol, pc_degree, pc_esteig_its, pc_ratio)
         it = C.c_int()
         rn = (C.c_double * 2)()
         self._ck(self.L.zzz_cg_solve(self.h, C.byref(o), C.byref(it), rn))

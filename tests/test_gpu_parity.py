@@ -1029,8 +1029,8 @@ def test_single_reduction_cg(ctx, problem, order, dims, norm):
 @pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (24, 22, 23)), ("poisson", 2, (8, 7, 9)),
                                                 ("poisson", 3, (5, 4, 6)), ("elasticity", 1, (8, 8, 9)),
                                                 ("elasticity", 2, (4, 3, 5))])
-@pytest.mark.parametrize("degree,ratio", [(1, 30.0), (2, 10.0), (3, 30.0), (5, 60.0)])
-def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, ratio):
+@pytest.mark.parametrize("degree,ratio,esteig", [(1, 30.0, -1), (2, 10.0, 0), (3, 30.0, -1), (3, 60.0, 0), (5, 60.0, 12)])
+def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, ratio, esteig):
     """ZZZ_PC_CHEBYSHEV_JACOBI (fewer all-reduces per solve) against its oracle restatement
     zo.pcg_chebyshev: same spectrum bound, iteration count +-2, solution 1e-6, residual within rtol; degree 1 is
     Jacobi scaled by a constant (the same iteration as PC_JACOBI); degree >= 2 takes fewer iterations than Jacobi."""
@@ -1042,8 +1042,20 @@ def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, rati
     ctx.assemble_vector(G.form)
     rowptr, cols, vals = ctx.csr_download()
     b = ctx.vec_download(zzz.VEC_B)
-    ito, uo, rno, r0o, est = zo.pcg_chebyshev(rowptr.astype(np.int64), cols, vals, b, degree=degree, ratio=ratio, rtol=1e-9)
-    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+    # spectrum bound: Gershgorin's alone (esteig < 0) or min(Gershgorin, 1.1 x the Lanczos estimate of `esteig` Jacobi-PCG
+    # iterations on the noise vector; 0 = the default, 10) -- the same hash of the caller's row number on both sides
+    est_its = 0 if esteig < 0 else (esteig or 10)
+    ito, uo, rno, r0o, est = zo.pcg_chebyshev(rowptr.astype(np.int64), cols, vals, b, degree=degree, ratio=ratio, rtol=1e-9,
+                                              est_its=est_its)
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((vals, cols, rowptr.astype(np.int64)), shape=(b.shape[0], b.shape[0]))
+    gersh = float((abs(A).sum(axis=1).A1 / np.abs(A.diagonal())).max())
+    assert est <= gersh * (1 + 1e-14)
+    if est_its and (order > 1 or problem == "elasticity"):
+        assert est < 0.8 * gersh   # where Gershgorin's bound is loose the estimate takes over
+    kw = dict(pc_degree=degree, pc_ratio=ratio, pc_esteig_its=esteig)
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, **kw)
     u = ctx.vec_download(zzz.VEC_U)
     assert ctx.cg_reason() == 2
     assert abs(ctx.cg_info()["pc_spectrum_bound"] - est) <= 2e-6 * est
@@ -1060,13 +1072,14 @@ def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, rati
     else:
         assert it < itj
     # run-to-run: every bit
-    it2, rn2, _ = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+    it2, rn2, _ = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, **kw)
     assert it2 == it and rn2 == rn and np.array_equal(ctx.vec_download(zzz.VEC_U), u)
+    assert np.array_equal(ctx.vec_download(zzz.VEC_B), b)   # the estimate's right-hand side never replaces b
     # the polynomial's terms as launches of their own (the tile kernel's form) instead of the product's epilogue: the
     # same iteration up to the grouping of the partial sums of <r,z>
     os.environ["ZZZ_CHEB_FUSED"] = "0"
     try:
-        it3, rn3, r03 = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+        it3, rn3, r03 = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, **kw)
         u3 = ctx.vec_download(zzz.VEC_U)
     finally:
         del os.environ["ZZZ_CHEB_FUSED"]
@@ -1078,16 +1091,17 @@ def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, rati
             c.pattern_build()
             c.assemble_matrix(G.form)
             c.assemble_vector(G.form)
-            it4, rn4, r04 = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, pc_degree=degree, pc_ratio=ratio, rtol=1e-9)
+            it4, rn4, r04 = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, **kw)
             u4 = c.vec_download(zzz.VEC_U)
             assert c.spmv_operator_form() == 0
     finally:
         del os.environ["ZZZ_SELLP"]
     assert abs(it4 - it) <= 1 and np.linalg.norm(u4 - u) <= 1e-8 * np.linalg.norm(u)
     # KSPCG with the assembled operator only
-    for kw in (dict(variant=zzz.CG_CGH), dict(op=zzz.OP_MATFREE), dict(single_reduction=True), dict(pc_degree=-1)):
+    for bad in (dict(variant=zzz.CG_CGH), dict(op=zzz.OP_MATFREE), dict(single_reduction=True), dict(pc_degree=-1),
+                dict(pc_esteig_its=65)):
         with pytest.raises(zzz.ZzzError):
-            ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, **kw)
+            ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, **bad)
 
 
 @pytest.mark.parametrize("p2p", [False, True], ids=["allreduce-comm", "allreduce-peer-memory"])

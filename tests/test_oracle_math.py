@@ -255,6 +255,22 @@ def test_chebyshev_jacobi_restatement(problem, order, dims):
         assert np.linalg.norm(u - uref) <= 1e-7 * np.linalg.norm(uref)
     assert abs(its[1] - itj) <= 1 and its[6] < its[3] < its[2] < its[1]
 
+    # the Lanczos estimate of the largest eigenvalue of D^-1 A (PETSc's -ksp_chebyshev_esteig): from below, within a few
+    # per cent after 10 iterations from the noise vector, so that 1.1 x the estimate is an upper bound; it replaces
+    # Gershgorin's bound where that is loose (P2 / P3 / elasticity) and the solve then needs fewer products
+    lmax = float(spl.eigsh(sp.diags(np.sqrt(dinv)) @ A @ sp.diags(np.sqrt(dinv)), k=1, which="LA",
+                           return_eigenvectors=False)[0])
+    ritz = zo.esteig(P.rowptr, P.cols, P.vals, 10)
+    assert 0.95 * lmax <= ritz <= lmax * (1 + 1e-12) and lmax <= hi * (1 + 1e-12)
+    assert zo.esteig(P.rowptr, P.cols, P.vals, 30) >= ritz   # Ritz values grow with the Krylov space
+    it_e, u_e, rn_e, r0_e, bound = zo.pcg_chebyshev(P.rowptr, P.cols, P.vals, P.b, degree=3, ratio=60.0, rtol=1e-10, est_its=10)
+    assert abs(bound - min(hi, 1.1 * ritz)) <= 1e-13 * hi and lmax < bound
+    assert np.linalg.norm(u_e - uref) <= 1e-7 * np.linalg.norm(uref) and it_e <= its[3]
+    if hi > 1.5 * lmax:
+        assert it_e < 0.8 * its[3]
+    noise = np.array([zo.lib().zo_noise(i) for i in range(4096)])
+    assert abs(noise.mean()) < 0.02 and 0.27 < noise.std() < 0.31 and -0.5 <= noise.min() and noise.max() < 0.5
+
     # the polynomial itself: e_k = (I - M_k D^-1 A) e_0 must be the scaled Chebyshev polynomial T_k((theta - t) / delta) /
     # T_k(theta / delta) of t = D^-1 A; checked through one application (max_it = 1 from r = b: x_1 = alpha z, alpha > 0)
     for degree, ratio in ((2, 10.0), (4, 30.0)):
