@@ -382,6 +382,32 @@ def test_driver_binary_surface():
     for bad in (["--scaling_type", "sideways"], ["--problem_type", "stokes"], ["--order", "4"]):
         out = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
         assert out.returncode != 0
+    # the polynomial preconditioner through the options database: same solution norm as Jacobi's run above, fewer
+    # iterations; on 2 ranks (host-mediated communicator, both on this GPU) the same again; options checked
+    base = [exe, "--problem_type", "poisson", "--scaling_type", "weak", "--ndofs", "50000", "-ksp_type", "cg", "-ksp_rtol",
+            "1.0e-8", "-pc_type"]
+
+    def its_norm(args):
+        o = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert o.returncode == 0, o.stderr[-1000:]
+        return (int(o.stdout.split("*** Number of Krylov iterations: ")[1].split()[0]),
+                float(o.stdout.split("*** Solution norm:  ")[1].split()[0]), o.stdout)
+
+    seen = []
+    for extra, opts in (([], []),
+                        ([], ["-pc_chebyshev_jacobi_degree", "4", "-pc_chebyshev_jacobi_ratio", "40", "-pc_chebyshev_jacobi_esteig",
+                              "-1", "-ksp_view"]),
+                        (["--ngpus", "2", "--comm", "local"], [])):
+        its_j, nrm_j, _ = its_norm(base + ["jacobi"] + extra)
+        its_c, nrm_c, text = its_norm(base + ["chebyshev_jacobi"] + extra + opts)
+        assert 20 < its_c < 0.45 * its_j and abs(nrm_c - nrm_j) < 1e-6 * nrm_j, (extra, opts, its_c, its_j, nrm_c, nrm_j)
+        seen.append(its_c)
+        if "-ksp_view" in opts:
+            assert "PC Object: type: chebyshev_jacobi" in text
+    assert seen[1] < seen[0]   # degree 4 against 3
+    base = base + ["chebyshev_jacobi"]
+    out = subprocess.run(base + ["-ksp_cg_single_reduction"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0   # the polynomial preconditioner runs in the classical form only
     # --memory_profiling: the logging thread of src/mem.cpp (VSIZE / RSS in kB every 100 ms, here plus used HBM)
     out = subprocess.run([exe, "--problem_type", "poisson", "--ndofs", "2000000", "--memory_profiling", "-pc_type", "jacobi",
                           "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=300)
