@@ -168,6 +168,21 @@ def test_solver_edge_cases(ctx):
         assert it3 == 3 and ctx.cg_reason() == -3
         with pytest.raises(zzz.ZzzError, match="KSP_DIVERGED_ITS"):
             ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, max_it=3, single_reduction=sr, error_if_not_converged=True)
+    # the same limits with the polynomial preconditioner: max_it, divergence test, zero right-hand side, history
+    cheb = dict(pc=zzz.PC_CHEBYSHEV_JACOBI)
+    it3, _, _ = ctx.cg_solve(rtol=1e-14, max_it=3, **cheb)
+    assert it3 == 3 and ctx.cg_reason() == -3
+    with pytest.raises(zzz.ZzzError, match="KSP_DIVERGED_ITS"):
+        ctx.cg_solve(rtol=1e-14, max_it=3, error_if_not_converged=True, **cheb)
+    it_d, _, _ = ctx.cg_solve(rtol=1e-8, dtol=0.5, **cheb)
+    assert ctx.cg_reason() == -4 and 0 <= it_d < 100
+    it, rn, r0 = ctx.cg_solve(rtol=1e-8, **cheb)
+    hist = ctx.cg_history(it + 1)
+    assert 0 < it < 40 and ctx.cg_reason() == 2 and hist[0] == r0 and hist[-1] == rn and rn <= 1e-8 * r0
+    ctx.vec_upload(zzz.VEC_B, np.zeros_like(b))
+    it, rn, r0 = ctx.cg_solve(rtol=1e-8, **cheb)
+    assert it == 0 and rn == 0.0 and np.all(ctx.vec_download(zzz.VEC_U) == 0)
+    ctx.vec_upload(zzz.VEC_B, b)
     # argument errors surface as ZzzError, not crashes
     with pytest.raises(zzz.ZzzError):
         ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_JACOBI)
