@@ -456,11 +456,15 @@ def main():
             # of this node, which only a run on it can tell: time one solve of each combination on the
             # assembled warm-up system (untimed region), MAX over ranks, and keep the fastest for the timed steps.
             forms = (False,) if pc == zzz.PC_CHEBYSHEV_JACOBI else (True, False)
-            combos = [(sr, pm) for pm in ((True, False) if p2p else (False,)) for sr in forms]
+            # pm: 2 = scalars through the mailboxes AND the halo through the peer-memory window, 1 = scalars only (halo on
+            # the communicator's send / recv), 0 = both on the communicator
+            window = p2p and ctx.comm_p2p_halo(True)
+            combos = [(sr, pm) for pm in (((2, 1, 0) if window else (1, 0)) if p2p else (0,)) for sr in forms]
             tuning = {}
             for sr, pm in combos:
                 if p2p:
                     (ctx.comm_p2p_enable if pm else ctx.comm_p2p_disable)()
+                    ctx.comm_p2p_halo(pm == 2)
                 barrier()
                 ctx.sync()
                 t0 = time.perf_counter()
@@ -479,7 +483,8 @@ def main():
             single_reduction, use_pm = best
             if p2p:
                 (ctx.comm_p2p_enable if use_pm else ctx.comm_p2p_disable)()
-                p2p = use_pm
+                ctx.comm_p2p_halo(use_pm == 2)
+                p2p = bool(use_pm)
     if guard:
         guard.__exit__()
 
@@ -614,17 +619,20 @@ def main():
         if rank_info:
             out["config"]["ranks"] = rank_info
         if tuning:
+            tname = lambda sr, pm: (("single_reduction" if sr else "classical")  # noqa: E731
+                                    + {0: "+ncclAllReduce", 1: "+peer_memory", 2: "+peer_memory+peer_halo"}[int(pm)])
             out["config"]["cg_form_tuning_us_per_iteration"] = {
-                ("single_reduction" if sr else "classical") + ("+peer_memory" if pm else "+ncclAllReduce"):
-                (1e6 * v / max(iters, 1) if v != float("inf") else None) for (sr, pm), v in tuning.items()}
-            out["config"]["cg_form_tuning_s"] = {("single_reduction" if sr else "classical") + ("+peer_memory" if pm else "+ncclAllReduce"): v
-                                                 for (sr, pm), v in tuning.items()}
+                tname(sr, pm): (1e6 * v / max(iters, 1) if v != float("inf") else None) for (sr, pm), v in tuning.items()}
+            out["config"]["cg_form_tuning_s"] = {tname(sr, pm): v for (sr, pm), v in tuning.items()}
         if multi or a.force_comm:
             out["config"]["scalar_allreduce"] = ("peer-memory mailboxes over xGMI (one kernel: reduce + exchange)" if p2p
                                                  else "ncclAllReduce")
             # the combination the timed steps ran, and how it was chosen: --cg given = taken as asked, no tuning solves
             out["config"]["cg_form"] = {"form": "single_reduction" if single_reduction else "classical",
                                         "scalar_allreduce": "peer_memory" if p2p else "ncclAllReduce",
+                                        "halo": ("peer-memory window (device stores into the neighbour's memory)"
+                                                 if (rank_info and rank_info[0].get("halo_own_communicator") == 2)
+                                                 else "communicator send / recv"),
                                         "chosen_by": ("--cg " + a.cg) if a.cg != "auto" else
                                                      ("warm-up tuning (fastest of %d combinations)" % len(tuning) if tuning else "default")}
         out["config"]["feed"] = "host arrays uploaded (zzz_*_upload)" if P is not None else "generated on the device (zzz_cube_generate)"

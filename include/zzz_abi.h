@@ -337,7 +337,7 @@ int zzz_comm_load(void);
 const char* zzz_comm_library_path(void);
 /* What the multi-GPU path of this context does, for diagnostics (bench.py prints it per rank): info = {ranks,
  * rank, neighbours, bytes sent per forward scatter, bytes received, 1 = halo on its own communicator + stream
- * (ncclCommSplit), 1 = CG scalars through the peer-memory mailboxes, 1 = halo overlapped with the interior rows,
+ * (ncclCommSplit) / 2 = halo through peer memory (zzz_comm_p2p_halo), 1 = CG scalars through the peer-memory mailboxes, 1 = halo overlapped with the interior rows,
  * interior / boundary work items (groups of 256 rows or tiles) of the product, 1 = host-mediated local backend, mean exposed
  * halo wait per product of the last profiled solve in ns (main stream idle between its interior rows and the halo's arrival)}. */
 int zzz_comm_info(zzz_ctx* ctx, int64_t info[12]);
@@ -369,14 +369,23 @@ int zzz_comm_init_local(zzz_ctx* ctx, void* group, int rank);
  * communicator's own all-reduce stays in use (never an error).  The mailbox sums in rank order on
  * every rank (bit-identical everywhere); RCCL sums in its own order: the same iteration to round-off. */
 #define ZZZ_P2P_HANDLE_BYTES 128
-/* A communicator with no transport of its own: only the peer-memory all-reduce below works on it (no
- * halo).  For replicated runs and for exercising the mailbox transport between processes. */
+/* A communicator with no transport of its own: only the peer-memory all-reduce and halo below work on it.  For
+ * replicated runs and for exercising the peer-memory transport between processes. */
 int zzz_comm_init_peer_only(zzz_ctx* ctx, int nranks, int rank);
 int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle /* ZZZ_P2P_HANDLE_BYTES */);
 int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles /* nranks x ZZZ_P2P_HANDLE_BYTES */, int* enabled);
 int zzz_comm_p2p_disable(zzz_ctx* ctx);
 /* back on after zzz_comm_p2p_disable, only if attach had succeeded; every rank must make the same call */
 int zzz_comm_p2p_enable(zzz_ctx* ctx, int* enabled);
+/* The same allocation carries a halo window (ZZZ_P2P_HALO_MB, default 64): with the mailboxes enabled, the forward
+ * scatter of the product's input vector (common::Scatterer::scatter_fwd inside MatMult, src/poisson_problem.cpp:177;
+ * src/cgpoisson_problem.cpp:225-229) is then plain device stores into the NEIGHBOUR's window over xGMI plus an arrival
+ * tag, and a copy out of the own window on the receiving side -- no ncclSend / ncclRecv, no communicator in the solve
+ * loop at all (a peer-only communicator becomes a complete transport).  Plans that do not fit the window (more than 32
+ * neighbours, or a message beyond window / 2 / ranks) keep the communicator's send / recv.  on = 0 keeps the halo on
+ * the communicator while the all-reduces stay on the mailboxes (A/B; every rank must make the same call);
+ * *in_use = 1 when the next exchange goes through the window. */
+int zzz_comm_p2p_halo(zzz_ctx* ctx, int on, int* in_use);
 
 /* The forward scatter of common::Scatterer / IndexMap (src/cgpoisson_problem.cpp:187-190,
  * 225-229): for neighbour k, this rank sends x[send_idx[send_off[k]..send_off[k+1])] (owned

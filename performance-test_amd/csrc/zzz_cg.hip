@@ -619,9 +619,9 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     ZZZ_HIP(ctx, ctx->p_alt.alloc((size_t)ctx->nloc()));
   double* pbuf[2] = {ctx->p.p, fused ? ctx->p_alt.p : ctx->p.p};
 
-  ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->alpha_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->alpha_hist.reserve((size_t)max_it + 2));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
 
@@ -1113,9 +1113,9 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
   const int degree = o->pc_degree > 0 ? o->pc_degree : 3;
   const double ratio = o->pc_ratio > 1.0 ? o->pc_ratio : 60.0;
   ctx->last_solve_fused = false;
-  ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->alpha_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->alpha_hist.reserve((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->sr_s.alloc((size_t)ctx->nloc())); // Chebyshev direction d (ghost entries: the product gathers it)
   ZZZ_HIP(ctx, ctx->p_alt.alloc((size_t)ctx->nloc())); // Chebyshev residual g
   double *chd = ctx->sr_s.p, *chg = ctx->p_alt.p;
@@ -1148,9 +1148,9 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
     if (ritz > 0.0 && std::isfinite(ritz) && 1.1 * ritz < hi)
       hi = 1.1 * ritz;
     // the estimate ran through the classical loop: its state is this solve's to reset
-    ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
-    ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
-    ZZZ_HIP(ctx, ctx->alpha_hist.alloc((size_t)max_it + 2));
+    ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
+    ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
+    ZZZ_HIP(ctx, ctx->alpha_hist.reserve((size_t)max_it + 2));
     ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
     ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
     ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s));
@@ -1374,9 +1374,9 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   auto kern_sr_update = loop_exceeds_cache(ctx, 8) ? k_sr_update<true> : k_sr_update<false>;
   ctx->last_solve_fused = false;
 
-  ZZZ_HIP(ctx, ctx->beta_hist.alloc((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->dp_hist.alloc((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->dpi_hist.alloc((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dpi_hist.reserve((size_t)max_it + 2));
   ZZZ_HIP(ctx, ctx->sr_s.alloc((size_t)ctx->nloc()));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));

@@ -237,11 +237,23 @@ struct P2P
   double* tail_mem = nullptr;           // partial arrays + tickets of the folded all-reduce (zzz_tail.h)
   bool tail_on = false;                 // ZZZ_TAIL=1 when the mailbox was created (A/B variant, off by default)
   int64_t seq = 0;                      // round counter = tag; identical call sequence on every rank
+  // halo window (behind the mailbox in the same allocation, so the same IPC handle maps it): the forward scatter of
+  // the product's input vector as plain device stores into the NEIGHBOUR's memory over xGMI instead of ncclSend /
+  // ncclRecv.  Layout: 4 KiB of arrival tags [parity][sender rank] (int64 = exchange number), then
+  // [parity][sender rank] data regions of halo_stride doubles each.
+  size_t halo_off = 0;                  // doubles from the start of the box; 0 = no window
+  size_t halo_stride = 0;               // doubles per (parity, sender) region
+  bool halo_on = false;                 // in use (zzz_comm_p2p_halo; needs `enabled`)
+  bool inproc = false;                  // some peer is a context of THIS process on THIS GPU (validation on one GPU)
+  int64_t halo_seq = 0;                 // exchange counter: the same call sequence on every rank
+  zzz::DevBuf<int32_t> halo_ticket;     // arrival counter of the push kernel's workgroups
   bool enabled = false;
   bool verified = false;                // attach passed on every rank: may be switched on and off
 };
 constexpr long long P2P_TIMEOUT_TICKS = 300000000LL; // 3 s
 constexpr int P2P_SLOT = 4;                          // doubles per mailbox slot
+constexpr size_t P2P_HALO_HDR = 512;                 // doubles: the halo window's tag header (4 KiB)
+constexpr int P2P_HALO_MAX_NEIGH = 32;
 
 struct P2PHandle // ZZZ_P2P_HANDLE_BYTES
 {
@@ -513,6 +525,141 @@ int comm_allreduce_sum(zzz_ctx* ctx, double* dev, int n)
   return ZZZ_OK;
 }
 
+// ---- forward halo through peer memory ----------------------------------------------------------------------------
+struct HaloPlanDev
+{
+  int nneigh;
+  int rank[P2P_HALO_MAX_NEIGH];
+  long long soff[P2P_HALO_MAX_NEIGH + 1]; // scalar entries sent to neighbour k: [soff[k], soff[k+1])
+  long long roff[P2P_HALO_MAX_NEIGH + 1]; // ... received from neighbour k, relative to the ghost range
+};
+
+// Every owned entry a neighbour needs goes straight into that neighbour's window; the workgroup that finishes last
+// publishes the exchange number in each neighbour's tag (release at system scope behind everybody's stores).
+__global__ __launch_bounds__(256) void k_halo_push(const int* __restrict__ stop, const double* __restrict__ vec,
+                                                   const int32_t* __restrict__ send_idx, int bs, HaloPlanDev H,
+                                                   double* const* peers, size_t halo_off, size_t stride, int nranks, int me,
+                                                   long long seq, int* __restrict__ ticket)
+{
+  if (stop && *stop) // converged (the same verdict on every rank): the consumer skips its wait as well
+    return;
+  const size_t region = ((size_t)(seq & 1) * nranks + me) * stride;
+  const long long total = H.soff[H.nneigh];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+  {
+    int k = 0;
+    while (k + 1 < H.nneigh && i >= H.soff[k + 1])
+      ++k;
+    double* dst = peers[H.rank[k]] + halo_off + P2P_HALO_HDR + region + (i - H.soff[k]);
+    *dst = vec[(long long)send_idx[i / bs] * bs + i % bs];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (int)gridDim.x - 1)
+    {
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int k = 0; k < H.nneigh; ++k)
+        __hip_atomic_store(reinterpret_cast<long long*>(peers[H.rank[k]] + halo_off) + (size_t)(seq & 1) * nranks + me, seq,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// Waits (bounded) for the tags of all neighbours, then copies their regions of the own window behind the owned entries.
+__global__ __launch_bounds__(256) void k_halo_pull(const int* __restrict__ stop, double* __restrict__ ghost, HaloPlanDev H,
+                                                   const double* window, size_t stride, int nranks, long long seq,
+                                                   int* __restrict__ fail, long long timeout)
+{
+  if (stop && *stop)
+    return;
+  __shared__ int timed_out;
+  if (threadIdx.x == 0)
+    timed_out = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < H.nneigh)
+  {
+    const long long* tag = reinterpret_cast<const long long*>(window) + (size_t)(seq & 1) * nranks + H.rank[threadIdx.x];
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq)
+    {
+      if (wall_clock64() - t0 > timeout)
+      {
+        timed_out = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (timed_out)
+  {
+    if (threadIdx.x == 0)
+      *fail = 1;
+    return;
+  }
+  const long long total = H.roff[H.nneigh];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+  {
+    int k = 0;
+    while (k + 1 < H.nneigh && i >= H.roff[k + 1])
+      ++k;
+    const double* src = window + P2P_HALO_HDR + ((size_t)(seq & 1) * nranks + H.rank[k]) * stride + (i - H.roff[k]);
+    ghost[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// can this context's halo plan travel through the window?
+static bool halo_peer_usable(const zzz_ctx* ctx)
+{
+  if (!ctx->comm || !ctx->comm->p2p)
+    return false;
+  const P2P* P = ctx->comm->p2p;
+  if (!P->enabled || !P->halo_on || !P->halo_off || ctx->nneigh < 1 || ctx->nneigh > P2P_HALO_MAX_NEIGH)
+    return false;
+  for (int k = 0; k < ctx->nneigh; ++k)
+    if ((size_t)((ctx->send_off[(size_t)k + 1] - ctx->send_off[(size_t)k]) * ctx->bs) > P->halo_stride
+        || ctx->neigh_rank[(size_t)k] < 0 || ctx->neigh_rank[(size_t)k] >= P->nranks || ctx->neigh_rank[(size_t)k] == P->rank)
+      return false;
+  return true;
+}
+
+static int halo_peer(zzz_ctx* ctx, double* vec, hipStream_t st, const int* stop)
+{
+  P2P* P = ctx->comm->p2p;
+  HaloPlanDev H;
+  H.nneigh = ctx->nneigh;
+  H.soff[0] = H.roff[0] = 0;
+  for (int k = 0; k < ctx->nneigh; ++k)
+  {
+    H.rank[k] = ctx->neigh_rank[(size_t)k];
+    H.soff[k + 1] = ctx->send_off[(size_t)k + 1] * ctx->bs;
+    H.roff[k + 1] = H.roff[k] + ctx->recv_cnt[(size_t)k] * ctx->bs;
+  }
+  const long long seq = ++P->halo_seq;
+  const long long ns = H.soff[H.nneigh], nr = H.roff[H.nneigh];
+  int gp = (int)std::min<long long>((ns + 255) / 256, 64);
+  if (gp < 1)
+    gp = 1;
+  hipLaunchKernelGGL(k_halo_push, dim3((unsigned)gp), dim3(256), 0, st, stop, vec, ctx->send_idx.p, ctx->bs, H, P->peer_dev.p,
+                     P->halo_off, P->halo_stride, P->nranks, P->rank, seq, P->halo_ticket.p);
+  // Ranks that share a GPU inside one process (validation) also share its legacy default stream: a rank still in
+  // set-up (synchronous copies) would wait for this rank's waiting kernel, and that kernel for the other's push.  They
+  // therefore meet on the host first: every push is enqueued before any wait is.
+  if (P->inproc && ctx->comm->local)
+    ZZZ_LOCAL_WAIT(ctx, ctx->comm->local);
+  int gl = (int)std::min<long long>((nr + 255) / 256, 32);
+  if (gl < 1)
+    gl = 1;
+  hipLaunchKernelGGL(k_halo_pull, dim3((unsigned)gl), dim3(256), 0, st, stop, vec + ctx->n_owned * ctx->bs, H,
+                     P->box + P->halo_off, P->halo_stride, P->nranks, seq, P->fail.p, P2P_TIMEOUT_TICKS);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+
 static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st);
 
 int comm_halo_forward(zzz_ctx* ctx, double* vec) { return halo_on_stream(ctx, vec, ctx->stream); }
@@ -523,8 +670,15 @@ int comm_halo_begin(zzz_ctx* ctx, double* vec)
 {
   if (!ctx->comm || (ctx->nneigh == 0 && !ctx->comm->local))
     return ZZZ_OK;
-  if (ctx->comm->local || !ctx->comm->comm_halo) // host-synchronous backend / no second communicator:
-    return halo_on_stream(ctx, vec, ctx->stream); // nothing to overlap, same results
+  ctx->halo_pending = false;
+  const bool peer = halo_peer_usable(ctx);
+  // Ranks that are contexts of one process on one GPU share its few hardware queues: a waiting kernel on a second
+  // stream per rank could sit in front of the very kernel it waits for.  There (validation only) the exchange stays on
+  // the main stream, like the mailbox all-reduce.
+  if (peer && ctx->comm->p2p->inproc)
+    return halo_on_stream(ctx, vec, ctx->stream);
+  if (!peer && (ctx->comm->local || !ctx->comm->comm_halo)) // host-synchronous backend / no second communicator:
+    return halo_on_stream(ctx, vec, ctx->stream);           // nothing to overlap, same results
   if (!ctx->comm_stream)
   {
     int prio_lo = 0, prio_hi = 0;
@@ -539,13 +693,15 @@ int comm_halo_begin(zzz_ctx* ctx, double* vec)
   if (rc)
     return rc;
   ZZZ_HIP(ctx, hipEventRecord(ctx->ev_halo_done, ctx->comm_stream));
+  ctx->halo_pending = true;
   return ZZZ_OK;
 }
 
 int comm_halo_end(zzz_ctx* ctx)
 {
-  if (!ctx->comm || ctx->comm->local || !ctx->comm->comm_halo || ctx->nneigh == 0 || !ctx->comm_stream)
+  if (!ctx->comm || !ctx->halo_pending || !ctx->comm_stream)
     return ZZZ_OK;
+  ctx->halo_pending = false;
   // timed iteration: how long the main stream sits between the interior rows and the halo's arrival
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof_now && ctx->prof_halo_n < 256)
@@ -571,6 +727,8 @@ static int halo_on_stream(zzz_ctx* ctx, double* vec, hipStream_t st)
 {
   if (!ctx->comm || (ctx->nneigh == 0 && !ctx->comm->local))
     return ZZZ_OK;
+  if (halo_peer_usable(ctx))
+    return halo_peer(ctx, vec, st, nullptr);
   const int bs = ctx->bs;
   const int64_t nsend = ctx->send_off[ctx->nneigh];
   // pack only what is not already contiguous in the vector (z-slab partitions send contiguous ranges)
@@ -815,6 +973,8 @@ int zzz_comm_info(zzz_ctx* ctx, int64_t info[12])
   info[3] = (ctx->nneigh ? ctx->send_off[(size_t)ctx->nneigh] : 0) * ctx->bs * 8; // bytes sent per forward scatter
   info[4] = nrecv * ctx->bs * 8;
   info[5] = (ctx->comm && ctx->comm->comm_halo) ? 1 : 0; // second communicator (ncclCommSplit): halo on its own stream
+  if (halo_peer_usable(ctx))
+    info[5] = 2; // the halo travels through peer memory (device stores into the neighbour's window), no communicator
   info[6] = comm_p2p_enabled(ctx) ? 1 : 0;                // CG scalars through the peer-memory mailboxes
   const bool stream_split = sellp_active(ctx) && ctx->have_group_split;
   info[7] = (ctx->comm && ctx->overlap && (stream_split || ctx->have_tile_split)) ? 1 : 0; // halo overlapped with interior rows
@@ -907,16 +1067,44 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
   P->rank = ctx->comm->rank;
   if (const char* e = getenv("ZZZ_TAIL"))
     P->tail_on = atoi(e) == 1;
-  const size_t bytes = sizeof(double) * 2 * (size_t)P->nranks * P2P_SLOT;
+  size_t bytes = sizeof(double) * 2 * (size_t)P->nranks * P2P_SLOT;
+  bytes = (bytes + 4095) / 4096 * 4096;
+  // the halo window behind the mailbox (ZZZ_P2P_HALO_MB, default 64; 0 = none: halo through the communicator)
+  size_t halo_mb = 64;
+  if (const char* hm = getenv("ZZZ_P2P_HALO_MB"))
+    halo_mb = (size_t)std::max(0, atoi(hm));
+  size_t halo_bytes = halo_mb << 20;
+  if ((size_t)P->nranks * 16 > P2P_HALO_HDR * sizeof(double))
+    halo_bytes = 0; // more ranks than the tag header holds
+  if (halo_bytes)
+  {
+    P->halo_off = bytes / sizeof(double);
+    P->halo_stride = (halo_bytes / sizeof(double) - P2P_HALO_HDR) / 2 / (size_t)P->nranks;
+  }
   // uncached: remote stores must be visible to the local poll without a kernel boundary
-  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes < 4096 ? 4096 : bytes, hipDeviceMallocUncached);
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes + halo_bytes, hipDeviceMallocUncached);
   if (e != hipSuccess)
   {
     (void)hipGetLastError();
-    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes < 4096 ? 4096 : bytes, hipDeviceMallocFinegrained);
+    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes + halo_bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess && halo_bytes)
+  {
+    (void)hipGetLastError();
+    halo_bytes = 0; // the mailbox alone
+    P->halo_off = P->halo_stride = 0;
+    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&P->box), bytes, hipDeviceMallocUncached);
   }
   if (e == hipSuccess)
-    e = hipMemset(P->box, 0xff, bytes < 4096 ? 4096 : bytes); // tags = -1: no round has that number
+    e = hipMemset(P->box, 0xff, bytes + (halo_bytes ? P2P_HALO_HDR * sizeof(double) : 0)); // tags = -1: no round has that number
+  if (e == hipSuccess && halo_bytes && (P->halo_ticket.alloc(4) != hipSuccess || hipMemset(P->halo_ticket.p, 0, 16) != hipSuccess))
+  {
+    (void)hipGetLastError();
+    P->halo_off = P->halo_stride = 0;
+  }
+  P->halo_on = P->halo_off != 0;
+  if (const char* hk = getenv("ZZZ_P2P_HALO")) // A/B knob: 0 keeps the halo on the communicator
+    P->halo_on = P->halo_on && atoi(hk) != 0;
   if (e == hipSuccess)
   {
     // partial arrays + tickets of the folded all-reduce (producers on all eight XCDs, one reader)
@@ -994,6 +1182,8 @@ int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles, int* enabled)
         }
       }
       P->peer[r] = H[r].raw;
+      if (H[r].device == ctx->device)
+        P->inproc = true;
     }
     else if (H[r].ok == 1)
     {
@@ -1082,6 +1272,17 @@ int zzz_comm_p2p_enable(zzz_ctx* ctx, int* enabled)
     ctx->comm->p2p->enabled = true;
   if (enabled)
     *enabled = comm_p2p_enabled(ctx) ? 1 : 0;
+  return ZZZ_OK;
+}
+
+int zzz_comm_p2p_halo(zzz_ctx* ctx, int on, int* in_use)
+{
+  if (!ctx)
+    return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
+  if (ctx->comm && ctx->comm->p2p)
+    ctx->comm->p2p->halo_on = on != 0 && ctx->comm->p2p->halo_off != 0;
+  if (in_use)
+    *in_use = halo_peer_usable(ctx) ? 1 : 0;
   return ZZZ_OK;
 }
 

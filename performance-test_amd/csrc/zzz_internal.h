@@ -48,6 +48,18 @@ struct DevBuf
   // Contents are NOT preserved.  An existing allocation is reused when it is large enough (and not
   // more than twice too large): hipFree/hipMalloc of GB-sized buffers cost milliseconds each and a
   // re-assembly of the same problem asks for the same sizes again.
+  // Grows only: an existing allocation of at least `count` elements is kept whatever its size (the solvers' history
+  // arrays: a short estimate solve inside a long one must not free and re-allocate them -- hipFree waits for the
+  // whole device, other contexts' kernels included).
+  hipError_t reserve(size_t count)
+  {
+    if (p && cap >= count)
+    {
+      n = count ? count : 1;
+      return hipSuccess;
+    }
+    return alloc(count);
+  }
   hipError_t alloc(size_t count)
   {
     if (count == 0)
@@ -244,6 +256,7 @@ struct zzz_ctx
   std::vector<double> history;
   int last_iters = 0;
   int last_reason = 0; // KSPConvergedReason of the last solve (zzz_cg_info)
+  bool halo_pending = false; // comm_halo_begin put an exchange on the comm stream: comm_halo_end waits for it
   double last_pc_bound = 0.0; // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound the last solve used
   bool last_solve_fused = false; // the last solve ran the fused product + direction kernel
 

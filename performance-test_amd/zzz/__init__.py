@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
     "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_cg_info", "zzz_internal_order_download", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
-    "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable",
+    "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
 HOST_SYMBOLS = [
     "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_create_native", "zzzh_part_destroy", "zzzh_part_global_verts",
@@ -592,6 +592,13 @@ class Context:
         en = C.c_int(0)
         self._ck(self.L.zzz_comm_p2p_enable(self.h, C.byref(en)))
         return bool(en.value)
+
+    def comm_p2p_halo(self, on=True):
+        """halo through the peer-memory window (True) or the communicator's send / recv (False); returns whether the
+        next exchange goes through the window"""
+        used = C.c_int(0)
+        self._ck(self.L.zzz_comm_p2p_halo(self.h, 1 if on else 0, C.byref(used)))
+        return bool(used.value)
 
     def upload_halo(self, P):
         nn = len(P.neigh)

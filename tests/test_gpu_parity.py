@@ -1339,6 +1339,68 @@ def test_peer_memory_allreduce_between_processes(single_reduction):
         assert nrm == pytest.approx(np.sqrt(2.0) * nrm0, rel=1e-14)
 
 
+@pytest.mark.parametrize("problem,order,dims,n", [("poisson", 1, (10, 9, 12), 2), ("elasticity", 1, (5, 5, 8), 2),
+                                                  ("poisson", 2, (5, 4, 9), 3)])
+def test_peer_memory_halo_between_processes(problem, order, dims, n):
+    """The forward halo through peer memory across PROCESS boundaries: n processes on this GPU, one z-slab each, joined
+    by a communicator with no transport of its own -- every ghost value of every product arrives as a device store into
+    a window mapped with hipIpcOpenMemHandle, every scalar through the mailboxes.  The partitioned runs must reproduce
+    the single-rank product (round-off) and solves (iterations +-1, solution 1e-9) in all three CG forms."""
+    import multiprocessing as mp
+
+    import p2p_worker
+
+    G = zzz.Part(problem, order, *dims)
+    ref = {}
+    with zzz.Context(0) as c0:
+        c0.upload_part(G)
+        c0.pattern_build()
+        c0.assemble_matrix(G.form)
+        c0.assemble_vector(G.form)
+        y0 = c0.spmv(np.sin(0.37 * np.arange(G.n_owned * G.bs)))
+        for name, kw in (("jacobi", dict(pc=zzz.PC_JACOBI)), ("sr", dict(pc=zzz.PC_JACOBI, single_reduction=True)),
+                         ("cheb", dict(pc=zzz.PC_CHEBYSHEV_JACOBI))):
+            it, rn, r0 = c0.cg_solve(rtol=1e-9, **kw)
+            ref[name] = (it, c0.vec_download(zzz.VEC_U), c0.vec_norm(zzz.VEC_U))
+    mpx = mp.get_context("spawn")
+    pipes = [mpx.Pipe() for _ in range(n)]
+    procs = [mpx.Process(target=p2p_worker.run_partition, args=(r, n, pipes[r][1], problem, order, dims)) for r in range(n)]
+    for p in procs:
+        p.start()
+    try:
+        handles = []
+        for r in range(n):
+            assert pipes[r][0].poll(120), "worker did not export a handle"
+            h = pipes[r][0].recv()
+            assert isinstance(h, bytes) and len(h) == zzz.P2P_HANDLE_BYTES, h
+            handles.append(h)
+        for r in range(n):
+            pipes[r][0].send(b"".join(handles))
+        out = []
+        for r in range(n):
+            assert pipes[r][0].poll(240), "worker hung"
+            out.append(pipes[r][0].recv())
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(o[0] == "ok" for o in out), out
+    res = sorted((o[1] for o in out), key=lambda d: d["offset"])
+    for d in res:
+        assert d["info"]["halo_own_communicator"] == 2 and d["info"]["peer_memory_allreduce"] == 1  # 2: through the window
+        assert d["info"]["neighbours"] >= 1 and d["info"]["halo_bytes_sent"] > 0 and not d["info"]["local_backend"]
+        assert "no transport" in d["no_transport"]
+    y = np.concatenate([d["y"] for d in res])
+    assert np.abs(y - y0).max() <= 1e-13 * np.abs(y0).max()
+    for name in ("jacobi", "sr", "cheb"):
+        it0, u0, n0 = ref[name]
+        assert {d[name][0] for d in res} <= {it0 - 1, it0, it0 + 1} and len({d[name][0] for d in res}) == 1, name
+        u = np.concatenate([d[name][2] for d in res])
+        assert np.linalg.norm(u - u0) <= 1e-9 * np.linalg.norm(u0), name
+        assert all(d[name][1] <= 1e-9 and abs(d[name][3] - n0) <= 1e-9 * n0 for d in res), name
+
+
 def test_full_size_baseline_config_properties():
     """BASELINE configs[1] at its FULL size (216x206x222 sub-cubes, 10 016 937 dofs, 59 268 672 cells,
     149 140 873 nonzeros), fed by the device generator: size-independent properties only -- sizes of
