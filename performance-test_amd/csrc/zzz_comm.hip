@@ -493,8 +493,8 @@ int comm_p2p_check(zzz_ctx* ctx)
   if (f)
   {
     ZZZ_HIP(ctx, hipMemsetAsync(ctx->comm->p2p->fail.p, 0, sizeof(int32_t), ctx->stream));
-    return fail(ctx, ZZZ_ERR_RCCL, "peer-memory all-reduce timed out (rank %d of %d)", ctx->comm->p2p->rank,
-                ctx->comm->p2p->nranks);
+    return fail(ctx, ZZZ_ERR_RCCL, "peer-memory all-reduce timed out (rank %d of %d; all-reduce mailbox or halo window)",
+                ctx->comm->p2p->rank, ctx->comm->p2p->nranks);
   }
   return ZZZ_OK;
 }

@@ -617,7 +617,8 @@ void solve(int argc, char** argv)
               << " norm type for convergence test\n"
               << (o.ksp_cg_single_reduction ? "  using single-reduction variant\n" : "") << "PC Object: type: " << o.pc_type
               << "\n  linear system matrix: type=csr (fp64 values, int32 indices) on " << S.nranks << " MI355X\n"
-              << (S.nranks > 1 ? (S.p2p_enabled[0] ? "  scalar all-reduces: peer-memory mailboxes\n" : "  scalar all-reduces: communicator\n")
+              << (S.nranks > 1 ? (S.p2p_enabled[0] ? "  scalar all-reduces: peer-memory mailboxes; halo: peer-memory window where the plan fits\n"
+                                                    : "  scalar all-reduces and halo: communicator\n")
                                : "");
   g_timers.list(); // dolfinx::list_timings, src/main.cpp:226
   // src/main.cpp:229-234
