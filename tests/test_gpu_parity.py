@@ -724,6 +724,64 @@ def test_coordinate_bin_order_on_a_mesh_that_is_no_lattice(ctx, problem, order):
     test_unsorted_cells_and_foreign_numbering(ctx, problem, order, renumber="2")
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_knob_combinations_keep_results(seed):
+    """The environment knobs select among code paths that are each tested alone; here RANDOM
+    COMBINATIONS of them run three small problems end to end: CSR indices and values identical to the default build's
+    (bit for bit: no knob may change what is assembled), the product within round-off of it (knobs that regroup row sums
+    are in the draw), Jacobi and Chebyshev-Jacobi solves with the default's iteration count +-2 and solution to 1e-7."""
+    rng = np.random.default_rng(1000 + seed)
+    knobs = {"ZZZ_SPMV_VARIANT": ["1", "2", "3", "8", "9"], "ZZZ_SELLP": ["0", "2", "3"], "ZZZ_SELLP_DROP": ["0"],
+             "ZZZ_SELLP_AFFINE": ["0"], "ZZZ_SELLP_PERIODIC": ["0"], "ZZZ_SELLP_ALIGN": ["0"], "ZZZ_SELLP_SYNC": ["1"],
+             "ZZZ_CG_FUSED": ["2"], "ZZZ_SPMV_TILE": ["4096"], "ZZZ_SPMV_LPR": ["1", "2", "4"], "ZZZ_COLS16": ["0", "11", "13"],
+             "ZZZ_PATTERN": ["host"], "ZZZ_PATTERN_WAVE": ["1"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
+             "ZZZ_ADJ_SORT": ["1"], "ZZZ_ASM_SEARCH": ["1"], "ZZZ_ASM_NO_COMPACT": ["1"], "ZZZ_ASM_LPR": ["4", "8"],
+             "ZZZ_VGRID_PER": ["2", "8"]}
+    names = sorted(knobs)
+    chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
+    problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4))]
+
+    def run_all():
+        out = []
+        for problem, order, dims in problems:
+            G = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(G)
+                c.pattern_build()
+                c.assemble_matrix(G.form)
+                c.assemble_vector(G.form)
+                rp, cl, v = c.csr_download()
+                x = np.cos(0.61 * np.arange(G.n_owned * G.bs))
+                y = c.spmv(x)
+                itj, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                uj = c.vec_download(zzz.VEC_U)
+                itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9)
+                uc = c.vec_download(zzz.VEC_U)
+                out.append((rp, cl, v, c.vec_download(zzz.VEC_B), y, itj, uj, itc, uc))
+        return out
+
+    saved = {k: os.environ.get(k) for k in names}
+    try:
+        for k in names:
+            os.environ.pop(k, None)
+        ref = run_all()
+        os.environ.update(chosen)
+        got = run_all()
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    for (rp0, cl0, v0, b0, y0, itj0, uj0, itc0, uc0), (rp, cl, v, b, y, itj, uj, itc, uc) in zip(ref, got):
+        assert np.array_equal(rp, rp0) and np.array_equal(cl, cl0), chosen
+        assert np.array_equal(v, v0) and np.array_equal(b, b0), chosen
+        assert np.abs(y - y0).max() <= 1e-13 * np.abs(y0).max(), chosen
+        assert abs(itj - itj0) <= 2 and abs(itc - itc0) <= 2, (chosen, itj, itj0, itc, itc0)
+        assert np.linalg.norm(uj - uj0) <= 1e-7 * np.linalg.norm(uj0), chosen
+        assert np.linalg.norm(uc - uc0) <= 1e-7 * np.linalg.norm(uc0), chosen
+
+
 def test_size_limits_are_errors_not_crashes():
     """Maximum sizes: local indices are int32; a partition beyond that range is refused up front
     (before anything is allocated) with ZZZ_ERR_LIMIT and a message that says what to do."""
