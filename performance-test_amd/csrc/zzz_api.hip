@@ -743,11 +743,11 @@ int zzz_spmv(zzz_ctx* ctx, const double* x, double* y)
     ZZZ_HIP(ctx, hipMemcpyAsync(xin.data(), ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     to_caller(ctx, xin.data(), y, true);
-    return ZZZ_OK;
+    return ctx->comm ? comm_p2p_check(ctx) : ZZZ_OK; // a ghost value that never arrived through the peer-memory window
   }
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZZZ_OK;
+  return ctx->comm ? comm_p2p_check(ctx) : ZZZ_OK;
 }
 
 int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
@@ -813,11 +813,11 @@ int zzz_action(zzz_ctx* ctx, const double* x, double* y)
     ZZZ_HIP(ctx, hipMemcpyAsync(xin.data(), ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     to_caller(ctx, xin.data(), y, true);
-    return ZZZ_OK;
+    return ctx->comm ? comm_p2p_check(ctx) : ZZZ_OK;
   }
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZZZ_OK;
+  return ctx->comm ? comm_p2p_check(ctx) : ZZZ_OK;
 }
 
 int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)

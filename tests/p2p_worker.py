@@ -35,7 +35,7 @@ def run(rank, nranks, conn, single_reduction):
         conn.send(("error", repr(e)))
 
 
-def run_partition(rank, nranks, conn, problem, order, dims):
+def run_partition(rank, nranks, conn, problem, order, dims, desert=False):
     """Worker of test_peer_memory_halo_between_processes: one rank = one PROCESS, all on GPU 0, each with its z-slab of
     one partitioned problem and a communicator that has NO transport but the peer memory (zzz_comm_init_peer_only):
     the forward halo of every product travels as device stores into the neighbour's window (mapped here through
@@ -60,6 +60,21 @@ def run_partition(rank, nranks, conn, problem, order, dims):
             c.assemble_matrix(P.form)
             c.assemble_vector(P.form)
             info = c.comm_info()
+            if desert:
+                # rank 1 leaves before the first exchange: rank 0 must get an error within the bound of its wait
+                if rank == 1:
+                    conn.send(("ok", {"deserted": True}))
+                    return
+                import time
+
+                t0 = time.perf_counter()
+                try:
+                    c.spmv(np.ones(P.n_owned * P.bs))
+                    verdict = "no error"
+                except zzz.ZzzError as e:
+                    verdict = repr(e)
+                conn.send(("ok", {"deserted": False, "verdict": verdict, "seconds": time.perf_counter() - t0}))
+                return
             lo, hi = P.own_offset * P.bs, (P.own_offset + P.n_owned) * P.bs
             x = np.sin(0.37 * np.arange(lo, hi))           # a known global vector: halo + product
             y = c.spmv(x)

@@ -1459,6 +1459,37 @@ def test_peer_memory_halo_between_processes(problem, order, dims, n):
         assert all(d[name][1] <= 1e-9 and abs(d[name][3] - n0) <= 1e-9 * n0 for d in res), name
 
 
+def test_peer_memory_halo_neighbour_gone():
+    """A neighbour that never sends: the waiting kernel of the peer-memory halo gives up after its bound (3 s) and the call
+    returns an error -- never a hang."""
+    import multiprocessing as mp
+
+    import p2p_worker
+
+    mpx = mp.get_context("spawn")
+    n = 2
+    pipes = [mpx.Pipe() for _ in range(n)]
+    procs = [mpx.Process(target=p2p_worker.run_partition, args=(r, n, pipes[r][1], "poisson", 1, (6, 5, 8), True)) for r in range(n)]
+    for p in procs:
+        p.start()
+    try:
+        handles = [pipes[r][0].recv() if pipes[r][0].poll(120) else None for r in range(n)]
+        assert all(isinstance(h, bytes) for h in handles)
+        for r in range(n):
+            pipes[r][0].send(b"".join(handles))
+        out = []
+        for r in range(n):
+            assert pipes[r][0].poll(120), "worker hung"
+            out.append(pipes[r][0].recv())
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert out[1] == ("ok", {"deserted": True})
+    assert out[0][0] == "ok" and "timed out" in out[0][1]["verdict"] and 2.0 < out[0][1]["seconds"] < 30.0, out[0]
+
+
 def test_full_size_baseline_config_properties():
     """BASELINE configs[1] at its FULL size (216x206x222 sub-cubes, 10 016 937 dofs, 59 268 672 cells,
     149 140 873 nonzeros), fed by the device generator: size-independent properties only -- sizes of
