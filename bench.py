@@ -403,8 +403,6 @@ def main():
     pc = {"jacobi": zzz.PC_JACOBI, "none": zzz.PC_NONE, "chebyshev_jacobi": zzz.PC_CHEBYSHEV_JACOBI}[a.pc]
     pc_kw = dict(pc_degree=a.pc_degree, pc_ratio=a.pc_ratio, pc_esteig_its=a.pc_esteig) if pc == zzz.PC_CHEBYSHEV_JACOBI else {}
     single_reduction = a.cg == "single_reduction" or (a.cg == "auto" and (multi or a.force_comm))
-    if pc == zzz.PC_CHEBYSHEV_JACOBI:
-        single_reduction = False  # the polynomial preconditioner runs in the classical KSPCG form
 
     def step(profile=False):
         t = {}
@@ -455,7 +453,7 @@ def main():
             # N > 1: which CG form and which all-reduce transport are faster depends on the all-reduce latency
             # of this node, which only a run on it can tell: time one solve of each combination on the
             # assembled warm-up system (untimed region), MAX over ranks, and keep the fastest for the timed steps.
-            forms = (False,) if pc == zzz.PC_CHEBYSHEV_JACOBI else (True, False)
+            forms = (True, False)
             # pm: 2 = scalars through the mailboxes AND the halo through the peer-memory window, 1 = scalars only (halo on
             # the communicator's send / recv), 0 = both on the communicator
             window = p2p and ctx.comm_p2p_halo(True)
@@ -658,11 +656,13 @@ def main():
                     print(json.dumps(out))
 
             with deadline(600, "Chebyshev-Jacobi solve beside the measurement", last_words=line_without_it):
-                ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
+                ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000,
+                             single_reduction=single_reduction)
                 barrier()
                 ctx.sync()
                 t0 = time.perf_counter()
-                ita, rna, r0a = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000)
+                ita, rna, r0a = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=a.rtol, max_it=10000,
+                                             single_reduction=single_reduction)
                 ctx.sync()
                 dt = time.perf_counter() - t0
                 if dist is not None:
@@ -671,7 +671,8 @@ def main():
                     dt = float(tt[0])
                 alt_pc = {"pc_type": "chebyshev_jacobi (degree 3, ratio 60: the library's defaults)", "ZZZ Solve ms": dt * 1e3,
                           "krylov_iterations": ita, "relative_residual": rna / r0a if r0a else 0.0,
-                          "products_per_iteration": 3, "allreduces_per_iteration": 2,
+                          "products_per_iteration": 3, "allreduces_per_iteration": 1 if single_reduction else 2,
+                          "cg_form": "single_reduction" if single_reduction else "classical",
                           "jacobi ZZZ Solve ms": float(np.mean([p["solve"] for p in phases])) * 1e3,
                           "note": "one solve of the timed steps' system, outside the timed region; not part of value"}
         except zzz.ZzzError as e:

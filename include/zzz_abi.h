@@ -83,7 +83,7 @@ enum
    * preconditioner" of README.md:61-62,108-110 that needs only the product and no reduction inside its application:
    * fewer CG iterations, i.e. fewer all-reduces per solve, for more products -- for multi-GPU runs.  Spectrum
    * bounds [hi / pc_ratio, hi] with hi = min(Gershgorin's bound of D^-1 A, 1.1 x a Lanczos estimate: pc_esteig_its).
-   * ZZZ_CG_PETSC + ZZZ_OP_CSR only. */
+   * ZZZ_CG_PETSC + ZZZ_OP_CSR only (classical or single-reduction form). */
   ZZZ_PC_CHEBYSHEV_JACOBI = 2
 };
 enum

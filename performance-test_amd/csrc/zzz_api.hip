@@ -837,8 +837,8 @@ int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rno
     return fail(ctx, ZZZ_ERR_ARG, "unsupported preconditioner %d (none, jacobi, chebyshev-jacobi)", o->pc);
   if (o->pc != ZZZ_PC_NONE && o->op != ZZZ_OP_CSR)
     return fail(ctx, ZZZ_ERR_ARG, "Jacobi needs the assembled operator");
-  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI && (o->variant != ZZZ_CG_PETSC || o->single_reduction || o->pc_degree < 0 || o->pc_degree > 64 || o->pc_esteig_its > 64))
-    return fail(ctx, ZZZ_ERR_ARG, "the Chebyshev-Jacobi preconditioner applies to the classical KSPCG form, degree 1..64");
+  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI && (o->variant != ZZZ_CG_PETSC || o->pc_degree < 0 || o->pc_degree > 64 || o->pc_esteig_its > 64))
+    return fail(ctx, ZZZ_ERR_ARG, "the Chebyshev-Jacobi preconditioner applies to KSPCG (either form), degree 1..64, estimate <= 64 steps");
   if (o->norm < 0 || o->norm > 2)
     return fail(ctx, ZZZ_ERR_ARG, "unknown norm type %d", o->norm);
   if (o->single_reduction && (o->variant != ZZZ_CG_PETSC || o->op != ZZZ_OP_CSR))

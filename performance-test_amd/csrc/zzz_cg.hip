@@ -320,14 +320,17 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
 //   p = z + b p;  w = s + b w  (= A p by recurrence);  x += a p;  r -= a w;  z = D^-1 r
 // so a whole iteration has ONE reduction point (after the SpMV) instead of two.
 // pa/pb/pc: partials (or the single all-reduced values) of <r,z>, the test norm^2 and <z,s>.
-template <bool NT>
+// CHEB (Chebyshev-Jacobi preconditioner, cg_solve_single_reduction): z = D^-1 r becomes the polynomial's first term --
+// g = D^-1 r, d = g / theta, z = d (k_cheb_xr's tail) -- and its further terms follow as product epilogues.
+template <bool NT, bool CHEB = false>
 __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, double* __restrict__ beta_hist,
                                                   double* __restrict__ dpi_hist, double* __restrict__ dp_hist, int it,
                                                   CgParams P, const double* __restrict__ pa, const double* __restrict__ pb,
                                                   const double* __restrict__ pc, int np, const double* __restrict__ dinv,
                                                   const double* __restrict__ s, double* __restrict__ z, double* __restrict__ p,
                                                   double* __restrict__ w, double* __restrict__ x, double* __restrict__ r,
-                                                  int64_t n, int scalars_only)
+                                                  int64_t n, int scalars_only, double theta = 0.0, double* __restrict__ chg = nullptr,
+                                                  double* __restrict__ chd = nullptr)
 {
   // first entries requested before the scalar prologue (see k_update_p): seven 16-B loads in flight per thread while
   // the workgroup walks the flag, the three partial sums and the convergence logic
@@ -417,7 +420,15 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     x[i] = a * pn + x[i];
     const double ri = -a * wn + r[i];
     r[i] = ri;
-    z[i] = dinv[i] * ri;
+    const double zi = dinv[i] * ri;
+    if (CHEB)
+    {
+      chg[i] = zi;
+      chd[i] = zi / theta;
+      z[i] = zi / theta;
+    }
+    else
+      z[i] = zi;
   };
   for (int64_t i = i0; i < n2; i += stride)
   {
@@ -452,7 +463,17 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     vstore<NT>(wn, w2 + i);
     vstore<NT>(xi, x2 + i);
     vstore<NT>(ri, r2 + i);
-    z2[i] = zn;
+    if (CHEB)
+    {
+      dbl2 dn;
+      dn.x = zn.x / theta;
+      dn.y = zn.y / theta;
+      reinterpret_cast<dbl2*>(chg)[i] = zn;
+      reinterpret_cast<dbl2*>(chd)[i] = dn;
+      z2[i] = dn;
+    }
+    else
+      z2[i] = zn;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
     one(n - 1);
@@ -590,7 +611,7 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
 int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
 {
   ctx->last_pc_bound = 0.0;
-  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI)
+  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI && !o->single_reduction)
     return cg_solve_chebyshev(ctx, o, iters, rnorm);
   if (o->single_reduction)
     return cg_solve_single_reduction(ctx, o, iters, rnorm);
@@ -1101,28 +1122,26 @@ static int chebyshev_esteig(zzz_ctx* ctx, const zzz_solver_opts* o, int its, dou
   return ZZZ_OK;
 }
 
-static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
+// What both forms of the Chebyshev-Jacobi solve share: the polynomial's constants, its work vectors, the choice between
+// terms as product epilogues and terms as launches of their own.
+struct ChebPlan
+{
+  int degree = 3;
+  double hi = 0.0, theta = 0.0, delta = 0.0, sigma = 0.0;
+  double *g = nullptr, *d = nullptr, *d2 = nullptr; // residual of the polynomial's recurrence; its direction, two buffers
+  bool fused = false, split = false;
+};
+
+// Spectrum bound (Gershgorin, tightened by the Lanczos estimate), constants, buffers.  Runs the estimate's short Jacobi
+// solve through the classical loop: call it BEFORE the caller initialises its own solve.
+static int chebyshev_setup(zzz_ctx* ctx, const zzz_solver_opts* o, ChebPlan& C)
 {
   const int64_t n = ctx->n_owned * ctx->bs;
-  const int max_it = o->max_it;
-  // the scalar logic is KSPCG's with a preconditioner: k_update_p / k_update_xr take pc = Jacobi semantics for alpha, beta
-  CgParams P{o->variant, ZZZ_PC_JACOBI, o->norm, o->rtol, o->atol, o->dtol > 0.0 ? o->dtol : 1.0e4};
   const bool multi = ctx->comm != nullptr;
   const int g = vgrid(n);
   hipStream_t s = ctx->stream;
-  const int degree = o->pc_degree > 0 ? o->pc_degree : 3;
+  C.degree = o->pc_degree > 0 ? o->pc_degree : 3;
   const double ratio = o->pc_ratio > 1.0 ? o->pc_ratio : 60.0;
-  ctx->last_solve_fused = false;
-  ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->alpha_hist.reserve((size_t)max_it + 2));
-  ZZZ_HIP(ctx, ctx->sr_s.alloc((size_t)ctx->nloc())); // Chebyshev direction d (ghost entries: the product gathers it)
-  ZZZ_HIP(ctx, ctx->p_alt.alloc((size_t)ctx->nloc())); // Chebyshev residual g
-  double *chd = ctx->sr_s.p, *chg = ctx->p_alt.p;
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
-  ZZZ_HIP(ctx, hipMemsetAsync(chd, 0, sizeof(double) * (size_t)ctx->nloc(), s));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
   hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n, 1);
   // spectrum bound: Gershgorin's for D^-1 A, maximum over the ranks
   hipLaunchKernelGGL(k_row_abs_max, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->vals.p, ctx->dinv.p, n, ctx->part_b.p);
@@ -1147,17 +1166,120 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
       return rc;
     if (ritz > 0.0 && std::isfinite(ritz) && 1.1 * ritz < hi)
       hi = 1.1 * ritz;
-    // the estimate ran through the classical loop: its state is this solve's to reset
-    ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
-    ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
-    ZZZ_HIP(ctx, ctx->alpha_hist.reserve((size_t)max_it + 2));
-    ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
-    ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
-    ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s));
-    hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n, 1);
   }
   const double lo = hi / ratio;
-  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+  C.hi = hi;
+  C.theta = 0.5 * (hi + lo);
+  C.delta = 0.5 * (hi - lo);
+  C.sigma = C.theta / C.delta;
+  // On the operator stream a term is the EPILOGUE of its product (ChebEpi, zzz_sellp.hip): w = A d never travels through
+  // memory and the term costs no launch of its own; d then alternates between two buffers (other lanes still gather the
+  // old one).  A/B knob ZZZ_CHEB_FUSED=0: product and k_cheb_step as two launches (the tile kernel's form) -- same bits.
+  C.fused = sellp_active(ctx);
+  if (const char* e = getenv("ZZZ_CHEB_FUSED"))
+    C.fused = C.fused && atoi(e) != 0;
+  C.split = multi && ctx->overlap && ctx->have_tile_split;
+  if (C.split && !ctx->have_group_split)
+    C.fused = false;
+  ZZZ_HIP(ctx, ctx->cheb_d.alloc((size_t)ctx->nloc())); // ghost entries: the product gathers it
+  ZZZ_HIP(ctx, ctx->cheb_d2.alloc((size_t)ctx->nloc()));
+  ZZZ_HIP(ctx, ctx->cheb_g.alloc((size_t)ctx->nloc()));
+  C.d = ctx->cheb_d.p;
+  C.d2 = ctx->cheb_d2.p;
+  C.g = ctx->cheb_g.p;
+  ZZZ_HIP(ctx, hipMemsetAsync(C.d, 0, sizeof(double) * (size_t)ctx->nloc(), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(C.d2, 0, sizeof(double) * (size_t)ctx->nloc(), s));
+  return ZZZ_OK;
+}
+
+// The terms after the first of z = p_k(D^-1 A) D^-1 r (g, d and z hold the first).  dots: the LAST term also sums the
+// partials of <r,z> and of the test norm -- into the product's partial arrays at strides 1 and 2 (*np_last of them)
+// when the term is an epilogue, into pa / pb (vgrid of them) otherwise.
+static int chebyshev_terms(zzz_ctx* ctx, const ChebPlan& C, int norm, bool dots, double* pa, double* pb, int* np_last)
+{
+  const int64_t n = ctx->n_owned * ctx->bs;
+  const bool multi = ctx->comm != nullptr;
+  const int g = vgrid(n);
+  hipStream_t s = ctx->stream;
+  const int* stop_flag = reinterpret_cast<const int*>(ctx->state.p);
+  const int nn_is_rr = norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
+  double rho = 1.0 / C.sigma;
+  double *dcur = C.d, *dalt = C.d2;
+  for (int st = 1; st < C.degree; ++st)
+  {
+    const bool last = dots && st + 1 == C.degree;
+    const double rhon = 1.0 / (2.0 * C.sigma - rho);
+    const double c1 = rhon * rho, c2 = 2.0 * rhon / C.delta;
+    rho = rhon;
+    if (C.fused)
+    {
+      ChebEpi E;
+      E.dinv = ctx->dinv.p;
+      E.g = C.g;
+      E.z = ctx->z.p;
+      E.r = ctx->r.p;
+      E.c1 = c1;
+      E.c2 = c2;
+      double* parts = last ? ctx->part_a.p : nullptr;
+      int rc;
+      if (C.split)
+        rc = launch_sellp_overlapped(ctx, dcur, dalt, parts, last ? np_last : nullptr, nullptr, nn_is_rr, &E);
+      else
+      {
+        if (multi)
+          if (int rh = comm_halo_forward(ctx, dcur))
+            return rh;
+        rc = launch_sellp(ctx, dcur, dalt, parts, last ? np_last : nullptr, nullptr, nn_is_rr, &E);
+      }
+      if (rc)
+        return rc;
+      std::swap(dcur, dalt);
+      continue;
+    }
+    // terms as launches of their own: the product's output goes to the second direction buffer (free in this form; the
+    // CG vector w is the single-reduction form's A p and must survive)
+    int rc;
+    if (C.split)
+      rc = launch_spmv_overlapped(ctx, dcur, C.d2, nullptr, nullptr);
+    else
+    {
+      if (multi)
+        if (int rh = comm_halo_forward(ctx, dcur))
+          return rh;
+      rc = launch_spmv(ctx, dcur, C.d2, nullptr, nullptr);
+    }
+    if (rc)
+      return rc;
+    hipLaunchKernelGGL(k_cheb_step, dim3(g), dim3(VB), 0, s, stop_flag, C.d2, ctx->dinv.p, c1, c2, last ? 1 : 0, C.g, dcur,
+                       ctx->z.p, ctx->r.p, norm, pa, pb, n);
+  }
+  return ZZZ_OK;
+}
+
+static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
+{
+  const int64_t n = ctx->n_owned * ctx->bs;
+  const int max_it = o->max_it;
+  // the scalar logic is KSPCG's with a preconditioner: k_update_p / k_update_xr take pc = Jacobi semantics for alpha, beta
+  CgParams P{o->variant, ZZZ_PC_JACOBI, o->norm, o->rtol, o->atol, o->dtol > 0.0 ? o->dtol : 1.0e4};
+  const bool multi = ctx->comm != nullptr;
+  const int g = vgrid(n);
+  hipStream_t s = ctx->stream;
+  ChebPlan C;
+  if (int rc = chebyshev_setup(ctx, o, C))
+    return rc;
+  const int degree = C.degree;
+  const double hi = C.hi, theta = C.theta;
+  const bool fused = C.fused;
+  double *chd = C.d, *chg = C.g;
+  ctx->last_solve_fused = false;
+  ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->dp_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, ctx->alpha_hist.reserve((size_t)max_it + 2));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(CgState), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->p.p, 0, sizeof(double) * ctx->p.n, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
+  hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n, 1);
 
   const int* stop_flag = reinterpret_cast<const int*>(ctx->state.p);
   auto apply = [&](double* x, double* y, double* parts, int* np) -> int {
@@ -1170,65 +1292,12 @@ static int cg_solve_chebyshev(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters
   };
   double* pa = ctx->part_b.p;
   double* pb = ctx->part_b.p + VGRID_MAX;
-  // the terms after the first of z = p_k(D^-1 A) D^-1 r (g, d and z hold the first), then the partials of <r,z> and the
-  // norm (all-reduced when a communicator is attached).  On the operator stream a term is the EPILOGUE of its product
-  // (ChebEpi, zzz_sellp.hip): w = A d never travels through memory and the term costs no launch of its own; d then
-  // alternates between two buffers (other lanes still gather the old one).  A/B knob ZZZ_CHEB_FUSED=0: product and
-  // k_cheb_step as two launches (the tile kernel's form) -- same bits.
-  bool fused = sellp_active(ctx);
-  if (const char* e = getenv("ZZZ_CHEB_FUSED"))
-    fused = fused && atoi(e) != 0;
-  const bool split = multi && ctx->overlap && ctx->have_tile_split;
-  if (split && !ctx->have_group_split)
-    fused = false;
-  double* chd2 = nullptr;
-  if (fused && degree > 2)
-  {
-    ZZZ_HIP(ctx, ctx->cheb_d2.alloc((size_t)ctx->nloc()));
-    chd2 = ctx->cheb_d2.p;
-    ZZZ_HIP(ctx, hipMemsetAsync(chd2, 0, sizeof(double) * (size_t)ctx->nloc(), s));
-  }
-  const int nn_is_rr = P.norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
   int np_last = g;
+  // the polynomial's terms after the first, then the partials of <r,z> and the norm (all-reduced when a communicator
+  // is attached)
   auto polynomial = [&]() -> int {
-    double rho = 1.0 / sigma;
-    double *dcur = chd, *dalt = chd2;
-    for (int st = 1; st < degree; ++st)
-    {
-      const bool last = st + 1 == degree;
-      const double rhon = 1.0 / (2.0 * sigma - rho);
-      const double c1 = rhon * rho, c2 = 2.0 * rhon / delta;
-      rho = rhon;
-      if (fused)
-      {
-        ChebEpi E;
-        E.dinv = ctx->dinv.p;
-        E.g = chg;
-        E.z = ctx->z.p;
-        E.r = ctx->r.p;
-        E.c1 = c1;
-        E.c2 = c2;
-        double* parts = last ? ctx->part_a.p : nullptr;
-        int rc;
-        if (split)
-          rc = launch_sellp_overlapped(ctx, dcur, dalt, parts, last ? &np_last : nullptr, nullptr, nn_is_rr, &E);
-        else
-        {
-          if (multi)
-            if (int rh = comm_halo_forward(ctx, dcur))
-              return rh;
-          rc = launch_sellp(ctx, dcur, dalt, parts, last ? &np_last : nullptr, nullptr, nn_is_rr, &E);
-        }
-        if (rc)
-          return rc;
-        std::swap(dcur, dalt);
-        continue;
-      }
-      if (int rc = apply(dcur, ctx->w.p, nullptr, nullptr))
-        return rc;
-      hipLaunchKernelGGL(k_cheb_step, dim3(g), dim3(VB), 0, s, stop_flag, ctx->w.p, ctx->dinv.p, c1, c2, last ? 1 : 0, chg, dcur,
-                         ctx->z.p, ctx->r.p, P.norm, pa, pb, n);
-    }
+    if (int rc = chebyshev_terms(ctx, C, P.norm, true, pa, pb, &np_last))
+      return rc;
     if (degree == 1)
       hipLaunchKernelGGL(k_dots_rz, dim3(g), dim3(VB), 0, s, stop_flag, ctx->r.p, ctx->z.p, n, P.norm, pa, pb);
     if (multi)
@@ -1371,7 +1440,14 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   const int g = vgrid(n);
   hipStream_t s = ctx->stream;
   const int nn_is_rr = o->norm == ZZZ_NORM_UNPRECONDITIONED ? 1 : 0;
-  auto kern_sr_update = loop_exceeds_cache(ctx, 8) ? k_sr_update<true> : k_sr_update<false>;
+  // Chebyshev-Jacobi in this form: ONE reduction point per k products (the classical form has two) and k + 1 launches
+  const bool cheb = o->pc == ZZZ_PC_CHEBYSHEV_JACOBI;
+  ChebPlan C;
+  if (cheb)
+    if (int rc = chebyshev_setup(ctx, o, C))
+      return rc;
+  const bool ntv = loop_exceeds_cache(ctx, 8);
+  auto kern_sr_update = cheb ? (ntv ? k_sr_update<true, true> : k_sr_update<false, true>) : (ntv ? k_sr_update<true> : k_sr_update<false>);
   ctx->last_solve_fused = false;
 
   ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
@@ -1384,10 +1460,21 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->z.p, 0, sizeof(double) * ctx->z.n, s)); // ghost entries of z are exchanged
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
   hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n,
-                     o->pc == ZZZ_PC_JACOBI ? 1 : 0);
+                     o->pc != ZZZ_PC_NONE ? 1 : 0);
   // r = b, z = D^-1 r (the partials of this kernel are not used: the SpMV below leaves all three)
   hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(VB), 0, s, ctx->b.p, (const double*)nullptr, ctx->dinv.p, ctx->r.p,
                      ctx->z.p, n, P.norm, ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
+  // ... or z = p_k(D^-1 A) D^-1 r: first term, then the others (none of them sums anything: the product s = A z does)
+  auto polynomial = [&](bool first) -> int {
+    if (!cheb)
+      return ZZZ_OK;
+    if (first)
+      hipLaunchKernelGGL(k_cheb_init, dim3(g), dim3(VB), 0, s, reinterpret_cast<const int*>(ctx->state.p), ctx->r.p, ctx->dinv.p,
+                         C.theta, C.g, C.d, ctx->z.p, n);
+    return chebyshev_terms(ctx, C, P.norm, false, ctx->part_b.p, ctx->part_b.p + VGRID_MAX, nullptr);
+  };
+  if (int rc = polynomial(true))
+    return rc;
 
   double* parts = ctx->part_a.p; // <z,s> | <r,z> | norm, SPMV_PSTRIDE apart
   const double *zs_src = parts, *rz_src = parts + SPMV_PSTRIDE, *nn_src = parts + 2 * SPMV_PSTRIDE;
@@ -1464,7 +1551,9 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   {
     hipLaunchKernelGGL(kern_sr_update, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p,
                        it, P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p,
-                       ctx->r.p, n, 0);
+                       ctx->r.p, n, 0, C.theta, C.g, C.d);
+    if (int rc = polynomial(false))
+      return rc;
     const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
     ctx->prof_now = timed;
     if (timed)
@@ -1498,7 +1587,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   // convergence test of the last completed iteration: scalars only
   hipLaunchKernelGGL(kern_sr_update, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p, it,
                      P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p, ctx->r.p,
-                     n, 1);
+                     n, 1, C.theta, C.g, C.d);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
@@ -1545,6 +1634,8 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
       ctx->prof_halo_wait_ms /= cnt;
     (void)hipGetLastError();
   }
+  if (cheb)
+    ctx->last_pc_bound = C.hi;
   return finish_reason(ctx, o, fin, its);
 }
 } // namespace zzz

@@ -249,7 +249,8 @@ struct zzz_ctx
   zzz::DevBuf<double> part_a, part_b, red; // block partials; reduced scalars
   zzz::DevBuf<double> beta_hist, dp_hist, dpi_hist;
   zzz::DevBuf<double> sr_s; // single-reduction CG: s = A z
-  zzz::DevBuf<double> cheb_d2; // Chebyshev-Jacobi: second direction buffer of the polynomial's fused terms
+  zzz::DevBuf<double> cheb_d, cheb_d2, cheb_g; // Chebyshev-Jacobi: the polynomial's direction (two buffers: fused terms
+                                               // write the next one while lanes still gather the old) and residual
   zzz::DevBuf<double> cheb_noise; // ... and the right-hand side of its spectrum estimate
   zzz::DevBuf<zzz::CgState> state;
   zzz::CgState* h_state = nullptr; // pinned

@@ -11,5 +11,5 @@ s=d["phases_ms"]["ZZZ Solve"]; it=d["config"]["krylov_iterations"]
 print({"solve_ms":s,"its":it,"us_per_it":1e3*s/it,"rel":d["config"]["relative_residual"]})' >> $out 2>&1; }
 run --cg classical
 run --cg single_reduction
-for dr in "2 30" "3 30" "3 60" "4 60" "5 100" "6 100"; do set -- $dr; run --cg classical --pc chebyshev_jacobi --pc_degree $1 --pc_ratio $2; done
+for dr in "2 30" "3 60" "4 60" "5 100"; do set -- $dr; run --cg classical --pc chebyshev_jacobi --pc_degree $1 --pc_ratio $2; run --cg single_reduction --pc chebyshev_jacobi --pc_degree $1 --pc_ratio $2; done
 cat $out

@@ -80,7 +80,8 @@ def run_partition(rank, nranks, conn, problem, order, dims, desert=False):
             y = c.spmv(x)
             out = {"info": info, "offset": P.own_offset, "y": y}
             for name, kw in (("jacobi", dict(pc=zzz.PC_JACOBI)), ("sr", dict(pc=zzz.PC_JACOBI, single_reduction=True)),
-                             ("cheb", dict(pc=zzz.PC_CHEBYSHEV_JACOBI))):
+                             ("cheb", dict(pc=zzz.PC_CHEBYSHEV_JACOBI)),
+                             ("cheb_sr", dict(pc=zzz.PC_CHEBYSHEV_JACOBI, single_reduction=True))):
                 it, rn, r0 = c.cg_solve(rtol=1e-9, **kw)
                 out[name] = (it, rn / r0, c.vec_download(zzz.VEC_U), c.vec_norm(zzz.VEC_U))
             # the same solve with the window switched off has no transport left: an error, not a hang

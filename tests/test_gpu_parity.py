@@ -421,8 +421,8 @@ def test_driver_binary_surface():
             assert "PC Object: type: chebyshev_jacobi" in text
     assert seen[1] < seen[0]   # degree 4 against 3
     base = base + ["chebyshev_jacobi"]
-    out = subprocess.run(base + ["-ksp_cg_single_reduction"], capture_output=True, text=True, timeout=60)
-    assert out.returncode != 0   # the polynomial preconditioner runs in the classical form only
+    its_s, nrm_s, _ = its_norm(base + ["-ksp_cg_single_reduction"])   # one reduction point per three products
+    assert abs(its_s - seen[0]) <= 2 and abs(nrm_s - 47.56358) < 1e-3
     # --memory_profiling: the logging thread of src/mem.cpp (VSIZE / RSS in kB every 100 ms, here plus used HBM)
     out = subprocess.run([exe, "--problem_type", "poisson", "--ndofs", "2000000", "--memory_profiling", "-pc_type", "jacobi",
                           "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=300)
@@ -1197,8 +1197,20 @@ def test_chebyshev_jacobi_preconditioner(ctx, problem, order, dims, degree, rati
         del os.environ["ZZZ_SELLP"]
     assert abs(it4 - it) <= 1 and np.linalg.norm(u4 - u) <= 1e-8 * np.linalg.norm(u)
     # KSPCG with the assembled operator only
-    for bad in (dict(variant=zzz.CG_CGH), dict(op=zzz.OP_MATFREE), dict(single_reduction=True), dict(pc_degree=-1),
-                dict(pc_esteig_its=65)):
+    # -ksp_cg_single_reduction with the polynomial: one reduction point per k products; the same iteration to round-off
+    its, rns, r0s = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, single_reduction=True, **kw)
+    us = ctx.vec_download(zzz.VEC_U)
+    assert abs(its - it) <= 2 and abs(r0s - r0) <= 1e-12 * r0 and rns <= 1e-9 * r0s and ctx.cg_reason() == 2
+    assert np.linalg.norm(us - u) <= 1e-7 * np.linalg.norm(u)
+    assert abs(ctx.cg_info()["pc_spectrum_bound"] - est) <= 2e-6 * est
+    os.environ["ZZZ_CHEB_FUSED"] = "0"
+    try:
+        its2, _, _ = ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, single_reduction=True, **kw)
+        us2 = ctx.vec_download(zzz.VEC_U)
+    finally:
+        del os.environ["ZZZ_CHEB_FUSED"]
+    assert abs(its2 - its) <= 1 and np.linalg.norm(us2 - us) <= 1e-8 * np.linalg.norm(us)
+    for bad in (dict(variant=zzz.CG_CGH), dict(op=zzz.OP_MATFREE), dict(pc_degree=-1), dict(pc_esteig_its=65)):
         with pytest.raises(zzz.ZzzError):
             ctx.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, **bad)
 
@@ -1242,7 +1254,9 @@ def test_chebyshev_jacobi_partitioned_on_one_gpu(problem, order, dims, nparts, p
                 c.assemble_matrix(P.form)
                 c.assemble_vector(P.form)
                 it, rn, r0 = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-8)
-                out[rank] = (it, rn, r0, c.vec_download(zzz.VEC_U), c.cg_info()["pc_spectrum_bound"])
+                res = (it, rn, r0, c.vec_download(zzz.VEC_U), c.cg_info()["pc_spectrum_bound"])
+                its, rns, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-8, single_reduction=True)
+                out[rank] = res + (its, c.vec_download(zzz.VEC_U))
         except Exception as e:  # noqa: BLE001
             err.append((rank, repr(e)))
 
@@ -1259,6 +1273,9 @@ def test_chebyshev_jacobi_partitioned_on_one_gpu(problem, order, dims, nparts, p
     u = np.concatenate([o[3] for o in out])
     assert np.linalg.norm(u - u0) <= 1e-9 * np.linalg.norm(u0)
     assert all(o[1] == out[0][1] and o[2] == out[0][2] and o[1] <= 1e-8 * o[2] for o in out)
+    assert len({o[5] for o in out}) == 1 and abs(out[0][5] - it0) <= 2   # single-reduction form with the polynomial
+    us = np.concatenate([o[6] for o in out])
+    assert np.linalg.norm(us - u0) <= 1e-7 * np.linalg.norm(u0)
 
 
 def test_single_reduction_cg_breakdown_and_limits(ctx):
@@ -1417,7 +1434,8 @@ def test_peer_memory_halo_between_processes(problem, order, dims, n):
         c0.assemble_vector(G.form)
         y0 = c0.spmv(np.sin(0.37 * np.arange(G.n_owned * G.bs)))
         for name, kw in (("jacobi", dict(pc=zzz.PC_JACOBI)), ("sr", dict(pc=zzz.PC_JACOBI, single_reduction=True)),
-                         ("cheb", dict(pc=zzz.PC_CHEBYSHEV_JACOBI))):
+                         ("cheb", dict(pc=zzz.PC_CHEBYSHEV_JACOBI)),
+                         ("cheb_sr", dict(pc=zzz.PC_CHEBYSHEV_JACOBI, single_reduction=True))):
             it, rn, r0 = c0.cg_solve(rtol=1e-9, **kw)
             ref[name] = (it, c0.vec_download(zzz.VEC_U), c0.vec_norm(zzz.VEC_U))
     mpx = mp.get_context("spawn")
@@ -1451,7 +1469,7 @@ def test_peer_memory_halo_between_processes(problem, order, dims, n):
         assert "no transport" in d["no_transport"]
     y = np.concatenate([d["y"] for d in res])
     assert np.abs(y - y0).max() <= 1e-13 * np.abs(y0).max()
-    for name in ("jacobi", "sr", "cheb"):
+    for name in ("jacobi", "sr", "cheb", "cheb_sr"):
         it0, u0, n0 = ref[name]
         assert {d[name][0] for d in res} <= {it0 - 1, it0, it0 + 1} and len({d[name][0] for d in res}) == 1, name
         u = np.concatenate([d[name][2] for d in res])
