@@ -1005,6 +1005,77 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
   }
 }
 
+// ---- TIMING PROBE (ZZZ_EXP_WIN=<doubles>): what would an x window in LDS buy? ------------------------------------
+// The cost structure of a windowed product without its packer: per group of four slices the workgroup loads <doubles>
+// consecutive entries of x into LDS (coalesced 16-B loads), and every gather of the chunk loop reads LDS at a
+// pseudo-random index instead of global memory.  The RESULT IS WRONG by construction; only zzz_spmv_time may run it.
+template <bool NT>
+__global__ __launch_bounds__(SP_BLOCK) void spmv_sellp_win_probe_kernel(const int2* __restrict__ desc,
+                                                                    const double* __restrict__ svals,
+                                                                    const uint16_t* __restrict__ c16,
+                                                                    const int32_t* __restrict__ c32,
+                                                                    const int32_t* __restrict__ meta,
+                                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                                    int nrows, int64_t nslices, double* __restrict__ partials,
+                                                                    int wlen)
+{
+  extern __shared__ __attribute__((aligned(16))) double win[];
+  __shared__ double red[SP_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ngroups = (nslices + 3) / 4;
+  double dot = 0.0;
+  for (int i = 0;; ++i)
+  {
+    const int64_t g = sp_xcd_item(ngroups, blockIdx.x, gridDim.x, i);
+    if (g < 0)
+      break;
+    __syncthreads();
+    {
+      int64_t base = g * 256 - wlen / 2;
+      if (base < 0)
+        base = 0;
+      if (base + wlen > nrows)
+        base = nrows > wlen ? nrows - wlen : 0;
+      base &= ~(int64_t)1;
+      const dbl2* __restrict__ src = reinterpret_cast<const dbl2*>(x + base);
+      dbl2* dst = reinterpret_cast<dbl2*>(win);
+      for (int k = threadIdx.x; k < wlen / 2; k += SP_BLOCK)
+        dst[k] = src[k];
+    }
+    __syncthreads();
+    const int s = __builtin_amdgcn_readfirstlane((int)(4 * g + wv));
+    if (s >= nslices)
+      continue;
+    const int2 ds = desc[s];
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    const int r = s * 64 + lane < nrows ? s * 64 + lane : -1;
+    double sum = 0.0;
+    for (int j = 0; j < nch; ++j)
+    {
+      dbl2 v[4];
+      int cl[8];
+      if (j + 1 < nch || wl == 8)
+        read_chunk<NT, true>(c0 + j, 8, lane, svals, c16, c32, meta, v, cl);
+      else
+        read_chunk<NT, false>(c0 + j, wl, lane, svals, c16, c32, meta, v, cl);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        const unsigned idx = (unsigned)cl[e] % (unsigned)wlen;
+        sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * win[idx];
+      }
+    }
+    if (r >= 0)
+    {
+      y[r] = sum;
+      dot += sum;
+    }
+  }
+  const double sres = block_reduce_sum(dot, red);
+  if (threadIdx.x == 0 && partials)
+    partials[blockIdx.x] = sres;
+}
+
 // ---- product fused with the direction update -------------------------------------------------------------
 // One CG iteration as TWO kernels instead of three: the head of iteration `it` (convergence test, k_update_p of
 // zzz_cg.hip) and the product w = A p, with p = z + b p_old formed on the fly where the product gathers it
@@ -1552,6 +1623,29 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   const int gs = sp_grid((ctx->nslices + 3) / 4);
+  if (const char* e = getenv("ZZZ_EXP_WIN")) // timing probe, wrong results by construction (see the kernel)
+  {
+    const int wlen = atoi(e) & ~1;
+    if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows)
+    {
+      const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)wlen * 8 + 512))));
+      const int grid = std::min(gs, 256 * per_cu);
+      const bool nt = (double)sellp_stream_bytes(ctx) > 300.0e6;
+      const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
+      if (nt)
+        hipLaunchKernelGGL(spmv_sellp_win_probe_kernel<true>, dim3(grid), dim3(SP_BLOCK), (size_t)wlen * 8, ctx->stream, off,
+                           ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, x, y, (int)ctx->nrows,
+                           ctx->nslices, partials, wlen);
+      else
+        hipLaunchKernelGGL(spmv_sellp_win_probe_kernel<false>, dim3(grid), dim3(SP_BLOCK), (size_t)wlen * 8, ctx->stream, off,
+                           ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, x, y, (int)ctx->nrows,
+                           ctx->nslices, partials, wlen);
+      if (npartials)
+        *npartials = grid;
+      ZZZ_HIP(ctx, hipGetLastError());
+      return ZZZ_OK;
+    }
+  }
   if (partials)
   {
     TailArgs T;
