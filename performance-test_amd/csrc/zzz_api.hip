@@ -767,6 +767,12 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
   ZZZ_HIP(ctx, hipEventCreate(&e1));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(zzz::CgState), ctx->stream));
   int np = 0;
+  struct TimingOnly // the products below are timed, their results discarded (zzz_sellp.hip: the ZZZ_EXP_WIN probe)
+  {
+    zzz_ctx* c;
+    explicit TimingOnly(zzz_ctx* cc) : c(cc) { c->timing_only = true; }
+    ~TimingOnly() { c->timing_only = false; }
+  } timing_only(ctx);
   int rc = launch_spmv(ctx, ctx->p.p, ctx->w.p, ctx->part_a.p, &np); // warm-up
   ZZZ_HIP(ctx, hipEventRecord(e0, ctx->stream));
   for (int i = 0; i < reps && !rc; ++i)

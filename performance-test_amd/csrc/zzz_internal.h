@@ -257,6 +257,7 @@ struct zzz_ctx
   std::vector<double> history;
   int last_iters = 0;
   int last_reason = 0; // KSPConvergedReason of the last solve (zzz_cg_info)
+  bool timing_only = false;  // inside zzz_spmv_time: the products' results are discarded (the ZZZ_EXP_WIN probe may run)
   bool halo_pending = false; // comm_halo_begin put an exchange on the comm stream: comm_halo_end waits for it
   double last_pc_bound = 0.0; // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound the last solve used
   bool last_solve_fused = false; // the last solve ran the fused product + direction kernel

@@ -1623,7 +1623,8 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   const int gs = sp_grid((ctx->nslices + 3) / 4);
-  if (const char* e = getenv("ZZZ_EXP_WIN")) // timing probe, wrong results by construction (see the kernel)
+  const char* e = ctx->timing_only ? getenv("ZZZ_EXP_WIN") : nullptr; // timing probe, wrong results by construction (see
+  if (e)                                                               // the kernel): inside zzz_spmv_time only
   {
     const int wlen = atoi(e) & ~1;
     if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows)
