@@ -220,6 +220,7 @@ def run_other_config(name, steps=3):
         nrows, _, nnz = ctx.csr_sizes()
         spmv_ms, spmv_n = ctx.profile()
         bytes_pl, sinfo = physical_bytes_per_product(ctx, nrows, nnz)
+        ctx_windows = ctx.spmv_x_windows()[0] > 0
         unorm = ctx.vec_norm(zzz.VEC_U)
     ms = t_all / steps * 1e3
     phys = bytes_pl / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
@@ -230,7 +231,7 @@ def run_other_config(name, steps=3):
             "krylov_iterations": it, "relative_residual": rn / r0 if r0 else 0.0, "solution_norm": unorm,
             "product_ms": spmv_ms, "product_launches_timed": spmv_n, "product_bytes_per_launch": bytes_pl,
             "product_GBs": phys, "roofline_frac": phys / HBM_PEAK_GBS,
-            "operator": "sliced-ELL operator stream" if sinfo[5] else "CSR tile kernel"}
+            "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")) if sinfo[5] else "CSR tile kernel"}
 
 
 def main():
@@ -603,6 +604,11 @@ def main():
             out["config"]["spmv_operator"] = (f"sliced-ELL operator stream, {'length-sorted' if sinfo[5] == 2 else 'natural'} row order: "
                                               f"{sinfo[7]} entries ({sinfo[7] / nnz:.3f} of the {nnz}-entry pattern; exact zeros "
                                               f"dropped, chunks of 8 padded), {sinfo[6]} B per product")
+            xw = ctx.spmv_x_windows()
+            if xw[0]:
+                out["config"]["spmv_operator"] += (f"; x windows: per group of 256 rows the columns it reaches are loaded into LDS "
+                                                   f"({xw[0]} doubles per workgroup at most, {xw[1]} B per product mostly from L2; not "
+                                                   f"counted in the bytes above) and gathered from there")
         else:
             out["config"]["spmv_operator"] = "CSR tile kernel"
         out["config"]["spmv_column_stream"] = ("(CSR tile kernel not in use)" if sinfo[5] else

@@ -320,7 +320,9 @@ int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);
  * >= 128 nonzeros on average: lane j adds the j-th contiguous chunk of ceil(len/L) products in column
  * order, chunk sums combined pairwise ((c0+c1)+(c2+c3))+...); info[5] = 1 when the SpMV runs on the sliced-ELL
  * copy (chosen for matrices small enough to stay cache-resident between CG iterations; same column-order row
- * sums, bit-identical results) instead of the CSR tile kernel; info[6..7] = 0. */
+ * sums, bit-identical results) instead of the CSR tile kernel; info[6..7] = 0. * When the stream carries x windows (block size 3: the columns a group of 256 rows reaches are loaded into LDS once per
+ * group, the stream's codes are window indices) info[3] = -(LDS doubles per workgroup) and info[2] = bytes of x those
+ * loads move per product. */
 int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
 
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */

@@ -878,6 +878,13 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   info[1] = ctx->cols16_offb;
   info[2] = ctx->have_cols16 ? ctx->cols16_fallback_tiles : ctx->ntiles;
   info[3] = ctx->ntiles;
+  if (sellp_active(ctx) && ctx->sp_win_max > 0)
+  {
+    // x windows of the operator stream (no tile kernel in use then): bytes of x the product loads into LDS per launch
+    // in place of per-entry gathers, and the LDS doubles a workgroup holds
+    info[2] = ctx->sp_win_bytes;
+    info[3] = -(int64_t)ctx->sp_win_max;
+  }
   info[4] = sellp_active(ctx) ? 1 : (int64_t)1 << ctx->spmv_lpr_shift; // the stream sums a row serially
   info[5] = sellp_active(ctx) ? (ctx->sp_sorted ? 2 : 1) : 0;
   info[6] = sellp_active(ctx) ? sellp_stream_bytes(ctx) : 0; // bytes of the operator stream read per product

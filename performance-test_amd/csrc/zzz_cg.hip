@@ -632,7 +632,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   int fused_mode = 0;
   if (const char* e = getenv("ZZZ_CG_FUSED"))
     fused_mode = atoi(e);
-  const bool fused = o->op == ZZZ_OP_CSR && fused_mode == 2 && sellp_active(ctx);
+  const bool fused = o->op == ZZZ_OP_CSR && fused_mode == 2 && sellp_active(ctx) && ctx->sp_win_max == 0; // (its kernel gathers from memory)
   ctx->last_solve_fused = fused;
   // multi-GPU: the scalar all-reduce rides in the tail of the product launch when that launch is the operator stream's
   const bool fold_product = multi && !fused && o->op == ZZZ_OP_CSR && sellp_active(ctx);

@@ -257,6 +257,12 @@ struct zzz_ctx
   std::vector<double> history;
   int last_iters = 0;
   int last_reason = 0; // KSPConvergedReason of the last solve (zzz_cg_info)
+  // x windows of the operator stream (zzz_sellp.hip: k_sp_windows): per group of four slices the columns its rows reach,
+  // as a few contiguous segments that fit LDS; the stream's column codes of such a group are LDS indices
+  zzz::DevBuf<int32_t> sp_win_info; // [group] = {segments (0: the group gathers from memory), window length in doubles}
+  zzz::DevBuf<int32_t> sp_win_seg;  // [group][SP_WIN_NSEG] = {first column, length}
+  int sp_win_max = 0;               // doubles of LDS per workgroup the product launches with (0: no windowed group)
+  int64_t sp_win_bytes = 0;         // window bytes a product loads (all windowed groups)
   bool timing_only = false;  // inside zzz_spmv_time: the products' results are discarded (the ZZZ_EXP_WIN probe may run)
   bool halo_pending = false; // comm_halo_begin put an exchange on the comm stream: comm_halo_end waits for it
   double last_pc_bound = 0.0; // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound the last solve used

@@ -523,6 +523,183 @@ __global__ __launch_bounds__(256) void k_sp_compact(const rp_t* __restrict__ row
   }
 }
 
+// ---- x windows ------------------------------------------------------------------------------------------------
+// Rows with many entries (P2 / P3, block size 3) gather x at 30-100 scattered places each; the gathers, not the stream,
+// are then what the product waits for (-12 % / -17 % measured with the gathers taken off the memory
+// path).  Where the columns a group of four slices (256 rows) reaches form a few contiguous segments that fit LDS, the
+// product loads those segments once per group with wide coalesced loads and gathers from LDS.  The stream's column
+// codes of such a group are LDS indices: the map column -> index is monotone and a translation inside a segment, so the
+// chunk encodings (affine, periodic, 8- / 16-bit) and the ascending-column summation order are what they were.
+constexpr int SP_WIN_NSEG = 24;      // segments per group at most
+constexpr int SP_WIN_GAP = 8;        // gaps of up to this many columns are filled (fewer segments, a few unused slots)
+constexpr int SP_WIN_WORDS = 4096;   // bitmap words of the window search in k_sp_pack (16 KiB of LDS)
+constexpr int SP_WIN_SPAN = (SP_WIN_WORDS - 2) * 32; // columns between a group's smallest and largest at most
+
+// One workgroup per group of four slices (256 rows, natural order).  The group's kept columns (its CSR range swept with
+// coalesced loads; entries that are exactly zero do not count when the stream drops them) are looked at as a set --
+// bitmap over [smallest, largest], gaps of <= SP_WIN_GAP columns filled, runs = segments -- and where they form
+// <= SP_WIN_NSEG segments of <= wmax doubles in all the group gets an x window: info[g] = {segments, doubles},
+// seg[g][i] = {first column, length}; otherwise info[g] = {0, 0}.  count += window doubles.
+__global__ __launch_bounds__(256) void k_sp_windows(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                    const double* __restrict__ vals, int nrows, int64_t ngroups, int drop,
+                                                    int wmax, int2* __restrict__ info, int2* __restrict__ seg,
+                                                    unsigned long long* __restrict__ count)
+{
+  __shared__ unsigned bits[SP_WIN_WORDS];
+  __shared__ int win_red[8];
+  __shared__ int win_cnt[2][257];
+  __shared__ int win_pos[2][SP_WIN_NSEG];
+  __shared__ int2 win_sg[SP_WIN_NSEG];
+  __shared__ int win_hdr[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long win_w = 0;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x)
+  {
+    const int r0 = (int)(g * 256), r1 = min(r0 + 256, nrows);
+    const int64_t a = rowptr[r0], b = rowptr[r1];
+    // bounds from the rows' first and last PATTERN entries (columns ascend within a row): at most a little wider than
+    // the kept entries' own, and one sweep of the values instead of two
+    int lo = INT_MAX, hi = -1;
+    {
+      const int r = r0 + (int)threadIdx.x;
+      if (r < r1 && rowptr[r + 1] > rowptr[r])
+      {
+        lo = cols[rowptr[r]];
+        hi = cols[rowptr[r + 1] - 1];
+      }
+    }
+    lo = wave_min_i(lo);
+    hi = wave_max_i(hi);
+    __syncthreads(); // the previous group's shared state is done with
+    if (lane == 0)
+    {
+      win_red[wv] = lo;
+      win_red[4 + wv] = hi;
+    }
+    __syncthreads();
+    lo = min(min(win_red[0], win_red[1]), min(win_red[2], win_red[3]));
+    hi = max(max(win_red[4], win_red[5]), max(win_red[6], win_red[7]));
+    const long long span = (long long)hi - lo + 1;
+    bool ok = hi >= lo && span <= SP_WIN_SPAN; // (uniform over the workgroup)
+    int nseg = 0, wlen = 0;
+    if (ok)
+    {
+      const int nw = (int)((span + 31) / 32) + 1; // a spare word: the filled bitmap may carry into it
+      for (int k = threadIdx.x; k < nw; k += 256)
+        bits[k] = 0u;
+      __syncthreads();
+      for (int64_t k = a + threadIdx.x; k < b; k += 256)
+        if (!drop || vals[k] != 0.0)
+        {
+          const int c = cols[k] - lo;
+          atomicOr(&bits[c >> 5], 1u << (c & 31));
+        }
+      __syncthreads();
+      // F = the bitmap with gaps of <= SP_WIN_GAP columns filled; a thread owns a contiguous range of words, so that
+      // run starts and run ends come out in ascending order
+      auto fword = [&](int k) -> unsigned {
+        if (k < 0 || k >= nw)
+          return 0u;
+        const unsigned long long two = ((unsigned long long)bits[k] << 32) | (k > 0 ? bits[k - 1] : 0u);
+        unsigned long long f = 0;
+#pragma unroll
+        for (int sft = 0; sft <= SP_WIN_GAP; ++sft)
+          f |= two << sft;
+        return (unsigned)(f >> 32);
+      };
+      const int per = (nw + 255) / 256;
+      const int w0 = min((int)threadIdx.x * per, nw), w1 = min(w0 + per, nw);
+      int ns = 0, ne = 0;
+      for (int k = w0; k < w1; ++k)
+      {
+        const unsigned f = fword(k), below = fword(k - 1) >> 31, above = fword(k + 1) & 1u;
+        ns += __popc(f & ~((f << 1) | below));
+        ne += __popc(f & ~((f >> 1) | (above << 31)));
+      }
+      win_cnt[0][threadIdx.x] = ns;
+      win_cnt[1][threadIdx.x] = ne;
+      __syncthreads();
+      if (threadIdx.x < 2)
+      {
+        int acc = 0;
+        for (int k = 0; k < 256; ++k)
+        {
+          const int t = win_cnt[threadIdx.x][k];
+          win_cnt[threadIdx.x][k] = acc;
+          acc += t;
+        }
+        win_cnt[threadIdx.x][256] = acc;
+      }
+      __syncthreads();
+      nseg = win_cnt[0][256];
+      ok = nseg <= SP_WIN_NSEG && nseg == win_cnt[1][256];
+      if (ok)
+      {
+        int is = win_cnt[0][threadIdx.x], ie = win_cnt[1][threadIdx.x];
+        for (int k = w0; k < w1; ++k)
+        {
+          const unsigned f = fword(k), below = fword(k - 1) >> 31, above = fword(k + 1) & 1u;
+          unsigned st = f & ~((f << 1) | below), en = f & ~((f >> 1) | (above << 31));
+          while (st)
+          {
+            win_pos[0][is++] = k * 32 + __builtin_ctz(st);
+            st &= st - 1;
+          }
+          while (en)
+          {
+            win_pos[1][ie++] = k * 32 + __builtin_ctz(en);
+            en &= en - 1;
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+          int total = 0;
+          for (int q = 0; q < nseg; ++q)
+          {
+            const int a0 = win_pos[0][q];
+            int e0 = win_pos[1][q]; // last filled bit: at most SP_WIN_GAP past the run's last column
+            if (e0 >= (int)span)
+              e0 = (int)span - 1;
+            win_sg[q] = make_int2(lo + a0, e0 - a0 + 1);
+            total += e0 - a0 + 1;
+          }
+          win_hdr[0] = total <= wmax ? nseg : 0;
+          win_hdr[1] = total;
+        }
+        __syncthreads();
+        nseg = win_hdr[0];
+        wlen = win_hdr[1];
+        ok = nseg > 0;
+      }
+    }
+    if (ok && (int)threadIdx.x < nseg)
+      seg[g * SP_WIN_NSEG + threadIdx.x] = win_sg[threadIdx.x];
+    if (threadIdx.x == 0)
+    {
+      info[g] = ok ? make_int2(nseg, wlen) : make_int2(0, 0);
+      if (ok)
+        win_w += (unsigned long long)wlen;
+    }
+  }
+  if (threadIdx.x == 0 && win_w)
+    atomicAdd(count, win_w);
+}
+
+// column -> index into the group's window (segments in ascending order, laid out back to back)
+__device__ inline int win_index(const int2* __restrict__ sg, int nseg, int col)
+{
+  int off = 0, idx = 0;
+  for (int i = 0; i < nseg; ++i)
+  {
+    const int2 q = sg[i];
+    if (col >= q.x)
+      idx = off + (col - q.x);
+    off += q.y;
+  }
+  return idx;
+}
+
 template <bool PERM>
 __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ crow, const int32_t* __restrict__ rownnz,
                                                    const double* __restrict__ cvals, const int32_t* __restrict__ ccols,
@@ -626,14 +803,18 @@ __global__ __launch_bounds__(256) void k_sp_bounds(const rp_t* __restrict__ rowp
 //   3. every lane reads its row's entries back from LDS, chunk by chunk, and the chunk is written exactly as
 //      k_sp_fill writes it.
 // desc[s] = {first chunk, chunks | width of the last chunk << 24}.  ghost_flag as in k_sp_fill.
+// WINB: groups with an x window (k_sp_windows) get window indices for columns before the chunks are written.
+template <bool WINB>
 __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                  const double* __restrict__ vals, int nrows, int64_t nslices, int drop, int cap,
                                                  int* __restrict__ counter, int2* __restrict__ desc,
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
                                                  int32_t* __restrict__ c32, int32_t* __restrict__ meta,
-                                                 uint8_t* __restrict__ ghost_flag, int tail_codes)
+                                                 uint8_t* __restrict__ ghost_flag, int tail_codes,
+                                                 const int2* __restrict__ win_info, const int2* __restrict__ win_seg)
 {
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   double* lv = reinterpret_cast<double*>(sp_smem + (size_t)wv * cap * 12);
   int* lc = reinterpret_cast<int*>(sp_smem + (size_t)wv * cap * 12 + (size_t)cap * 8);
@@ -707,13 +888,30 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
     for (int q = 0; q < wv; ++q)
       c0 += wg_nch[q];
     __syncthreads(); // wg_sh is rewritten next round
+    bool gh = false;
+    int limit = nrows;
+    if (WINB)
+    {
+      // the group's x window (k_sp_windows, before this kernel): its columns become window indices
+      const int2 wi = live ? win_info[s >> 2] : make_int2(0, 0);
+      if (wi.x > 0 && live)
+      {
+        const int2* __restrict__ sg = win_seg + (s >> 2) * SP_WIN_NSEG;
+        for (int k = lane; k < running; k += 64)
+        {
+          const int c = lc[k];
+          gh |= c >= nrows;
+          lc[k] = win_index(sg, wi.x, c);
+        }
+        limit = wi.y;
+      }
+    }
     if (!live)
       continue;
     if (lane == 0)
       desc[s] = make_int2(c0, nch | (wl << 24));
     kept_w += (unsigned long long)running;
     const int tc = ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes) | (((tail_codes & 16) && nch == 1) ? 8 : 0);
-    bool gh = false;
     for (int j = 0; j < nch; ++j)
     {
       double v[8];
@@ -726,7 +924,9 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
         v[e] = has ? lv[cstart + q] : 0.0;
         cl[e] = has ? lc[cstart + q] : INT_MAX;
       }
-      bytes_w += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc);
+      bool gh2 = false; // (windowed: the ghost test was made on the columns themselves, above)
+      bytes_w += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, limit, (WINB && limit != nrows) ? gh2 : gh,
+                                                svals, c16, c32, meta, tc);
     }
     if (ghost_flag)
     {
@@ -741,6 +941,7 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
     atomicAdd(reinterpret_cast<unsigned long long*>(counter + 2), kept_w);  // entries kept
     atomicAdd(reinterpret_cast<unsigned long long*>(counter + 8), bytes_w); // stream bytes a product reads
   }
+
 }
 
 // sorted form: {first chunk, chunks} of every slice from the scanned offsets
@@ -854,7 +1055,7 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
 }
 
 // sum += the chunk's products in ascending column order, mul and add rounded separately (the scalar CPU loop's bits)
-template <bool NT, bool FULL>
+template <bool NT, bool FULL, bool LDS = false>
 __device__ inline void chunk_product(int c, int w, int lane, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
                                      const int32_t* __restrict__ c32, const int32_t* __restrict__ meta,
                                      const double* __restrict__ x, double& sum)
@@ -865,14 +1066,14 @@ __device__ inline void chunk_product(int c, int w, int lane, const double* __res
   double xv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    xv[e] = (FULL || e < w) ? gather(x, cl[e]) : 0.0;
+    xv[e] = (FULL || e < w) ? (LDS ? x[cl[e]] : gather(x, cl[e])) : 0.0; // LDS: x is the group's window, cl its index
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     if (FULL || e < w)
       sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * xv[e];
 }
 
-template <bool DOT, bool NT, bool PERM, bool CHEB = false>
+template <bool DOT, bool NT, bool PERM, bool CHEB = false, bool WIN = false>
 __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __restrict__ desc,
                                                               const double* __restrict__ svals,
                                                               const uint16_t* __restrict__ c16,
@@ -884,8 +1085,10 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
                                                               const int* __restrict__ stop_flag,
                                                               const int32_t* __restrict__ group_list, int64_t nlist,
                                                               const double* __restrict__ rvec, int pstride, int nn_is_rr,
-                                                              TailArgs tail, ChebEpi epi)
+                                                              TailArgs tail, ChebEpi epi, const int2* __restrict__ win_info,
+                                                              const int2* __restrict__ win_seg)
 {
+  extern __shared__ __attribute__((aligned(16))) double xwin[]; // WIN: the group's x window (launch: sp_win_max doubles)
   // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
   // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
   // spmv_tile_kernel
@@ -919,6 +1122,29 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     const int st = st_n, s = s_n;
     const int2 ds = ds_n;
     st_n = next_slice(i + 1, s_n, ds_n);
+    // WIN: the four wavefronts work on one group; where the group has a window its segments of x are loaded into LDS
+    // first (every wavefront takes part, also one without a slice of its own at the end of the matrix)
+    int nwin = 0;
+    if (WIN)
+    {
+      const int2 wi = win_info[s >> 2];
+      nwin = __builtin_amdgcn_readfirstlane(wi.x);
+      if (nwin > 0)
+      {
+        const int2* __restrict__ sg = win_seg + (int64_t)(s >> 2) * SP_WIN_NSEG;
+        __syncthreads(); // the previous group's window is done with
+        int off = 0;
+        for (int q = 0; q < nwin; ++q)
+        {
+          const int2 sq = sg[q];
+          const int c0s = __builtin_amdgcn_readfirstlane(sq.x), len = __builtin_amdgcn_readfirstlane(sq.y);
+          for (int k = threadIdx.x; k < len; k += SP_BLOCK)
+            xwin[off + k] = x[c0s + k];
+          off += len;
+        }
+        __syncthreads();
+      }
+    }
     if (st == 0)
       continue;
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
@@ -927,14 +1153,29 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
       r = -1;
     const double xr = ((DOT || CHEB) && r >= 0) ? x[r] : 0.0;
     double sum = 0.0;
-    for (int j = 0; j + 1 < nch; ++j)
-      chunk_product<NT, true>(c0 + j, 8, lane, svals, c16, c32, meta, x, sum);
-    if (nch)
+    if (WIN && nwin > 0)
     {
-      if (wl == 8)
-        chunk_product<NT, true>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, x, sum);
-      else
-        chunk_product<NT, false>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, x, sum);
+      for (int j = 0; j + 1 < nch; ++j)
+        chunk_product<NT, true, true>(c0 + j, 8, lane, svals, c16, c32, meta, xwin, sum);
+      if (nch)
+      {
+        if (wl == 8)
+          chunk_product<NT, true, true>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, xwin, sum);
+        else
+          chunk_product<NT, false, true>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, xwin, sum);
+      }
+    }
+    else
+    {
+      for (int j = 0; j + 1 < nch; ++j)
+        chunk_product<NT, true>(c0 + j, 8, lane, svals, c16, c32, meta, x, sum);
+      if (nch)
+      {
+        if (wl == 8)
+          chunk_product<NT, true>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, x, sum);
+        else
+          chunk_product<NT, false>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, x, sum);
+      }
     }
     if (CHEB)
     {
@@ -1379,8 +1620,9 @@ int sellp_pattern_bounds(zzz_ctx* ctx)
   hipStream_t s = ctx->stream;
   const int64_t nsl = (ctx->nrows + 63) / 64;
   ctx->nslices = nsl;
-  ZZZ_HIP(ctx, ctx->sp_counter.alloc(12)); // [0] chunk allocator, [2,3] entries kept, [4..7] pattern bounds, [8,9] stream bytes
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 12 * sizeof(int), s));
+  ZZZ_HIP(ctx, ctx->sp_counter.alloc(16)); // [0] chunk allocator, [2,3] entries kept, [4..7] pattern bounds, [8,9] stream bytes,
+                                           // [10..13] windowed groups / window doubles
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 16 * sizeof(int), s));
   hipLaunchKernelGGL(k_sp_bounds, dim3(grid_cap(nsl, 4, 1024)), dim3(256), 0, s, ctx->rowptr.p, (int)ctx->nrows, nsl,
                      ctx->sp_counter.p + 4);
   int h[4] = {0, 0, 0, 0};
@@ -1401,6 +1643,8 @@ int sell_update(zzz_ctx* ctx, bool structure)
 {
   (void)structure;
   ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
+  ctx->sp_win_max = 0; // (set again by the long-row packer when most groups get an x window)
+  ctx->sp_win_bytes = 0;
   const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
   if (ctx->sellp_mode == 0 || (!ctx->spmv_auto && !forced) || !ctx->vals.p)
     return ZZZ_OK;
@@ -1485,23 +1729,50 @@ int sell_update(zzz_ctx* ctx, bool structure)
     ZZZ_HIP(ctx, ctx->sp_gflag.alloc((size_t)nsl));
     gflag = ctx->sp_gflag.p;
   }
+  // x windows (k_sp_pack<true>): block size 3 -- 45 entries per row at 15 places of x, which a group of 256 rows
+  // shares almost completely (1400 doubles in 3-7 segments); needs the four wavefronts of a workgroup on one group and
+  // room for the bitmap beside the parked entries.  ZZZ_SELLP_WIN: doubles of LDS per workgroup of the product
+  // (default 2048 = 16 KiB: eight workgroups per CU as before; 0: off)
+  const int win_knob = getenv("ZZZ_SELLP_WIN") ? atoi(getenv("ZZZ_SELLP_WIN")) : 2048;
+  const bool winb = ctx->bs == 3 && win_knob >= 256 && win_knob <= 8192;
   if (lds * waves > 64 * 1024 && !ctx->sp_lds_attr)
   {
-    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024 - 64)); // the kernel's 32 B of static LDS count too
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 64));
     ctx->sp_lds_attr = true;
   }
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 4 * sizeof(int), s));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p + 8, 0, 2 * sizeof(int), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p + 8, 0, 4 * sizeof(int), s));
   const int cap = (ctx->sp_max_range + 63) & ~63;
-  hipLaunchKernelGGL(k_sp_pack, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p, ctx->cols.p,
-                     ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p, reinterpret_cast<int2*>(ctx->sp_desc.p),
-                     ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
+  const int tcodes = ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0);
+  // workgroups of the packer take slices in fours only when they have four wavefronts: the group of a slice is s >> 2
+  // either way, and a workgroup of one or two wavefronts starts at a multiple of its size inside the group
+  if (winb)
+  {
+    const int64_t ngroups = (nsl + 3) / 4;
+    ZZZ_HIP(ctx, ctx->sp_win_info.alloc(2 * (size_t)ngroups));
+    ZZZ_HIP(ctx, ctx->sp_win_seg.alloc(2 * (size_t)ngroups * SP_WIN_NSEG));
+    hipLaunchKernelGGL(k_sp_windows, dim3((unsigned)std::min<int64_t>(ngroups, 256 * 8)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p,
+                       ctx->vals.p, nrows, ngroups, ctx->sellp_drop ? 1 : 0, win_knob, reinterpret_cast<int2*>(ctx->sp_win_info.p),
+                       reinterpret_cast<int2*>(ctx->sp_win_seg.p), reinterpret_cast<unsigned long long*>(ctx->sp_counter.p + 10));
+    hipLaunchKernelGGL(k_sp_pack<true>, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p,
+                       ctx->cols.p, ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p,
+                       reinterpret_cast<int2*>(ctx->sp_desc.p), ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,
+                       gflag, tcodes, reinterpret_cast<const int2*>(ctx->sp_win_info.p), reinterpret_cast<const int2*>(ctx->sp_win_seg.p));
+    ctx->sp_win_max = win_knob; // the product reads win_info per group; a group without a window gathers from memory
+  }
+  else
+    hipLaunchKernelGGL(k_sp_pack<false>, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p,
+                       ctx->cols.p, ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p,
+                       reinterpret_cast<int2*>(ctx->sp_desc.p), ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,
+                       gflag, tcodes, (const int2*)nullptr, (const int2*)nullptr);
   ZZZ_HIP(ctx, hipGetLastError());
   if (!ctx->sp_event)
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));
   int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 5); // pinned
-  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 12 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipEventRecord(ctx->sp_event, s));
   ctx->sp_sorted = false;
   ctx->sp_pending = true;
@@ -1527,6 +1798,9 @@ int sellp_resolve(zzz_ctx* ctx)
   memcpy(&hb, hc + 8, sizeof(hb));
   ctx->sp_bytes = (int64_t)hb;
   ctx->sp_chunks = t0;
+  unsigned long long hw = 0;
+  memcpy(&hw, hc + 10, sizeof(hw));
+  ctx->sp_win_bytes = ctx->sp_win_max > 0 ? (int64_t)hw * 8 : 0;
   const double full = (double)ctx->nnz + 64.0 * 512.0;
   const bool always = ctx->sellp_mode == 2 || ctx->sp_forced;
   // Natural row order unless its padding makes it slower than the alternatives: the length-sorted form (priced only
@@ -1563,7 +1837,7 @@ bool sellp_active(zzz_ctx* ctx)
 }
 
 // bytes one product reads from the stream (values + codes + bases; int32 chunks are not counted separately)
-int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_bytes + ctx->nslices * 8; }
+int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_bytes + ctx->nslices * 8; } // (x windows: sp_win_bytes, reported apart)
 
 static int sp_grid(int64_t ngroups)
 {
@@ -1587,21 +1861,33 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
   if (!ctx->spmv_auto)
     nt = (ctx->spmv_variant & 1) != 0;
   const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
-#define ZZZ_SP_GO(NT, PERM)                                                                                            \
+  const int2* winfo = reinterpret_cast<const int2*>(ctx->sp_win_info.p);
+  const int2* wseg = reinterpret_cast<const int2*>(ctx->sp_win_seg.p);
+#define ZZZ_SP_GO5(NT, PERM, WIN, LDSB)                                                                                \
   do                                                                                                                   \
   {                                                                                                                    \
     if (epi)                                                                                                           \
-      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, true>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off,       \
-                         ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,       \
+      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, true, WIN>), dim3(grid), dim3(SP_BLOCK), LDSB, ctx->stream,   \
+                         off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,  \
                          (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr,   \
-                         TailArgs(), *epi);                                                                            \
+                         TailArgs(), *epi, winfo, wseg);                                                               \
     else                                                                                                               \
-      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM>), dim3(grid), dim3(SP_BLOCK), 0, ctx->stream, off,             \
-                         ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,       \
+      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, false, WIN>), dim3(grid), dim3(SP_BLOCK), LDSB, ctx->stream,  \
+                         off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,  \
                          (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr,   \
-                         tail, ChebEpi());                                                                             \
+                         tail, ChebEpi(), winfo, wseg);                                                                \
   } while (0)
-  if (ctx->sp_sorted)
+#define ZZZ_SP_GO(NT, PERM) ZZZ_SP_GO5(NT, PERM, false, 0)
+  if (ctx->sp_win_max > 0 && !ctx->sp_sorted)
+  {
+    // windowed groups: their codes index the LDS window the kernel loads per group
+    const size_t ldsb = (size_t)ctx->sp_win_max * sizeof(double);
+    if (nt)
+      ZZZ_SP_GO5(true, false, true, ldsb);
+    else
+      ZZZ_SP_GO5(false, false, true, ldsb);
+  }
+  else if (ctx->sp_sorted)
   {
     if (nt)
       ZZZ_SP_GO(true, true);
@@ -1616,6 +1902,7 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
       ZZZ_SP_GO(false, false);
   }
 #undef ZZZ_SP_GO
+#undef ZZZ_SP_GO5
 }
 
 int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr,
@@ -1627,7 +1914,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
   if (e)                                                               // the kernel): inside zzz_spmv_time only
   {
     const int wlen = atoi(e) & ~1;
-    if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows)
+    if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows && ctx->sp_win_max == 0)
     {
       const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)wlen * 8 + 512))));
       const int grid = std::min(gs, 256 * per_cu);

@@ -513,6 +513,12 @@ class Context:
         self._ck(self.L.zzz_spmv_info(self.h, info))
         return [int(v) for v in info]
 
+    def spmv_x_windows(self):
+        """(LDS doubles per workgroup, bytes of x loaded into LDS per product) when the operator stream carries x windows,
+        else (0, 0)"""
+        info = self.spmv_info_raw()
+        return (int(-info[3]), int(info[2])) if info[5] and info[3] < 0 else (0, 0)
+
     def spmv_lanes_per_row(self):
         info = (C.c_int64 * 8)()
         self._ck(self.L.zzz_spmv_info(self.h, info))

@@ -736,6 +736,7 @@ def test_knob_combinations_keep_results(seed):
              "ZZZ_CG_FUSED": ["2"], "ZZZ_SPMV_TILE": ["4096"], "ZZZ_SPMV_LPR": ["1", "2", "4"], "ZZZ_COLS16": ["0", "11", "13"],
              "ZZZ_PATTERN": ["host"], "ZZZ_PATTERN_WAVE": ["1"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
              "ZZZ_ADJ_SORT": ["1"], "ZZZ_ASM_SEARCH": ["1"], "ZZZ_ASM_NO_COMPACT": ["1"], "ZZZ_ASM_LPR": ["4", "8"],
+             "ZZZ_SELLP_WIN": ["0", "1024", "8192"],
              "ZZZ_VGRID_PER": ["2", "8"]}
     names = sorted(knobs)
     chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
@@ -780,6 +781,49 @@ def test_knob_combinations_keep_results(seed):
         assert abs(itj - itj0) <= 2 and abs(itc - itc0) <= 2, (chosen, itj, itj0, itc, itc0)
         assert np.linalg.norm(uj - uj0) <= 1e-7 * np.linalg.norm(uj0), chosen
         assert np.linalg.norm(uc - uc0) <= 1e-7 * np.linalg.norm(uc0), chosen
+
+
+@pytest.mark.parametrize("order,dims", [(1, (12, 11, 13)), (2, (5, 4, 5))])
+def test_x_windows_of_the_operator_stream_keep_every_bit(order, dims):
+    """Block size 3: the columns a group of 256 rows reaches are loaded into LDS once per group and the stream's codes
+    are window indices (k_sp_windows, spmv_sellp_kernel<..., WIN>).  Same entries, same ascending-column order: the
+    product, the CG history and the Chebyshev-Jacobi solve must be BIT-identical with and without windows, for a
+    single rank and partitioned (ghost columns sit in segments of their own)."""
+    G = zzz.Part("elasticity", order, *dims)
+    x = np.cos(0.37 * np.arange(G.n_owned * G.bs))
+    res = {}
+    for win in ("0", "2048", "8192"):
+        os.environ["ZZZ_SELLP_WIN"] = win
+        try:
+            with zzz.Context(0) as c:
+                c.upload_part(G)
+                c.pattern_build()
+                c.assemble_matrix(G.form)
+                c.assemble_vector(G.form)
+                y = c.spmv(x)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                u = c.vec_download(zzz.VEC_U)
+                hist = c.cg_history(it + 1)
+                its, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9, single_reduction=True)
+                us = c.vec_download(zzz.VEC_U)
+                itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9)
+                uc = c.vec_download(zzz.VEC_U)
+                res[win] = (y, it, hist, u, its, us, itc, uc, c.spmv_x_windows(), c.spmv_operator_form())
+        finally:
+            del os.environ["ZZZ_SELLP_WIN"]
+    assert res["0"][8] == (0, 0) and res["0"][9] == 1
+    if order == 1:  # (P2 rows are too long for the one-pass packer: its stream is built without windows)
+        assert any(res[w][8][0] > 0 and res[w][8][1] > 0 for w in ("2048", "8192")), [res[w][8] for w in res]
+    for w in ("2048", "8192"):
+        for a, b in zip(res["0"][:8], res[w][:8]):
+            assert np.array_equal(a, b), w
+    rp, cl, v = None, None, None
+    with zzz.Context(0) as c:
+        c.upload_part(G)
+        c.pattern_build()
+        c.assemble_matrix(G.form)
+        rp, cl, v = c.csr_download()
+    assert np.array_equal(res["2048"][0], zo.spmv(rp.astype(np.int64), cl, v, x))  # and the serial CSR loop's bits
 
 
 def test_size_limits_are_errors_not_crashes():
@@ -2032,9 +2076,10 @@ def test_fused_direction_kernel_keeps_every_bit():
     cache-resident loops) against the three-kernel form: the same operations on the same operands, so the
     iteration count, the whole residual history and the solution are bit-identical -- for KSPCG with each norm
     type, for src/cg.h, on natural and length-sorted streams."""
-    keys = ("ZZZ_CG_FUSED", "ZZZ_SELLP")
+    keys = ("ZZZ_CG_FUSED", "ZZZ_SELLP", "ZZZ_SELLP_WIN")
     old = {k: os.environ.get(k) for k in keys}
     try:
+        os.environ["ZZZ_SELLP_WIN"] = "0"  # the fused kernel gathers from memory: an A/B variant of window-free streams
         for problem, order, dims, sellp in (("poisson", 1, (17, 15, 19), "1"), ("elasticity", 1, (7, 6, 8), "1"),
                                             ("poisson", 2, (7, 6, 5), "3"), ("poisson", 3, (4, 4, 5), "2")):
             P = zzz.Part(problem, order, *dims)
