@@ -1733,8 +1733,12 @@ int sell_update(zzz_ctx* ctx, bool structure)
   // shares almost completely (1400 doubles in 3-7 segments); needs the four wavefronts of a workgroup on one group and
   // room for the bitmap beside the parked entries.  ZZZ_SELLP_WIN: doubles of LDS per workgroup of the product
   // (default 2048 = 16 KiB: eight workgroups per CU as before; 0: off)
-  const int win_knob = getenv("ZZZ_SELLP_WIN") ? atoi(getenv("ZZZ_SELLP_WIN")) : 2048;
-  const bool winb = ctx->bs == 3 && win_knob >= 256 && win_knob <= 8192;
+  // ... and a stream that comes from HBM: where the loop is cache-resident (the 8-GPU per-rank share of C4: 22 M
+  // nonzeros) the two barriers and the window load per group cost more than the gathers they replace (product 34.5 ->
+  // 37.9 us), so without the knob windows are built for matrices beyond ~300 MB of values only
+  const char* win_env = getenv("ZZZ_SELLP_WIN");
+  const int win_knob = win_env ? atoi(win_env) : 2048;
+  const bool winb = ctx->bs == 3 && win_knob >= 256 && win_knob <= 8192 && (win_env || (double)ctx->nnz * 8.0 > 300.0e6);
   if (lds * waves > 64 * 1024 && !ctx->sp_lds_attr)
   {
     ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack<false>), hipFuncAttributeMaxDynamicSharedMemorySize,

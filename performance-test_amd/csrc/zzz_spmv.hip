@@ -287,7 +287,7 @@ static void launch_variant(zzz_ctx* ctx, int grid, const double* x, double* y, d
   const int64_t nt = tile_list ? nlist : ctx->ntiles;
   // bit 4 of the variant: ignore the packed columns (A/B and parity of the two index streams)
   const uint16_t* c16 = (ctx->have_cols16 && !(ctx->spmv_variant & 16)) ? ctx->cols16.p : nullptr;
-  const int col_max = (int)(ctx->nloc() * ctx->bs) - 1;
+  const int col_max = (int)ctx->nloc() - 1; // nloc() counts scalar entries (a clamp bs times too far read past the end of x)
 #define ZZZ_SPMV_GO(NT, PIPE, TILE)                                                                                   \
   hipLaunchKernelGGL((spmv_tile_kernel<DOT, NT, PIPE, TILE>), dim3(grid), dim3(SPMV_BLOCK), 0, ctx->stream,           \
                      ctx->rowptr.p, ctx->cols.p, ctx->vals.p, x, y, tiles, nt, nnz_even, partials, stop, tile_list,    \
