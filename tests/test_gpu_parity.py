@@ -826,6 +826,64 @@ def test_x_windows_of_the_operator_stream_keep_every_bit(order, dims):
     assert np.array_equal(res["2048"][0], zo.spmv(rp.astype(np.int64), cl, v, x))  # and the serial CSR loop's bits
 
 
+def test_x_windows_in_a_partitioned_run():
+    """x windows with a communicator attached: ghost columns sit in window segments of their own, the interior / boundary
+    split of the product and the halo exchange are what they were -- two ranks (contexts of one process, host-mediated
+    communicator) give the same bits with and without windows, and the single-rank solution."""
+    import threading
+
+    problem, order, dims, nparts = "elasticity", 1, (6, 5, 11), 2
+    G = zzz.Part(problem, order, *dims)
+    with zzz.Context(0) as c0:
+        c0.upload_part(G)
+        c0.pattern_build()
+        c0.assemble_matrix(G.form)
+        c0.assemble_vector(G.form)
+        it0, _, _ = c0.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+        u0 = c0.vec_download(zzz.VEC_U)
+    res = {}
+    for win in ("0", "2048"):
+        os.environ["ZZZ_SELLP_WIN"] = win
+        grp = zzz.LocalGroup(nparts)
+        out, err = [None] * nparts, []
+
+        def run(rank):
+            try:
+                P = zzz.Part(problem, order, *dims, nparts, rank)
+                with zzz.Context(0) as c:
+                    c.comm_init_local(grp.h, rank)
+                    c.cube_generate(problem, order, *dims, nparts, rank)
+                    c.pattern_build()
+                    c.assemble_matrix(P.form)
+                    c.assemble_vector(P.form)
+                    lo, hi = P.own_offset * P.bs, (P.own_offset + P.n_owned) * P.bs
+                    y = c.spmv(np.sin(0.23 * np.arange(lo, hi)))
+                    it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                    u = c.vec_download(zzz.VEC_U)
+                    itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9)
+                    out[rank] = (y, it, u, itc, c.vec_download(zzz.VEC_U), c.spmv_x_windows(), c.comm_info()["halo_overlapped"])
+            except Exception as e:  # noqa: BLE001
+                err.append((rank, repr(e)))
+
+        try:
+            th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(timeout=300)
+        finally:
+            grp.close()
+            del os.environ["ZZZ_SELLP_WIN"]
+        assert not err, err
+        res[win] = out
+    assert all(o[5] == (0, 0) for o in res["0"]) and all(o[5][0] == 2048 and o[5][1] > 0 for o in res["2048"])
+    for a, b in zip(res["0"], res["2048"]):
+        for x, y in zip(a[:5], b[:5]):
+            assert np.array_equal(x, y)
+    u = np.concatenate([o[2] for o in res["2048"]])
+    assert abs(res["2048"][0][1] - it0) <= 1 and np.linalg.norm(u - u0) <= 1e-9 * np.linalg.norm(u0)
+
+
 def test_size_limits_are_errors_not_crashes():
     """Maximum sizes: local indices are int32; a partition beyond that range is refused up front
     (before anything is allocated) with ZZZ_ERR_LIMIT and a message that says what to do."""
