@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(SP_BLOCK) void spmv_sellp_win_probe_kernel(const in
                                                                     const int32_t* __restrict__ meta,
                                                                     const double* __restrict__ x, double* __restrict__ y,
                                                                     int nrows, int64_t nslices, double* __restrict__ partials,
-                                                                    int wlen)
+                                                                    int wlen, int lds_slots)
 {
   extern __shared__ __attribute__((aligned(16))) double win[];
   __shared__ double red[SP_BLOCK / 64];
@@ -1302,8 +1302,10 @@ __global__ __launch_bounds__(SP_BLOCK) void spmv_sellp_win_probe_kernel(const in
 #pragma unroll
       for (int e = 0; e < 8; ++e)
       {
+        // the first lds_slots slots of every chunk gather from the window, the others from memory (a PARTIAL window)
         const unsigned idx = (unsigned)cl[e] % (unsigned)wlen;
-        sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * win[idx];
+        const double xv = e < lds_slots ? win[idx] : gather(x, min(cl[e], nrows - 1));
+        sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * xv;
       }
     }
     if (r >= 0)
@@ -1920,6 +1922,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
     const int wlen = atoi(e) & ~1;
     if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows && ctx->sp_win_max == 0)
     {
+      const int lds_slots = getenv("ZZZ_EXP_WIN_SLOTS") ? atoi(getenv("ZZZ_EXP_WIN_SLOTS")) : 8;
       const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)wlen * 8 + 512))));
       const int grid = std::min(gs, 256 * per_cu);
       const bool nt = (double)sellp_stream_bytes(ctx) > 300.0e6;
@@ -1927,11 +1930,11 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
       if (nt)
         hipLaunchKernelGGL(spmv_sellp_win_probe_kernel<true>, dim3(grid), dim3(SP_BLOCK), (size_t)wlen * 8, ctx->stream, off,
                            ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, x, y, (int)ctx->nrows,
-                           ctx->nslices, partials, wlen);
+                           ctx->nslices, partials, wlen, lds_slots);
       else
         hipLaunchKernelGGL(spmv_sellp_win_probe_kernel<false>, dim3(grid), dim3(SP_BLOCK), (size_t)wlen * 8, ctx->stream, off,
                            ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, x, y, (int)ctx->nrows,
-                           ctx->nslices, partials, wlen);
+                           ctx->nslices, partials, wlen, lds_slots);
       if (npartials)
         *npartials = grid;
       ZZZ_HIP(ctx, hipGetLastError());
