@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_sp_compact(const rp_t* __restrict__ row
 // chunk encodings (affine, periodic, 8- / 16-bit) and the ascending-column summation order are what they were.
 constexpr int SP_WIN_NSEG = 24;      // segments per group at most
 constexpr int SP_WIN_GAP = 8;        // gaps of up to this many columns are filled (fewer segments, a few unused slots)
-constexpr int SP_WIN_WORDS = 4096;   // bitmap words of the window search in k_sp_pack (16 KiB of LDS)
+constexpr int SP_WIN_WORDS = 8192;   // bitmap words of k_sp_windows (32 KiB of LDS): two mesh planes of up to 131 k entries each
 constexpr int SP_WIN_SPAN = (SP_WIN_WORDS - 2) * 32; // columns between a group's smallest and largest at most
 
 // One workgroup per group of four slices (256 rows, natural order).  The group's kept columns (its CSR range swept with
