@@ -724,7 +724,7 @@ def test_coordinate_bin_order_on_a_mesh_that_is_no_lattice(ctx, problem, order):
     test_unsorted_cells_and_foreign_numbering(ctx, problem, order, renumber="2")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ZZZ_TEST_SEEDS", "24"))))
 def test_knob_combinations_keep_results(seed):
     """The environment knobs select among code paths that are each tested alone; here RANDOM
     COMBINATIONS of them run three small problems end to end: CSR indices and values identical to the default build's
