@@ -727,9 +727,10 @@ def test_coordinate_bin_order_on_a_mesh_that_is_no_lattice(ctx, problem, order):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ZZZ_TEST_SEEDS", "24"))))
 def test_knob_combinations_keep_results(seed):
     """The environment knobs select among code paths that are each tested alone; here RANDOM
-    COMBINATIONS of them run three small problems end to end: CSR indices and values identical to the default build's
+    COMBINATIONS of them run four small problems end to end: CSR indices and values identical to the default build's
     (bit for bit: no knob may change what is assembled), the product within round-off of it (knobs that regroup row sums
-    are in the draw), Jacobi and Chebyshev-Jacobi solves with the default's iteration count +-2 and solution to 1e-7."""
+    are in the draw), Jacobi and Chebyshev-Jacobi solves with the default's iteration count +-2 and solution to 1e-7.
+    ZZZ_TEST_SEEDS=<n> draws more combinations (a soak run of 400 passes)."""
     rng = np.random.default_rng(1000 + seed)
     knobs = {"ZZZ_SPMV_VARIANT": ["1", "2", "3", "8", "9"], "ZZZ_SELLP": ["0", "2", "3"], "ZZZ_SELLP_DROP": ["0"],
              "ZZZ_SELLP_AFFINE": ["0"], "ZZZ_SELLP_PERIODIC": ["0"], "ZZZ_SELLP_ALIGN": ["0"], "ZZZ_SELLP_SYNC": ["1"],
@@ -740,7 +741,8 @@ def test_knob_combinations_keep_results(seed):
              "ZZZ_VGRID_PER": ["2", "8"]}
     names = sorted(knobs)
     chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
-    problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4))]
+    problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4)),
+                ("elasticity", 1, (6, 5, 7))]  # (the last one: the one-pass packer with x windows when the knob asks)
 
     def run_all():
         out = []
