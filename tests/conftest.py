@@ -14,3 +14,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "performance-te
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """ZZZ_TEST_ORDER=reverse | shuffle:<seed>: run the collected tests in another order (soak runs: faults that depend on
+    what was allocated and freed before -- an out-of-bounds read that only sometimes leaves a mapping -- show up this way)."""
+    order = os.environ.get("ZZZ_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
