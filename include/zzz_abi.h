@@ -250,8 +250,22 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms);
 
 /* y = action(x): the matrix-free operator lambda of cgpoisson (src/cgpoisson_problem.cpp:193-230):
  * assemble_vector of form M = action(a, un) with un = x, rows of constrained dofs zeroed, ghosts
- * of x updated first.  Needs zzz_csr_pattern_build (for the dof->cell adjacency), not the matrix. */
+ * of x updated first.  Needs mesh, dofmap and Dirichlet dofs only: no pattern, no matrix (the reference's cgpoisson
+ * creates neither, src/cgpoisson_problem.cpp:47-247).  Builds the operator's plan on first use (zzz_matfree_setup). */
 int zzz_action(zzz_ctx* ctx, const double* x, double* y);
+
+/* What cgpoisson sets up once before its solve: fem::create_form of M (src/cgpoisson_problem.cpp:133-145), the
+ * coefficient storage of `un` (:182) and the Scatterer with its buffers (:187-190).  Here: the plan of the one-pass
+ * matrix-free kernel (csrc/zzz_matfree.hip) -- cells cut into blocks by the Morton order of their centroids, block-local
+ * dof lists and 16-bit indices, the order in which a block adds its element vectors, P2/P3 geometry factors.  Optional:
+ * zzz_action and zzz_cg_solve(op = ZZZ_OP_MATFREE) build it on first use.  Invalidated by mesh, dofmap and bc uploads. */
+int zzz_matfree_setup(zzz_ctx* ctx);
+/* info[0] plan valid, [1] cell blocks, [2] cells per block, [3] threads per workgroup, [4] most dofs a block touches,
+ * [5] dofs shared between blocks, [6] their partial sums per action, [7] bytes one action addresses (plan + vectors). */
+int zzz_matfree_info(zzz_ctx* ctx, int64_t info[8]);
+/* Measurement aid, as zzz_spmv_time: HIP-event time of `reps` back-to-back actions w = action(p) with the <p,w>
+ * partials (what one iteration of linalg::cg launches at src/cg.h:62,65). */
+int zzz_action_time(zzz_ctx* ctx, int reps, double* avg_ms);
 
 /* ---- the reference's native partition ----------------------------------------------------- */
 

@@ -235,6 +235,7 @@ int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncell
   rc = upload(ctx, ctx->cell_verts, cell_verts, (size_t)(4 * ncells));
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
+  ctx->mf.valid = false;
   return rc;
 }
 
@@ -276,6 +277,7 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
+  ctx->mf.valid = false;
   // the library's own locality order of the owned dofs (zzz_renumber.hip): from here on the device connectivity is in
   // internal numbering and every entry point below translates at the boundary
   rc = renumber_build(ctx);
@@ -306,6 +308,7 @@ int zzz_bc_upload(zzz_ctx* ctx, int64_t nbc, const int32_t* bc_dofs)
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->bc.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_bc = true;
+  ctx->mf.valid = false; // the plan of the matrix-free action carries the Dirichlet markers of its dof lists
   return ZZZ_OK;
 }
 
@@ -792,8 +795,8 @@ int zzz_spmv_time(zzz_ctx* ctx, int reps, int variant, double* avg_ms)
 int zzz_action(zzz_ctx* ctx, const double* x, double* y)
 {
   ZZZ_ENTER(ctx);
-  if (!ctx->have_pattern || !x || !y)
-    return fail(ctx, ZZZ_ERR_ARG, "zzz_action: no pattern/adjacency or NULL vector");
+  if (ctx->order == 0 || !x || !y)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_action: no dofmap or NULL vector");
   const size_t n = (size_t)(ctx->n_owned * ctx->bs);
   std::vector<double> xin;
   if (ctx->renumbered)
@@ -824,6 +827,52 @@ int zzz_action(zzz_ctx* ctx, const double* x, double* y)
   ZZZ_HIP(ctx, hipMemcpyAsync(y, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ctx->comm ? comm_p2p_check(ctx) : ZZZ_OK;
+}
+
+int zzz_matfree_setup(zzz_ctx* ctx)
+{
+  ZZZ_ENTER(ctx);
+  return mf_plan_build(ctx);
+}
+
+int zzz_matfree_info(zzz_ctx* ctx, int64_t info[8])
+{
+  if (!ctx || !info)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_matfree_info: bad arguments");
+  const zzz::MfPlan& M = ctx->mf;
+  info[0] = M.valid ? 1 : 0;
+  info[1] = M.nblocks;
+  info[2] = M.nc;
+  info[3] = M.threads;
+  info[4] = M.nloc_max;
+  info[5] = M.nshared;
+  info[6] = M.nslots;
+  info[7] = M.bytes_per_action;
+  return ZZZ_OK;
+}
+
+int zzz_action_time(zzz_ctx* ctx, int reps, double* avg_ms)
+{
+  ZZZ_ENTER(ctx);
+  if (reps <= 0 || !avg_ms || ctx->order == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_action_time: bad arguments");
+  hipEvent_t e0, e1;
+  ZZZ_HIP(ctx, hipEventCreate(&e0));
+  ZZZ_HIP(ctx, hipEventCreate(&e1));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(zzz::CgState), ctx->stream));
+  int np = 0;
+  int rc = launch_matfree_action(ctx, ctx->p.p, ctx->w.p, ctx->part_a.p, &np); // warm-up (and the plan, if missing)
+  ZZZ_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps && !rc; ++i)
+    rc = launch_matfree_action(ctx, ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+  ZZZ_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  ZZZ_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  ZZZ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / reps;
+  return rc;
 }
 
 int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)

@@ -1542,7 +1542,20 @@ int build_adjT(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
+// The operator of cgpoisson: the one-pass cell-block kernel of zzz_matfree.hip on its plan (built on first use, or by
+// zzz_matfree_setup); ZZZ_MF_LEGACY=1 keeps the two-pass form below (A/B, and the parity test between the two).
 int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
+{
+  static const bool legacy = getenv("ZZZ_MF_LEGACY") && atoi(getenv("ZZZ_MF_LEGACY")) != 0;
+  if (legacy)
+    return launch_matfree_legacy(ctx, u, y, partials, npartials);
+  if (!ctx->mf.valid)
+    if (int rc = mf_plan_build(ctx))
+      return rc;
+  return mf_action(ctx, u, y, partials, npartials);
+}
+
+int launch_matfree_legacy(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
 {
   if (ctx->bs != 1)
     return fail(ctx, ZZZ_ERR_ARG, "the matrix-free operator exists for the Poisson form M only (src/Poisson.py:33)");

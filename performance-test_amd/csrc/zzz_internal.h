@@ -101,6 +101,31 @@ struct CgParams
   int variant, pc, norm;
   double rtol, atol, dtol;
 };
+
+// Plan of the matrix-free action (zzz_matfree.hip): the cells in blocks of `nc` (contiguous in the Morton order of their
+// centroids), every block with the list of the dofs it touches, 16-bit block-local indices per cell and, per (cell,
+// local dof), the RANK of that incidence among the cells of its step that touch the same dof -- the order in which
+// the contributions are added in LDS.  Built once per mesh / dofmap / Dirichlet set.
+struct MfPlan
+{
+  bool valid = false, failed = false;
+  int nd = 0, nc = 0, threads = 0, nsb = 0; // dofs per cell; cells per block; workgroup size; steps per block (nc / threads)
+  int ndw = 0, nrw = 0;                     // 32-bit words of indices / of ranks per cell
+  int64_t nblocks = 0, nshared = 0, nslots = 0;
+  int nloc_max = 0;
+  int64_t bytes_per_action = 0; // what one action addresses (plan streams + vectors)
+  DevBuf<int32_t> hdr;          // [block][8]: dof_off, nloc, n_int, n_sh, part_off, 0, 0, 0
+  DevBuf<int32_t> dof_ids;      // block-local dof lists: interior | shared with other blocks | ghost, ascending inside
+  DevBuf<uint8_t> dof_flag;     // Dirichlet marker of each list entry
+  DevBuf<double> xyz;           // P1: coordinates of each list entry
+  DevBuf<uint32_t> idxw, rnkw;  // [block][word][cell of the block]
+  DevBuf<uint8_t> rmax;         // [block][step][4 nrw]: rounds needed by local dof i in that step
+  DevBuf<double> geom;          // P2/P3: [block][6][cell]  |detJ| K K^T
+  DevBuf<double> dtab;          // P2/P3: the factorised reference tables (ZZZ_DTAB_P2/P3)
+  DevBuf<double> ypart;         // partial sums of the shared dofs, [slot]
+  DevBuf<int32_t> sh_dof, sh_off, sh_slot; // shared dof -> its slots (ascending block)
+  DevBuf<int32_t> mf_cell;      // [block][cell] -> cell of the context (-1: none), kept for rebuilding the geometry
+};
 } // namespace zzz
 
 struct zzz_ctx
@@ -265,6 +290,7 @@ struct zzz_ctx
   int64_t sp_win_bytes = 0;         // window bytes a product loads (all windowed groups)
   bool timing_only = false;  // inside zzz_spmv_time: the products' results are discarded (the ZZZ_EXP_WIN probe may run)
   bool halo_pending = false; // comm_halo_begin put an exchange on the comm stream: comm_halo_end waits for it
+  zzz::MfPlan mf; // matrix-free action
   double last_pc_bound = 0.0; // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound the last solve used
   bool last_solve_fused = false; // the last solve ran the fused product + direction kernel
 
@@ -352,6 +378,10 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
 int launch_assemble_matrix(zzz_ctx* ctx, int form);
 int launch_assemble_vector(zzz_ctx* ctx, int form);
 int launch_matfree_action(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+int launch_matfree_legacy(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+// zzz_matfree.hip
+int mf_plan_build(zzz_ctx* ctx);
+int mf_action(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
 
 // kernels_cg
 int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);

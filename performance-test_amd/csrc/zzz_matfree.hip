@@ -1,0 +1,1007 @@
+// Matrix-free operator of --problem_type cgpoisson on gfx950:  y = action(a, un = x), then y[bc] = 0
+// (form M of src/Poisson.py:33, applied as in src/cgpoisson_problem.cpp:193-230: y = 0, assemble_vector(y, M) with
+// un = x, bc->set(y, 0)); it is the operator linalg::cg iterates on (src/cg.h:46,62, called at
+// src/cgpoisson_problem.cpp:233).  No element matrix is stored and nothing per cell travels through HBM twice.
+//
+// ONE pass, cell blocks in LDS:
+//   * the cells are cut into blocks of `nc` that are contiguous in the Morton order of their centroids (any mesh: no
+//     lattice is assumed); a block knows the dofs it touches (`dof_ids`: interior to the block | shared with other
+//     blocks | ghost) and every cell carries 16-bit indices into that list;
+//   * a workgroup owns a block: it stages u (P1: and the vertex coordinates) of the block's dofs in LDS, then walks the
+//     block in steps of one cell per lane.  The cells of a step are dealt out so that neighbours in space sit in
+//     different steps;
+//   * P1: geometry from the staged coordinates (cofactors, one division), y_e = c (c^T u) / (6 |det J|);
+//     P2/P3: FACTORISED stiffness.  d_a phi_j lies in P_(k-1), so with an orthonormal basis psi_q of P_(k-1)
+//       S^ab_ij = sum_q D_a[q][i] D_b[q][j]   =>   y_e = sum_a D_a^T ( sum_b G_ab (D_b u_e) ),   G = |detJ| K K^T
+//     (ZZZ_DTAB_P2/P3 of element_tables.inc, 2 x 3 nq nd + 9 nq multiply-adds per cell with the tables' zeros skipped
+//     at compile time: 872 for P3 instead of 2 400 for the six nd x nd tensors); G per cell is read, not recomputed;
+//   * the element vector is added into the block's y in LDS in ROUNDS: the plan gives every (cell, local dof) incidence
+//     its rank among the incidences of the same dof in the same step; round r adds the incidences of rank r, so no two
+//     lanes meet on an address, nothing is atomic and the order of additions is fixed: reproducible bit for bit;
+//   * dofs interior to the block leave as y directly; dofs shared with other blocks leave as partial sums and
+//     `k_mf_finish` adds each one's partials in ascending block order.
+// The partial sums of <x, y> for the CG's dot product ride along (src/cg.h:65).
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+
+#include "zzz_device.h"
+#include "zzz_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include "element_tables.inc"
+
+namespace zzz
+{
+namespace
+{
+constexpr int MF_HDR = 8;
+
+// ---- plan build ------------------------------------------------------------------------------------------------------
+__device__ inline uint32_t spread10(uint32_t v)
+{
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_mf_bbox(const double* __restrict__ x, int64_t nverts, double* __restrict__ out)
+{
+  __shared__ double sh[6][4];
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t v = blockIdx.x * 256ll + threadIdx.x; v < nverts; v += gridDim.x * 256ll)
+    for (int a = 0; a < 3; ++a)
+    {
+      const double c = x[3 * v + a];
+      lo[a] = fmin(lo[a], c);
+      hi[a] = fmax(hi[a], c);
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      lo[a] = fmin(lo[a], __shfl_down(lo[a], o, 64));
+      hi[a] = fmax(hi[a], __shfl_down(hi[a], o, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; ++a)
+    {
+      sh[a][threadIdx.x >> 6] = lo[a];
+      sh[3 + a][threadIdx.x >> 6] = hi[a];
+    }
+  __syncthreads();
+  if (threadIdx.x < 6)
+  {
+    double v = sh[threadIdx.x][0];
+    for (int i = 1; i < 4; ++i)
+      v = threadIdx.x < 3 ? fmin(v, sh[threadIdx.x][i]) : fmax(v, sh[threadIdx.x][i]);
+    out[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+struct Box
+{
+  double lo[3], scale[3];
+};
+
+__global__ __launch_bounds__(256) void k_mf_cell_keys(const double* __restrict__ x, const int32_t* __restrict__ cell_verts,
+                                                      int64_t ncells, Box B, uint32_t* __restrict__ key,
+                                                      int32_t* __restrict__ val)
+{
+  for (int64_t c = blockIdx.x * 256ll + threadIdx.x; c < ncells; c += gridDim.x * 256ll)
+  {
+    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * c);
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      const double m = 0.25 * (x[3ll * v.x + a] + x[3ll * v.y + a] + x[3ll * v.z + a] + x[3ll * v.w + a]);
+      const double t = (m - B.lo[a]) * B.scale[a];
+      q[a] = (uint32_t)min(1023, max(0, (int)t));
+    }
+    key[c] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    val[c] = (int32_t)c;
+  }
+}
+
+// execution order inside a block: position e = step * T + lane holds the cell of spatial rank kk = lane * nsb + step,
+// so the cells of one step are every nsb-th cell of the block (neighbours in space meet in different steps)
+__global__ __launch_bounds__(256) void k_mf_deal(const int32_t* __restrict__ sorted, int64_t ncells, int nc, int T, int nsb,
+                                                 int64_t total, int32_t* __restrict__ mf_cell)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll)
+  {
+    const int64_t b = i / nc;
+    const int e = (int)(i - b * nc);
+    const int s = e / T, t = e - s * T;
+    const int64_t k = b * nc + (int64_t)t * nsb + s;
+    mf_cell[i] = k < ncells ? sorted[k] : -1;
+  }
+}
+
+// one (block, dof) key per incidence; value = position in the block * nd + local index
+__global__ __launch_bounds__(256) void k_mf_pairs(const int32_t* __restrict__ mf_cell, const int32_t* __restrict__ cell_dofs,
+                                                  int nd, int nc, int64_t total, uint64_t* __restrict__ key,
+                                                  uint32_t* __restrict__ val)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total * nd; i += gridDim.x * 256ll)
+  {
+    const int64_t pe = i / nd;
+    const int li = (int)(i - pe * nd);
+    const int64_t b = pe / nc;
+    const int e = (int)(pe - b * nc);
+    const int32_t c = mf_cell[pe];
+    key[i] = c < 0 ? ~0ull : (((uint64_t)b << 32) | (uint32_t)cell_dofs[(int64_t)c * nd + li]);
+    val[i] = (uint32_t)(e * nd + li);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mf_heads(const uint64_t* __restrict__ key, int64_t n, int32_t* __restrict__ flag)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+    flag[i] = (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
+}
+
+// at the head of every run: the unique's key and where its run starts; how many blocks hold each dof
+__global__ __launch_bounds__(256) void k_mf_uniques(const uint64_t* __restrict__ key, const int32_t* __restrict__ flag,
+                                                    const int32_t* __restrict__ uidx, int64_t n, uint64_t* __restrict__ ukey,
+                                                    int32_t* __restrict__ run_start, int32_t* __restrict__ nblk_of)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+    if (flag[i])
+    {
+      const int32_t j = uidx[i];
+      ukey[j] = key[i];
+      run_start[j] = (int32_t)i;
+      atomicAdd(&nblk_of[(uint32_t)key[i]], 1);
+    }
+}
+
+// class of every unique (0 interior to its block, 1 shared, 2 ghost), the sort key that groups them, counts per block
+__global__ __launch_bounds__(256) void k_mf_classify(const uint64_t* __restrict__ ukey, int64_t nu,
+                                                     const int32_t* __restrict__ nblk_of, int64_t n_owned,
+                                                     uint64_t* __restrict__ key2, int32_t* __restrict__ val2,
+                                                     int32_t* __restrict__ cnt3)
+{
+  for (int64_t j = blockIdx.x * 256ll + threadIdx.x; j < nu; j += gridDim.x * 256ll)
+  {
+    const uint64_t k = ukey[j];
+    const uint32_t g = (uint32_t)k;
+    const uint64_t b = k >> 32;
+    const int c = (int64_t)g >= n_owned ? 2 : (nblk_of[g] > 1 ? 1 : 0);
+    key2[j] = (b << 34) | ((uint64_t)c << 32) | g;
+    val2[j] = (int32_t)j;
+    atomicAdd(&cnt3[b * 3 + c], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mf_block_sizes(const int32_t* __restrict__ cnt3, int64_t nb, int32_t* __restrict__ nloc,
+                                                        int32_t* __restrict__ nsh)
+{
+  for (int64_t b = blockIdx.x * 256ll + threadIdx.x; b <= nb; b += gridDim.x * 256ll)
+  {
+    nloc[b] = b < nb ? cnt3[3 * b] + cnt3[3 * b + 1] + cnt3[3 * b + 2] : 0;
+    nsh[b] = b < nb ? cnt3[3 * b + 1] : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mf_headers(const int32_t* __restrict__ cnt3, const int32_t* __restrict__ dof_off,
+                                                    const int32_t* __restrict__ part_off, int64_t nb, int32_t* __restrict__ hdr,
+                                                    int32_t* __restrict__ nloc_max)
+{
+  int m = 0;
+  for (int64_t b = blockIdx.x * 256ll + threadIdx.x; b < nb; b += gridDim.x * 256ll)
+  {
+    const int nl = cnt3[3 * b] + cnt3[3 * b + 1] + cnt3[3 * b + 2];
+    hdr[MF_HDR * b + 0] = dof_off[b];
+    hdr[MF_HDR * b + 1] = nl;
+    hdr[MF_HDR * b + 2] = cnt3[3 * b];
+    hdr[MF_HDR * b + 3] = cnt3[3 * b + 1];
+    hdr[MF_HDR * b + 4] = part_off[b];
+    hdr[MF_HDR * b + 5] = hdr[MF_HDR * b + 6] = hdr[MF_HDR * b + 7] = 0;
+    m = max(m, nl);
+  }
+  m = wave_max_i(m);
+  if ((threadIdx.x & 63) == 0 && m)
+    atomicMax(nloc_max, m);
+}
+
+// the block-local lists in their final order (sorted key2): global dof, Dirichlet flag, coordinates; local index of every
+// unique; (dof, slot) of the shared ones
+__global__ __launch_bounds__(256) void k_mf_lists(const uint64_t* __restrict__ key2s, const int32_t* __restrict__ val2s, int64_t nu,
+                                                  const int32_t* __restrict__ hdr, const uint8_t* __restrict__ bc,
+                                                  const double* __restrict__ xq, int32_t* __restrict__ dof_ids,
+                                                  uint8_t* __restrict__ dof_flag, double* __restrict__ xyz,
+                                                  int32_t* __restrict__ loc_of, uint32_t* __restrict__ sh_key,
+                                                  int32_t* __restrict__ sh_val)
+{
+  for (int64_t q = blockIdx.x * 256ll + threadIdx.x; q < nu; q += gridDim.x * 256ll)
+  {
+    const uint64_t k = key2s[q];
+    const uint32_t g = (uint32_t)k;
+    const int c = (int)((k >> 32) & 3);
+    const int64_t b = (int64_t)(k >> 34);
+    const int32_t* h = hdr + MF_HDR * b;
+    const int loc = (int)(q - h[0]);
+    dof_ids[q] = (int32_t)g;
+    dof_flag[q] = bc[g];
+    if (xyz)
+    {
+      xyz[3 * q + 0] = xq[3ll * g + 0];
+      xyz[3 * q + 1] = xq[3ll * g + 1];
+      xyz[3 * q + 2] = xq[3ll * g + 2];
+    }
+    loc_of[val2s[q]] = loc;
+    sh_key[q] = c == 1 ? g : 0xffffffffu;
+    sh_val[q] = c == 1 ? h[4] + (loc - h[2]) : -1;
+  }
+}
+
+// per incidence (in the order of the sorted pairs): its 16-bit local index and its rank among the incidences of the same
+// dof in the same step (the run of a (block, dof) key holds them by ascending position)
+__global__ __launch_bounds__(256) void k_mf_cells(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                  const int32_t* __restrict__ uidx, const int32_t* __restrict__ flag, int64_t n,
+                                                  const int32_t* __restrict__ run_start, const int32_t* __restrict__ loc_of, int nd,
+                                                  int nc, int T, int ndw, int nrw, uint32_t* __restrict__ idxw,
+                                                  uint32_t* __restrict__ rnkw, int32_t* __restrict__ err)
+{
+  uint16_t* idx16 = reinterpret_cast<uint16_t*>(idxw);
+  uint8_t* rnk8 = reinterpret_cast<uint8_t*>(rnkw);
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+  {
+    const uint64_t k = key[i];
+    if (k == ~0ull)
+      continue;
+    const int32_t j = uidx[i] - (flag[i] ? 0 : 1); // uidx is the exclusive scan of the head flags
+    const int64_t b = (int64_t)(k >> 32);
+    const uint32_t v = val[i];
+    const int e = (int)(v / (uint32_t)nd), li = (int)(v - (uint32_t)e * nd);
+    const int s = e / T;
+    int rank = 0;
+    for (int64_t p = run_start[j]; p < i; ++p)
+      rank += ((int)(val[p] / (uint32_t)nd) / T == s) ? 1 : 0;
+    if (rank > 254)
+    {
+      *err = 1;
+      rank = 254;
+    }
+    idx16[((b * ndw + (li >> 1)) * nc + e) * 2 + (li & 1)] = (uint16_t)loc_of[j];
+    rnk8[((b * nrw + (li >> 2)) * nc + e) * 4 + (li & 3)] = (uint8_t)rank;
+  }
+}
+// rounds local dof i needs in every (block, step): 1 + the largest rank among the step's cells
+__global__ __launch_bounds__(256) void k_mf_rmax(const uint32_t* __restrict__ rnkw, int64_t nb, int nc, int T, int nsb, int nrw,
+                                                 uint8_t* __restrict__ rmax)
+{
+  // one wavefront per (block, step, word of four local dofs); a rank byte of 0xff = no cell
+  const int lane = threadIdx.x & 63;
+  const int64_t items = nb * nsb * nrw;
+  for (int64_t it = blockIdx.x * 4ll + (threadIdx.x >> 6); it < items; it += gridDim.x * 4ll)
+  {
+    const int w = (int)(it % nrw);
+    const int64_t bs_ = it / nrw;
+    const int s = (int)(bs_ % nsb);
+    const int64_t b = bs_ / nsb;
+    const uint32_t* src = rnkw + (b * nrw + w) * nc + (int64_t)s * T;
+    int m[4] = {0, 0, 0, 0};
+    for (int t = lane; t < T; t += 64)
+    {
+      const uint32_t r = src[t];
+      for (int k = 0; k < 4; ++k)
+      {
+        const int rb = (int)((r >> (8 * k)) & 255u);
+        m[k] = max(m[k], rb == 255 ? 0 : rb + 1);
+      }
+    }
+    for (int k = 0; k < 4; ++k)
+      m[k] = wave_max_i(m[k]);
+    if (lane == 0)
+      reinterpret_cast<uint32_t*>(rmax)[(b * nsb + s) * nrw + w] =
+          (uint32_t)m[0] | ((uint32_t)m[1] << 8) | ((uint32_t)m[2] << 16) | ((uint32_t)m[3] << 24);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mf_sh_heads(const uint32_t* __restrict__ key, int64_t n, int32_t* __restrict__ flag)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+    flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_mf_sh_fill(const uint32_t* __restrict__ key, const int32_t* __restrict__ flag,
+                                                    const int32_t* __restrict__ uidx, int64_t n, int32_t* __restrict__ sh_dof,
+                                                    int32_t* __restrict__ sh_off, int64_t nshared)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i <= n; i += gridDim.x * 256ll)
+  {
+    if (i == n)
+      sh_off[nshared] = (int32_t)n;
+    else if (flag[i])
+    {
+      sh_dof[uidx[i]] = (int32_t)key[i];
+      sh_off[uidx[i]] = (int32_t)i;
+    }
+  }
+}
+
+// P2/P3: |detJ| K K^T of every cell, in plan order, component-major inside the block
+__global__ __launch_bounds__(256) void k_mf_geom(const double* __restrict__ x, const int32_t* __restrict__ cell_verts,
+                                                 const int32_t* __restrict__ mf_cell, int nc, int64_t total,
+                                                 double* __restrict__ geom)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll)
+  {
+    const int64_t b = i / nc;
+    const int e = (int)(i - b * nc);
+    const int32_t c = mf_cell[i];
+    double G[6] = {0, 0, 0, 0, 0, 0};
+    if (c >= 0)
+    {
+      const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4ll * c);
+      const int vv[4] = {v.x, v.y, v.z, v.w};
+      double p[4][3];
+      for (int k = 0; k < 4; ++k)
+        for (int a = 0; a < 3; ++a)
+          p[k][a] = x[3ll * vv[k] + a];
+      double J[3][3];
+      for (int a = 0; a < 3; ++a)
+        for (int al = 0; al < 3; ++al)
+          J[a][al] = p[al + 1][a] - p[0][a];
+      // K = J^-1 = C / det, K[al][a] = dX_al / dx_a
+      double C[3][3];
+      C[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+      C[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+      C[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+      C[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+      C[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+      C[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+      C[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+      C[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+      C[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      const double det = J[0][0] * C[0][0] + J[0][1] * C[1][0] + J[0][2] * C[2][0];
+      const double sc = 1.0 / fabs(det); // |det| K K^T = C C^T / |det|
+      const int pa[6] = {0, 1, 2, 0, 0, 1}, pb[6] = {0, 1, 2, 1, 2, 2};
+      for (int t = 0; t < 6; ++t)
+        G[t] = (C[pa[t]][0] * C[pb[t]][0] + C[pa[t]][1] * C[pb[t]][1] + C[pa[t]][2] * C[pb[t]][2]) * sc;
+    }
+    for (int t = 0; t < 6; ++t)
+      geom[(b * 6 + t) * nc + e] = G[t];
+  }
+}
+
+// ---- the action ------------------------------------------------------------------------------------------------------
+struct MfArgs
+{
+  const int32_t* hdr;
+  const int32_t* dof_ids;
+  const uint8_t* dof_flag;
+  const double* xyz;
+  const uint32_t* idxw;
+  const uint32_t* rnkw;
+  const uint8_t* rmax;
+  const double* geom;
+  const double* dtab;
+  double* ypart;
+  const double* u;
+  double* y;
+  double* partials;
+  const int* stop;
+  int64_t nblocks;
+  int nc, nsb, nloc_cap;
+};
+
+// The factorised tables: constexpr copies decide at compile time which entries are zero; the values are staged in LDS
+// by every (persistent) workgroup and reach the multiply-adds as broadcast reads.  (As literals they occupied ~200
+// vector registers of every lane; as scalar loads from constant memory the compiler hoisted them all and spilled 865
+// scalar registers.)
+template <int ND>
+struct MfTab;
+template <>
+struct MfTab<10>
+{
+  static constexpr int NQ = 4;
+  static constexpr bool nz(int a, int q, int j) { return ZZZ_DTAB_P2[(a * 4 + q) * 10 + j] != 0.0; }
+};
+template <>
+struct MfTab<20>
+{
+  static constexpr int NQ = 10;
+  static constexpr bool nz(int a, int q, int j) { return ZZZ_DTAB_P3[(a * 10 + q) * 20 + j] != 0.0; }
+};
+
+// y_e = sum_q sum_a D_a[q][:]^T h_a(q),  h(q) = G g(q),  g_a(q) = D_a[q][:] . u_e -- mode q by mode q, so that only u_e,
+// y_e and six scalars are live.  A table entry is READ TWICE, once for each of its uses, the second time from a second
+// copy of the table laid out for that use ([q][j][a]; the compiler cannot tell that the two are equal): kept in
+// registers between the uses, the ~39 entries of a mode cost 78 vector registers, 220 in all, two wavefronts per SIMD.  Multiply-adds are fused here (the library is otherwise built with
+// -ffp-contract=off): the action is compared with the oracle to a tolerance, not bit for bit.
+template <int ND>
+__device__ inline void mf_element_pk(const double* __restrict__ tab, const double* __restrict__ tabT, const double (&ue)[ND],
+                                     const double (&G)[6], double (&ye)[ND])
+{
+#pragma clang fp contract(fast)
+  constexpr int NQ = MfTab<ND>::NQ;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+    ye[j] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    double g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        if (MfTab<ND>::nz(a, q, j))
+          acc += tab[(a * NQ + q) * ND + j] * ue[j];
+      g[a] = acc;
+    }
+    const double h0 = G[0] * g[0] + G[3] * g[1] + G[4] * g[2];
+    const double h1 = G[3] * g[0] + G[1] * g[1] + G[5] * g[2];
+    const double h2 = G[4] * g[0] + G[5] * g[1] + G[2] * g[2];
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+    {
+      if (MfTab<ND>::nz(0, q, j))
+        ye[j] += tabT[(q * ND + j) * 3 + 0] * h0;
+      if (MfTab<ND>::nz(1, q, j))
+        ye[j] += tabT[(q * ND + j) * 3 + 1] * h1;
+      if (MfTab<ND>::nz(2, q, j))
+        ye[j] += tabT[(q * ND + j) * 3 + 2] * h2;
+    }
+  }
+}
+
+template <int ND, int T>
+__global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArgs A)
+{
+  if (A.stop && *A.stop)
+    return;
+  constexpr int NDW = ND / 2, NRW = (ND + 3) / 4;
+  extern __shared__ __align__(32) unsigned char mf_lds[];
+  // P1: rec[nloc_cap] = {x, y, z, u} then ys[nloc_cap]; P2/P3: us[nloc_cap] then ys[nloc_cap]
+  double* const rec = reinterpret_cast<double*>(mf_lds);
+  double* const ys = rec + (size_t)(ND == 4 ? 4 : 1) * A.nloc_cap;
+  __shared__ double red[T / 64];
+  constexpr int NTAB = ND == 4 ? 1 : 3 * ND * (ND == 10 ? 4 : 10);
+  __shared__ double tab_s[NTAB], tabT_s[NTAB];
+  const int tid = threadIdx.x;
+  if (ND != 4)
+    for (int k = tid; k < NTAB; k += T) // (the first block's barrier below orders this)
+    {
+      constexpr int NQ = ND == 10 ? 4 : 10;
+      const double v = A.dtab[k]; // [a][q][j]
+      const int a = k / (NQ * ND), q = (k / ND) % NQ, j = k % ND;
+      tab_s[k] = v;
+      tabT_s[(q * ND + j) * 3 + a] = v;
+    }
+  double dot = 0.0;
+  for (int step = 0;; ++step)
+  {
+    const int64_t b = xcd_stride_item(A.nblocks, step);
+    if (b < 0)
+      break;
+    const int32_t* __restrict__ h = A.hdr + MF_HDR * b;
+    const int dof_off = h[0], nloc = h[1], n_int = h[2], n_sh = h[3], part_off = h[4];
+    // stage the block's u (and coordinates), clear its y
+    for (int d = tid; d < nloc; d += T)
+    {
+      const int32_t g = A.dof_ids[dof_off + d];
+      const double uv = A.u[g];
+      if (ND == 4)
+      {
+        const double* __restrict__ q = A.xyz + 3ll * (dof_off + d);
+        *reinterpret_cast<double4*>(rec + 4 * d) = make_double4(q[0], q[1], q[2], uv);
+      }
+      else
+        rec[d] = uv;
+      ys[d] = 0.0;
+    }
+    for (int s = 0; s < A.nsb; ++s)
+    {
+      const int e = s * T + tid;
+      uint32_t iw[NDW], rw[NRW];
+#pragma unroll
+      for (int w = 0; w < NDW; ++w)
+        iw[w] = A.idxw[(b * NDW + w) * A.nc + e];
+#pragma unroll
+      for (int w = 0; w < NRW; ++w)
+        rw[w] = A.rnkw[(b * NRW + w) * A.nc + e];
+      double ye[ND];
+      if (s == 0)
+      {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads(); // the staged values are in LDS (the loads above are in flight meanwhile)
+      }
+      if constexpr (ND == 4)
+      {
+#pragma clang fp contract(fast)
+        const int i0 = iw[0] & 0xffff, i1 = iw[0] >> 16, i2 = iw[1] & 0xffff, i3 = iw[1] >> 16;
+        const double4 p0 = *reinterpret_cast<const double4*>(rec + 4 * i0);
+        const double4 p1 = *reinterpret_cast<const double4*>(rec + 4 * i1);
+        const double4 p2 = *reinterpret_cast<const double4*>(rec + 4 * i2);
+        const double4 p3 = *reinterpret_cast<const double4*>(rec + 4 * i3);
+        // J[a][al] = p_(al+1)[a] - p_0[a]; C = cofactors: K = J^-1 = C / det, grad phi_(al+1) = C[al][:] / det
+        const double J00 = p1.x - p0.x, J01 = p2.x - p0.x, J02 = p3.x - p0.x;
+        const double J10 = p1.y - p0.y, J11 = p2.y - p0.y, J12 = p3.y - p0.y;
+        const double J20 = p1.z - p0.z, J21 = p2.z - p0.z, J22 = p3.z - p0.z;
+        const double C00 = J11 * J22 - J12 * J21, C01 = J02 * J21 - J01 * J22, C02 = J01 * J12 - J02 * J11;
+        const double C10 = J12 * J20 - J10 * J22, C11 = J00 * J22 - J02 * J20, C12 = J02 * J10 - J00 * J12;
+        const double C20 = J10 * J21 - J11 * J20, C21 = J01 * J20 - J00 * J21, C22 = J00 * J11 - J01 * J10;
+        const double det = J00 * C00 + J01 * C10 + J02 * C20;
+        const double d1 = p1.w - p0.w, d2 = p2.w - p0.w, d3 = p3.w - p0.w;
+        const double sc = 1.0 / (6.0 * fabs(det));
+        const double t0 = (C00 * d1 + C10 * d2 + C20 * d3) * sc;
+        const double t1 = (C01 * d1 + C11 * d2 + C21 * d3) * sc;
+        const double t2 = (C02 * d1 + C12 * d2 + C22 * d3) * sc;
+        ye[1] = C00 * t0 + C01 * t1 + C02 * t2;
+        ye[2] = C10 * t0 + C11 * t1 + C12 * t2;
+        ye[3] = C20 * t0 + C21 * t1 + C22 * t2;
+        ye[0] = -(ye[1] + ye[2] + ye[3]);
+      }
+      else
+      {
+        double G[6], ue[ND];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+          G[t] = A.geom[(b * 6 + t) * A.nc + e];
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+          ue[j] = rec[(iw[j >> 1] >> (16 * (j & 1))) & 0xffff];
+        mf_element_pk<ND>(tab_s, tabT_s, ue, G, ye);
+      }
+      // rounds: the incidences of rank r of this step are added in round r (distinct addresses inside a round).  The
+      // additions are LDS atomics WITHOUT return (ds_add_f64: nothing to wait for inside a round; a read-add-write chain
+      // per incidence cost a round trip each: P3 3.3x, P1 2x the kernel); no two of a round meet on an address, so their
+      // order is immaterial and the sum of a dof is formed in round order: reproducible.  The local dofs of a cell come
+      // in classes of falling multiplicity (vertices, edges, faces): the late rounds look at the vertices only.
+      const uint32_t* __restrict__ rm = reinterpret_cast<const uint32_t*>(A.rmax) + (b * A.nsb + s) * NRW;
+      int Rc[3] = {0, 0, 0}; // rounds the classes [0, 4), [4, NE), [NE, ND) need
+      constexpr int NE = ND == 20 ? 16 : ND;
+#pragma unroll
+      for (int w = 0; w < NRW; ++w)
+      {
+        const uint32_t m = __builtin_amdgcn_readfirstlane(rm[w]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * w + k < ND)
+          {
+            const int c = 4 * w + k < 4 ? 0 : (4 * w + k < NE ? 1 : 2);
+            Rc[c] = max(Rc[c], (int)((m >> (8 * k)) & 255u));
+          }
+      }
+      const int R2 = Rc[2], R1 = max(R2, Rc[1]), R0 = max(R1, Rc[0]);
+      for (int r = 0; r < R0; ++r)
+      {
+        // hipcc (ROCm 7.2) emitted this loop's s_barrier WITHOUT a wait for the LDS store of the round before (seen in
+        // the ISA; one dof in 5 x 10^5 lost an addition every few launches): the wait is spelled out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int jend = r < R2 ? ND : (r < R1 ? NE : 4); // uniform
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          if (j < 4 || (j < NE ? jend > 4 : jend > NE))
+            if ((int)((rw[j >> 2] >> (8 * (j & 3))) & 255u) == r)
+            {
+              const int i = (iw[j >> 1] >> (16 * (j & 1))) & 0xffff;
+              __hip_atomic_fetch_add(&ys[i], ye[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // dofs interior to the block: final values; shared ones: this block's partial sum
+    for (int d = tid; d < n_int; d += T)
+    {
+      const int32_t g = A.dof_ids[dof_off + d];
+      const double v = A.dof_flag[dof_off + d] ? 0.0 : ys[d]; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
+      A.y[g] = v;
+      dot += v * (ND == 4 ? rec[4 * d + 3] : rec[d]);
+    }
+    for (int d = tid; d < n_sh; d += T)
+      A.ypart[part_off + d] = ys[n_int + d];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (A.partials)
+  {
+    const double t = block_reduce_sum(dot, red);
+    if (tid == 0)
+      A.partials[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mf_finish(const int32_t* __restrict__ sh_dof, const int32_t* __restrict__ sh_off,
+                                                   const int32_t* __restrict__ sh_slot, int64_t nshared,
+                                                   const double* __restrict__ ypart, const uint8_t* __restrict__ bc,
+                                                   const double* __restrict__ u, double* __restrict__ y,
+                                                   double* __restrict__ partials, const int* __restrict__ stop)
+{
+  if (stop && *stop)
+    return;
+  __shared__ double red[4];
+  double dot = 0.0;
+  for (int64_t k = blockIdx.x * 256ll + threadIdx.x; k < nshared; k += gridDim.x * 256ll)
+  {
+    const int32_t g = sh_dof[k];
+    double s = 0.0;
+    for (int p = sh_off[k]; p < sh_off[k + 1]; ++p)
+      s += ypart[sh_slot[p]]; // ascending block order
+    if (bc[g])
+      s = 0.0;
+    y[g] = s;
+    dot += s * u[g];
+  }
+  if (partials)
+  {
+    const double t = block_reduce_sum(dot, red);
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = t;
+  }
+}
+
+int grid_for(int64_t n)
+{
+  int64_t g = (n + 255) / 256;
+  return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 8192);
+}
+
+template <typename K, typename V>
+int sort_pairs(zzz_ctx* ctx, DevBuf<K>& kin, DevBuf<K>& kout, DevBuf<V>& vin, DevBuf<V>& vout, size_t n, unsigned end_bit)
+{
+  size_t tb = 0;
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, kin.p, kout.p, vin.p, vout.p, n, 0u, end_bit, ctx->stream));
+  DevBuf<unsigned char> tmp;
+  ZZZ_HIP(ctx, tmp.alloc(tb));
+  ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, kin.p, kout.p, vin.p, vout.p, n, 0u, end_bit, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
+int scan_excl(zzz_ctx* ctx, const int32_t* in, int32_t* out, size_t n)
+{
+  size_t tb = 0;
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, in, out, 0, n, rocprim::plus<int32_t>(), ctx->stream));
+  DevBuf<unsigned char> tmp;
+  ZZZ_HIP(ctx, tmp.alloc(tb));
+  ZZZ_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, in, out, 0, n, rocprim::plus<int32_t>(), ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZZZ_OK;
+}
+
+unsigned bits_for(uint64_t v)
+{
+  unsigned b = 1;
+  while (b < 64 && (v >> b))
+    ++b;
+  return b;
+}
+
+int lds_bytes(int nd, int nloc_cap) { return (nd == 4 ? 40 : 16) * nloc_cap; }
+
+// one attempt with blocks of nc cells; *retry: some block touches more dofs than LDS holds
+int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
+{
+  MfPlan& M = ctx->mf;
+  hipStream_t s = ctx->stream;
+  const int nd = ctx->nd;
+  const int64_t ncells = ctx->ncells;
+  const int nsb = nc / T;
+  const int64_t nb = (ncells + nc - 1) / nc, total = nb * nc;
+  *retry = false;
+  if (total * nd > (int64_t)INT32_MAX - 1024 || nb >= (1ll << 27))
+    return fail(ctx, ZZZ_ERR_LIMIT, "matrix-free plan: %lld incidences exceed int32: use more parts", (long long)(total * nd));
+  M.nd = nd;
+  M.nc = nc;
+  M.threads = T;
+  M.nsb = nsb;
+  M.ndw = nd / 2;
+  M.nrw = (nd + 3) / 4;
+  M.nblocks = nb;
+
+  // 1. cells in the Morton order of their centroids, dealt into execution order
+  DevBuf<int32_t> sorted_cells;
+  {
+    DevBuf<double> bb;
+    const int g = 256;
+    ZZZ_HIP(ctx, bb.alloc(6 * g));
+    hipLaunchKernelGGL(k_mf_bbox, dim3(g), dim3(256), 0, s, ctx->x.p, ctx->nverts, bb.p);
+    std::vector<double> hb(6 * g);
+    ZZZ_HIP(ctx, hipMemcpyAsync(hb.data(), bb.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    Box B;
+    for (int a = 0; a < 3; ++a)
+    {
+      double lo = 1e300, hi = -1e300;
+      for (int i = 0; i < g; ++i)
+      {
+        lo = std::min(lo, hb[6 * i + a]);
+        hi = std::max(hi, hb[6 * i + 3 + a]);
+      }
+      B.lo[a] = lo;
+      B.scale[a] = hi > lo ? 1024.0 / (hi - lo) : 0.0;
+    }
+    // one resolution for the three axes (the longest extent gets the 1024 bins): Morton cells are cubes in space
+    const double sc = std::min({B.scale[0] > 0 ? B.scale[0] : 1e300, B.scale[1] > 0 ? B.scale[1] : 1e300,
+                                B.scale[2] > 0 ? B.scale[2] : 1e300});
+    for (int a = 0; a < 3; ++a)
+      B.scale[a] = sc < 1e300 ? sc : 0.0;
+    DevBuf<uint32_t> k0, k1;
+    DevBuf<int32_t> v0;
+    ZZZ_HIP(ctx, k0.alloc((size_t)ncells));
+    ZZZ_HIP(ctx, k1.alloc((size_t)ncells));
+    ZZZ_HIP(ctx, v0.alloc((size_t)ncells));
+    ZZZ_HIP(ctx, sorted_cells.alloc((size_t)ncells));
+    hipLaunchKernelGGL(k_mf_cell_keys, dim3(grid_for(ncells)), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, ncells, B, k0.p, v0.p);
+    if (int rc = sort_pairs(ctx, k0, k1, v0, sorted_cells, (size_t)ncells, 30))
+      return rc;
+  }
+  ZZZ_HIP(ctx, M.mf_cell.alloc((size_t)total));
+  hipLaunchKernelGGL(k_mf_deal, dim3(grid_for(total)), dim3(256), 0, s, sorted_cells.p, ncells, nc, T, nsb, total, M.mf_cell.p);
+  sorted_cells.release();
+
+  // 2. (block, dof) incidences, sorted; their unique keys
+  const int64_t np = total * nd;
+  DevBuf<uint64_t> key;
+  DevBuf<uint32_t> val;
+  {
+    DevBuf<uint64_t> key0;
+    DevBuf<uint32_t> val0;
+    ZZZ_HIP(ctx, key0.alloc((size_t)np));
+    ZZZ_HIP(ctx, val0.alloc((size_t)np));
+    ZZZ_HIP(ctx, key.alloc((size_t)np));
+    ZZZ_HIP(ctx, val.alloc((size_t)np));
+    hipLaunchKernelGGL(k_mf_pairs, dim3(grid_for(np)), dim3(256), 0, s, M.mf_cell.p, ctx->cell_dofs.p, nd, nc, total, key0.p, val0.p);
+    if (int rc = sort_pairs(ctx, key0, key, val0, val, (size_t)np, 64))
+      return rc;
+  }
+  DevBuf<int32_t> flag, uidx;
+  ZZZ_HIP(ctx, flag.alloc((size_t)np + 1));
+  ZZZ_HIP(ctx, uidx.alloc((size_t)np + 1));
+  hipLaunchKernelGGL(k_mf_heads, dim3(grid_for(np)), dim3(256), 0, s, key.p, np, flag.p);
+  ZZZ_HIP(ctx, hipMemsetAsync(flag.p + np, 0, sizeof(int32_t), s));
+  if (int rc = scan_excl(ctx, flag.p, uidx.p, (size_t)np + 1))
+    return rc;
+  int32_t nu32 = 0;
+  ZZZ_HIP(ctx, hipMemcpy(&nu32, uidx.p + np, sizeof(int32_t), hipMemcpyDeviceToHost));
+  const int64_t nu = nu32;
+  const int64_t nloc_all = ctx->n_owned + ctx->n_ghost;
+  DevBuf<uint64_t> ukey;
+  DevBuf<int32_t> run_start, nblk_of;
+  ZZZ_HIP(ctx, ukey.alloc((size_t)nu));
+  ZZZ_HIP(ctx, run_start.alloc((size_t)nu + 1));
+  ZZZ_HIP(ctx, nblk_of.alloc((size_t)nloc_all));
+  ZZZ_HIP(ctx, hipMemsetAsync(nblk_of.p, 0, (size_t)nloc_all * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_mf_uniques, dim3(grid_for(np)), dim3(256), 0, s, key.p, flag.p, uidx.p, np, ukey.p, run_start.p, nblk_of.p);
+
+  // 3. classes, block-local order, headers
+  DevBuf<uint64_t> key2, key2s;
+  DevBuf<int32_t> val2, val2s, cnt3, nloc_b, nsh_b, dof_off, part_off, nlmax;
+  ZZZ_HIP(ctx, key2.alloc((size_t)nu));
+  ZZZ_HIP(ctx, key2s.alloc((size_t)nu));
+  ZZZ_HIP(ctx, val2.alloc((size_t)nu));
+  ZZZ_HIP(ctx, val2s.alloc((size_t)nu));
+  ZZZ_HIP(ctx, cnt3.alloc((size_t)nb * 3));
+  ZZZ_HIP(ctx, nloc_b.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, nsh_b.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, dof_off.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, part_off.alloc((size_t)nb + 1));
+  ZZZ_HIP(ctx, nlmax.alloc(2));
+  ZZZ_HIP(ctx, hipMemsetAsync(cnt3.p, 0, (size_t)nb * 3 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(nlmax.p, 0, 2 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_mf_classify, dim3(grid_for(nu)), dim3(256), 0, s, ukey.p, nu, nblk_of.p, ctx->n_owned, key2.p, val2.p, cnt3.p);
+  hipLaunchKernelGGL(k_mf_block_sizes, dim3(grid_for(nb + 1)), dim3(256), 0, s, cnt3.p, nb, nloc_b.p, nsh_b.p);
+  if (int rc = scan_excl(ctx, nloc_b.p, dof_off.p, (size_t)nb + 1))
+    return rc;
+  if (int rc = scan_excl(ctx, nsh_b.p, part_off.p, (size_t)nb + 1))
+    return rc;
+  ZZZ_HIP(ctx, M.hdr.alloc((size_t)nb * MF_HDR));
+  hipLaunchKernelGGL(k_mf_headers, dim3(grid_for(nb)), dim3(256), 0, s, cnt3.p, dof_off.p, part_off.p, nb, M.hdr.p, nlmax.p);
+  int32_t h_nlmax = 0, h_nslots = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&h_nlmax, nlmax.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(&h_nslots, part_off.p + nb, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (h_nlmax > nloc_limit)
+  {
+    *retry = true;
+    return ZZZ_OK;
+  }
+  M.nloc_max = h_nlmax;
+  M.nslots = h_nslots;
+  if (int rc = sort_pairs(ctx, key2, key2s, val2, val2s, (size_t)nu, 34 + bits_for((uint64_t)nb)))
+    return rc;
+  DevBuf<int32_t> loc_of, sh_val, sh_val_s;
+  DevBuf<uint32_t> sh_key, sh_key_s;
+  ZZZ_HIP(ctx, M.dof_ids.alloc((size_t)nu));
+  ZZZ_HIP(ctx, M.dof_flag.alloc((size_t)nu));
+  if (nd == 4)
+    ZZZ_HIP(ctx, M.xyz.alloc((size_t)nu * 3));
+  ZZZ_HIP(ctx, loc_of.alloc((size_t)nu));
+  ZZZ_HIP(ctx, sh_key.alloc((size_t)nu));
+  ZZZ_HIP(ctx, sh_key_s.alloc((size_t)nu));
+  ZZZ_HIP(ctx, sh_val.alloc((size_t)nu));
+  ZZZ_HIP(ctx, sh_val_s.alloc((size_t)nu));
+  hipLaunchKernelGGL(k_mf_lists, dim3(grid_for(nu)), dim3(256), 0, s, key2s.p, val2s.p, nu, M.hdr.p, ctx->bc.p,
+                     nd == 4 ? ctx->xq : (const double*)nullptr, M.dof_ids.p, M.dof_flag.p, nd == 4 ? M.xyz.p : (double*)nullptr,
+                     loc_of.p, sh_key.p, sh_val.p);
+
+  // 4. per cell: local indices, ranks; rounds per (block, step, local dof)
+  ZZZ_HIP(ctx, M.idxw.alloc((size_t)(nb * M.ndw * nc)));
+  ZZZ_HIP(ctx, M.rnkw.alloc((size_t)(nb * M.nrw * nc)));
+  ZZZ_HIP(ctx, M.rmax.alloc((size_t)(nb * nsb * M.nrw * 4)));
+  ZZZ_HIP(ctx, hipMemsetAsync(M.idxw.p, 0, (size_t)(nb * M.ndw * nc) * 4, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(M.rnkw.p, 0xff, (size_t)(nb * M.nrw * nc) * 4, s));
+  hipLaunchKernelGGL(k_mf_cells, dim3(grid_for(np)), dim3(256), 0, s, key.p, val.p, uidx.p, flag.p, np, run_start.p, loc_of.p, nd, nc,
+                     T, M.ndw, M.nrw, M.idxw.p, M.rnkw.p, nlmax.p + 1);
+  hipLaunchKernelGGL(k_mf_rmax, dim3((unsigned)std::min<int64_t>((nb * nsb * M.nrw + 3) / 4, 8192)), dim3(256), 0, s, M.rnkw.p, nb, nc,
+                     T, nsb, M.nrw, M.rmax.p);
+  int32_t h_err = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&h_err, nlmax.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (h_err)
+    return fail(ctx, ZZZ_ERR_LIMIT, "matrix-free plan: a dof meets more than 254 cells of one step");
+
+  // 5. the shared dofs and their slots
+  if (int rc = sort_pairs(ctx, sh_key, sh_key_s, sh_val, sh_val_s, (size_t)nu, 32))
+    return rc;
+  M.nshared = 0;
+  if (M.nslots > 0)
+  {
+    DevBuf<int32_t> f2, u2;
+    ZZZ_HIP(ctx, f2.alloc((size_t)M.nslots + 1));
+    ZZZ_HIP(ctx, u2.alloc((size_t)M.nslots + 1));
+    hipLaunchKernelGGL(k_mf_sh_heads, dim3(grid_for(M.nslots)), dim3(256), 0, s, sh_key_s.p, M.nslots, f2.p);
+    ZZZ_HIP(ctx, hipMemsetAsync(f2.p + M.nslots, 0, sizeof(int32_t), s));
+    if (int rc = scan_excl(ctx, f2.p, u2.p, (size_t)M.nslots + 1))
+      return rc;
+    int32_t ns = 0;
+    ZZZ_HIP(ctx, hipMemcpy(&ns, u2.p + M.nslots, sizeof(int32_t), hipMemcpyDeviceToHost));
+    M.nshared = ns;
+    ZZZ_HIP(ctx, M.sh_dof.alloc((size_t)ns));
+    ZZZ_HIP(ctx, M.sh_off.alloc((size_t)ns + 1));
+    ZZZ_HIP(ctx, M.sh_slot.alloc((size_t)M.nslots));
+    hipLaunchKernelGGL(k_mf_sh_fill, dim3(grid_for(M.nslots + 1)), dim3(256), 0, s, sh_key_s.p, f2.p, u2.p, M.nslots, M.sh_dof.p,
+                       M.sh_off.p, (int64_t)ns);
+    ZZZ_HIP(ctx, hipMemcpyAsync(M.sh_slot.p, sh_val_s.p, (size_t)M.nslots * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  }
+  ZZZ_HIP(ctx, M.ypart.alloc((size_t)std::max<int64_t>(M.nslots, 1)));
+
+  // 6. P2/P3: geometry factors per cell, the factorised reference tables
+  if (nd != 4)
+  {
+    const double* src = nd == 10 ? ZZZ_DTAB_P2 : ZZZ_DTAB_P3;
+    const size_t nt = nd == 10 ? 120 : 600;
+    ZZZ_HIP(ctx, M.dtab.alloc(nt));
+    ZZZ_HIP(ctx, hipMemcpyAsync(M.dtab.p, src, nt * sizeof(double), hipMemcpyHostToDevice, s));
+    ZZZ_HIP(ctx, M.geom.alloc((size_t)(nb * 6 * nc)));
+    hipLaunchKernelGGL(k_mf_geom, dim3(grid_for(total)), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, M.mf_cell.p, nc, total, M.geom.p);
+  }
+  ZZZ_HIP(ctx, hipGetLastError());
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  // what one action addresses: the per-cell streams, the block lists (ids, flags, coordinates), u gathered and y
+  // written per list entry, the partial sums out and back, the shared dofs' finish
+  M.bytes_per_action = total * (4ll * M.ndw + 4ll * M.nrw + (nd == 4 ? 0 : 48)) + nu * (4 + 1 + 8 + (nd == 4 ? 24 : 0))
+                       + (nu - M.nslots) * 8 + M.nslots * (8 + 8 + 4) + M.nshared * (4 + 4 + 1 + 8 + 8) + nb * (MF_HDR * 4 + nsb * M.nrw * 4);
+  return ZZZ_OK;
+}
+} // namespace
+
+int mf_plan_build(zzz_ctx* ctx)
+{
+  MfPlan& M = ctx->mf;
+  M.valid = false;
+  if (ctx->bs != 1)
+    return fail(ctx, ZZZ_ERR_ARG, "the matrix-free operator exists for the Poisson form M only (src/Poisson.py:33)");
+  if (ctx->order == 0 || ctx->ncells == 0)
+    return fail(ctx, ZZZ_ERR_ARG, "matrix-free operator before zzz_dofmap_upload");
+  if (int rc = ensure_p1_coords(ctx))
+    return rc;
+  const int nd = ctx->nd;
+  // defaults (measured): workgroup size and cells per block; ZZZ_MF_T / ZZZ_MF_NC override them
+  int T = nd == 4 ? 512 : 256;
+  int nc = nd == 4 ? 8192 : (nd == 10 ? 1024 : 512);
+  if (const char* e = getenv("ZZZ_MF_T"))
+  {
+    const int v = atoi(e);
+    if (v == 128 || v == 256 || v == 512 || v == 1024)
+      T = v;
+  }
+  if (const char* e = getenv("ZZZ_MF_NC"))
+  {
+    const int v = atoi(e);
+    if (v >= T && v <= 65536 && v % T == 0)
+      nc = v;
+  }
+  nc = std::max(nc, T);
+  // LDS budget per workgroup: 64 KiB unless ZZZ_MF_LDS_KB says otherwise (160 KiB per CU)
+  int lds_kb = nd == 4 ? 96 : 64;
+  if (const char* e = getenv("ZZZ_MF_LDS_KB"))
+    lds_kb = std::min(160, std::max(8, atoi(e)));
+  const int nloc_limit = std::min(65535, lds_kb * 1024 / (nd == 4 ? 40 : 16));
+  for (;;)
+  {
+    bool retry = false;
+    if (int rc = plan_attempt(ctx, nc, T, nloc_limit, &retry))
+      return rc;
+    if (!retry)
+      break;
+    if (nc / 2 < T || (nc / 2) % T)
+      return fail(ctx, ZZZ_ERR_LIMIT, "matrix-free plan: a block of %d cells touches more dofs than LDS holds", nc);
+    nc /= 2;
+  }
+  M.valid = true;
+  return ZZZ_OK;
+}
+
+template <int ND, int T>
+static int mf_launch(zzz_ctx* ctx, const MfArgs& A, int grid, int lds)
+{
+  static int attr_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per device: the limit this instantiation was given
+  if (lds > 48 * 1024 && lds > attr_lds[ctx->device & 15])
+  {
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_action<ND, T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_lds[ctx->device & 15] = lds;
+  }
+  hipLaunchKernelGGL((k_mf_action<ND, T>), dim3(grid), dim3(T), lds, ctx->stream, A);
+  return ZZZ_OK;
+}
+
+int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
+{
+  MfPlan& M = ctx->mf;
+  if (!M.valid)
+    return fail(ctx, ZZZ_ERR_ARG, "matrix-free plan missing");
+  const int lds = lds_bytes(M.nd, M.nloc_max);
+  // persistent workgroups: as many as fit a CU by LDS and threads, XCD-aware walk over the blocks
+  int per_cu = std::min((160 * 1024) / std::max(lds + 512, 1), 2048 / M.threads);
+  per_cu = std::max(1, std::min(per_cu, 8));
+  int grid = (int)std::min<int64_t>(256ll * per_cu, (M.nblocks + 7) / 8 * 8);
+  grid = std::max(8, grid / 8 * 8);
+  const int gf = (int)std::min<int64_t>(std::max<int64_t>((M.nshared + 255) / 256, 1), 512);
+  MfArgs A;
+  A.hdr = M.hdr.p;
+  A.dof_ids = M.dof_ids.p;
+  A.dof_flag = M.dof_flag.p;
+  A.xyz = M.xyz.p;
+  A.idxw = M.idxw.p;
+  A.rnkw = M.rnkw.p;
+  A.rmax = M.rmax.p;
+  A.geom = M.geom.p;
+  A.dtab = M.dtab.p;
+  A.ypart = M.ypart.p;
+  A.u = u;
+  A.y = y;
+  A.partials = partials;
+  A.stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
+  A.nblocks = M.nblocks;
+  A.nc = M.nc;
+  A.nsb = M.nsb;
+  A.nloc_cap = M.nloc_max;
+  int rc = ZZZ_OK;
+#define ZZZ_MF_T(ND_)                                                                                                    \
+  (M.threads == 128 ? mf_launch<ND_, 128>(ctx, A, grid, lds)                                                              \
+                    : M.threads == 256 ? mf_launch<ND_, 256>(ctx, A, grid, lds)                                           \
+                                       : M.threads == 512 ? mf_launch<ND_, 512>(ctx, A, grid, lds) : mf_launch<ND_, 1024>(ctx, A, grid, lds))
+  if (M.nd == 4)
+    rc = ZZZ_MF_T(4);
+  else if (M.nd == 10)
+    rc = ZZZ_MF_T(10);
+  else
+    rc = ZZZ_MF_T(20);
+#undef ZZZ_MF_T
+  if (rc)
+    return rc;
+  if (M.nshared > 0)
+    hipLaunchKernelGGL(k_mf_finish, dim3(gf), dim3(256), 0, ctx->stream, M.sh_dof.p, M.sh_off.p, M.sh_slot.p, M.nshared, M.ypart.p,
+                       ctx->bc.p, u, y, partials ? partials + grid : nullptr, A.stop);
+  if (npartials)
+    *npartials = grid + (M.nshared > 0 ? gf : 0);
+  ZZZ_HIP(ctx, hipGetLastError());
+  return ZZZ_OK;
+}
+} // namespace zzz

@@ -129,7 +129,33 @@ def tables(order):
     for lf in range(4):
         r = [restrict_to_facet(phi[i], lf) for i in range(nd)]
         F.append([[int_tri(poly_mul(r[i], r[j])) for j in range(nd)] for i in range(nd)])
-    return nd, S, M, F
+    return nd, S, M, F, dtables(order, nd, dphi, S)
+
+
+def dtables(order, nd, dphi, S):
+    """Factorised stiffness for the matrix-free action (csrc/zzz_matfree.hip): d_a phi_j lies in P_(k-1); with an
+    L2-orthonormal basis psi_q of P_(k-1) on the reference tetrahedron (Gram-Schmidt on the monomials, exact integrals)
+        D[a][q][j] = int_K^ psi_q d_a phi_j dX      =>      S[a][b][i][j] = sum_q D[a][q][i] D[b][q][j],
+    so Ae u = |detJ| sum_a D_a^T ( sum_b (K K^T)_ab D_b u ): 2 x 3 nq nd + 9 nq multiply-adds per cell instead of 6 nd^2."""
+    ex = monos(order - 1)
+    nq = len(ex)
+    psi = []
+    for e in ex:
+        p = {e: mp.mpf(1)}
+        for q in psi:
+            c = int_tet(poly_mul(p, q))
+            for ee, cc in q.items():
+                p[ee] = p.get(ee, 0) - c * cc
+        nrm = mp.sqrt(int_tet(poly_mul(p, p)))
+        psi.append({ee: cc / nrm for ee, cc in p.items()})
+    D = [[[int_tet(poly_mul(psi[q], dphi[j][a])) if dphi[j][a] else mp.mpf(0) for j in range(nd)] for q in range(nq)]
+         for a in range(3)]
+    for a in range(3):
+        for b in range(3):
+            for i in range(nd):
+                for j in range(nd):
+                    assert abs(sum(D[a][q][i] * D[b][q][j] for q in range(nq)) - S[a][b][i][j]) < mp.mpf(10) ** -40
+    return nq, D
 
 
 def fmt(v):
@@ -145,7 +171,7 @@ def main():
          "// Reference tensors of the Lagrange P1..P3 gll_warped tetrahedron (exact integration, 17 digits).",
          "// Layout per order k: S[9][nd][nd] (a*3+b major) | M[nd][nd] | F[4][nd][nd], doubles.", ""]
     for order in (1, 2, 3):
-        nd, S, M, F = tables(order)
+        nd, S, M, F, (nq, D) = tables(order)
         # sanity: P1 closed forms
         if order == 1:
             assert abs(M[0][0] - mp.mpf(1) / 60) < 1e-40 and abs(S[0][0][1][1] - mp.mpf(1) / 6) < 1e-40
@@ -163,6 +189,13 @@ def main():
         L.append(f"static const double ZZZ_TAB_P{order}[{len(flat)}] = {{")
         for k in range(0, len(flat), 6):
             L.append("    " + ", ".join(fmt(v) for v in flat[k:k + 6]) + ",")
+        L.append("};")
+        L.append("")
+        dflat = [D[a][q][j] for a in range(3) for q in range(nq) for j in range(nd)]
+        L.append(f"// D[3][{nq}][{nd}]: factorised stiffness, S[a][b][i][j] = sum_q D[a][q][i] D[b][q][j] (see dtables())")
+        L.append(f"static constexpr double ZZZ_DTAB_P{order}[{len(dflat)}] = {{")
+        for k in range(0, len(dflat), 6):
+            L.append("    " + ", ".join(fmt(v) for v in dflat[k:k + 6]) + ",")
         L.append("};")
         L.append("")
     open(out, "w").write("\n".join(L))
