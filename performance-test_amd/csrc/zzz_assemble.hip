@@ -1546,12 +1546,19 @@ int build_adjT(zzz_ctx* ctx)
 // zzz_matfree_setup); ZZZ_MF_LEGACY=1 keeps the two-pass form below (A/B, and the parity test between the two).
 int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
 {
-  static const bool legacy = getenv("ZZZ_MF_LEGACY") && atoi(getenv("ZZZ_MF_LEGACY")) != 0;
-  if (legacy)
+  const char* e = getenv("ZZZ_MF_LEGACY");
+  if (e && atoi(e) != 0)
     return launch_matfree_legacy(ctx, u, y, partials, npartials);
-  if (!ctx->mf.valid)
-    if (int rc = mf_plan_build(ctx))
+  if (!ctx->mf.valid && !ctx->mf.failed)
+  {
+    const int rc = mf_plan_build(ctx);
+    if (rc == ZZZ_ERR_LIMIT && ctx->have_pattern && ctx->have_adj_li)
+      ctx->mf.failed = true; // a mesh the plan cannot hold (a dof in more than 254 cells of one step): the two-pass form serves it
+    else if (rc)
       return rc;
+  }
+  if (ctx->mf.failed)
+    return launch_matfree_legacy(ctx, u, y, partials, npartials);
   return mf_action(ctx, u, y, partials, npartials);
 }
 

@@ -121,9 +121,11 @@ struct MfPlan
   DevBuf<uint32_t> idxw, rnkw;  // [block][word][cell of the block]
   DevBuf<uint8_t> rmax;         // [block][step][4 nrw]: rounds needed by local dof i in that step
   DevBuf<double> geom;          // P2/P3: [block][6][cell]  |detJ| K K^T
+  DevBuf<int32_t> gid;          // P3: [block][nd][cell] global dofs (u is gathered from memory, not staged)
   DevBuf<double> dtab;          // P2/P3: the factorised reference tables (ZZZ_DTAB_P2/P3)
   DevBuf<double> ypart;         // partial sums of the shared dofs, [slot]
-  DevBuf<int32_t> sh_dof, sh_off, sh_slot; // shared dof -> its slots (ascending block)
+  DevBuf<int32_t> sh_dof, sh_off, sh_slot; // shared dofs; where their partial sums start; (block, shared entry) -> slot
+  DevBuf<uint8_t> sh_flag;                 // Dirichlet marker of each shared dof
   DevBuf<int32_t> mf_cell;      // [block][cell] -> cell of the context (-1: none), kept for rebuilding the geometry
 };
 } // namespace zzz

@@ -309,19 +309,43 @@ __global__ __launch_bounds__(256) void k_mf_sh_heads(const uint32_t* __restrict_
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
     flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_mf_sh_fill(const uint32_t* __restrict__ key, const int32_t* __restrict__ flag,
-                                                    const int32_t* __restrict__ uidx, int64_t n, int32_t* __restrict__ sh_dof,
-                                                    int32_t* __restrict__ sh_off, int64_t nshared)
+// the partial sums of a shared dof sit side by side (ascending block): position p of the sorted (dof, old slot) pairs is
+// where the block that owns old slot `val[p]` stores that sum
+__global__ __launch_bounds__(256) void k_mf_sh_fill(const uint32_t* __restrict__ key, const int32_t* __restrict__ val,
+                                                    const int32_t* __restrict__ flag, const int32_t* __restrict__ uidx, int64_t n,
+                                                    const uint8_t* __restrict__ bc, int32_t* __restrict__ sh_dof,
+                                                    int32_t* __restrict__ sh_off, uint8_t* __restrict__ sh_flag,
+                                                    int32_t* __restrict__ pslot, int64_t nshared)
 {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i <= n; i += gridDim.x * 256ll)
   {
     if (i == n)
+    {
       sh_off[nshared] = (int32_t)n;
-    else if (flag[i])
+      continue;
+    }
+    pslot[val[i]] = (int32_t)i;
+    if (flag[i])
     {
       sh_dof[uidx[i]] = (int32_t)key[i];
       sh_off[uidx[i]] = (int32_t)i;
+      sh_flag[uidx[i]] = bc[key[i]];
     }
+  }
+}
+
+// P3: the global dofs of every cell in plan order, component-major inside the block (cells without a cell: dof 0)
+__global__ __launch_bounds__(256) void k_mf_gid(const int32_t* __restrict__ mf_cell, const int32_t* __restrict__ cell_dofs, int nd,
+                                                int nc, int64_t total, int32_t* __restrict__ gid)
+{
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total * nd; i += gridDim.x * 256ll)
+  {
+    const int64_t pe = i / nd;
+    const int j = (int)(i - pe * nd);
+    const int64_t b = pe / nc;
+    const int e = (int)(pe - b * nc);
+    const int32_t c = mf_cell[pe];
+    gid[(b * nd + j) * nc + e] = c < 0 ? 0 : cell_dofs[(int64_t)c * nd + j];
   }
 }
 
@@ -382,6 +406,8 @@ struct MfArgs
   const uint8_t* rmax;
   const double* geom;
   const double* dtab;
+  const int32_t* pslot;
+  const int32_t* gid;
   double* ypart;
   const double* u;
   double* y;
@@ -389,7 +415,13 @@ struct MfArgs
   const int* stop;
   int64_t nblocks;
   int nc, nsb, nloc_cap;
+  int dbg; // ZZZ_EXPERIMENTS builds only (ZZZ_MF_DEBUG): phases switched off for timing, results wrong
 };
+#ifdef ZZZ_EXPERIMENTS
+#define MF_DBG(bit) (A.dbg & (bit))
+#else
+#define MF_DBG(bit) 0
+#endif
 
 // The factorised tables: constexpr copies decide at compile time which entries are zero; the values are staged in LDS
 // by every (persistent) workgroup and reach the multiply-adds as broadcast reads.  (As literals they occupied ~200
@@ -461,9 +493,13 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
     return;
   constexpr int NDW = ND / 2, NRW = (ND + 3) / 4;
   extern __shared__ __align__(32) unsigned char mf_lds[];
-  // P1: rec[nloc_cap] = {x, y, z, u} then ys[nloc_cap]; P2/P3: us[nloc_cap] then ys[nloc_cap]
+  // P1: xy[nloc_cap] = {x, y}, zu[nloc_cap] = {z, u} (two arrays of 16-B entries: a 16-lane group of a ds_read_b128 meets
+  // 16 bank positions, not the 8 of 32-B records), then ys[nloc_cap]; P2: us[nloc_cap] then ys[nloc_cap]; P3 (GU): ys only,
+  // the cells gather u from memory through their global dof numbers (16 B per dof of LDS less: three workgroups per CU)
+  constexpr bool GU = ND == 20;
   double* const rec = reinterpret_cast<double*>(mf_lds);
-  double* const ys = rec + (size_t)(ND == 4 ? 4 : 1) * A.nloc_cap;
+  double* const zu = rec + 2 * (size_t)A.nloc_cap;
+  double* const ys = rec + (size_t)(ND == 4 ? 4 : (GU ? 0 : 1)) * A.nloc_cap;
   __shared__ double red[T / 64];
   constexpr int NTAB = ND == 4 ? 1 : 3 * ND * (ND == 10 ? 4 : 10);
   __shared__ double tab_s[NTAB], tabT_s[NTAB];
@@ -488,14 +524,15 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
     // stage the block's u (and coordinates), clear its y
     for (int d = tid; d < nloc; d += T)
     {
-      const int32_t g = A.dof_ids[dof_off + d];
-      const double uv = A.u[g];
+      const int32_t g = (GU || MF_DBG(4)) ? 0 : A.dof_ids[dof_off + d];
+      const double uv = (GU || MF_DBG(4)) ? 1.0 : A.u[g];
       if (ND == 4)
       {
         const double* __restrict__ q = A.xyz + 3ll * (dof_off + d);
-        *reinterpret_cast<double4*>(rec + 4 * d) = make_double4(q[0], q[1], q[2], uv);
+        *reinterpret_cast<double2*>(rec + 2 * d) = make_double2(q[0], q[1]);
+        *reinterpret_cast<double2*>(zu + 2 * d) = make_double2(q[2], uv);
       }
-      else
+      else if (!GU)
         rec[d] = uv;
       ys[d] = 0.0;
     }
@@ -519,10 +556,12 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
       {
 #pragma clang fp contract(fast)
         const int i0 = iw[0] & 0xffff, i1 = iw[0] >> 16, i2 = iw[1] & 0xffff, i3 = iw[1] >> 16;
-        const double4 p0 = *reinterpret_cast<const double4*>(rec + 4 * i0);
-        const double4 p1 = *reinterpret_cast<const double4*>(rec + 4 * i1);
-        const double4 p2 = *reinterpret_cast<const double4*>(rec + 4 * i2);
-        const double4 p3 = *reinterpret_cast<const double4*>(rec + 4 * i3);
+        const double2 a0 = *reinterpret_cast<const double2*>(rec + 2 * i0), b0 = *reinterpret_cast<const double2*>(zu + 2 * i0);
+        const double2 a1 = *reinterpret_cast<const double2*>(rec + 2 * i1), b1 = *reinterpret_cast<const double2*>(zu + 2 * i1);
+        const double2 a2 = *reinterpret_cast<const double2*>(rec + 2 * i2), b2 = *reinterpret_cast<const double2*>(zu + 2 * i2);
+        const double2 a3 = *reinterpret_cast<const double2*>(rec + 2 * i3), b3 = *reinterpret_cast<const double2*>(zu + 2 * i3);
+        const double4 p0 = make_double4(a0.x, a0.y, b0.x, b0.y), p1 = make_double4(a1.x, a1.y, b1.x, b1.y);
+        const double4 p2 = make_double4(a2.x, a2.y, b2.x, b2.y), p3 = make_double4(a3.x, a3.y, b3.x, b3.y);
         // J[a][al] = p_(al+1)[a] - p_0[a]; C = cofactors: K = J^-1 = C / det, grad phi_(al+1) = C[al][:] / det
         const double J00 = p1.x - p0.x, J01 = p2.x - p0.x, J02 = p3.x - p0.x;
         const double J10 = p1.y - p0.y, J11 = p2.y - p0.y, J12 = p3.y - p0.y;
@@ -547,10 +586,26 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
 #pragma unroll
         for (int t = 0; t < 6; ++t)
           G[t] = A.geom[(b * 6 + t) * A.nc + e];
+        if constexpr (GU)
+        {
 #pragma unroll
-        for (int j = 0; j < ND; ++j)
-          ue[j] = rec[(iw[j >> 1] >> (16 * (j & 1))) & 0xffff];
-        mf_element_pk<ND>(tab_s, tabT_s, ue, G, ye);
+          for (int j = 0; j < ND; ++j)
+            ue[j] = A.u[A.gid[(b * ND + j) * A.nc + e]];
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            ue[j] = rec[(iw[j >> 1] >> (16 * (j & 1))) & 0xffff];
+        }
+        if (MF_DBG(1))
+        {
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            ye[j] = ue[j] * G[j % 6];
+        }
+        else
+          mf_element_pk<ND>(tab_s, tabT_s, ue, G, ye);
       }
       // rounds: the incidences of rank r of this step are added in round r (distinct addresses inside a round).  The
       // additions are LDS atomics WITHOUT return (ds_add_f64: nothing to wait for inside a round; a read-add-write chain
@@ -572,7 +627,7 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
             Rc[c] = max(Rc[c], (int)((m >> (8 * k)) & 255u));
           }
       }
-      const int R2 = Rc[2], R1 = max(R2, Rc[1]), R0 = max(R1, Rc[0]);
+      const int R2 = Rc[2], R1 = max(R2, Rc[1]), R0 = MF_DBG(2) ? 1 : max(R1, Rc[0]);
       for (int r = 0; r < R0; ++r)
       {
         // hipcc (ROCm 7.2) emitted this loop's s_barrier WITHOUT a wait for the LDS store of the round before (seen in
@@ -595,15 +650,15 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     // dofs interior to the block: final values; shared ones: this block's partial sum
-    for (int d = tid; d < n_int; d += T)
+    for (int d = tid; d < (MF_DBG(8) ? 0 : n_int); d += T)
     {
       const int32_t g = A.dof_ids[dof_off + d];
       const double v = A.dof_flag[dof_off + d] ? 0.0 : ys[d]; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
       A.y[g] = v;
-      dot += v * (ND == 4 ? rec[4 * d + 3] : rec[d]);
+      dot += v * (ND == 4 ? zu[2 * d + 1] : (GU ? A.u[g] : rec[d]));
     }
     for (int d = tid; d < n_sh; d += T)
-      A.ypart[part_off + d] = ys[n_int + d];
+      A.ypart[A.pslot[part_off + d]] = ys[n_int + d];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -615,11 +670,12 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
   }
 }
 
+// the dofs shared between blocks: their partial sums (side by side, ascending block) added in that order
 __global__ __launch_bounds__(256) void k_mf_finish(const int32_t* __restrict__ sh_dof, const int32_t* __restrict__ sh_off,
-                                                   const int32_t* __restrict__ sh_slot, int64_t nshared,
-                                                   const double* __restrict__ ypart, const uint8_t* __restrict__ bc,
-                                                   const double* __restrict__ u, double* __restrict__ y,
-                                                   double* __restrict__ partials, const int* __restrict__ stop)
+                                                   const uint8_t* __restrict__ sh_flag, int64_t nshared,
+                                                   const double* __restrict__ ypart, const double* __restrict__ u,
+                                                   double* __restrict__ y, double* __restrict__ partials,
+                                                   const int* __restrict__ stop)
 {
   if (stop && *stop)
     return;
@@ -628,13 +684,16 @@ __global__ __launch_bounds__(256) void k_mf_finish(const int32_t* __restrict__ s
   for (int64_t k = blockIdx.x * 256ll + threadIdx.x; k < nshared; k += gridDim.x * 256ll)
   {
     const int32_t g = sh_dof[k];
-    double s = 0.0;
-    for (int p = sh_off[k]; p < sh_off[k + 1]; ++p)
-      s += ypart[sh_slot[p]]; // ascending block order
-    if (bc[g])
-      s = 0.0;
+    const int p0 = sh_off[k], p1 = sh_off[k + 1];
+    const double ug = u[g];
+    const bool fixed = sh_flag[k] != 0;
+    double s = ypart[p0];
+    for (int p = p0 + 1; p < p1; ++p)
+      s += ypart[p];
+    if (fixed)
+      s = 0.0; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
     y[g] = s;
-    dot += s * u[g];
+    dot += s * ug;
   }
   if (partials)
   {
@@ -681,7 +740,7 @@ unsigned bits_for(uint64_t v)
   return b;
 }
 
-int lds_bytes(int nd, int nloc_cap) { return (nd == 4 ? 40 : 16) * nloc_cap; }
+int lds_bytes(int nd, int nloc_cap) { return (nd == 4 ? 40 : (nd == 20 ? 8 : 16)) * nloc_cap; }
 
 // one attempt with blocks of nc cells; *retry: some block touches more dofs than LDS holds
 int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
@@ -864,9 +923,9 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
     ZZZ_HIP(ctx, M.sh_dof.alloc((size_t)ns));
     ZZZ_HIP(ctx, M.sh_off.alloc((size_t)ns + 1));
     ZZZ_HIP(ctx, M.sh_slot.alloc((size_t)M.nslots));
-    hipLaunchKernelGGL(k_mf_sh_fill, dim3(grid_for(M.nslots + 1)), dim3(256), 0, s, sh_key_s.p, f2.p, u2.p, M.nslots, M.sh_dof.p,
-                       M.sh_off.p, (int64_t)ns);
-    ZZZ_HIP(ctx, hipMemcpyAsync(M.sh_slot.p, sh_val_s.p, (size_t)M.nslots * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    ZZZ_HIP(ctx, M.sh_flag.alloc((size_t)ns));
+    hipLaunchKernelGGL(k_mf_sh_fill, dim3(grid_for(M.nslots + 1)), dim3(256), 0, s, sh_key_s.p, sh_val_s.p, f2.p, u2.p, M.nslots,
+                       ctx->bc.p, M.sh_dof.p, M.sh_off.p, M.sh_flag.p, M.sh_slot.p, (int64_t)ns);
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
   }
   ZZZ_HIP(ctx, M.ypart.alloc((size_t)std::max<int64_t>(M.nslots, 1)));
@@ -878,6 +937,11 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
     const size_t nt = nd == 10 ? 120 : 600;
     ZZZ_HIP(ctx, M.dtab.alloc(nt));
     ZZZ_HIP(ctx, hipMemcpyAsync(M.dtab.p, src, nt * sizeof(double), hipMemcpyHostToDevice, s));
+    if (nd == 20)
+    {
+      ZZZ_HIP(ctx, M.gid.alloc((size_t)(total * nd)));
+      hipLaunchKernelGGL(k_mf_gid, dim3(grid_for(total * nd)), dim3(256), 0, s, M.mf_cell.p, ctx->cell_dofs.p, nd, nc, total, M.gid.p);
+    }
     ZZZ_HIP(ctx, M.geom.alloc((size_t)(nb * 6 * nc)));
     hipLaunchKernelGGL(k_mf_geom, dim3(grid_for(total)), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, M.mf_cell.p, nc, total, M.geom.p);
   }
@@ -885,7 +949,8 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   // what one action addresses: the per-cell streams, the block lists (ids, flags, coordinates), u gathered and y
   // written per list entry, the partial sums out and back, the shared dofs' finish
-  M.bytes_per_action = total * (4ll * M.ndw + 4ll * M.nrw + (nd == 4 ? 0 : 48)) + nu * (4 + 1 + 8 + (nd == 4 ? 24 : 0))
+  M.bytes_per_action = total * (4ll * M.ndw + 4ll * M.nrw + (nd == 4 ? 0 : 48) + (nd == 20 ? 4 * nd + 8 * nd : 0))
+                       + nu * (nd == 20 ? 0 : 4 + 1 + 8 + (nd == 4 ? 24 : 0)) + (nd == 20 ? (nu - M.nslots) * (4 + 1 + 8) : 0)
                        + (nu - M.nslots) * 8 + M.nslots * (8 + 8 + 4) + M.nshared * (4 + 4 + 1 + 8 + 8) + nb * (MF_HDR * 4 + nsb * M.nrw * 4);
   return ZZZ_OK;
 }
@@ -894,7 +959,7 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
 int mf_plan_build(zzz_ctx* ctx)
 {
   MfPlan& M = ctx->mf;
-  M.valid = false;
+  M.valid = M.failed = false;
   if (ctx->bs != 1)
     return fail(ctx, ZZZ_ERR_ARG, "the matrix-free operator exists for the Poisson form M only (src/Poisson.py:33)");
   if (ctx->order == 0 || ctx->ncells == 0)
@@ -903,8 +968,10 @@ int mf_plan_build(zzz_ctx* ctx)
     return rc;
   const int nd = ctx->nd;
   // defaults (measured): workgroup size and cells per block; ZZZ_MF_T / ZZZ_MF_NC override them
-  int T = nd == 4 ? 512 : 256;
-  int nc = nd == 4 ? 8192 : (nd == 10 ? 1024 : 512);
+  // (tools/mf_sweep.sh, MI355X: P1 10 M dofs 0.70 ms at 2048 x 256 against 0.84 at 4096 x 512 and 1.30 at 8192 x 512 --
+  // small blocks share more dofs but keep five workgroups on a CU; P3 6.2 M dofs 0.30 ms at 768 x 256, 0.32 at 512, 0.38 at 1024)
+  int T = 256;
+  int nc = nd == 4 ? 2048 : (nd == 10 ? 1024 : 768);
   if (const char* e = getenv("ZZZ_MF_T"))
   {
     const int v = atoi(e);
@@ -919,10 +986,10 @@ int mf_plan_build(zzz_ctx* ctx)
   }
   nc = std::max(nc, T);
   // LDS budget per workgroup: 64 KiB unless ZZZ_MF_LDS_KB says otherwise (160 KiB per CU)
-  int lds_kb = nd == 4 ? 96 : 64;
+  int lds_kb = nd == 4 ? 40 : 64;
   if (const char* e = getenv("ZZZ_MF_LDS_KB"))
     lds_kb = std::min(160, std::max(8, atoi(e)));
-  const int nloc_limit = std::min(65535, lds_kb * 1024 / (nd == 4 ? 40 : 16));
+  const int nloc_limit = std::min(65535, lds_kb * 1024 / (nd == 4 ? 40 : (nd == 20 ? 8 : 16)));
   for (;;)
   {
     bool retry = false;
@@ -962,7 +1029,7 @@ int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* n
   per_cu = std::max(1, std::min(per_cu, 8));
   int grid = (int)std::min<int64_t>(256ll * per_cu, (M.nblocks + 7) / 8 * 8);
   grid = std::max(8, grid / 8 * 8);
-  const int gf = (int)std::min<int64_t>(std::max<int64_t>((M.nshared + 255) / 256, 1), 512);
+  const int gf = (int)std::min<int64_t>(std::max<int64_t>((M.nshared + 255) / 256, 1), 2048);
   MfArgs A;
   A.hdr = M.hdr.p;
   A.dof_ids = M.dof_ids.p;
@@ -974,6 +1041,8 @@ int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* n
   A.geom = M.geom.p;
   A.dtab = M.dtab.p;
   A.ypart = M.ypart.p;
+  A.pslot = M.sh_slot.p;
+  A.gid = M.gid.p;
   A.u = u;
   A.y = y;
   A.partials = partials;
@@ -982,6 +1051,11 @@ int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* n
   A.nc = M.nc;
   A.nsb = M.nsb;
   A.nloc_cap = M.nloc_max;
+  A.dbg = 0;
+#ifdef ZZZ_EXPERIMENTS
+  if (const char* e = getenv("ZZZ_MF_DEBUG"))
+    A.dbg = atoi(e);
+#endif
   int rc = ZZZ_OK;
 #define ZZZ_MF_T(ND_)                                                                                                    \
   (M.threads == 128 ? mf_launch<ND_, 128>(ctx, A, grid, lds)                                                              \
@@ -996,9 +1070,9 @@ int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* n
 #undef ZZZ_MF_T
   if (rc)
     return rc;
-  if (M.nshared > 0)
-    hipLaunchKernelGGL(k_mf_finish, dim3(gf), dim3(256), 0, ctx->stream, M.sh_dof.p, M.sh_off.p, M.sh_slot.p, M.nshared, M.ypart.p,
-                       ctx->bc.p, u, y, partials ? partials + grid : nullptr, A.stop);
+  if (M.nshared > 0 && !(A.dbg & 16))
+    hipLaunchKernelGGL(k_mf_finish, dim3(gf), dim3(256), 0, ctx->stream, M.sh_dof.p, M.sh_off.p, M.sh_flag.p, M.nshared, M.ypart.p, u,
+                       y, partials ? partials + grid : nullptr, A.stop);
   if (npartials)
     *npartials = grid + (M.nshared > 0 ? gf : 0);
   ZZZ_HIP(ctx, hipGetLastError());

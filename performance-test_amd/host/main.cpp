@@ -277,6 +277,7 @@ struct Shared
   std::vector<unsigned char> p2p_handles; // nranks x ZZZ_P2P_HANDLE_BYTES
   std::vector<int> p2p_enabled;
   std::vector<double> tmax;   // scratch for max-over-ranks timing
+  std::vector<double> tcg;    // cgpoisson: time of the linalg::cg call alone (the Gdof/s line)
   std::vector<int> iters;
   std::vector<double> norm, rnorm0, rnorm;
   std::vector<std::string> error;
@@ -432,7 +433,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     so.single_reduction = o.ksp_cg_single_reduction ? 1 : 0;
     so.error_if_not_converged = o.ksp_error_if_not_converged ? 1 : 0;
   }
-  double solve_s = 0;
+  double solve_s = 0, cg_s = 0;
   {
     Timer ts("ZZZ Solve");
     if (!failed)
@@ -440,8 +441,18 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
       try
       {
         double rn[2] = {0, 0};
+        // cgpoisson: what solver_function sets up before it calls linalg::cg -- coefficient storage of `un`, the
+        // Scatterer and its buffers (src/cgpoisson_problem.cpp:181-190) -- is inside ZZZ Solve and outside the
+        // timer of the Gdof/s line (:232-235); here that is the plan of the matrix-free kernel
+        if (cgpoisson)
+        {
+          ZCK(ctx, zzz_matfree_setup(ctx));
+          ZCK(ctx, zzz_sync(ctx));
+        }
+        Timer tcg("cg");
         ZCK(ctx, zzz_cg_solve(ctx, &so, &S.iters[rank], rn));
         ZCK(ctx, zzz_sync(ctx));
+        S.tcg[rank] = tcg.stop();
         S.rnorm[rank] = rn[0];
         S.rnorm0[rank] = rn[1];
       }
@@ -453,6 +464,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     S.tmax[rank] = ts.stop();
     bar.arrive_and_wait();
     solve_s = *std::max_element(S.tmax.begin(), S.tmax.end());
+    cg_s = *std::max_element(S.tcg.begin(), S.tcg.end());
     if (root)
       g_timers.add("ZZZ Solve", solve_s);
     bar.arrive_and_wait();
@@ -460,7 +472,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   if (root && cgpoisson && !failed)
   {
     // src/cgpoisson_problem.cpp:236-241
-    const double gdofs = (S.iters[0] * (double)S.num_dofs) / solve_s / 1e9;
+    const double gdofs = (S.iters[0] * (double)S.num_dofs) / cg_s / 1e9;
     std::cout << "CG matrix-free action processed: " << gdofs << " Gdof/s\n";
   }
   if (!failed)
@@ -555,6 +567,7 @@ void solve(int argc, char** argv)
     if (zzz_comm_unique_id(S.uid) != 0)
       throw std::runtime_error(zzz_last_error(nullptr));
   S.tmax.assign(S.nranks, 0.0);
+  S.tcg.assign(S.nranks, 0.0);
   S.iters.assign(S.nranks, 0);
   S.norm.assign(S.nranks, 0.0);
   S.rnorm.assign(S.nranks, 0.0);

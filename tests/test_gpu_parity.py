@@ -1173,9 +1173,13 @@ def test_bench_contract_line():
         assert "workload" in d["config"] and "model" not in d["config"]
         r = d["roofline"]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        it = r["iteration"]
+        assert it["bytes"] > r["bytes_per_launch"] and abs(it["frac"] - it["achieved"] / r["peak"]) < 1e-12
         if not extra:
             c = d["cpu_baseline"]
             assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+            # the CPU leg solves the whole problem (nothing extrapolated) and reports its own iteration count
+            assert abs(c["krylov_iterations"] - d["config"]["krylov_iterations"]) <= 2 and c["solve_s"] > 0
     # the N > 1 machinery on one GPU (1-rank communicator): mailbox attach, warm-up probe, CG-form tuning
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ndofs", "60000", "--steps", "2", "--warmup", "1",
                           "--no_cpu_baseline", "--force_comm"], capture_output=True, text=True, timeout=600)
@@ -2395,3 +2399,62 @@ def test_more_than_2_31_nonzeros_on_one_gpu():
         assert np.linalg.norm(b - c.spmv(u)) <= 1e-6 * np.linalg.norm(b)
         bcrows = np.nonzero(b == 0)[0][:1000]
         np.testing.assert_array_equal(Ax[bcrows][np.abs(xv[bcrows]) > 0], xv[bcrows][np.abs(xv[bcrows]) > 0])
+
+
+@pytest.mark.parametrize("order,dims,nc,t", [
+    (1, (26, 23, 19), 512, 256), (1, (26, 23, 19), 1024, 128), (1, (40, 31, 37), 0, 0), (1, (9, 8, 7), 256, 64 * 4),
+    (2, (14, 13, 11), 256, 256), (2, (20, 17, 19), 0, 0), (3, (9, 8, 7), 256, 128), (3, (13, 12, 14), 0, 0),
+])
+def test_matrix_free_cell_blocks_against_oracle(ctx, order, dims, nc, t):
+    """The one-pass matrix-free kernel (csrc/zzz_matfree.hip) on plans of MANY cell blocks (the small cases of
+    test_matrix_free_operator_and_cg fit one block): dofs shared between blocks, partial sums finished in block order,
+    rounds of the in-LDS accumulation.  y = action(x) against the oracle's serial assembly of form M
+    (src/cgpoisson_problem.cpp:193-230), constrained rows zero, bit-identical from call to call and from plan to plan."""
+    zo.set_num_threads(8)
+    env = {"ZZZ_MF_NC": str(nc), "ZZZ_MF_T": str(t)} if nc else {}
+    old = {k: os.environ.get(k) for k in ("ZZZ_MF_NC", "ZZZ_MF_T")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        P = zzz.Part("poisson", order, *dims)
+        ctx.upload_part(P)
+        ctx.matfree_setup()
+        info = ctx.matfree_info()
+        assert info["valid"] == 1 and info["blocks"] > 1 and info["shared_dofs"] > 0
+        if nc:
+            assert info["cells_per_block"] <= nc and info["threads"] == t
+        bc = P.bc_marker()
+        v = np.random.default_rng(order).standard_normal(P.n_owned)
+        oy = zo.action_poisson(order, P.x, P.cells, P.cell_dofs, bc, v)
+        y = ctx.action(v)
+        assert np.abs(y - oy).max() <= 1e-12 * np.abs(oy).max()
+        assert np.all(y[bc.astype(bool)] == 0)
+        for _ in range(4):
+            np.testing.assert_array_equal(ctx.action(v), y)
+        ctx.matfree_setup()  # a second plan of the same mesh is the same plan
+        np.testing.assert_array_equal(ctx.action(v), y)
+        # Dirichlet set changed: the plan follows (it carries the markers)
+        ctx.upload_bc(np.zeros(0, np.int32))
+        oy0 = zo.action_poisson(order, P.x, P.cells, P.cell_dofs, np.zeros_like(bc), v)
+        y0 = ctx.action(v)
+        assert np.abs(y0 - oy0).max() <= 1e-12 * np.abs(oy0).max()
+        # symmetry and constants in the kernel of the unconstrained operator
+        w = np.random.default_rng(7).standard_normal(P.n_owned)
+        assert abs(w @ y0 - v @ ctx.action(w)) <= 1e-10 * abs(w @ y0)
+        assert np.abs(ctx.action(np.ones(P.n_owned))).max() <= 1e-9 * np.abs(y0).max()
+        # the two-pass form of rounds 1-3 (the fallback for meshes the plan cannot hold) computes the same operator
+        ctx.upload_bc(np.nonzero(bc)[0].astype(np.int32))
+        ctx.pattern_build()
+        os.environ["ZZZ_MF_LEGACY"] = "1"
+        yl = ctx.action(v)
+        del os.environ["ZZZ_MF_LEGACY"]
+        assert np.abs(yl - y).max() <= 1e-12 * np.abs(oy).max()
+        np.testing.assert_array_equal(ctx.action(v), y)
+    finally:
+        os.environ.pop("ZZZ_MF_LEGACY", None)
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
