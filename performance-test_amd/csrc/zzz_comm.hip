@@ -244,6 +244,10 @@ struct P2P
   size_t halo_off = 0;                  // doubles from the start of the box; 0 = no window
   size_t halo_stride = 0;               // doubles per (parity, sender) region
   bool halo_on = false;                 // in use (zzz_comm_p2p_halo; needs `enabled`)
+  int halo_agreed = -1;                 // the ranks' COMMON verdict on "this halo plan travels through the windows": -1 not
+                                        // taken yet (the communicator carries the halo), 0 no, 1 yes.  Taken by the collective
+                                        // entry points only (attach, zzz_halo_upload, zzz_comm_p2p_halo, enable / disable), so
+                                        // every rank is in the same state at every exchange
   bool inproc = false;                  // some peer is a context of THIS process on THIS GPU (validation on one GPU)
   int64_t halo_seq = 0;                 // exchange counter: the same call sequence on every rank
   zzz::DevBuf<int32_t> halo_ticket;     // arrival counter of the push kernel's workgroups
@@ -261,7 +265,8 @@ struct P2PHandle // ZZZ_P2P_HANDLE_BYTES
   int64_t pid;
   double* raw;           // valid in the exporting process only
   int32_t device, ok;
-  char pad[128 - 64 - 8 - 8 - 8];
+  uint64_t halo_off, halo_stride; // geometry of the halo window behind the mailbox (0: none): must be the same on every rank
+  char pad[128 - 64 - 8 - 8 - 8 - 16];
 };
 static_assert(sizeof(P2PHandle) == ZZZ_P2P_HANDLE_BYTES, "p2p handle size");
 
@@ -612,19 +617,29 @@ __global__ __launch_bounds__(256) void k_halo_pull(const int* __restrict__ stop,
   }
 }
 
-// can this context's halo plan travel through the window?
-static bool halo_peer_usable(const zzz_ctx* ctx)
+// can THIS rank's halo plan travel through the windows?  (A rank without neighbours has nothing to send: yes.)
+static bool halo_peer_local_ok(const zzz_ctx* ctx)
 {
   if (!ctx->comm || !ctx->comm->p2p)
     return false;
   const P2P* P = ctx->comm->p2p;
-  if (!P->enabled || !P->halo_on || !P->halo_off || ctx->nneigh < 1 || ctx->nneigh > P2P_HALO_MAX_NEIGH)
+  if (!P->enabled || !P->halo_on || !P->halo_off || ctx->nneigh > P2P_HALO_MAX_NEIGH)
     return false;
   for (int k = 0; k < ctx->nneigh; ++k)
     if ((size_t)((ctx->send_off[(size_t)k + 1] - ctx->send_off[(size_t)k]) * ctx->bs) > P->halo_stride
         || ctx->neigh_rank[(size_t)k] < 0 || ctx->neigh_rank[(size_t)k] >= P->nranks || ctx->neigh_rank[(size_t)k] == P->rank)
       return false;
   return true;
+}
+// The transport of an exchange must be the SAME on both ends (a rank that pushes into windows while its neighbour sits in
+// ncclRecv: a time-out on one side, an unbounded block on the other), and what decides it is rank-local (message sizes
+// against the window's regions, neighbour count, the ZZZ_P2P_HALO* knobs).  So the ranks take one common verdict -- one
+// round of the mailbox all-reduce over "my plan does not fit" -- whenever an input of it changes, and every exchange
+// goes by that verdict.  Collective; a no-op verdict of "no" while the mailboxes are off.
+static int halo_peer_agree(zzz_ctx* ctx);
+static bool halo_peer_usable(const zzz_ctx* ctx)
+{
+  return ctx->comm && ctx->comm->p2p && ctx->comm->p2p->enabled && ctx->comm->p2p->halo_agreed == 1 && ctx->nneigh >= 1;
 }
 
 static int halo_peer(zzz_ctx* ctx, double* vec, hipStream_t st, const int* stop)
@@ -1037,6 +1052,42 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
   return ZZZ_OK;
 }
 
+int zzz::halo_peer_agree(zzz_ctx* ctx)
+{
+  if (!ctx->comm || !ctx->comm->p2p)
+    return ZZZ_OK;
+  P2P* P = ctx->comm->p2p;
+  P->halo_agreed = -1;
+  if (!P->enabled) // (the same on every rank: attach, enable and disable are collective)
+    return ZZZ_OK;
+  zzz::DevBuf<double> tv;
+  ZZZ_HIP(ctx, tv.alloc(8));
+  const double in[3] = {halo_peer_local_ok(ctx) ? 0.0 : 1.0, (double)ctx->nneigh, 0.0}; // (no neighbours anywhere: nothing to carry)
+  ZZZ_HIP(ctx, hipMemcpyAsync(tv.p, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->comm->local)
+  {
+    // ranks that are threads of one process: through the host mailboxes.  (A kernel that waits for a peer must not run
+    // while that peer is still in set-up: its hipFree / synchronous copies wait for the whole device, this kernel included.)
+    if (int rc = comm_allreduce_sum(ctx, tv.p, 2))
+      return rc;
+    double nb[2] = {1.0, 0.0};
+    ZZZ_HIP(ctx, hipMemcpyAsync(nb, tv.p, sizeof(nb), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P->halo_agreed = (nb[0] == 0.0 && nb[1] > 0.0) ? 1 : 0;
+    return ZZZ_OK;
+  }
+  const long long seq = ++P->seq;
+  hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(1024), 0, ctx->stream, (const int*)nullptr, tv.p, tv.p + 1, tv.p + 2, 1, 3,
+                     tv.p + 4, P->peer_dev.p, P->box, P->nranks, P->rank, seq, P->fail.p, 10 * P2P_TIMEOUT_TICKS);
+  double nbad[2] = {1.0, 0.0};
+  ZZZ_HIP(ctx, hipMemcpyAsync(nbad, tv.p + 4, sizeof(nbad), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = comm_p2p_check(ctx))
+    return rc;
+  P->halo_agreed = (nbad[0] == 0.0 && nbad[1] > 0.0) ? 1 : 0;
+  return ZZZ_OK;
+}
+
 int zzz_comm_init_peer_only(zzz_ctx* ctx, int nranks, int rank)
 {
   if (!ctx)
@@ -1126,6 +1177,8 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
     h.pid = (int64_t)getpid();
     h.raw = P->box;
     h.device = ctx->device;
+    h.halo_off = P->halo_off;
+    h.halo_stride = P->halo_stride;
     if (hipIpcGetMemHandle(&h.ipc, P->box) != hipSuccess)
     {
       (void)hipGetLastError();
@@ -1155,6 +1208,22 @@ int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles, int* enabled)
   const P2PHandle* H = static_cast<const P2PHandle*>(handles);
   const int n = P->nranks;
   P->enabled = false;
+  P->halo_agreed = -1;
+  // a rank stores at peers[r] + halo_off + ...: the windows must have one geometry (every rank reads the same handles
+  // here, so every rank drops the windows together).  A rank that allocated the mailbox alone exports 0 / 0.
+  for (int r = 0; r < n; ++r)
+    if (H[r].ok && (H[r].halo_off != (uint64_t)P->halo_off || H[r].halo_stride != (uint64_t)P->halo_stride))
+    {
+      P->halo_off = P->halo_stride = 0;
+      P->halo_on = false;
+    }
+  for (int r = 0; r < n; ++r) // (a second pass: a mismatch between two OTHER ranks must switch this one off as well)
+    for (int q = 0; q < n; ++q)
+      if (H[r].ok && H[q].ok && (H[r].halo_off != H[q].halo_off || H[r].halo_stride != H[q].halo_stride))
+      {
+        P->halo_off = P->halo_stride = 0;
+        P->halo_on = false;
+      }
   P->peer.assign((size_t)n, nullptr);
   P->ipc_opened.assign((size_t)n, false);
   bool ok = P->box != nullptr;
@@ -1252,7 +1321,7 @@ int zzz_comm_p2p_attach(zzz_ctx* ctx, const void* handles, int* enabled)
   P->enabled = P->verified = verdict == 1.0;
   if (enabled)
     *enabled = P->enabled ? 1 : 0;
-  return ZZZ_OK;
+  return halo_peer_agree(ctx); // (a halo plan uploaded before the mailboxes existed)
 }
 
 int zzz_comm_p2p_disable(zzz_ctx* ctx)
@@ -1260,7 +1329,10 @@ int zzz_comm_p2p_disable(zzz_ctx* ctx)
   if (!ctx)
     return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
   if (ctx->comm && ctx->comm->p2p)
+  {
     ctx->comm->p2p->enabled = false;
+    ctx->comm->p2p->halo_agreed = -1;
+  }
   return ZZZ_OK;
 }
 
@@ -1272,7 +1344,7 @@ int zzz_comm_p2p_enable(zzz_ctx* ctx, int* enabled)
     ctx->comm->p2p->enabled = true;
   if (enabled)
     *enabled = comm_p2p_enabled(ctx) ? 1 : 0;
-  return ZZZ_OK;
+  return halo_peer_agree(ctx);
 }
 
 int zzz_comm_p2p_halo(zzz_ctx* ctx, int on, int* in_use)
@@ -1281,9 +1353,10 @@ int zzz_comm_p2p_halo(zzz_ctx* ctx, int on, int* in_use)
     return fail(nullptr, ZZZ_ERR_ARG, "NULL context");
   if (ctx->comm && ctx->comm->p2p)
     ctx->comm->p2p->halo_on = on != 0 && ctx->comm->p2p->halo_off != 0;
+  const int rc = halo_peer_agree(ctx); // collective: the ranks' common verdict
   if (in_use)
-    *in_use = halo_peer_usable(ctx) ? 1 : 0;
-  return ZZZ_OK;
+    *in_use = (ctx->comm && ctx->comm->p2p && ctx->comm->p2p->halo_agreed == 1) ? 1 : 0;
+  return rc;
 }
 
 int zzz_local_group_create(int nranks, void** group)
@@ -1392,7 +1465,7 @@ int zzz_halo_upload(zzz_ctx* ctx, int nneigh, const int32_t* neigh_rank, const i
     G->send_off[me] = ctx->send_off;
     G->bs[me] = ctx->bs;
   }
-  return ZZZ_OK;
+  return halo_peer_agree(ctx); // a new plan: the ranks decide again whether it travels through the windows
 }
 
 } // extern "C"
