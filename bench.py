@@ -185,17 +185,35 @@ def physical_bytes_per_product(ctx, nrows, nnz, single_reduction=False):
     return (10 if sinfo[0] else 12) * nnz + 4 * (nrows + 1) + 16 * nrows + extra, sinfo
 
 
-def run_other_config(name, steps=3):
+def run_other_config(name, steps=3, unstructured=None):
     """One of the other BASELINE configurations as a one-GPU workload, OUTSIDE the headline's timed region: the same
     step (pattern + A + b + Jacobi-CG to 1e-8) on a device-generated feed, one warm-up + `steps` timed steps, so that
-    the driver's record carries a number for every config, not only builder-run profiles."""
-    c = CONFIGS[name]
-    bs = 3 if c["problem_type"] == "elasticity" else 1
-    nx, ny, nz, r = zzz.mesh_size(c["ndofs"], c["scaling_type"] == "strong", c["mesh_nproc"], bs, c["order"])
-    nx, ny, nz = nx << r, ny << r, nz << r
-    form = zzz.FORM_ELASTICITY if bs == 3 else zzz.FORM_POISSON
+    the driver's record carries a number for every config, not only builder-run profiles.
+    unstructured = target dofs: `--mesh_type unstructured` instead (src/mesh.cpp:209-453, host/spoke_mesh.cpp: a mesh that is
+    no lattice; P1 Poisson, the whole exterior boundary constrained), fed through the upload entry points."""
+    extra = {}
+    if unstructured:
+        c = dict(problem_type="poisson", order=1, scaling_type="strong", ndofs=unstructured, mesh_nproc=1,
+                 note="--mesh_type unstructured: the ring-with-spurs mesh, every block cut m x m x m; no lattice")
+        bs, form = 1, zzz.FORM_POISSON
+        t0 = time.perf_counter()
+        m = zzz.host().zzzh_spoke_size(int(unstructured), 1)
+        P = zzz.Part.spoke("poisson", 1, m)
+        extra["feed_s"] = time.perf_counter() - t0
+        extra["mesh"] = f"119 blocks x {m}^3 sub-blocks x 6 tetrahedra, {P.nverts} vertices, {P.ncells} cells"
+    else:
+        c = CONFIGS[name]
+        bs = 3 if c["problem_type"] == "elasticity" else 1
+        nx, ny, nz, r = zzz.mesh_size(c["ndofs"], c["scaling_type"] == "strong", c["mesh_nproc"], bs, c["order"])
+        nx, ny, nz = nx << r, ny << r, nz << r
+        form = zzz.FORM_ELASTICITY if bs == 3 else zzz.FORM_POISSON
     with zzz.Context(0) as ctx:
-        info = ctx.cube_generate(c["problem_type"], c["order"], nx, ny, nz, 1, 0)
+        if unstructured:
+            ctx.upload_part(P)
+            info = [P.n_owned, P.ncells]
+            del P
+        else:
+            info = ctx.cube_generate(c["problem_type"], c["order"], nx, ny, nz, 1, 0)
         ph = {"pattern": [], "assemble_matrix": [], "assemble_vector": [], "solve": []}
         it = 0
         t_all = 0.0
@@ -224,6 +242,14 @@ def run_other_config(name, steps=3):
         bytes_pl, sinfo = physical_bytes_per_product(ctx, nrows, nnz)
         ctx_windows = ctx.spmv_x_windows()[0] > 0
         unorm = ctx.vec_norm(zzz.VEC_U)
+        if unstructured:
+            # what the structured feed's luck was worth: entries kept in the stream, and the matrix-free action here
+            extra["stream_entries_over_pattern"] = sinfo[7] / nnz
+            _, ikind = ctx.internal_order()
+            extra["internal_numbering"] = {0: "the caller's order kept", 1: "lattice order", 2: "coordinate-bin order"}[ikind]
+            ctx.matfree_setup()
+            extra["matfree_action_ms"] = ctx.action_time(20)
+            extra["matfree_plan"] = ctx.matfree_info()
     ms = t_all / steps * 1e3
     phys = bytes_pl / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     return {"workload": f"--problem_type {c['problem_type']} --order {c['order']} --scaling_type {c['scaling_type']} "
@@ -233,7 +259,8 @@ def run_other_config(name, steps=3):
             "krylov_iterations": it, "relative_residual": rn / r0 if r0 else 0.0, "solution_norm": unorm,
             "product_ms": spmv_ms, "product_launches_timed": spmv_n, "product_bytes_per_launch": bytes_pl,
             "product_GBs": phys, "roofline_frac": phys / HBM_PEAK_GBS,
-            "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")) if sinfo[5] else "CSR tile kernel"}
+            "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")) if sinfo[5] else "CSR tile kernel",
+            **extra}
 
 
 def run_cgpoisson(order, ndofs, note, solves=3):
@@ -343,6 +370,8 @@ def main():
                          "the structured generator's own order; rcm / random / reverse = what a DOLFINx-style feed may look "
                          "like (src/mesh.cpp:153-162,182-186).  The library renumbers internally (zzz_renumber.hip), so "
                          "`ZZZ Solve` should not depend on this; ZZZ_RENUMBER=0 shows what the caller's order would cost")
+    ap.add_argument("--only", default=None, help="run only this record of other_configs (c1, c4_total, c5_rank, c5_whole, "
+                    "unstructured_p1, cgpoisson_p1_c2, cgpoisson_p3_c5rank) and print it")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt_pc", action="store_true", help="skip the Chebyshev-Jacobi solve beside the measurement")
     ap.add_argument("--no_other_configs", action="store_true",
@@ -357,6 +386,14 @@ def main():
                     help="KSPCG form: classical (PETSc default, two reductions per iteration) or "
                          "-ksp_cg_single_reduction (one); auto = classical on one GPU, single_reduction on N > 1")
     a = ap.parse_args()
+    if a.only:
+        zzz.hip()
+        rec = {"unstructured_p1": lambda: run_other_config(None, steps=2, unstructured=5000000),
+               "cgpoisson_p1_c2": lambda: run_cgpoisson(1, 10000000, "the mesh of BASELINE configs[1]"),
+               "cgpoisson_p3_c5rank": lambda: run_cgpoisson(3, 6250000, "the per-GPU share of BASELINE configs[4]"),
+               "c5_whole": lambda: run_other_config("c5", steps=2)}.get(a.only, lambda: run_other_config(a.only))()
+        print(json.dumps({a.only: rec}))
+        return
     cfg_note = None
     if a.config:
         c = CONFIGS[a.config]
@@ -792,6 +829,10 @@ def main():
                 out["other_configs"]["c5_whole" if name == "c5" else name] = run_other_config(name, steps=2 if name == "c5" else 3)
             except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
                 out["other_configs"]["c5_whole" if name == "c5" else name] = {"error": repr(e)}
+        try:
+            out["other_configs"]["unstructured_p1"] = run_other_config(None, steps=2, unstructured=5000000)
+        except Exception as e:  # noqa: BLE001
+            out["other_configs"]["unstructured_p1"] = {"error": repr(e)}
         for key, order, nd_, note in (("cgpoisson_p1_c2", 1, 10000000, "the mesh of BASELINE configs[1]"),
                                       ("cgpoisson_p3_c5rank", 3, 6250000, "the per-GPU share of BASELINE configs[4]")):
             try:

@@ -76,6 +76,15 @@ zzzh_part* zzzh_part_create(int problem, int order, int64_t nx, int64_t ny, int6
  * dofs on the partition interface are then incomplete locally (the reference completes them in MatAssemblyBegin/
  * End and scatter_rev, src/poisson_problem.cpp:132-137,154); feed for zzz_ghost_layer_build (include/zzz_abi.h). */
 zzzh_part* zzzh_part_create_native(int problem, int order, int64_t nx, int64_t ny, int64_t nz, int nparts, int part);
+/* `--mesh_type unstructured`: the ring-with-spurs mesh of create_spoke_mesh (src/mesh.cpp:209-453), every one of its 119
+ * hexahedral blocks cut into m x m x m sub-blocks x 6 tetrahedra (in place of the reference's Plaza refinement and edge
+ * bisection, :357-452: same geometry and coarse topology, conforming, not a lattice -- but not the reference's refined
+ * mesh entity for entity).  One partition.  Generic dofmaps by sorting (P1-P3, scalar and vector-valued).
+ * bc_mode 0: the reference's Dirichlet markers (src/poisson_problem.cpp:60-71, src/elasticity_problem.cpp:127-138) --
+ * on this geometry possibly an empty set, as in the reference; 1: every dof of the exterior boundary. */
+zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int bc_mode);
+/* smallest m whose mesh has (about) `target_nodes` nodes of the order-k space: the refinement loop of src/mesh.cpp:357-368 */
+int zzzh_spoke_size(int64_t target_nodes, int order);
 void zzzh_part_destroy(zzzh_part* p);
 const char* zzzh_last_error(void);
 

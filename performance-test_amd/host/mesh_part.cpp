@@ -8,6 +8,7 @@
 // (no unpack kernel), and rows that are neighbours in the mesh are neighbours in memory.
 #include "../../include/zzz_host.h"
 #include "cube_layout.h"
+#include "part_struct.h"
 
 #include <algorithm>
 #include <cmath>
@@ -18,9 +19,9 @@
 #include <utility>
 #include <vector>
 
+static thread_local std::string g_err;
 namespace
 {
-thread_local std::string g_err;
 
 void set_err(const char* fmt, ...)
 {
@@ -66,15 +67,7 @@ int64_t num_pdofs(int64_t i, int64_t j, int64_t k, int nrefine, int order)
 
 } // namespace
 
-struct zzzh_part
-{
-  int problem, order, bs, nd, nparts, part;
-  int64_t nx, ny, nz;
-  int64_t sizes[ZZZH_NSIZES];
-  std::vector<double> x, dof_x, coeff[2];
-  std::vector<int32_t> cells, cell_dofs, facets, bc_dofs, neigh, send_idx;
-  std::vector<int64_t> global_dofs, global_verts, send_off, recv_cnt;
-};
+void zzzh_set_error(const char* msg) { g_err = msg; }
 
 extern "C" {
 

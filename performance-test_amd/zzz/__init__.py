@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
 HOST_SYMBOLS = [
-    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_create_native", "zzzh_part_destroy", "zzzh_part_global_verts",
+    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_create_native", "zzzh_part_create_spoke", "zzzh_spoke_size", "zzzh_part_destroy", "zzzh_part_global_verts",
     "zzzh_last_error", "zzzh_part_sizes", "zzzh_part_x", "zzzh_part_cells", "zzzh_part_cell_dofs",
     "zzzh_part_facets", "zzzh_part_bc_dofs", "zzzh_part_dof_x", "zzzh_part_global_dofs", "zzzh_part_coeff",
     "zzzh_part_neigh", "zzzh_part_send_off", "zzzh_part_send_idx", "zzzh_part_recv_cnt",
@@ -149,6 +149,10 @@ def host():
         L.zzzh_part_create.restype = C.c_void_p
         L.zzzh_part_create.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int]
         L.zzzh_part_create_native.restype = C.c_void_p
+        L.zzzh_part_create_spoke.restype = C.c_void_p
+        L.zzzh_part_create_spoke.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.zzzh_spoke_size.restype = C.c_int
+        L.zzzh_spoke_size.argtypes = [C.c_int64, C.c_int]
         L.zzzh_part_create_native.argtypes = L.zzzh_part_create.argtypes
         L.zzzh_part_destroy.argtypes = [C.c_void_p]
         L.zzzh_part_destroy.restype = None
@@ -205,10 +209,14 @@ def _arr(ptr, n, dtype, shape=None):
 class Part:
     """One z-slab partition of the cube problem (host/mesh_part.cpp)."""
 
-    def __init__(self, problem, order, nx, ny, nz, nparts=1, part=0, native=False):
+    def __init__(self, problem, order, nx, ny, nz, nparts=1, part=0, native=False, spoke=None):
         H = host()
         pid = FORM_ELASTICITY if problem == "elasticity" else FORM_POISSON
-        h = (H.zzzh_part_create_native if native else H.zzzh_part_create)(pid, order, nx, ny, nz, nparts, part)
+        if spoke is not None:
+            # the unstructured ring-with-spurs mesh (host/spoke_mesh.cpp): nx = ny = nz = m sub-blocks per block edge
+            h = H.zzzh_part_create_spoke(pid, order, nx, int(spoke))
+        else:
+            h = (H.zzzh_part_create_native if native else H.zzzh_part_create)(pid, order, nx, ny, nz, nparts, part)
         if not h:
             raise ValueError(H.zzzh_last_error().decode())
         try:
@@ -241,6 +249,12 @@ class Part:
             self.recv_cnt = _arr(H.zzzh_part_recv_cnt(h), nn, np.int64)
         finally:
             H.zzzh_part_destroy(h)
+
+    @classmethod
+    def spoke(cls, problem, order, m, bc_mode=1):
+        """`--mesh_type unstructured` (src/mesh.cpp:209-453) with m sub-blocks per block edge; bc_mode 1: the whole exterior
+        boundary is constrained (0: the reference's markers, possibly an empty set on this geometry)"""
+        return cls(problem, order, m, m, m, spoke=bc_mode)
 
     def bc_marker(self):
         m = np.zeros(self.nloc * self.bs, np.uint8)

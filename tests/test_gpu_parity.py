@@ -2458,3 +2458,62 @@ def test_matrix_free_cell_blocks_against_oracle(ctx, order, dims, nc, t):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
+
+
+@pytest.mark.parametrize("problem,order,m,numbering", [
+    ("poisson", 1, 12, "native"), ("poisson", 1, 9, "random"), ("poisson", 2, 6, "native"), ("poisson", 2, 5, "rcm"),
+    ("poisson", 3, 3, "native"), ("elasticity", 1, 6, "native"),
+])
+def test_unstructured_spoke_mesh_against_oracle(ctx, problem, order, m, numbering):
+    """`--mesh_type unstructured` (src/mesh.cpp:209-453; host/spoke_mesh.cpp): a mesh that is NO lattice -- curved, tapered,
+    block-structured with valence changes where the spurs meet the ring -- so nothing of the structured feed's luck applies
+    (no exact zeros in A, no code-free chunks, no monotone runs of the connectivity, no lattice order to restore).  Same
+    bars as on the cube: pattern bit-exact, A and b to 1e-12, product bit-exact, Jacobi-PCG +-2 iterations and 1e-6, and
+    the matrix-free action (whose cell blocks come from the Morton order of the centroids: nothing lattice-bound)."""
+    zo.set_num_threads(8)
+    P = zzz.Part.spoke(problem, order, m)
+    if numbering != "native":
+        P = P.renumbered(numbering, seed=3)
+    n = P.n_owned * P.bs
+    assert n > 30000
+    ctx.upload_part(P)
+    ctx.pattern_build()
+    ctx.assemble_matrix(P.form)
+    ctx.assemble_vector(P.form)
+    rp, cl, v = ctx.csr_download()
+    orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, P.bs)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(cl, ocl)
+    bc = P.bc_marker()
+    ov = zo.assemble_matrix(P.form, order, P.x, P.cells, P.cell_dofs, bc, orp, ocl)
+    ob = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets if problem == "poisson" else None, bc)
+    assert np.abs(v - ov).max() <= 1e-12 * np.abs(ov).max()
+    b = ctx.vec_download(zzz.VEC_B)
+    assert np.abs(b - ob).max() <= 1e-12 * np.abs(ob).max()
+    # no lattice: (nearly) no entry of A is an exact zero away from the constrained rows and columns
+    free = bc == 0
+    rows = np.repeat(np.arange(n), np.diff(orp))
+    inner = free[rows] & free[ocl]
+    assert np.count_nonzero(ov[inner] == 0.0) <= 0.02 * np.count_nonzero(inner)
+    xv = np.random.default_rng(5).standard_normal(n)
+    iperm, kind = ctx.internal_order()
+    if np.array_equal(iperm, np.arange(iperm.size)):
+        np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv(orp, ocl, v, xv))  # the caller's order kept: the serial loop's bits
+    else:
+        assert np.abs(ctx.spmv(xv) - zo.spmv(orp, ocl, v, xv)).max() <= 1e-13 * np.abs(v).max() * np.abs(xv).max() * 64
+    it, rn, r0 = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+    oit, ou, _, _ = zo.pcg(orp, ocl, ov, ob, rtol=1e-8)
+    u = ctx.vec_download(zzz.VEC_U)
+    assert abs(it - oit) <= 2 and rn <= 1e-8 * r0
+    assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+    if problem == "poisson":
+        ya = ctx.action(xv)
+        oya = zo.action_poisson(order, P.x, P.cells, P.cell_dofs, bc, xv)
+        assert np.abs(ya - oya).max() <= 1e-12 * np.abs(oya).max()
+        info = ctx.matfree_info()
+        assert info["valid"] == 1 and info["blocks"] > 1
+        ctx.vec_upload(zzz.VEC_U, np.zeros(n))
+        k, _, _ = ctx.cg_solve(variant=zzz.CG_CGH, pc=zzz.PC_NONE, op=zzz.OP_MATFREE, rtol=1e-6, max_it=100)
+        ok, ouk = zo.cg_matfree_poisson(order, P.x, P.cells, P.cell_dofs, bc, ob, kmax=100, rtol=1e-6)
+        assert abs(k - ok) <= 2
+        assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ouk) <= 1e-6 * np.linalg.norm(ouk)

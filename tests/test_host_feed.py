@@ -238,3 +238,39 @@ def test_renumbered_feed_is_the_same_problem(problem, order, dims, kind):
     assert A.nnz == Aq.nnz
     assert D.nnz == 0 or np.abs(D.data).max() <= 1e-12 * np.abs(v).max()
     assert np.abs(bq[s] - b).max() <= 1e-12 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_unstructured_spoke_mesh_feed(order):
+    """host/spoke_mesh.cpp (`--mesh_type unstructured`, src/mesh.cpp:209-453): conforming (the generator refuses a face with
+    three cells; here: every face has one or two), positive volumes whose sum does not depend on the subdivision, the
+    coarse mesh's 714 cells / 476 points at m = 1, generic dofmaps that pass the patch test through the oracle's element
+    tables (a linear function is in the kernel of the stiffness matrix at every dof off the boundary), constants in the
+    kernel everywhere."""
+    import zzz_oracle as zo
+
+    vols = []
+    for m in (1, 2, 3):
+        P = zzz.Part.spoke("poisson", order, m)
+        if m == 1:
+            assert P.nverts == 476 and P.ncells == 714  # src/mesh.cpp:243-244
+        x, cells = P.x, P.cells
+        assert np.all(np.diff(cells, axis=1) > 0)
+        vol = np.abs(np.linalg.det(x[cells[:, 1:]] - x[cells[:, :1]])) / 6
+        assert vol.min() > 0
+        vols.append(vol.sum())
+        faces = np.sort(np.concatenate([cells[:, [1, 2, 3]], cells[:, [0, 2, 3]], cells[:, [0, 1, 3]], cells[:, [0, 1, 2]]]), axis=1)
+        _, cnt = np.unique(faces, axis=0, return_counts=True)
+        assert set(cnt.tolist()) <= {1, 2} and np.count_nonzero(cnt == 1) == P.facets.shape[0]
+        rp, cl = zo.pattern(P.n_owned, P.cell_dofs, 1)
+        v = zo.assemble_matrix(0, order, P.x, P.cells, P.cell_dofs, np.zeros(P.n_owned, np.uint8), rp, cl)
+        lin = 0.3 + P.dof_x @ np.array([1.0, -2.0, 0.5])
+        y = zo.spmv(rp, cl, v, lin)
+        interior = P.bc_marker() == 0  # bc_mode 1: the whole exterior boundary
+        if interior.any():
+            assert np.abs(y[interior]).max() <= 1e-13 * np.abs(v).max() * np.abs(lin).max()
+        assert np.abs(zo.spmv(rp, cl, v, np.ones(P.n_owned))).max() <= 1e-13 * np.abs(v).max()
+    assert max(vols) - min(vols) <= 1e-12 * max(vols)
+    # the reference's own Dirichlet markers select nothing (or nearly nothing) on this geometry
+    P0 = zzz.Part("poisson", order, 2, 2, 2, spoke=0)
+    assert P0.bc_dofs.size <= P.bc_dofs.size
