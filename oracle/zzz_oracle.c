@@ -1002,6 +1002,10 @@ int zo_assemble_matrix(int form, int order, const double* x, i64 nc, const i32* 
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < n; ++j)
       {
+        /* a partition's feed (owned rows, then ghosts): rows of ghost dofs belong to their owners, who hold every cell
+         * that touches them (ghost-cell layer) -- what MatSetValuesLocal + MatAssembly leave on this rank is the owned rows */
+        if (dofs[i] >= nrows)
+          continue;
         i64 p = find_col(rowptr, cols, dofs[i], dofs[j]);
         if (p < 0)
         {

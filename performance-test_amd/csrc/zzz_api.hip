@@ -124,8 +124,10 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   }
   memset(ctx->h_state, 0, 8 * sizeof(zzz::CgState));
   // tuning knobs for A/B measurements (defaults are the measured best)
-  if (const char* e = getenv("ZZZ_SPMV_TILE"))
+#ifdef ZZZ_EXPERIMENTS
+  if (const char* e = getenv("ZZZ_SPMV_TILE")) // (tools build only: the 4096-nonzero tiles lost)
     ctx->spmv_tile = atoi(e) == 4096 ? 4096 : 2048;
+#endif
   if (const char* e = getenv("ZZZ_SPMV_VARIANT"))
   {
     ctx->spmv_variant = atoi(e) & 27;
@@ -235,6 +237,7 @@ int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncell
   rc = upload(ctx, ctx->cell_verts, cell_verts, (size_t)(4 * ncells));
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
+  ctx->asm_order_ok = false;
   ctx->mf.valid = false;
   return rc;
 }
@@ -277,6 +280,7 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
+  ctx->asm_order_ok = false;
   ctx->mf.valid = false;
   // the library's own locality order of the owned dofs (zzz_renumber.hip): from here on the device connectivity is in
   // internal numbering and every entry point below translates at the boundary

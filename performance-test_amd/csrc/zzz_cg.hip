@@ -541,11 +541,15 @@ static int vgrid(int64_t n)
   // at least 8 entries per thread: every workgroup starts by summing the producer's per-workgroup partials, so for
   // small vectors fewer, longer workgroups are faster (1.25 M rows: 57.8 -> 52.9 us per iteration with 610 instead of
   // 2048 workgroups, 0.5 M rows 40.8 -> 37.0 us; 16 per thread the same, 32 slower); large vectors keep 8 per CU
+#ifdef ZZZ_EXPERIMENTS
   static const int per = [] {
-    const char* e = getenv("ZZZ_VGRID_PER"); // measurement knob (entries per thread)
+    const char* e = getenv("ZZZ_VGRID_PER"); // measurement knob (entries per thread), tools build only
     const int v = e ? atoi(e) : 0;
     return v >= 1 && v <= 64 ? v : 8;
   }();
+#else
+  constexpr int per = 8;
+#endif
   int64_t g = (n + VB * per - 1) / (VB * per);
   if (g > VGRID_MAX)
     g = VGRID_MAX;
@@ -630,8 +634,10 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   // second gather and the row updates lengthen every wavefront's dependent chain, and at that size the product is
   // latency-bound: ~2.4 slices per wavefront); for HBM-sized loops it saves 4 % of the bytes at best.  Off by default.
   int fused_mode = 0;
+#ifdef ZZZ_EXPERIMENTS
   if (const char* e = getenv("ZZZ_CG_FUSED"))
     fused_mode = atoi(e);
+#endif
   const bool fused = o->op == ZZZ_OP_CSR && fused_mode == 2 && sellp_active(ctx) && ctx->sp_win_max == 0; // (its kernel gathers from memory)
   ctx->last_solve_fused = fused;
   // multi-GPU: the scalar all-reduce rides in the tail of the product launch when that launch is the operator stream's
@@ -746,9 +752,13 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       ctx->tail_used = false;
     }
     {
+#ifdef ZZZ_EXPERIMENTS
       int rc = fused ? launch_sellp_dir(ctx, ctx->z.p, pbuf[it & 1], pbuf[(it + 1) & 1], ctx->u.p, ctx->w.p, ctx->part_a.p, &np,
                                         it, P, rz_src, nn_src, n_rz, multi && ctx->overlap)
                      : apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+#else
+      int rc = apply(ctx->p.p, ctx->w.p, ctx->part_a.p, &np);
+#endif
       folded = ctx->tail_used;
       ctx->tail_armed = ctx->tail_used = false;
       if (rc)

@@ -466,6 +466,10 @@ int comm_reduce_allreduce(zzz_ctx* ctx, const int* stop, const double* pa, const
 
 bool comm_tail_args(zzz_ctx* ctx, TailArgs& T, int nv, double* out)
 {
+#ifndef ZZZ_EXPERIMENTS
+  (void)ctx, (void)T, (void)nv, (void)out;
+  return false; // the folded all-reduce (zzz_tail.h) exists in the tools build only: measured 1 us slower per reduction point
+#else
   // A/B knob ZZZ_TAIL=1 (read when the mailbox is created): fold the all-reduce into the producer's tail.  Measured
   // slower than the kernel of its own (zzz_tail.h has the numbers), so off unless asked for.
   const bool off = !(ctx->comm && ctx->comm->p2p && ctx->comm->p2p->tail_on);
@@ -485,6 +489,7 @@ bool comm_tail_args(zzz_ctx* ctx, TailArgs& T, int nv, double* out)
   T.fail = P->fail.p;
   T.timeout = P2P_TIMEOUT_TICKS;
   return true;
+#endif
 }
 
 // did a peer all-reduce time out since the last call?  (checked at the end of a solve)
@@ -1116,8 +1121,10 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
   P2P* P = new P2P();
   P->nranks = ctx->comm->nranks;
   P->rank = ctx->comm->rank;
+#ifdef ZZZ_EXPERIMENTS
   if (const char* e = getenv("ZZZ_TAIL"))
     P->tail_on = atoi(e) == 1;
+#endif
   size_t bytes = sizeof(double) * 2 * (size_t)P->nranks * P2P_SLOT;
   bytes = (bytes + 4095) / 4096 * 4096;
   // the halo window behind the mailbox (ZZZ_P2P_HALO_MB, default 64; 0 = none: halo through the communicator)
@@ -1156,6 +1163,7 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
   P->halo_on = P->halo_off != 0;
   if (const char* hk = getenv("ZZZ_P2P_HALO")) // A/B knob: 0 keeps the halo on the communicator
     P->halo_on = P->halo_on && atoi(hk) != 0;
+#ifdef ZZZ_EXPERIMENTS
   if (e == hipSuccess)
   {
     // partial arrays + tickets of the folded all-reduce (producers on all eight XCDs, one reader)
@@ -1171,6 +1179,7 @@ int zzz_comm_p2p_export(zzz_ctx* ctx, void* handle)
       P->tail_mem = nullptr; // the separate all-reduce kernel stays in use
     }
   }
+#endif
   if (e == hipSuccess)
   {
     h.ok = 1;

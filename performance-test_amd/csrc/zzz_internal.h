@@ -265,6 +265,11 @@ struct zzz_ctx
   // assembly tiling: contiguous owned block-dof ranges whose CSR segment fits LDS
   zzz::DevBuf<int32_t> asm_tile;
   int64_t n_asm_tiles = 0;
+  // P1 assembly: the order in which the tiles (matrix) / 256-row blocks (vector) are handed to the workgroups -- by the
+  // Morton code of a tile's middle vertex, so that the rows that visit a cell are worked on at about the same time by the
+  // same XCD (rows a mesh plane apart in the numbering used to re-fetch the cell's records from HBM)
+  zzz::DevBuf<int32_t> asm_order, vec_order;
+  bool asm_order_ok = false;
   bool have_pattern = false, have_matrix = false;
   bool tiles_ok = true; // false: 2^31 nonzeros or more -- the CSR tile kernel (32-bit tile windows) is not available,
                         // the product must run on the operator stream

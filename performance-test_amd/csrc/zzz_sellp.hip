@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
   }
 }
 
+#ifdef ZZZ_EXPERIMENTS // measurement-only kernels: the tools build (libzzz_hip_exp.so), never the product library
 // ---- TIMING PROBE (ZZZ_EXP_WIN=<doubles>): what would an x window in LDS buy? ------------------------------------
 // The cost structure of a windowed product without its packer: per group of four slices the workgroup loads <doubles>
 // consecutive entries of x into LDS (coalesced 16-B loads), and every gather of the chunk loop reads LDS at a
@@ -1402,6 +1403,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void spmv_sellp_dir_kernel(
   if (threadIdx.x == 0)
     partials[blockIdx.x] = sres;
 }
+
+#endif // ZZZ_EXPERIMENTS
 
 // ---- host side ------------------------------------------------------------------------------------------
 static int grid_cap(int64_t items, int per, int cap)
@@ -1739,8 +1742,10 @@ int sell_update(zzz_ctx* ctx, bool structure)
   // nonzeros) the two barriers and the window load per group cost more than the gathers they replace (product 34.5 ->
   // 37.9 us), so without the knob windows are built for matrices beyond ~300 MB of values only
   const char* win_env = getenv("ZZZ_SELLP_WIN");
-  const int win_knob = win_env ? atoi(win_env) : 2048;
-  const bool winb = ctx->bs == 3 && win_knob >= 256 && win_knob <= 8192 && (win_env || (double)ctx->nnz * 8.0 > 300.0e6);
+  // (at most 8064 doubles: the product's dynamic LDS plus its static words must stay inside the 64 KiB a launch gets
+  // without raising the kernel's limit -- a window of 8192 would fail at the first product, after the stream was packed)
+  const int win_knob = win_env ? std::min(atoi(win_env), 8064) : 2048;
+  const bool winb = ctx->bs == 3 && win_knob >= 256 && (win_env || (double)ctx->nnz * 8.0 > 300.0e6);
   if (lds * waves > 64 * 1024 && !ctx->sp_lds_attr)
   {
     ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_pack<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1916,6 +1921,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   const int gs = sp_grid((ctx->nslices + 3) / 4);
+#ifdef ZZZ_EXPERIMENTS
   const char* e = ctx->timing_only ? getenv("ZZZ_EXP_WIN") : nullptr; // timing probe, wrong results by construction (see
   if (e)                                                               // the kernel): inside zzz_spmv_time only
   {
@@ -1941,6 +1947,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
       return ZZZ_OK;
     }
   }
+#endif
   if (partials)
   {
     TailArgs T;
@@ -2013,6 +2020,7 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
+#ifdef ZZZ_EXPERIMENTS
 // the fused product + direction kernel on the whole matrix, or (partitioned matrix) interior groups, halo of z,
 // boundary groups.  Partials of <p,w>: interior workgroups first.
 int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new, double* xsol, double* y, double* partials,
@@ -2078,4 +2086,5 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
+#endif // ZZZ_EXPERIMENTS
 } // namespace zzz

@@ -60,6 +60,10 @@ struct TailArgs
 #else
 #define ZZZ_TT(i)
 #endif
+#ifndef ZZZ_EXPERIMENTS
+// the product library: no folded all-reduce (comm_tail_args never arms it); the call sites compile to nothing
+__device__ inline void tail_arrive(const TailArgs&, double, double, double) {}
+#else
 __device__ inline void tail_arrive(const TailArgs& T, double v0, double v1, double v2)
 {
 #ifdef ZZZ_TAIL_DEBUG
@@ -215,4 +219,5 @@ __device__ inline void tail_arrive(const TailArgs& T, double v0, double v1, doub
       }
   }
 }
+#endif // ZZZ_EXPERIMENTS
 } // namespace zzz

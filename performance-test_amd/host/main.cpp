@@ -276,6 +276,9 @@ struct Shared
   void* local_group = nullptr; // --comm local
   std::vector<unsigned char> p2p_handles; // nranks x ZZZ_P2P_HANDLE_BYTES
   std::vector<int> p2p_enabled;
+  int spoke_m = 0;            // --mesh_type unstructured: sub-blocks per block edge
+  std::vector<std::int64_t> out_rows; // --output: owned dofs per rank
+  int out_bs = 1;
   std::vector<double> tmax;   // scratch for max-over-ranks timing
   std::vector<double> tcg;    // cgpoisson: time of the linalg::cg call alone (the Gdof/s line)
   std::vector<int> iters;
@@ -349,7 +352,43 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     else if (S.nranks > 1)
       ZCK(ctx, zzz_comm_init(ctx, S.nranks, rank, S.uid));
     const int r = (int)S.dims[3];
-    ZCK(ctx, zzz_cube_generate(ctx, form, (int)o.order, S.dims[0] << r, S.dims[1] << r, S.dims[2] << r, S.nranks, rank, info));
+    if (o.mesh_type == "cube")
+      ZCK(ctx, zzz_cube_generate(ctx, form, (int)o.order, S.dims[0] << r, S.dims[1] << r, S.dims[2] << r, S.nranks, rank, info));
+    else
+    {
+      // create_spoke_mesh (src/mesh.cpp:209-453) through the host feed and the upload entry points (one process).  The
+      // reference's Dirichlet markers (|x| or |x - 1| < 1e-8; |y| < 1e-8) may select nothing on this geometry -- the
+      // reference then solves a singular system; here the whole exterior boundary is constrained instead, and it says so
+      zzzh_part* P = zzzh_part_create_spoke(problem, (int)o.order, S.spoke_m, 0);
+      if (!P)
+        throw std::runtime_error(zzzh_last_error());
+      std::int64_t sz[ZZZH_NSIZES];
+      zzzh_part_sizes(P, sz);
+      if (sz[ZZZH_NBC] == 0)
+      {
+        zzzh_part_destroy(P);
+        P = zzzh_part_create_spoke(problem, (int)o.order, S.spoke_m, 1);
+        if (!P)
+          throw std::runtime_error(zzzh_last_error());
+        zzzh_part_sizes(P, sz);
+        std::cout << "Unstructured mesh: the reference's Dirichlet markers select no facet of this geometry; the whole "
+                     "exterior boundary is constrained (" << sz[ZZZH_NBC] << " dofs)" << std::endl;
+      }
+      struct Guard
+      {
+        zzzh_part* p;
+        ~Guard() { zzzh_part_destroy(p); }
+      } guard{P};
+      ZCK(ctx, zzz_mesh_upload(ctx, sz[ZZZH_NVERTS], zzzh_part_x(P), sz[ZZZH_NCELLS], zzzh_part_cells(P)));
+      ZCK(ctx, zzz_dofmap_upload(ctx, (int)o.order, (int)sz[ZZZH_BS], zzzh_part_cell_dofs(P), sz[ZZZH_NOWNED], 0));
+      ZCK(ctx, zzz_bc_upload(ctx, sz[ZZZH_NBC], zzzh_part_bc_dofs(P)));
+      ZCK(ctx, zzz_facets_upload(ctx, sz[ZZZH_NFACETS], zzzh_part_facets(P)));
+      ZCK(ctx, zzz_coeff_upload(ctx, ZZZ_COEFF_F, zzzh_part_coeff(P, 0)));
+      if (problem == ZZZH_POISSON)
+        ZCK(ctx, zzz_coeff_upload(ctx, ZZZ_COEFF_G, zzzh_part_coeff(P, 1)));
+      info[0] = sz[ZZZH_GLOBAL_DOFS];
+      info[1] = sz[ZZZH_GLOBAL_CELLS];
+    }
   });
   if (root && !failed)
   {
@@ -475,6 +514,58 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     const double gdofs = (S.iters[0] * (double)S.num_dofs) / cg_s / 1e9;
     std::cout << "CG matrix-free action processed: " << gdofs << " Gdof/s\n";
   }
+  // --output <dir> (src/main.cpp:213-223: io::XDMFFile(...).write_mesh / write_function under `ZZZ Output`).  A minimal,
+  // HDF5-free XDMF: one Polyvertex grid per process -- the coordinates of its owned dofs and the solution there as raw
+  // little-endian float64 files (u_p<rank>.bin, x_p<rank>.bin), tied together by <dir>/solution.xdmf (ParaView reads
+  // it; the cell connectivity is not written: the mesh lives on the device and only the solution is the run's result)
+  if (!o.output.empty())
+  {
+    phase("ZZZ Output", [&] {
+      std::int64_t ls[6] = {0, 0, 0, 0, 0, 0};
+      ZCK(ctx, zzz_local_sizes(ctx, ls));
+      const std::int64_t n_owned = ls[2], n_ghost = ls[3], bsz = problem == ZZZH_ELASTICITY ? 3 : 1;
+      std::vector<double> u((size_t)((n_owned + n_ghost) * bsz));
+      ZCK(ctx, zzz_vec_download(ctx, ZZZ_VEC_U, u.data()));
+      zzzh_part* P = o.mesh_type == "cube"
+                         ? zzzh_part_create(problem, (int)o.order, S.dims[0] << S.dims[3], S.dims[1] << S.dims[3],
+                                            S.dims[2] << S.dims[3], S.nranks, rank)
+                         : zzzh_part_create_spoke(problem, (int)o.order, S.spoke_m, 1);
+      if (!P)
+        throw std::runtime_error(zzzh_last_error());
+      const std::string base = o.output + "/";
+      {
+        std::ofstream fu(base + "u_p" + std::to_string(rank) + ".bin", std::ios::binary);
+        fu.write(reinterpret_cast<const char*>(u.data()), (std::streamsize)(n_owned * bsz * 8));
+        std::ofstream fx(base + "x_p" + std::to_string(rank) + ".bin", std::ios::binary);
+        fx.write(reinterpret_cast<const char*>(zzzh_part_dof_x(P)), (std::streamsize)(n_owned * 3 * 8));
+        if (!fu || !fx)
+        {
+          zzzh_part_destroy(P);
+          throw std::runtime_error("--output: cannot write under '" + o.output + "'");
+        }
+      }
+      zzzh_part_destroy(P);
+      S.out_rows[rank] = n_owned;
+      S.out_bs = (int)bsz;
+    });
+    if (root && !failed)
+    {
+      std::ofstream fx(o.output + "/solution.xdmf");
+      fx << "<?xml version=\"1.0\" ?>\n<Xdmf Version=\"3.0\">\n <Domain>\n  <Grid Name=\"u\" GridType=\"Collection\" "
+            "CollectionType=\"Spatial\">\n";
+      for (int r = 0; r < S.nranks; ++r)
+      {
+        const std::int64_t n = S.out_rows[r];
+        fx << "   <Grid Name=\"p" << r << "\" GridType=\"Uniform\">\n    <Topology TopologyType=\"Polyvertex\" NumberOfElements=\""
+           << n << "\"/>\n    <Geometry GeometryType=\"XYZ\"><DataItem Format=\"Binary\" DataType=\"Float\" Precision=\"8\" "
+              "Endian=\"Little\" Dimensions=\"" << n << " 3\">x_p" << r << ".bin</DataItem></Geometry>\n    <Attribute Name=\"u\" "
+              "AttributeType=\"" << (S.out_bs == 3 ? "Vector" : "Scalar") << "\" Center=\"Node\"><DataItem Format=\"Binary\" "
+              "DataType=\"Float\" Precision=\"8\" Endian=\"Little\" Dimensions=\"" << n << (S.out_bs == 3 ? " 3" : "")
+           << "\">u_p" << r << ".bin</DataItem></Attribute>\n   </Grid>\n";
+      }
+      fx << "  </Grid>\n </Domain>\n</Xdmf>\n";
+    }
+  }
   if (!failed)
   {
     try
@@ -526,11 +617,9 @@ void solve(int argc, char** argv)
     throw std::runtime_error("Scaling type '" + o.scaling_type + "` unknown"); // src/main.cpp:115
   if (o.problem_type != "poisson" && o.problem_type != "cgpoisson" && o.problem_type != "elasticity")
     throw std::runtime_error("Unknown problem type: " + o.problem_type); // src/main.cpp:170
-  if (o.mesh_type != "cube")
-    throw std::runtime_error("mesh_type '" + o.mesh_type + "': only the cube mesh is built (the unstructured spoke mesh of "
-                                                             "src/mesh.cpp:209-453 is outside the hot-path scope)");
-  if (!o.output.empty())
-    std::cerr << "warning: --output (XDMF, src/main.cpp:213-223) is outside the hot-path scope; ignored\n";
+  // src/main.cpp:131-141: "cube", anything else is the unstructured (spoke) mesh
+  if (o.mesh_type != "cube" && o.ngpus != 1)
+    throw std::runtime_error("--mesh_type " + o.mesh_type + ": the unstructured mesh is fed from one process (--ngpus 1)");
   if (o.ksp_type != "cg")
     throw std::runtime_error("-ksp_type " + o.ksp_type + ": only cg is built");
   if (o.pc_type != "jacobi" && o.pc_type != "none" && o.pc_type != "chebyshev_jacobi")
@@ -552,12 +641,25 @@ void solve(int argc, char** argv)
   S.opt = o;
   S.nranks = o.ngpus;
   const int ndofs_per_node = (o.problem_type == "elasticity") ? 3 : 1; // src/main.cpp:128
-  zzzh_mesh_size((std::int64_t)o.ndofs, strong ? 1 : 0, S.nranks, ndofs_per_node, (int)o.order, S.dims);
-  if (S.dims[0] < 1 || S.dims[1] < 1 || S.dims[2] < 1)
-    throw std::runtime_error("mesh size search returned a non-positive dimension (ndofs too small)");
-  // src/mesh.cpp:190-194
-  std::cout << "UnitCube (" << S.dims[0] << "x" << S.dims[1] << "x" << S.dims[2] << ") to be refined " << S.dims[3]
-            << " times" << std::endl;
+  if (o.mesh_type == "cube")
+  {
+    zzzh_mesh_size((std::int64_t)o.ndofs, strong ? 1 : 0, S.nranks, ndofs_per_node, (int)o.order, S.dims);
+    if (S.dims[0] < 1 || S.dims[1] < 1 || S.dims[2] < 1)
+      throw std::runtime_error("mesh size search returned a non-positive dimension (ndofs too small)");
+    // src/mesh.cpp:190-194
+    std::cout << "UnitCube (" << S.dims[0] << "x" << S.dims[1] << "x" << S.dims[2] << ") to be refined " << S.dims[3]
+              << " times" << std::endl;
+  }
+  else
+  {
+    // create_spoke_mesh's target (src/mesh.cpp:213-216) and what stands in for its refinement loop (:357-452)
+    std::int64_t target = (std::int64_t)o.ndofs / ndofs_per_node;
+    if (!strong)
+      target *= S.nranks;
+    S.spoke_m = zzzh_spoke_size(target, (int)o.order);
+    std::cout << "Create unstructured mesh: 119 blocks of the ring-with-spurs geometry, each cut " << S.spoke_m << "x" << S.spoke_m
+              << "x" << S.spoke_m << " (x 6 tetrahedra)" << std::endl;
+  }
   if (o.comm == "local")
   {
     if (zzz_local_group_create(S.nranks, &S.local_group) != 0)
@@ -568,6 +670,7 @@ void solve(int argc, char** argv)
       throw std::runtime_error(zzz_last_error(nullptr));
   S.tmax.assign(S.nranks, 0.0);
   S.tcg.assign(S.nranks, 0.0);
+  S.out_rows.assign(S.nranks, 0);
   S.iters.assign(S.nranks, 0);
   S.norm.assign(S.nranks, 0.0);
   S.rnorm.assign(S.nranks, 0.0);

@@ -308,12 +308,22 @@ extern "C" zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int 
               = (x[3 * (size_t)v[FACE_V[f][0]] + d] + x[3 * (size_t)v[FACE_V[f][1]] + d] + x[3 * (size_t)v[FACE_V[f][2]] + d]) / 3.0;
       }
   }
-  // dofs on the closure of the exterior facets
+  // dofs on the closure of the exterior facets (bc_mode 1), or of those exterior facets ALL of whose vertices satisfy the
+  // reference's marker (bc_mode 0: mesh::locate_entities(mesh, 2, marker) + locate_dofs_topological,
+  // src/poisson_problem.cpp:58-75 -- a line of marked vertices that spans no facet constrains nothing)
   for (size_t k = 0; k < facets.size() / 2; ++k)
   {
     const int64_t c = facets[2 * k];
     const int f = facets[2 * k + 1];
     const int32_t* cd = &P->cell_dofs[(size_t)(nd * c)];
+    if (bc_mode != 1)
+    {
+      bool all = true;
+      for (int q = 0; q < 3; ++q)
+        all = all && zzzcube::is_dirichlet(problem, &x[3 * (size_t)cells[(size_t)(4 * c + FACE_V[f][q])]]);
+      if (!all)
+        continue;
+    }
     for (int q = 0; q < 3; ++q)
       dof_on_boundary[(size_t)cd[FACE_V[f][q]]] = 1;
     if (order >= 2)
@@ -324,15 +334,12 @@ extern "C" zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int 
     if (order == 3)
       dof_on_boundary[(size_t)cd[16 + f]] = 1;
   }
-  // Dirichlet dofs.  bc_mode 0: the reference's marker lambdas on the dof coordinates (src/poisson_problem.cpp:60-71,
-  // src/elasticity_problem.cpp:127-138: |x| or |x - 1| < 1e-8, |y| < 1e-8) -- on this geometry that set may be EMPTY
-  // (the reference then solves a singular system); bc_mode 1: every dof of the exterior boundary (a well-posed problem
-  // for tests and measurements)
+  // Dirichlet dofs.  bc_mode 0: the reference's markers (src/poisson_problem.cpp:60-71, src/elasticity_problem.cpp:127-138:
+  // |x| or |x - 1| < 1e-8, |y| < 1e-8) on whole facets -- on this geometry that set is EMPTY (the reference then solves a
+  // singular system); bc_mode 1: every dof of the exterior boundary (a well-posed problem for tests and measurements)
   for (int64_t l = 0; l < ndofs; ++l)
   {
-    const bool fixed = bc_mode == 1 ? dof_on_boundary[(size_t)l] != 0
-                                    : (dof_on_boundary[(size_t)l] != 0 && zzzcube::is_dirichlet(problem, &P->dof_x[3 * (size_t)l]));
-    if (fixed)
+    if (dof_on_boundary[(size_t)l])
       for (int k = 0; k < bs; ++k)
         P->bc_dofs.push_back((int32_t)(l * bs + k));
   }
