@@ -267,6 +267,16 @@ int zzz_matfree_info(zzz_ctx* ctx, int64_t info[8]);
  * partials (what one iteration of linalg::cg launches at src/cg.h:62,65). */
 int zzz_action_time(zzz_ctx* ctx, int reps, double* avg_ms);
 
+/* `ZZZ Create near-nullspace`: build_near_nullspace of src/elasticity_problem.cpp:36-94 (called at :233-244) -- the six
+ * rigid-body modes of the vector-valued space at the dof coordinates (tabulate_dof_coordinates: every dof's reference
+ * node pushed through its cell's affine map), orthonormalised in basis order as la::orthonormalize does, checked as
+ * la::is_orthonormal does (error "Space not orthonormal" otherwise; *max_deviation = largest |<x_i,x_j> - delta_ij|).
+ * Inner products over the owned entries, summed over the ranks (collective with a communicator attached).  The
+ * reference passes the basis to MatSetNearNullSpace for GAMG; Jacobi-CG does not consume it. */
+int zzz_near_nullspace_build(zzz_ctx* ctx, double* max_deviation);
+/* mode k (0..5) of that basis, owned part, 3 * n_owned entries in the caller's numbering */
+int zzz_near_nullspace_download(zzz_ctx* ctx, int k, double* out);
+
 /* ---- the reference's native partition ----------------------------------------------------- */
 
 /* Global indices of the local block dofs (index_map.local_to_global: owned, then ghosts) and of the local mesh

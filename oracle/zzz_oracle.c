@@ -1727,3 +1727,54 @@ void zo_set_num_threads(int n)
   (void)n;
 #endif
 }
+
+/* build_near_nullspace, src/elasticity_problem.cpp:36-94: basis[k] (k < 3) = 1 in component k; rotations
+ * x3 = (-x1, x0, 0), x4 = (x2, 0, -x0), x5 = (0, -x2, x1) at the dof coordinates (:56-71); la::orthonormalize
+ * [EXT: dolfinx/la/utils.h]: for i: for k < i: x_i -= <x_i, x_k> x_k; x_i /= |x_i| (:74-75); la::is_orthonormal (:76-81):
+ * returns the largest |<x_i, x_j> - delta_ij|.  B: [6][3 n], row-major.  One rank: all entries are owned. */
+double zo_near_nullspace(i64 n, const double* dof_x, double* B)
+{
+  const i64 ld = 3 * n;
+  memset(B, 0, sizeof(double) * (size_t)(6 * ld));
+  for (i64 i = 0; i < n; ++i)
+  {
+    const double x0 = dof_x[3 * i], x1 = dof_x[3 * i + 1], x2 = dof_x[3 * i + 2];
+    for (int k = 0; k < 3; ++k)
+      B[k * ld + 3 * i + k] = 1.0;
+    B[3 * ld + 3 * i + 0] = -x1;
+    B[3 * ld + 3 * i + 1] = x0;
+    B[4 * ld + 3 * i + 0] = x2;
+    B[4 * ld + 3 * i + 2] = -x0;
+    B[5 * ld + 3 * i + 2] = x1;
+    B[5 * ld + 3 * i + 1] = -x2;
+  }
+  for (int i = 0; i < 6; ++i)
+  {
+    for (int k = 0; k < i; ++k)
+    {
+      double d = 0.0;
+      for (i64 j = 0; j < ld; ++j)
+        d += B[i * ld + j] * B[k * ld + j];
+      for (i64 j = 0; j < ld; ++j)
+        B[i * ld + j] -= d * B[k * ld + j];
+    }
+    double nn = 0.0;
+    for (i64 j = 0; j < ld; ++j)
+      nn += B[i * ld + j] * B[i * ld + j];
+    nn = sqrt(nn);
+    for (i64 j = 0; j < ld; ++j)
+      B[i * ld + j] /= nn;
+  }
+  double dev = 0.0;
+  for (int i = 0; i < 6; ++i)
+    for (int k = 0; k <= i; ++k)
+    {
+      double d = 0.0;
+      for (i64 j = 0; j < ld; ++j)
+        d += B[i * ld + j] * B[k * ld + j];
+      d = fabs(d - (i == k ? 1.0 : 0.0));
+      if (d > dev)
+        dev = d;
+    }
+  return dev;
+}

@@ -224,6 +224,16 @@ def assemble_vector(form, order, x, cells, cell_dofs, f, g, facets, bc_scalar):
     return b
 
 
+def near_nullspace(dof_x):
+    """build_near_nullspace (src/elasticity_problem.cpp:36-94): (basis [6][3 n], largest deviation from orthonormality)"""
+    n = dof_x.shape[0]
+    B = np.zeros((6, 3 * n))
+    lib().zo_near_nullspace.restype = C.c_double
+    lib().zo_near_nullspace.argtypes = [C.c_int64, np.ctypeslib.ndpointer(np.float64, flags="C"), np.ctypeslib.ndpointer(np.float64, flags="C")]
+    dev = lib().zo_near_nullspace(n, np.ascontiguousarray(dof_x, np.float64), B)
+    return B, float(dev)
+
+
 def action_poisson(order, x, cells, cell_dofs, bc, u):
     y = np.zeros_like(u)
     lib().zo_action_poisson(order, x, cells.shape[0], cells, cell_dofs, bc, u.shape[0], u, y)

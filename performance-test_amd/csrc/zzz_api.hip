@@ -237,7 +237,6 @@ int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncell
   rc = upload(ctx, ctx->cell_verts, cell_verts, (size_t)(4 * ncells));
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
-  ctx->asm_order_ok = false;
   ctx->mf.valid = false;
   return rc;
 }
@@ -280,8 +279,8 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
-  ctx->asm_order_ok = false;
   ctx->mf.valid = false;
+  ctx->near_null_ld = 0;
   // the library's own locality order of the owned dofs (zzz_renumber.hip): from here on the device connectivity is in
   // internal numbering and every entry point below translates at the boundary
   rc = renumber_build(ctx);
@@ -377,6 +376,7 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->have_adj_li = false;
   ctx->have_asm_pos = false;
+  ++ctx->mat_version;
   const char* mode = getenv("ZZZ_PATTERN"); // "host": the C++ host builder (kept for meshes whose
                                             // vertex valence exceeds the device kernel's LDS budget)
   int rc;
@@ -616,6 +616,7 @@ int zzz_csr_upload_values(zzz_ctx* ctx, const double* vals)
   ZZZ_ENTER(ctx);
   if (!ctx->have_pattern || !vals)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_upload_values: no pattern or NULL values");
+  ++ctx->mat_version;
   std::vector<double> vi;
   if (ctx->renumbered)
   {

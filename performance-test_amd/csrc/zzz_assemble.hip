@@ -208,15 +208,17 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
                                                            const uint8_t* __restrict__ bc,
                                                            const rp_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ cols, double* __restrict__ vals,
-                                                           const int32_t* __restrict__ tiles, int64_t ntiles,
-                                                           const int32_t* __restrict__ order)
+                                                           const int32_t* __restrict__ tiles, int64_t ntiles)
 {
   __shared__ double vals_s[NNZ];
   __shared__ int32_t cols_s[NNZ];
-  const int64_t item = xcd_item(ntiles);
-  if (item < 0)
+  // (Handing the tiles out in the Morton order of their middle vertex instead of row order -- so that the rows that
+  // visit a cell would be in flight on one XCD at about the same time -- was measured in round 4: a tile is a stick of
+  // ~126 rows along a mesh line, and the fabric-side fetch counter went UP, 5.1 -> 9.3 GB here and 4.6 -> 12.1 GB in the
+  // vector kernel, at 1-6 % more time.  Row order stays.)
+  const int64_t tile = xcd_item(ntiles);
+  if (tile < 0)
     return;
-  const int64_t tile = order ? order[item] : item; // (the schedule only: which workgroup takes which tile)
   const int d0 = tiles[tile], d1 = tiles[tile + 1];
   const int row0 = d0 * BS, row1 = d1 * BS;
   const int64_t s = rowptr[row0];
@@ -361,11 +363,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
                                                            const uint8_t* __restrict__ bc,
                                                            const uint8_t* __restrict__ facet_mask,
                                                            const double* __restrict__ f, const double* __restrict__ gc,
-                                                           double* __restrict__ b, int64_t nrows,
-                                                           const int32_t* __restrict__ order)
+                                                           double* __restrict__ b, int64_t nrows)
 {
-  const int64_t item = xcd_item((nrows + ASM_BLOCK - 1) / ASM_BLOCK);
-  const int64_t blk = (item >= 0 && order) ? order[item] : item;
+  const int64_t blk = xcd_item((nrows + ASM_BLOCK - 1) / ASM_BLOCK);
   const int64_t r = blk * (int64_t)ASM_BLOCK + threadIdx.x;
   if (blk < 0 || r >= nrows)
     return;
@@ -854,119 +854,6 @@ int ensure_p1_coords(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-// ---- P1: schedule of the assembly tiles / row blocks by the Morton code of their middle vertex ----------------------
-__global__ __launch_bounds__(256) void k_p1_bbox(const double* __restrict__ x, int64_t n, double* __restrict__ out)
-{
-  __shared__ double sh[6][4];
-  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  for (int64_t v = blockIdx.x * 256ll + threadIdx.x; v < n; v += gridDim.x * 256ll)
-    for (int a = 0; a < 3; ++a)
-    {
-      lo[a] = fmin(lo[a], x[3 * v + a]);
-      hi[a] = fmax(hi[a], x[3 * v + a]);
-    }
-  for (int a = 0; a < 3; ++a)
-    for (int o = 32; o > 0; o >>= 1)
-    {
-      lo[a] = fmin(lo[a], __shfl_down(lo[a], o, 64));
-      hi[a] = fmax(hi[a], __shfl_down(hi[a], o, 64));
-    }
-  if ((threadIdx.x & 63) == 0)
-    for (int a = 0; a < 3; ++a)
-    {
-      sh[a][threadIdx.x >> 6] = lo[a];
-      sh[3 + a][threadIdx.x >> 6] = hi[a];
-    }
-  __syncthreads();
-  if (threadIdx.x < 6)
-  {
-    double v = sh[threadIdx.x][0];
-    for (int i = 1; i < 4; ++i)
-      v = threadIdx.x < 3 ? fmin(v, sh[threadIdx.x][i]) : fmax(v, sh[threadIdx.x][i]);
-    out[blockIdx.x * 6 + threadIdx.x] = v;
-  }
-}
-__device__ inline uint32_t p1_spread10(uint32_t v)
-{
-  v &= 0x3ffu;
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-// item t covers block dofs [first(t), first(t + 1)): tiles (boundaries given) or blocks of `per` rows of bs scalars
-__global__ __launch_bounds__(256) void k_p1_keys(const double* __restrict__ xq, const int32_t* __restrict__ tiles, int per, int bs,
-                                                 int64_t nblock, int64_t nitems, double lx, double ly, double lz, double sc,
-                                                 uint32_t* __restrict__ key, int32_t* __restrict__ val)
-{
-  for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < nitems; t += gridDim.x * 256ll)
-  {
-    int64_t mid = tiles ? ((int64_t)tiles[t] + tiles[t + 1]) / 2 : (t * per + per / 2) / bs;
-    mid = min(mid, nblock - 1);
-    const uint32_t q0 = (uint32_t)min(1023, max(0, (int)((xq[3 * mid] - lx) * sc)));
-    const uint32_t q1 = (uint32_t)min(1023, max(0, (int)((xq[3 * mid + 1] - ly) * sc)));
-    const uint32_t q2 = (uint32_t)min(1023, max(0, (int)((xq[3 * mid + 2] - lz) * sc)));
-    key[t] = p1_spread10(q0) | (p1_spread10(q1) << 1) | (p1_spread10(q2) << 2);
-    val[t] = (int32_t)t;
-  }
-}
-
-static int p1_schedule_build(zzz_ctx* ctx)
-{
-  hipStream_t s = ctx->stream;
-  const int64_t nblock = ctx->n_owned;
-  DevBuf<double> bb;
-  ZZZ_HIP(ctx, bb.alloc(6 * 256));
-  hipLaunchKernelGGL(k_p1_bbox, dim3(256), dim3(256), 0, s, ctx->xq, nblock, bb.p);
-  std::vector<double> hb(6 * 256);
-  ZZZ_HIP(ctx, hipMemcpyAsync(hb.data(), bb.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  for (int i = 0; i < 256; ++i)
-    for (int a = 0; a < 3; ++a)
-    {
-      lo[a] = std::min(lo[a], hb[(size_t)(6 * i + a)]);
-      hi[a] = std::max(hi[a], hb[(size_t)(6 * i + 3 + a)]);
-    }
-  const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
-  const double sc = ext > 0 ? 1024.0 / ext : 0.0;
-  for (int which = 0; which < 2; ++which)
-  {
-    const int64_t n = which == 0 ? ctx->n_asm_tiles : (ctx->n_owned * ctx->bs + ASM_BLOCK - 1) / ASM_BLOCK;
-    DevBuf<int32_t>& out = which == 0 ? ctx->asm_order : ctx->vec_order;
-    DevBuf<uint32_t> k0, k1;
-    DevBuf<int32_t> v0;
-    DevBuf<unsigned char> tmp;
-    ZZZ_HIP(ctx, k0.alloc((size_t)n));
-    ZZZ_HIP(ctx, k1.alloc((size_t)n));
-    ZZZ_HIP(ctx, v0.alloc((size_t)n));
-    ZZZ_HIP(ctx, out.alloc((size_t)n));
-    hipLaunchKernelGGL(k_p1_keys, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, ctx->xq,
-                       which == 0 ? ctx->asm_tile.p : (const int32_t*)nullptr, ASM_BLOCK, ctx->bs, nblock, n, lo[0], lo[1], lo[2], sc,
-                       k0.p, v0.p);
-    size_t tb = 0;
-    ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, k0.p, k1.p, v0.p, out.p, (size_t)n, 0u, 30u, s));
-    ZZZ_HIP(ctx, tmp.alloc(tb));
-    ZZZ_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tb, k0.p, k1.p, v0.p, out.p, (size_t)n, 0u, 30u, s));
-    ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  }
-  ctx->asm_order_ok = true;
-  return ZZZ_OK;
-}
-
-// the schedule of the P1 kernels (null: in row order; ZZZ_ASM_ORDER=0 keeps that for A/B runs)
-static const int32_t* p1_order(zzz_ctx* ctx, bool matrix)
-{
-  static const bool off = getenv("ZZZ_ASM_ORDER") && atoi(getenv("ZZZ_ASM_ORDER")) == 0;
-  if (off || ctx->order != 1 || !ctx->xq)
-    return nullptr;
-  // (kept across rebuilds of the same pattern: the tiles depend on the row lengths alone)
-  if ((!ctx->asm_order_ok || (int64_t)ctx->asm_order.n != ctx->n_asm_tiles) && p1_schedule_build(ctx) != ZZZ_OK)
-    return nullptr;
-  return matrix ? ctx->asm_order.p : ctx->vec_order.p;
-}
-
 int ensure_tables(zzz_ctx* ctx)
 {
   if (ctx->tables_order == ctx->order)
@@ -1367,6 +1254,7 @@ static void launch_vector_pk(zzz_ctx* ctx, int64_t nrows)
 int launch_assemble_matrix(zzz_ctx* ctx, int form)
 {
   ctx->sp_rownnz_fresh = ctx->sp_compact_fresh = false;
+  ++ctx->mat_version;
   const int bs = form == ZZZ_FORM_ELASTICITY ? 3 : 1;
   if (bs != ctx->bs)
     return fail(ctx, ZZZ_ERR_ARG, "form %d needs block size %d, dofmap has %d", form, bs, ctx->bs);
@@ -1379,11 +1267,11 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
       // one thread per row: a 1920-nonzero tile holds ~126 rows of 15, so 128 threads leave no lane idle
       hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_P1, 128>), grid, dim3(128), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                         ctx->asm_tile.p, ctx->n_asm_tiles, p1_order(ctx, true));
+                         ctx->asm_tile.p, ctx->n_asm_tiles);
     else
       hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ, ASM_BLOCK>), grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
-                         ctx->asm_tile.p, ctx->n_asm_tiles, p1_order(ctx, true));
+                         ctx->asm_tile.p, ctx->n_asm_tiles);
   }
   else
   {
@@ -1435,11 +1323,11 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
     if (bs == 1)
       hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
-                         ctx->coeff[1].p, ctx->b.p, nrows, p1_order(ctx, false));
+                         ctx->coeff[1].p, ctx->b.p, nrows);
     else
       hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
-                         (const double*)nullptr, ctx->b.p, nrows, p1_order(ctx, false));
+                         (const double*)nullptr, ctx->b.p, nrows);
   }
   else
   {

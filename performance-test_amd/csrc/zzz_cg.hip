@@ -1153,12 +1153,20 @@ static int chebyshev_setup(zzz_ctx* ctx, const zzz_solver_opts* o, ChebPlan& C)
   C.degree = o->pc_degree > 0 ? o->pc_degree : 3;
   const double ratio = o->pc_ratio > 1.0 ? o->pc_ratio : 60.0;
   hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n, 1);
+  const int est_its = o->pc_esteig_its == 0 ? 10 : o->pc_esteig_its;
+  double hi = 0.0;
+  // the bound belongs to the matrix, not to the solve: kept until the values change (every rank sees the same sequence of
+  // assemblies and uploads, so all of them take or skip the estimate's collectives together)
+  const bool cached = ctx->cheb_version == ctx->mat_version && ctx->cheb_est_its == est_its && ctx->cheb_hi > 0.0;
+  if (cached)
+    hi = ctx->cheb_hi;
+  else
+  {
   // spectrum bound: Gershgorin's for D^-1 A, maximum over the ranks
   hipLaunchKernelGGL(k_row_abs_max, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->vals.p, ctx->dinv.p, n, ctx->part_b.p);
   std::vector<double> hp((size_t)g);
   ZZZ_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->part_b.p, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  double hi = 0.0;
   for (double v : hp)
     hi = std::max(hi, v);
   if (multi)
@@ -1168,7 +1176,6 @@ static int chebyshev_setup(zzz_ctx* ctx, const zzz_solver_opts* o, ChebPlan& C)
     hi = 1.0;
   // ... tightened by the Lanczos estimate where that is lower (Gershgorin's bound is exact for P1 Laplacians, 2, and up to
   // 2.7 x too high for P2 / P3 / elasticity, which costs 1.6 x the products); safety factor 1.1 as in PETSc
-  const int est_its = o->pc_esteig_its == 0 ? 10 : o->pc_esteig_its;
   if (est_its > 0)
   {
     double ritz = 0.0;
@@ -1176,6 +1183,10 @@ static int chebyshev_setup(zzz_ctx* ctx, const zzz_solver_opts* o, ChebPlan& C)
       return rc;
     if (ritz > 0.0 && std::isfinite(ritz) && 1.1 * ritz < hi)
       hi = 1.1 * ritz;
+  }
+  ctx->cheb_hi = hi;
+  ctx->cheb_version = ctx->mat_version;
+  ctx->cheb_est_its = est_its;
   }
   const double lo = hi / ratio;
   C.hi = hi;

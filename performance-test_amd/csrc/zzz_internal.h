@@ -265,11 +265,6 @@ struct zzz_ctx
   // assembly tiling: contiguous owned block-dof ranges whose CSR segment fits LDS
   zzz::DevBuf<int32_t> asm_tile;
   int64_t n_asm_tiles = 0;
-  // P1 assembly: the order in which the tiles (matrix) / 256-row blocks (vector) are handed to the workgroups -- by the
-  // Morton code of a tile's middle vertex, so that the rows that visit a cell are worked on at about the same time by the
-  // same XCD (rows a mesh plane apart in the numbering used to re-fetch the cell's records from HBM)
-  zzz::DevBuf<int32_t> asm_order, vec_order;
-  bool asm_order_ok = false;
   bool have_pattern = false, have_matrix = false;
   bool tiles_ok = true; // false: 2^31 nonzeros or more -- the CSR tile kernel (32-bit tile windows) is not available,
                         // the product must run on the operator stream
@@ -298,6 +293,13 @@ struct zzz_ctx
   bool timing_only = false;  // inside zzz_spmv_time: the products' results are discarded (the ZZZ_EXP_WIN probe may run)
   bool halo_pending = false; // comm_halo_begin put an exchange on the comm stream: comm_halo_end waits for it
   zzz::MfPlan mf; // matrix-free action
+  zzz::DevBuf<double> near_null; // the six orthonormalised rigid-body modes (zzz_nullspace.hip), [6][near_null_ld]
+  int64_t near_null_ld = 0;
+  // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound of the matrix as it stands (Gershgorin and Lanczos estimate cost ~10 products
+  // and ~20 all-reduces: taken once per set of matrix values, not once per solve); mat_version counts assemblies / uploads
+  uint64_t mat_version = 0, cheb_version = ~0ull;
+  int cheb_est_its = 0;
+  double cheb_hi = 0.0;
   double last_pc_bound = 0.0; // ZZZ_PC_CHEBYSHEV_JACOBI: the spectrum bound the last solve used
   bool last_solve_fused = false; // the last solve ran the fused product + direction kernel
 

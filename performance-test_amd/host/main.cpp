@@ -416,7 +416,12 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     phase("ZZZ Assemble matrix", [&] { ZCK(ctx, zzz_assemble_matrix(ctx, form)); });
   phase("ZZZ Assemble vector", [&] { ZCK(ctx, zzz_assemble_vector(ctx, form)); });
   if (problem == ZZZH_ELASTICITY)
-    phase("ZZZ Create near-nullspace", [&] {}); // consumed by GAMG only; out of scope for Jacobi-CG
+    // build_near_nullspace (src/elasticity_problem.cpp:233-244): six orthonormalised rigid-body modes; GAMG would consume
+    // them (MatSetNearNullSpace), Jacobi-CG does not
+    phase("ZZZ Create near-nullspace", [&] {
+      double dev = 0;
+      ZCK(ctx, zzz_near_nullspace_build(ctx, &dev));
+    });
   {
     S.tmax[rank] = umbrella.stop();
     bar.arrive_and_wait();

@@ -19,7 +19,8 @@ KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel"), ("k_sp_pack", r"k_sp_pa
         ("k_row_pattern", r"k_row_pattern"), ("k_row_copy", r"k_row_copy"), ("k_tile_encode_cols", r"k_tile_encode_cols"),
         ("k_adjT_fill", r"k_adjT_fill"), ("k_make_pairs", r"k_make_pairs"), ("radix_sort", r"radix_sort_onesweep_iteration"),
         ("k_cube_cells", r"k_cube_cells"), ("k_extract_dinv", r"k_extract_dinv"), ("k_adj_window", r"k_adj_window"),
-        ("k_cell_geom", r"k_cell_geom"), ("k_sp_compact", r"k_sp_compact")]
+        ("k_cell_geom", r"k_cell_geom"), ("k_sp_compact", r"k_sp_compact"), ("k_mf_action", r"k_mf_action"),
+        ("k_mf_finish", r"k_mf_finish")]
 
 
 def reduce_counter(d, counter):
@@ -122,8 +123,47 @@ def merge(pdir, tag, cfg="c2"):
                           "ratio": round(v.get("corrected_over_algorithmic", 0), 3)} for k, v in kern.items()}, indent=1))
 
 
+def merge_only(pdir, tag, rec):
+    """profiles/<tag>_<rec>.json, _kernel_stats.csv, <tag>_pmc_<rec>.json from tools/profile_only.sh's directory"""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = os.path.join(root, "profiles")
+    bench = json.loads(open(os.path.join(pdir, "bench_plain.json")).read().strip().splitlines()[-1])[rec]
+    json.dump(bench, open(os.path.join(out, f"{tag}_{rec}.json"), "w"), indent=1)
+    under = json.loads(open(os.path.join(pdir, "bench_under_rocprof.json")).read().strip().splitlines()[-1])[rec]
+    json.dump(under, open(os.path.join(out, f"{tag}_{rec}_under_rocprof.json"), "w"), indent=1)
+    stats = glob.glob(os.path.join(pdir, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.reader(open(stats, newline="")))
+    with open(os.path.join(out, f"{tag}_{rec}_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        for r in rows:
+            r[0] = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", r[0])[:160]
+            w.writerow(r)
+    fetch = json.load(open(os.path.join(pdir, "pmc_FETCH_SIZE.reduced.json")))
+    write = json.load(open(os.path.join(pdir, "pmc_WRITE_SIZE.reduced.json")))
+    kern = {}
+    for k in fetch:
+        e = dict(fetch[k])
+        e.update({"WRITE_SIZE_KiB": write.get(k, {}).get("WRITE_SIZE_KiB", 0.0)})
+        e["hbm_bytes_corrected"] = (2.0 * e["FETCH_SIZE_KiB"] + e["WRITE_SIZE_KiB"]) * 1024.0
+        kern[k] = e
+    doc = {"command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --only {rec} "
+                      "(one pass per counter; performance-test_amd/tools/profile_only.sh)",
+           "correction": "gfx950: FETCH_SIZE x2 for coalesced streams (MI355X_MICROARCH.md, HBM); gathered accesses are "
+                         "uncalibrated: read ratios",
+           "record": bench, "kernels": kern}
+    if "k_mf_action" in kern and "bytes_addressed" in bench:
+        tot = kern["k_mf_action"]["hbm_bytes_corrected"] + kern.get("k_mf_finish", {}).get("hbm_bytes_corrected", 0.0)
+        doc["action_hbm_bytes_corrected"] = tot
+        doc["action_hbm_over_addressed"] = tot / bench["bytes_addressed"]
+        doc["action_hbm_over_algorithmic"] = tot / bench["algorithmic_bytes"]
+    json.dump(doc, open(os.path.join(out, f"{tag}_pmc_{rec}.json"), "w"), indent=1)
+    print(json.dumps({k: round(v["hbm_bytes_corrected"] / 1e9, 3) for k, v in kern.items()}))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "reduce":
         print(json.dumps(reduce_counter(sys.argv[2], sys.argv[3])))
+    elif sys.argv[1] == "merge_only":
+        merge_only(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         merge(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
-    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_action_time", "zzz_cg_solve", "zzz_cg_history",
+    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_cg_info", "zzz_internal_order_download", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
@@ -114,6 +114,8 @@ def hip():
         L.zzz_matfree_setup.argtypes = [C.c_void_p]
         L.zzz_matfree_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.zzz_action_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.zzz_near_nullspace_build.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.zzz_near_nullspace_download.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_cg_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -499,6 +501,16 @@ class Context:
         y = np.zeros_like(x)
         self._ck(self.L.zzz_action(self.h, x, y))
         return y
+
+    def near_nullspace(self):
+        """build_near_nullspace (src/elasticity_problem.cpp:36-94): returns (basis [6][3 n_owned], largest deviation from
+        orthonormality)"""
+        dev = C.c_double()
+        self._ck(self.L.zzz_near_nullspace_build(self.h, C.byref(dev)))
+        B = np.zeros((6, 3 * self.n_owned))
+        for k in range(6):
+            self._ck(self.L.zzz_near_nullspace_download(self.h, k, B[k]))
+        return B, dev.value
 
     def matfree_setup(self):
         self._ck(self.L.zzz_matfree_setup(self.h))

@@ -2608,3 +2608,33 @@ def test_unstructured_spoke_mesh_against_oracle(ctx, problem, order, m, numberin
         ok, ouk = zo.cg_matfree_poisson(order, P.x, P.cells, P.cell_dofs, bc, ob, kmax=100, rtol=1e-6)
         assert abs(k - ok) <= 2
         assert np.linalg.norm(ctx.vec_download(zzz.VEC_U) - ouk) <= 1e-6 * np.linalg.norm(ouk)
+
+
+@pytest.mark.parametrize("order,dims,numbering", [(1, (6, 5, 7), "native"), (2, (4, 3, 5), "native"), (3, (3, 2, 3), "native"),
+                                                  (2, (4, 4, 3), "random")])
+def test_near_nullspace_against_oracle(ctx, order, dims, numbering):
+    """`ZZZ Create near-nullspace` (build_near_nullspace, src/elasticity_problem.cpp:36-94): the six orthonormalised
+    rigid-body modes against the oracle's restatement on the feed's dof coordinates (the library derives the coordinates
+    from cells, vertices and reference nodes); orthonormal to 1e-12; and they ARE the near-nullspace: the unconstrained
+    elasticity operator annihilates them."""
+    P = zzz.Part("elasticity", order, *dims)
+    if numbering != "native":
+        P = P.renumbered(numbering, seed=2)
+    ctx.upload_part(P)
+    B, dev = ctx.near_nullspace()
+    OB, odev = zo.near_nullspace(P.dof_x[:P.n_owned])
+    assert dev <= 1e-12 and odev <= 1e-12
+    assert np.abs(B - OB).max() <= 1e-12 * np.abs(OB).max()
+    G = B @ B.T
+    assert np.abs(G - np.eye(6)).max() <= 1e-12
+    ctx.upload_bc(np.zeros(0, np.int32))
+    ctx.pattern_build()
+    ctx.assemble_matrix(zzz.FORM_ELASTICITY)
+    _, _, v = ctx.csr_download()
+    for k in range(6):
+        assert np.abs(ctx.spmv(B[k])).max() <= 1e-9 * np.abs(v).max() * np.abs(B[k]).max()
+    # a scalar space has no such basis
+    Q = zzz.Part("poisson", 1, 3, 3, 3)
+    ctx.upload_part(Q)
+    with pytest.raises(zzz.ZzzError):
+        ctx.near_nullspace()

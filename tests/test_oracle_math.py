@@ -304,3 +304,20 @@ def test_chunked_spmv_is_the_serial_spmv_to_roundoff():
     for lanes in (2, 4, 8, 16):
         y = zo.spmv_chunked(P.rowptr, P.cols, P.vals, x, lanes)
         assert 0 < np.abs(y - y1).max() <= 2e-15 * np.abs(y1).max()
+
+
+def test_near_nullspace_restatement():
+    """zo_near_nullspace (build_near_nullspace, src/elasticity_problem.cpp:36-94): orthonormal, spans the rigid-body
+    motions (every translation and infinitesimal rotation field is reproduced by its projection), and the unconstrained
+    elasticity matrix annihilates it."""
+    P = zo.Problem("elasticity", 2, 3, 4, 3)
+    B, dev = zo.near_nullspace(P.dof_x)
+    assert dev <= 1e-13 and np.abs(B @ B.T - np.eye(6)).max() <= 1e-13
+    x = P.dof_x
+    w = np.array([0.3, -1.1, 0.7])
+    field = (np.array([0.5, 0.25, -2.0]) + np.cross(w, x)).reshape(-1)
+    assert np.abs(B.T @ (B @ field) - field).max() <= 1e-12 * np.abs(field).max()
+    rp, cl = zo.pattern(P.nblock, P.cell_dofs, 3)
+    v = zo.assemble_matrix(1, 2, P.x, P.cells, P.cell_dofs, np.zeros(P.n, np.uint8), rp, cl)
+    for k in range(6):
+        assert np.abs(zo.spmv(rp, cl, v, B[k])).max() <= 1e-9 * np.abs(v).max()
