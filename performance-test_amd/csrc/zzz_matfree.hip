@@ -506,7 +506,9 @@ struct MfArgs
 // The factorised tables: constexpr copies decide at compile time which entries are zero; the values are staged in LDS
 // by every (persistent) workgroup and reach the multiply-adds as broadcast reads.  (As literals they occupied ~200
 // vector registers of every lane; as scalar loads from constant memory the compiler hoisted them all and spilled 865
-// scalar registers.)
+// scalar registers; with the loads chained section by section through empty asm statements -- rows of the table as
+// scalar operands, no LDS traffic for them -- the kernel still spilled 410 scalar registers into vector lanes and was
+// 3 % faster at P3 6.2 M dofs, 0.281 against 0.291 ms, 1 % at P2: measured in round 4, not kept.)
 template <int ND>
 struct MfTab;
 template <>
@@ -566,63 +568,7 @@ __device__ inline void mf_element_pk(const double* __restrict__ tab, const doubl
   }
 }
 
-// The same with the table entries as SCALAR operands (trial): rows of the table in constant memory, read through the
-// scalar cache into scalar registers, one (mode, half, direction) row per section; an empty asm makes a section's
-// loads wait for the value of the section before the last, so that they run one section ahead of the arithmetic
-// without the compiler hoisting all 244 loads to the top (865 scalar registers spilled when it may).
-__constant__ double mf_ctab_p2[120];
-__constant__ double mf_ctab_p3[600];
-typedef const double __attribute__((address_space(4)))* mf_cptr;
-template <int ND>
-__device__ inline void mf_element_pk_s(const double (&ue)[ND], const double (&G)[6], double (&ye)[ND])
-{
-#pragma clang fp contract(fast)
-  constexpr int NQ = MfTab<ND>::NQ;
-  const mf_cptr tab = ND == 10 ? (mf_cptr)mf_ctab_p2 : (mf_cptr)mf_ctab_p3;
-#pragma unroll
-  for (int j = 0; j < ND; ++j)
-    ye[j] = 0.0;
-  double dep0 = ue[0], dep1 = ue[1];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-  {
-    double g[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-    {
-      mf_cptr row = tab + (a * NQ + q) * ND;
-      asm volatile("" : "+s"(row) : "v"(dep0));
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < ND; ++j)
-        if (MfTab<ND>::nz(a, q, j))
-          acc += row[j] * ue[j];
-      g[a] = acc;
-      dep0 = dep1;
-      dep1 = acc;
-    }
-    const double h[3] = {G[0] * g[0] + G[3] * g[1] + G[4] * g[2], G[3] * g[0] + G[1] * g[1] + G[5] * g[2],
-                         G[4] * g[0] + G[5] * g[1] + G[2] * g[2]};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-    {
-      mf_cptr row = tab + (a * NQ + q) * ND;
-      asm volatile("" : "+s"(row) : "v"(dep0));
-      int jl = 0;
-#pragma unroll
-      for (int j = 0; j < ND; ++j)
-        if (MfTab<ND>::nz(a, q, j))
-        {
-          ye[j] += row[j] * h[a];
-          jl = j;
-        }
-      dep0 = dep1;
-      dep1 = ye[jl];
-    }
-  }
-}
-
-template <int ND, int T, bool ST = false>
+template <int ND, int T>
 __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArgs A)
 {
   if (A.stop && *A.stop)
@@ -740,8 +686,6 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
           for (int j = 0; j < ND; ++j)
             ye[j] = ue[j] * G[j % 6];
         }
-        else if constexpr (ST)
-          mf_element_pk_s<ND>(ue, G, ye);
         else
           mf_element_pk<ND>(tab_s, tabT_s, ue, G, ye);
       }
@@ -1089,10 +1033,6 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
     const size_t nt = nd == 10 ? 120 : 600;
     ZZZ_HIP(ctx, M.dtab.alloc(nt));
     ZZZ_HIP(ctx, hipMemcpyAsync(M.dtab.p, src, nt * sizeof(double), hipMemcpyHostToDevice, s));
-    if (nd == 10)
-      ZZZ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(mf_ctab_p2), src, nt * sizeof(double), 0, hipMemcpyHostToDevice, s));
-    else
-      ZZZ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(mf_ctab_p3), src, nt * sizeof(double), 0, hipMemcpyHostToDevice, s));
     if (nd == 20)
     {
       ZZZ_HIP(ctx, M.gid.alloc((size_t)(total * nd)));
@@ -1161,16 +1101,16 @@ int mf_plan_build(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-template <int ND, int T, bool ST = false>
+template <int ND, int T>
 static int mf_launch(zzz_ctx* ctx, const MfArgs& A, int grid, int lds)
 {
   static int attr_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per device: the limit this instantiation was given
   if (lds > 48 * 1024 && lds > attr_lds[ctx->device & 15])
   {
-    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_action<ND, T, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_action<ND, T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds[ctx->device & 15] = lds;
   }
-  hipLaunchKernelGGL((k_mf_action<ND, T, ST>), dim3(grid), dim3(T), lds, ctx->stream, A);
+  hipLaunchKernelGGL((k_mf_action<ND, T>), dim3(grid), dim3(T), lds, ctx->stream, A);
   return ZZZ_OK;
 }
 
@@ -1217,13 +1157,12 @@ int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* n
   (M.threads == 128 ? mf_launch<ND_, 128>(ctx, A, grid, lds)                                                              \
                     : M.threads == 256 ? mf_launch<ND_, 256>(ctx, A, grid, lds)                                           \
                                        : M.threads == 512 ? mf_launch<ND_, 512>(ctx, A, grid, lds) : mf_launch<ND_, 1024>(ctx, A, grid, lds))
-  static const bool stab = getenv("ZZZ_MF_STAB") && atoi(getenv("ZZZ_MF_STAB")) != 0; // trial: table entries as scalar operands
   if (M.nd == 4)
     rc = ZZZ_MF_T(4);
   else if (M.nd == 10)
-    rc = (stab && M.threads == 256) ? mf_launch<10, 256, true>(ctx, A, grid, lds) : ZZZ_MF_T(10);
+    rc = ZZZ_MF_T(10);
   else
-    rc = (stab && M.threads == 256) ? mf_launch<20, 256, true>(ctx, A, grid, lds) : ZZZ_MF_T(20);
+    rc = ZZZ_MF_T(20);
 #undef ZZZ_MF_T
   if (rc)
     return rc;
