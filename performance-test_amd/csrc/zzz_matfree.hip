@@ -108,30 +108,31 @@ __global__ __launch_bounds__(256) void k_mf_cell_keys(const double* __restrict__
 }
 
 // Which step of its block a cell runs in.  The element vectors of a step are added into the block's y in rounds (one per
-// incidence of the most-visited dof of the step), so the steps should spread the cells around every dof evenly: one
-// wavefront per block walks the block's cells in Morton order and gives each to the step in which its dofs have the
-// fewest cells so far (lane s prices step s: max over the cell's dofs of the cells that step already holds there; full
-// steps are out; ties go to the emptier step) -- P1, 8 steps: 4.0 rounds per step against 6.4 for dealing the cells
-// out in turn, P3, 3 steps: 8.4 against 11.3.  Counts per (dof, step) live in an LDS hash table keyed by the global dof.
-// Position e = step * T + (cells the step held before) is where the cell's record goes.  Deterministic (the walk is
-// sequential; which hash slot a dof gets does not matter).  More than 64 steps: dealt out in turn.
+// incidence of the most-visited dof of the step), so the steps should spread the cells around every dof evenly.  One
+// wavefront per block walks the block's cells in 64 interleaved Morton sequences (lane l takes cells l * nbatch, l * nbatch
+// + 1, ...: the 64 cells of a batch lie far apart, consecutive batches are neighbours): every lane prices the steps for its
+// cell -- max over the cell's dofs of the cells a step already holds there, from byte counters per (dof, step) in an LDS hash
+// table keyed by the global dof -- and takes the cheapest step that has room (ties: the emptier step); the lanes that picked
+// one step get consecutive places in it in lane order, those beyond its capacity pick again.  P1, 8 steps: ~4 rounds per
+// step against 6.4 for dealing the cells out in turn; P3, 3 steps: 8.4 against 11.3.  Deterministic: picks depend on the
+// counters at the start of the batch and on lane order only (which hash slot a dof gets does not matter).  A first version
+// walked the cells one by one (57 ms at P1 10 M dofs: a chain of dependent LDS reads per cell); this one takes ~1 ms.
+// More than 16 steps: dealt out in turn.
 __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ sorted, const int32_t* __restrict__ cell_dofs, int nd,
-                                                  int64_t ncells, int nc, int T, int nsb, int H, int64_t nblocks,
+                                                  int64_t ncells, int nc, int T, int nsb, int cw, int H, int W, int64_t nblocks,
                                                   int32_t* __restrict__ mf_cell)
 {
   extern __shared__ __align__(16) unsigned char as_lds[];
-  int32_t* const keys = reinterpret_cast<int32_t*>(as_lds);      // [H] global dof or -1
-  int32_t* const cbuf = keys + H;                                 // [64][nd] dofs of the 64 cells in hand
-  int32_t* const slot = cbuf + 64 * nd;                           // [nd] hash slots of the cell being placed
-  int32_t* const fill = slot + 32;                                // [64] cells per step
-  uint8_t* const cnt = reinterpret_cast<uint8_t*>(fill + 64);     // [H][nsb] cells of step s at the dof of slot h
+  int32_t* const keys = reinterpret_cast<int32_t*>(as_lds);  // [H] global dof or -1
+  int32_t* const fill = keys + H;                             // [16] cells per step
+  uint32_t* const cntw = reinterpret_cast<uint32_t*>(fill + 16); // [H][cw] words = 4 cw byte counters per slot (cw 1, 2 or 4)
   const int lane = threadIdx.x;
   for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x)
   {
     const int ncb = (int)min((int64_t)nc, ncells - b * nc);
     for (int i = lane; i < nc; i += 64)
       mf_cell[b * nc + i] = -1;
-    if (nsb > 64)
+    if (nsb > 16)
     {
       for (int kk = lane; kk < ncb; kk += 64)
         mf_cell[b * nc + (kk % nsb) * T + kk / nsb] = sorted[b * nc + kk];
@@ -139,24 +140,31 @@ __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ so
     }
     for (int i = lane; i < H; i += 64)
       keys[i] = -1;
-    for (int i = lane; i < H * nsb; i += 64)
-      cnt[i] = 0;
-    fill[lane] = 0;
+    for (int i = lane; i < H * cw; i += 64)
+      cntw[i] = 0;
+    if (lane < 16)
+      fill[lane] = 0;
     __syncthreads();
-    for (int base = 0; base < ncb; base += 64)
+    const int nbatch = (ncb + W - 1) / W;
+    for (int t = 0; t < nbatch; ++t)
     {
-      const int mine = base + lane < ncb ? sorted[b * nc + base + lane] : -1;
-      for (int j = 0; j < nd; ++j)
-        cbuf[lane * nd + j] = mine >= 0 ? cell_dofs[(int64_t)mine * nd + j] : -1;
-      __syncthreads();
-      const int nhere = min(64, ncb - base);
-      for (int i = 0; i < nhere; ++i)
+      const int kk = lane * nbatch + t;
+      const bool have = lane < W && kk < ncb;
+      const int32_t cell = have ? sorted[b * nc + kk] : -1;
+      // hash slots of the cell's dofs and the price of every step
+      int hs[20];
+      int cost[16];
+#pragma unroll
+      for (int sI = 0; sI < 16; ++sI)
+        cost[sI] = 0;
+#pragma unroll
+      for (int j = 0; j < 20; ++j)
       {
-        const int ci = __shfl(mine, i, 64); // the cell being placed
-        if (lane < nd)
+        int found = -1;
+        if (have && j < nd)
         {
-          const int32_t g = cbuf[i * nd + lane];
-          int h = (int)(((uint32_t)g * 2654435761u) >> 7) & (H - 1), found = -1;
+          const int32_t g = cell_dofs[(int64_t)cell * nd + j];
+          int h = (int)(((uint32_t)g * 2654435761u) >> 7) & (H - 1);
           for (int probe = 0; probe < H; ++probe)
           {
             const int32_t old = atomicCAS(&keys[h], -1, g);
@@ -167,36 +175,63 @@ __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ so
             }
             h = (h + 1) & (H - 1);
           }
-          slot[lane] = found; // -1: table full (a block far beyond the LDS budget: the plan is retried smaller anyway)
         }
-        __syncthreads();
-        int key = INT_MAX;
-        if (lane < nsb && fill[lane] < T)
-        {
-          int cost = 0;
-          for (int j = 0; j < nd; ++j)
-          {
-            const int h = slot[j];
-            if (h >= 0)
-              cost = max(cost, (int)cnt[h * nsb + lane]);
-          }
-          key = (cost << 20) | (fill[lane] << 6) | lane;
-        }
-        const int best = wave_min_i(key) & 63;
-        __syncthreads();
-        if (lane < nd && slot[lane] >= 0)
-        {
-          uint8_t& c = cnt[slot[lane] * nsb + best];
-          if (c < 255)
-            c = (uint8_t)(c + 1);
-        }
-        if (lane == 0)
-        {
-          mf_cell[b * nc + best * T + fill[best]] = ci;
-          fill[best] = fill[best] + 1;
-        }
-        __syncthreads();
+        hs[j] = found; // -1: table full (a block far beyond the LDS budget: the plan is retried smaller anyway)
       }
+      __syncthreads(); // (counters as they stand at the start of the batch)
+#pragma unroll
+      for (int j = 0; j < 20; ++j)
+        if (hs[j] >= 0)
+        {
+          const uint32_t* const w = cntw + cw * hs[j];
+          const uint32_t ww[4] = {w[0], cw > 1 ? w[1] : 0u, cw > 2 ? w[2] : 0u, cw > 2 ? w[3] : 0u};
+#pragma unroll
+          for (int sI = 0; sI < 16; ++sI)
+            cost[sI] = max(cost[sI], (int)((ww[sI >> 2] >> (8 * (sI & 3))) & 255u));
+        }
+      int pick = -1, pos = 0;
+      bool placed = !have;
+      for (int guard = 0; guard < 64 && __ballot(!placed) != 0ull; ++guard)
+      {
+        // cheapest step with room (ties: the emptier, then the lower step)
+        int best = INT_MAX;
+        if (!placed)
+        {
+#pragma unroll
+          for (int sI = 0; sI < 16; ++sI)
+            if (sI < nsb && fill[sI] < T)
+              best = min(best, (cost[sI] << 20) | (fill[sI] << 6) | sI);
+        }
+        const int want = (!placed && best != INT_MAX) ? (best & 63) : -1;
+        __syncthreads();
+        for (int sI = 0; sI < nsb; ++sI)
+        {
+          const unsigned long long m = __ballot(want == sI);
+          if (m == 0ull)
+            continue;
+          const int room = T - fill[sI];
+          const int rank = __popcll(m & ((1ull << lane) - 1ull));
+          if (want == sI && rank < room)
+          {
+            placed = true;
+            pick = sI;
+            pos = fill[sI] + rank;
+          }
+          __syncthreads();
+          if (lane == 0)
+            fill[sI] += min(room, (int)__popcll(m));
+          __syncthreads();
+        }
+      }
+      if (have && pick >= 0)
+      {
+        mf_cell[b * nc + pick * T + pos] = cell;
+#pragma unroll
+        for (int j = 0; j < 20; ++j)
+          if (hs[j] >= 0)
+            atomicAdd(&cntw[cw * hs[j] + (pick >> 2)], 1u << (8 * (pick & 3))); // (a byte counter: at most nc / T... < 256 cells)
+      }
+      __syncthreads();
     }
     __syncthreads();
   }
@@ -204,7 +239,7 @@ __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ so
 
 // one (block, dof) key per incidence; value = position in the block * nd + local index
 __global__ __launch_bounds__(256) void k_mf_pairs(const int32_t* __restrict__ mf_cell, const int32_t* __restrict__ cell_dofs,
-                                                  int nd, int nc, int64_t total, uint64_t* __restrict__ key,
+                                                  int nd, int nc, int64_t total, uint64_t invalid, uint64_t* __restrict__ key,
                                                   uint32_t* __restrict__ val)
 {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total * nd; i += gridDim.x * 256ll)
@@ -214,15 +249,16 @@ __global__ __launch_bounds__(256) void k_mf_pairs(const int32_t* __restrict__ mf
     const int64_t b = pe / nc;
     const int e = (int)(pe - b * nc);
     const int32_t c = mf_cell[pe];
-    key[i] = c < 0 ? ~0ull : (((uint64_t)b << 32) | (uint32_t)cell_dofs[(int64_t)c * nd + li]);
+    key[i] = c < 0 ? invalid : (((uint64_t)b << 32) | (uint32_t)cell_dofs[(int64_t)c * nd + li]);
     val[i] = (uint32_t)(e * nd + li);
   }
 }
 
-__global__ __launch_bounds__(256) void k_mf_heads(const uint64_t* __restrict__ key, int64_t n, int32_t* __restrict__ flag)
+__global__ __launch_bounds__(256) void k_mf_heads(const uint64_t* __restrict__ key, int64_t n, uint64_t invalid,
+                                                  int32_t* __restrict__ flag)
 {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
-    flag[i] = (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
+    flag[i] = (key[i] != invalid && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
 }
 
 // at the head of every run: the unique's key and where its run starts; how many blocks hold each dof
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(256) void k_mf_lists(const uint64_t* __restrict__ k
 // dof in the same step (the run of a (block, dof) key holds them by ascending position)
 __global__ __launch_bounds__(256) void k_mf_cells(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                   const int32_t* __restrict__ uidx, const int32_t* __restrict__ flag, int64_t n,
-                                                  const int32_t* __restrict__ run_start, const int32_t* __restrict__ loc_of, int nd,
+                                                  uint64_t invalid, const int32_t* __restrict__ run_start, const int32_t* __restrict__ loc_of, int nd,
                                                   int nc, int T, int ndw, int nrw, uint32_t* __restrict__ idxw,
                                                   uint32_t* __restrict__ rnkw, int32_t* __restrict__ err)
 {
@@ -333,7 +369,7 @@ __global__ __launch_bounds__(256) void k_mf_cells(const uint64_t* __restrict__ k
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
   {
     const uint64_t k = key[i];
-    if (k == ~0ull)
+    if (k == invalid)
       continue;
     const int32_t j = uidx[i] - (flag[i] ? 0 : 1); // uidx is the exclusive scan of the head flags
     const int64_t b = (int64_t)(k >> 32);
@@ -885,7 +921,8 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   {
     // hash table of the block's dofs: twice the dofs a block may touch, as far as LDS goes (a table that fills up only
     // costs the assignment some of its quality: dofs without a slot are not priced)
-    const int per_slot = 4 + std::min(nsb, 64), fixed = 64 * nd * 4 + 32 * 4 + 64 * 4;
+    const int cw = nsb <= 4 ? 1 : (nsb <= 8 ? 2 : 4); // words of byte counters per slot
+    const int per_slot = 4 + 4 * cw, fixed = 16 * 4 + 16;
     int H = 64;
     while (H < 2 * std::min<int64_t>(nloc_limit, (int64_t)nc * nd) && 2 * H * per_slot + fixed <= 144 * 1024)
       H <<= 1;
@@ -893,14 +930,20 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
     if (lds > 48 * 1024)
       ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_assign), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int per_cu = std::max(1, std::min(16, (160 * 1024) / (lds + 256)));
+    int W = 64;
+#ifdef ZZZ_EXPERIMENTS
+    if (const char* e = getenv("ZZZ_MF_ASSIGN_W"))
+      W = std::max(1, std::min(64, atoi(e)));
+#endif
     hipLaunchKernelGGL(k_mf_assign, dim3((unsigned)std::min<int64_t>(nb, 256ll * per_cu)), dim3(64), lds, s, sorted_cells.p,
-                       ctx->cell_dofs.p, nd, ncells, nc, T, nsb, H, nb, M.mf_cell.p);
+                       ctx->cell_dofs.p, nd, ncells, nc, T, nsb, cw, H, W, nb, M.mf_cell.p);
     ZZZ_HIP(ctx, hipGetLastError());
   }
   sorted_cells.release();
 
   // 2. (block, dof) incidences, sorted; their unique keys
   const int64_t np = total * nd;
+  const uint64_t invalid = ((uint64_t)nb << 32) | 0xffffffffull;
   DevBuf<uint64_t> key;
   DevBuf<uint32_t> val;
   {
@@ -910,14 +953,16 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
     ZZZ_HIP(ctx, val0.alloc((size_t)np));
     ZZZ_HIP(ctx, key.alloc((size_t)np));
     ZZZ_HIP(ctx, val.alloc((size_t)np));
-    hipLaunchKernelGGL(k_mf_pairs, dim3(grid_for(np)), dim3(256), 0, s, M.mf_cell.p, ctx->cell_dofs.p, nd, nc, total, key0.p, val0.p);
-    if (int rc = sort_pairs(ctx, key0, key, val0, val, (size_t)np, 64))
+    // (keys of cells that are not there -- the last block's tail -- sort behind everything else)
+    hipLaunchKernelGGL(k_mf_pairs, dim3(grid_for(np)), dim3(256), 0, s, M.mf_cell.p, ctx->cell_dofs.p, nd, nc, total, invalid, key0.p,
+                       val0.p);
+    if (int rc = sort_pairs(ctx, key0, key, val0, val, (size_t)np, 32 + bits_for((uint64_t)nb)))
       return rc;
   }
   DevBuf<int32_t> flag, uidx;
   ZZZ_HIP(ctx, flag.alloc((size_t)np + 1));
   ZZZ_HIP(ctx, uidx.alloc((size_t)np + 1));
-  hipLaunchKernelGGL(k_mf_heads, dim3(grid_for(np)), dim3(256), 0, s, key.p, np, flag.p);
+  hipLaunchKernelGGL(k_mf_heads, dim3(grid_for(np)), dim3(256), 0, s, key.p, np, invalid, flag.p);
   ZZZ_HIP(ctx, hipMemsetAsync(flag.p + np, 0, sizeof(int32_t), s));
   if (int rc = scan_excl(ctx, flag.p, uidx.p, (size_t)np + 1))
     return rc;
@@ -990,7 +1035,7 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   ZZZ_HIP(ctx, M.rmax.alloc((size_t)(nb * nsb * M.nrw * 4)));
   ZZZ_HIP(ctx, hipMemsetAsync(M.idxw.p, 0, (size_t)(nb * M.ndw * nc) * 4, s));
   ZZZ_HIP(ctx, hipMemsetAsync(M.rnkw.p, 0xff, (size_t)(nb * M.nrw * nc) * 4, s));
-  hipLaunchKernelGGL(k_mf_cells, dim3(grid_for(np)), dim3(256), 0, s, key.p, val.p, uidx.p, flag.p, np, run_start.p, loc_of.p, nd, nc,
+  hipLaunchKernelGGL(k_mf_cells, dim3(grid_for(np)), dim3(256), 0, s, key.p, val.p, uidx.p, flag.p, np, invalid, run_start.p, loc_of.p, nd, nc,
                      T, M.ndw, M.nrw, M.idxw.p, M.rnkw.p, nlmax.p + 1);
   hipLaunchKernelGGL(k_mf_rmax, dim3((unsigned)std::min<int64_t>((nb * nsb * M.nrw + 3) / 4, 8192)), dim3(256), 0, s, M.rnkw.p, nb, nc,
                      T, nsb, M.nrw, M.rmax.p);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Quality against cost of the step assignment: W lanes of the wavefront take cells per batch (ZZZ_EXPERIMENTS build).
+cd "$(dirname "$0")/../.."
+export ZZZ_HIP_LIB=$PWD/performance-test_amd/libzzz_hip_exp.so
+for c in ${CASES:-p1 p3 p2}; do
+for w in 64 32 16 8 1; do
+  ZZZ_MF_ASSIGN_W=$w python performance-test_amd/tools/mf_bench.py $c 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$c W $w setup_warm_ms %.2f action_ms %.4f' % (d['setup_warm_ms'], d['action_ms']))"
+done; done
