@@ -263,6 +263,54 @@ def run_other_config(name, steps=3, unstructured=None):
             **extra}
 
 
+def run_matfree_operator(name, steps=3):
+    """A BASELINE configuration with `--operator matfree` (an extension, not the reference's path): the same KSPCG + PCJACOBI
+    to 1e-8, but the operator is never assembled -- every product is the matrix-free action of cgpoisson
+    (csrc/zzz_matfree.hip) and Jacobi's diagonal comes from the element matrices.  The step: dof -> cell adjacency (the
+    right-hand side's assembly walks it), the action's plan (what takes the matrix's place), b, solve.  Beside the
+    assembled record of the same name so that the two can be compared: from P2 up recomputing beats streaming."""
+    c = CONFIGS[name]
+    nx, ny, nz, r = zzz.mesh_size(c["ndofs"], c["scaling_type"] == "strong", c["mesh_nproc"], 1, c["order"])
+    nx, ny, nz = nx << r, ny << r, nz << r
+    with zzz.Context(0) as ctx:
+        info = ctx.cube_generate(c["problem_type"], c["order"], nx, ny, nz, 1, 0)
+        ph = {"adjacency": [], "plan": [], "assemble_vector": [], "solve": []}
+        it, t_all = 0, 0.0
+        for k in range(steps + 1):
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.pattern_build()
+            ctx.sync()
+            t1 = time.perf_counter()
+            ctx.matfree_setup()
+            ctx.sync()
+            t2 = time.perf_counter()
+            ctx.assemble_vector(zzz.FORM_POISSON)
+            ctx.sync()
+            t3 = time.perf_counter()
+            it, rn, r0 = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_JACOBI, op=zzz.OP_MATFREE, rtol=1e-8, max_it=10000,
+                                      profile=True)
+            ctx.sync()
+            t4 = time.perf_counter()
+            if k == 0:
+                continue
+            for key, dt in zip(("adjacency", "plan", "assemble_vector", "solve"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                ph[key].append(dt)
+            t_all += t4 - t0
+        act_ms, act_n = ctx.profile()
+        plan = ctx.matfree_info()
+        unorm = ctx.vec_norm(zzz.VEC_U)
+    ms = t_all / steps * 1e3
+    return {"workload": f"--problem_type {c['problem_type']} --order {c['order']} --scaling_type {c['scaling_type']} "
+                        f"--ndofs {c['ndofs']} --operator matfree -ksp_type cg -pc_type jacobi -ksp_rtol 1e-08 [{c['note']}; "
+                        "extension: no matrix, the reference multiplies with the assembled one]",
+            "dofs": int(info[0]), "steps": steps, "ms_per_step": ms, "value_dofs_per_s": int(info[0]) / (ms * 1e-3),
+            "phases_ms": {k: float(np.mean(v)) * 1e3 for k, v in ph.items()},
+            "krylov_iterations": it, "relative_residual": rn / r0 if r0 else 0.0, "solution_norm": unorm,
+            "action_ms": act_ms, "action_launches_timed": act_n, "us_per_iteration": float(np.mean(ph["solve"])) / max(it, 1) * 1e6,
+            "bytes_addressed_per_action": plan["bytes_per_action"], "plan": plan}
+
+
 def run_cgpoisson(order, ndofs, note, solves=3):
     """--problem_type cgpoisson (src/cgpoisson_problem.cpp): linalg::cg(u, b, action, 100, 1e-6) on the matrix-free
     operator, the reference's only caller of src/cg.h.  Gdof/s as the reference prints it (:236-241: iterations x global
@@ -391,6 +439,8 @@ def main():
         rec = {"unstructured_p1": lambda: run_other_config(None, steps=2, unstructured=5000000),
                "cgpoisson_p1_c2": lambda: run_cgpoisson(1, 10000000, "the mesh of BASELINE configs[1]"),
                "cgpoisson_p3_c5rank": lambda: run_cgpoisson(3, 6250000, "the per-GPU share of BASELINE configs[4]"),
+               "c5_rank_matfree_operator": lambda: run_matfree_operator("c5_rank"),
+               "c5_whole_matfree_operator": lambda: run_matfree_operator("c5", steps=2),
                "c5_whole": lambda: run_other_config("c5", steps=2)}.get(a.only, lambda: run_other_config(a.only))()
         print(json.dumps({a.only: rec}))
         return
@@ -837,6 +887,11 @@ def main():
                                       ("cgpoisson_p3_c5rank", 3, 6250000, "the per-GPU share of BASELINE configs[4]")):
             try:
                 out["other_configs"][key] = run_cgpoisson(order, nd_, note)
+            except Exception as e:  # noqa: BLE001
+                out["other_configs"][key] = {"error": repr(e)}
+        for key, name, st in (("c5_rank_matfree_operator", "c5_rank", 3), ("c5_whole_matfree_operator", "c5", 2)):
+            try:
+                out["other_configs"][key] = run_matfree_operator(name, steps=st)
             except Exception as e:  # noqa: BLE001
                 out["other_configs"][key] = {"error": repr(e)}
     if dist is not None:

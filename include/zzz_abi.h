@@ -106,7 +106,7 @@ enum
 typedef struct
 {
   int32_t variant;  /* ZZZ_CG_PETSC | ZZZ_CG_CGH */
-  int32_t pc;       /* ZZZ_PC_* (ZZZ_CG_CGH requires ZZZ_PC_NONE) */
+  int32_t pc;       /* ZZZ_PC_* (ZZZ_CG_CGH requires ZZZ_PC_NONE; with ZZZ_OP_MATFREE: none or jacobi) */
   int32_t norm;     /* ZZZ_NORM_* (ZZZ_CG_PETSC only) */
   int32_t op;       /* ZZZ_OP_* */
   int32_t max_it;   /* -ksp_max_it (PETSc default 10000) / kmax */
@@ -263,6 +263,12 @@ int zzz_matfree_setup(zzz_ctx* ctx);
 /* info[0] plan valid, [1] cell blocks, [2] cells per block, [3] threads per workgroup, [4] most dofs a block touches,
  * [5] dofs shared between blocks, [6] their partial sums per action, [7] bytes one action addresses (plan + vectors). */
 int zzz_matfree_info(zzz_ctx* ctx, int64_t info[8]);
+/* diag[n_owned] = the diagonal of the operator zzz_action applies, as the assembled matrix holds it (MatGetDiagonal after
+ * fem::set_diagonal: 1.0 on constrained rows, src/poisson_problem.cpp:146-157) -- computed from the element matrices in
+ * the matrix-free kernel's pass, nothing assembled.  It is what PCJACOBI uses when zzz_cg_solve runs KSPCG on
+ * op = ZZZ_OP_MATFREE (an extension: the reference's KSP path always multiplies with the assembled AIJ matrix,
+ * src/poisson_problem.cpp:159-181; same mathematics, the operator recomputed per product instead of streamed). */
+int zzz_matfree_diagonal(zzz_ctx* ctx, double* diag);
 /* Measurement aid, as zzz_spmv_time: HIP-event time of `reps` back-to-back actions w = action(p) with the <p,w>
  * partials (what one iteration of linalg::cg launches at src/cg.h:62,65). */
 int zzz_action_time(zzz_ctx* ctx, int reps, double* avg_ms);

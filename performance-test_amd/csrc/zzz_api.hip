@@ -840,6 +840,23 @@ int zzz_matfree_setup(zzz_ctx* ctx)
   return mf_plan_build(ctx);
 }
 
+int zzz_matfree_diagonal(zzz_ctx* ctx, double* diag)
+{
+  ZZZ_ENTER(ctx);
+  if (ctx->order == 0 || !diag)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_matfree_diagonal: no dofmap or NULL vector");
+  if (int rc = launch_matfree_diagonal(ctx, ctx->w.p))
+    return rc;
+  const size_t n = (size_t)(ctx->n_owned * ctx->bs);
+  std::vector<double> tmp(ctx->renumbered ? n : 0);
+  double* dst = ctx->renumbered ? tmp.data() : diag;
+  ZZZ_HIP(ctx, hipMemcpyAsync(dst, ctx->w.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->renumbered)
+    to_caller(ctx, tmp.data(), diag, true);
+  return ZZZ_OK;
+}
+
 int zzz_matfree_info(zzz_ctx* ctx, int64_t info[8])
 {
   if (!ctx || !info)
@@ -895,8 +912,8 @@ int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rno
     return fail(ctx, ZZZ_ERR_ARG, "src/cg.h has no preconditioner: use pc = ZZZ_PC_NONE");
   if (o->pc != ZZZ_PC_NONE && o->pc != ZZZ_PC_JACOBI && o->pc != ZZZ_PC_CHEBYSHEV_JACOBI)
     return fail(ctx, ZZZ_ERR_ARG, "unsupported preconditioner %d (none, jacobi, chebyshev-jacobi)", o->pc);
-  if (o->pc != ZZZ_PC_NONE && o->op != ZZZ_OP_CSR)
-    return fail(ctx, ZZZ_ERR_ARG, "Jacobi needs the assembled operator");
+  if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI && o->op != ZZZ_OP_CSR)
+    return fail(ctx, ZZZ_ERR_ARG, "the Chebyshev-Jacobi preconditioner needs the assembled operator");
   if (o->pc == ZZZ_PC_CHEBYSHEV_JACOBI && (o->variant != ZZZ_CG_PETSC || o->pc_degree < 0 || o->pc_degree > 64 || o->pc_esteig_its > 64))
     return fail(ctx, ZZZ_ERR_ARG, "the Chebyshev-Jacobi preconditioner applies to KSPCG (either form), degree 1..64, estimate <= 64 steps");
   if (o->norm < 0 || o->norm > 2)

@@ -1576,6 +1576,20 @@ int launch_matfree_action(zzz_ctx* ctx, const double* u, double* y, double* part
   return mf_action(ctx, u, y, partials, npartials);
 }
 
+// diag(A) without the matrix (1.0 on constrained rows): the cell-block pass with the element matrices' diagonals, for
+// Jacobi on the matrix-free operator.  Needs the plan (no two-pass form of it exists).
+int launch_matfree_diagonal(zzz_ctx* ctx, double* d)
+{
+  if (!ctx->mf.valid)
+  {
+    if (ctx->mf.failed)
+      return fail(ctx, ZZZ_ERR_LIMIT, "the matrix-free diagonal needs the cell-block plan, which this mesh does not fit");
+    if (int rc = mf_plan_build(ctx))
+      return rc;
+  }
+  return mf_diagonal(ctx, d);
+}
+
 int launch_matfree_legacy(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
 {
   if (ctx->bs != 1)

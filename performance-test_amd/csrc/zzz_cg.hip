@@ -54,6 +54,12 @@ __device__ inline void vstore(T v, T* p)
 }
 
 
+__global__ void k_invert(double* __restrict__ d, int64_t n)
+{
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+    d[r] = 1.0 / d[r];
+}
+
 __global__ void k_extract_dinv(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                const double* __restrict__ vals, double* __restrict__ dinv, int64_t n, int jacobi)
 {
@@ -656,6 +662,13 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   if (o->op == ZZZ_OP_CSR)
     hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n,
                        o->pc == ZZZ_PC_JACOBI ? 1 : 0);
+  else if (o->pc == ZZZ_PC_JACOBI)
+  {
+    // the operator is never assembled: its diagonal from the element matrices (zzz_matfree.hip), inverted in place
+    if (int rc = launch_matfree_diagonal(ctx, ctx->dinv.p))
+      return rc;
+    hipLaunchKernelGGL(k_invert, dim3(g), dim3(VB), 0, s, ctx->dinv.p, n);
+  }
   else
     hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, (const rp_t*)nullptr, (const int32_t*)nullptr,
                        (const double*)nullptr, ctx->dinv.p, n, 0);

@@ -388,9 +388,11 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form);
 int launch_assemble_vector(zzz_ctx* ctx, int form);
 int launch_matfree_action(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
 int launch_matfree_legacy(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+int launch_matfree_diagonal(zzz_ctx* ctx, double* d);
 // zzz_matfree.hip
 int mf_plan_build(zzz_ctx* ctx);
 int mf_action(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials);
+int mf_diagonal(zzz_ctx* ctx, double* y);
 
 // kernels_cg
 int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm);

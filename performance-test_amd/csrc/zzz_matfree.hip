@@ -604,7 +604,32 @@ __device__ inline void mf_element_pk(const double* __restrict__ tab, const doubl
   }
 }
 
-template <int ND, int T>
+// the element matrix's diagonal: S_jj = sum_q d(q, j)^T G d(q, j), d_a(q, j) = D_a[q][j]
+template <int ND>
+__device__ inline void mf_element_diag_pk(const double* __restrict__ tabT, const double (&G)[6], double (&ye)[ND])
+{
+#pragma clang fp contract(fast)
+  constexpr int NQ = MfTab<ND>::NQ;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      if (!(MfTab<ND>::nz(0, q, j) || MfTab<ND>::nz(1, q, j) || MfTab<ND>::nz(2, q, j)))
+        continue;
+      const double d0 = tabT[(q * ND + j) * 3 + 0], d1 = tabT[(q * ND + j) * 3 + 1], d2 = tabT[(q * ND + j) * 3 + 2];
+      acc += d0 * (G[0] * d0 + G[3] * d1 + G[4] * d2) + d1 * (G[3] * d0 + G[1] * d1 + G[5] * d2)
+             + d2 * (G[4] * d0 + G[5] * d1 + G[2] * d2);
+    }
+    ye[j] = acc;
+  }
+}
+
+// DIAG: the same pass with the element matrix's diagonal in place of the element vector: y = diag(A) in the action's own
+// summation order (1.0 on constrained rows, fem::set_diagonal) -- what Jacobi needs when the operator is never assembled
+template <int ND, int T, bool DIAG>
 __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArgs A)
 {
   if (A.stop && *A.stop)
@@ -642,8 +667,8 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
     // stage the block's u (and coordinates), clear its y
     for (int d = tid; d < nloc; d += T)
     {
-      const int32_t g = (GU || MF_DBG(4)) ? 0 : A.dof_ids[dof_off + d];
-      const double uv = (GU || MF_DBG(4)) ? 1.0 : A.u[g];
+      const int32_t g = (GU || DIAG || MF_DBG(4)) ? 0 : A.dof_ids[dof_off + d];
+      const double uv = (GU || DIAG || MF_DBG(4)) ? 1.0 : A.u[g];
       if (ND == 4)
       {
         const double* __restrict__ q = A.xyz + 3ll * (dof_off + d);
@@ -690,6 +715,16 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
         const double det = J00 * C00 + J01 * C10 + J02 * C20;
         const double d1 = p1.w - p0.w, d2 = p2.w - p0.w, d3 = p3.w - p0.w;
         const double sc = 1.0 / (6.0 * fabs(det));
+        if constexpr (DIAG)
+        {
+          const double s0 = C00 + C10 + C20, s1 = C01 + C11 + C21, s2 = C02 + C12 + C22;
+          ye[0] = (s0 * s0 + s1 * s1 + s2 * s2) * sc;
+          ye[1] = (C00 * C00 + C01 * C01 + C02 * C02) * sc;
+          ye[2] = (C10 * C10 + C11 * C11 + C12 * C12) * sc;
+          ye[3] = (C20 * C20 + C21 * C21 + C22 * C22) * sc;
+        }
+        else
+        {
         const double t0 = (C00 * d1 + C10 * d2 + C20 * d3) * sc;
         const double t1 = (C01 * d1 + C11 * d2 + C21 * d3) * sc;
         const double t2 = (C02 * d1 + C12 * d2 + C22 * d3) * sc;
@@ -697,6 +732,7 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
         ye[2] = C10 * t0 + C11 * t1 + C12 * t2;
         ye[3] = C20 * t0 + C21 * t1 + C22 * t2;
         ye[0] = -(ye[1] + ye[2] + ye[3]);
+        }
       }
       else
       {
@@ -704,7 +740,9 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
 #pragma unroll
         for (int t = 0; t < 6; ++t)
           G[t] = A.geom[(b * 6 + t) * A.nc + e];
-        if constexpr (GU)
+        if constexpr (DIAG)
+          mf_element_diag_pk<ND>(tabT_s, G, ye);
+        else if constexpr (GU)
         {
 #pragma unroll
           for (int j = 0; j < ND; ++j)
@@ -716,7 +754,9 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
           for (int j = 0; j < ND; ++j)
             ue[j] = rec[(iw[j >> 1] >> (16 * (j & 1))) & 0xffff];
         }
-        if (MF_DBG(1))
+        if constexpr (DIAG)
+          ;
+        else if (MF_DBG(1))
         {
 #pragma unroll
           for (int j = 0; j < ND; ++j)
@@ -771,9 +811,11 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
     for (int d = tid; d < (MF_DBG(8) ? 0 : n_int); d += T)
     {
       const int32_t g = A.dof_ids[dof_off + d];
-      const double v = A.dof_flag[dof_off + d] ? 0.0 : ys[d]; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
+      // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207; the diagonal: 1.0 there
+      const double v = A.dof_flag[dof_off + d] ? (DIAG ? 1.0 : 0.0) : ys[d];
       A.y[g] = v;
-      dot += v * (ND == 4 ? zu[2 * d + 1] : (GU ? A.u[g] : rec[d]));
+      if constexpr (!DIAG)
+        dot += v * (ND == 4 ? zu[2 * d + 1] : (GU ? A.u[g] : rec[d]));
     }
     for (int d = tid; d < n_sh; d += T)
       A.ypart[A.pslot[part_off + d]] = ys[n_int + d];
@@ -793,7 +835,7 @@ __global__ __launch_bounds__(256) void k_mf_finish(const int32_t* __restrict__ s
                                                    const uint8_t* __restrict__ sh_flag, int64_t nshared,
                                                    const double* __restrict__ ypart, const double* __restrict__ u,
                                                    double* __restrict__ y, double* __restrict__ partials,
-                                                   const int* __restrict__ stop)
+                                                   const int* __restrict__ stop, double fixed_value)
 {
   if (stop && *stop)
     return;
@@ -803,13 +845,13 @@ __global__ __launch_bounds__(256) void k_mf_finish(const int32_t* __restrict__ s
   {
     const int32_t g = sh_dof[k];
     const int p0 = sh_off[k], p1 = sh_off[k + 1];
-    const double ug = u[g];
+    const double ug = u ? u[g] : 0.0;
     const bool fixed = sh_flag[k] != 0;
     double s = ypart[p0];
     for (int p = p0 + 1; p < p1; ++p)
       s += ypart[p];
     if (fixed)
-      s = 0.0; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207
+      s = fixed_value; // bc->set(y.array(), std::nullopt, 0.0), src/cgpoisson_problem.cpp:207 (the diagonal: 1.0)
     y[g] = s;
     dot += s * ug;
   }
@@ -1146,20 +1188,30 @@ int mf_plan_build(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-template <int ND, int T>
+template <int ND, int T, bool DIAG>
 static int mf_launch(zzz_ctx* ctx, const MfArgs& A, int grid, int lds)
 {
   static int attr_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per device: the limit this instantiation was given
   if (lds > 48 * 1024 && lds > attr_lds[ctx->device & 15])
   {
-    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_action<ND, T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_action<ND, T, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds[ctx->device & 15] = lds;
   }
-  hipLaunchKernelGGL((k_mf_action<ND, T>), dim3(grid), dim3(T), lds, ctx->stream, A);
+  hipLaunchKernelGGL((k_mf_action<ND, T, DIAG>), dim3(grid), dim3(T), lds, ctx->stream, A);
   return ZZZ_OK;
 }
 
+static int mf_run(zzz_ctx* ctx, bool diag, const double* u, double* y, double* partials, int* npartials);
+
 int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* npartials)
+{
+  return mf_run(ctx, false, u, y, partials, npartials);
+}
+
+// y = diag(A) (1.0 on constrained rows), summed in the order of the action
+int mf_diagonal(zzz_ctx* ctx, double* y) { return mf_run(ctx, true, nullptr, y, nullptr, nullptr); }
+
+static int mf_run(zzz_ctx* ctx, bool diag, const double* u, double* y, double* partials, int* npartials)
 {
   MfPlan& M = ctx->mf;
   if (!M.valid)
@@ -1198,22 +1250,23 @@ int mf_action(zzz_ctx* ctx, const double* u, double* y, double* partials, int* n
     A.dbg = atoi(e);
 #endif
   int rc = ZZZ_OK;
-#define ZZZ_MF_T(ND_)                                                                                                    \
-  (M.threads == 128 ? mf_launch<ND_, 128>(ctx, A, grid, lds)                                                              \
-                    : M.threads == 256 ? mf_launch<ND_, 256>(ctx, A, grid, lds)                                           \
-                                       : M.threads == 512 ? mf_launch<ND_, 512>(ctx, A, grid, lds) : mf_launch<ND_, 1024>(ctx, A, grid, lds))
+#define ZZZ_MF_T(ND_, DG_)                                                                                              \
+  (M.threads == 128 ? mf_launch<ND_, 128, DG_>(ctx, A, grid, lds)                                                         \
+                    : M.threads == 256 ? mf_launch<ND_, 256, DG_>(ctx, A, grid, lds)                                      \
+                                       : M.threads == 512 ? mf_launch<ND_, 512, DG_>(ctx, A, grid, lds)                   \
+                                                          : mf_launch<ND_, 1024, DG_>(ctx, A, grid, lds))
   if (M.nd == 4)
-    rc = ZZZ_MF_T(4);
+    rc = diag ? ZZZ_MF_T(4, true) : ZZZ_MF_T(4, false);
   else if (M.nd == 10)
-    rc = ZZZ_MF_T(10);
+    rc = diag ? ZZZ_MF_T(10, true) : ZZZ_MF_T(10, false);
   else
-    rc = ZZZ_MF_T(20);
+    rc = diag ? ZZZ_MF_T(20, true) : ZZZ_MF_T(20, false);
 #undef ZZZ_MF_T
   if (rc)
     return rc;
   if (M.nshared > 0 && !(A.dbg & 16))
     hipLaunchKernelGGL(k_mf_finish, dim3(gf), dim3(256), 0, ctx->stream, M.sh_dof.p, M.sh_off.p, M.sh_flag.p, M.nshared, M.ypart.p, u,
-                       y, partials ? partials + grid : nullptr, A.stop);
+                       y, partials ? partials + grid : nullptr, A.stop, diag ? 1.0 : 0.0);
   if (npartials)
     *npartials = grid + (M.nshared > 0 ? gf : 0);
   ZZZ_HIP(ctx, hipGetLastError());

@@ -107,6 +107,9 @@ struct Options
   int ngpus = 1;
   std::string comm = "rccl"; // "local": host-mediated exchange, all ranks on GPU 0 (validation on one GPU)
   std::string allreduce = "peer"; // CG scalar all-reduces: "peer" memory mailboxes (falls back) | "comm" (RCCL / local)
+  // poisson only: "assembled" = the reference's path (AIJ matrix, MatMult); "matfree" = KSPCG + PCJACOBI on the matrix-free
+  // operator of cgpoisson: no matrix, the diagonal from the element matrices (an extension; faster from P2 up)
+  std::string op = "assembled";
   // PETSc options database (README.md:66-82)
   std::string ksp_type = "cg", pc_type = "jacobi", ksp_norm_type = "preconditioned";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_divtol = 1e4; // PETSc defaults (KSPCreate)
@@ -136,6 +139,8 @@ void usage()
                "  --ngpus arg (=1)                number of GPUs (takes the place of mpirun -np)\n"
                "  --comm arg (=rccl)              rccl | local (host-mediated, all ranks on GPU 0: validation)\n"
                "  --allreduce arg (=peer)         peer (xGMI peer-memory mailboxes, else falls back) | comm\n"
+               "  --operator arg (=assembled)     poisson: assembled (the AIJ matrix) | matfree (KSPCG on the matrix-free\n"
+               "                                  operator, Jacobi from the element matrices' diagonals; no matrix)\n"
                "PETSc-style solver options honoured: -ksp_type cg -pc_type {jacobi,none,chebyshev_jacobi} -ksp_rtol -ksp_atol\n"
                "  -ksp_divtol -pc_chebyshev_jacobi_degree (=3) -pc_chebyshev_jacobi_ratio (=60) -pc_chebyshev_jacobi_esteig (=10)\n"
                "  -ksp_max_it -ksp_norm_type {preconditioned,unpreconditioned,natural} -ksp_view -ksp_monitor\n"
@@ -183,6 +188,8 @@ Options parse(int argc, char** argv)
         o.comm = value(i, arg, key);
       else if (key == "allreduce")
         o.allreduce = value(i, arg, key);
+      else if (key == "operator")
+        o.op = value(i, arg, key);
       else if (key == "memory_profiling")
         o.mem_profile = true;
       else if (key == "subcomm_partition")
@@ -341,6 +348,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
   const int problem = o.problem_type == "elasticity" ? ZZZH_ELASTICITY : ZZZH_POISSON;
   const int form = problem == ZZZH_ELASTICITY ? ZZZ_FORM_ELASTICITY : ZZZ_FORM_POISSON;
   const bool cgpoisson = o.problem_type == "cgpoisson";
+  const bool matfree_op = o.op == "matfree";
 
   // The structured feed (mesh, function space, Dirichlet set, coefficients, halo plan) is generated
   // on the GPU in closed form (zzz_cube_generate); the reference's setup timers are kept as rows.
@@ -412,7 +420,10 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     phase("ZZZ Create forms", [&] {});
   // fem::petsc::create_matrix: untimed in the reference, inside the ZZZ Assemble umbrella
   phase(nullptr, [&] { ZCK(ctx, zzz_csr_pattern_build(ctx)); });
-  if (!cgpoisson)
+  if (matfree_op)
+    // no matrix: what takes its place is the plan of the matrix-free kernel (the diagonal is PCSetUp's, in ZZZ Solve)
+    phase("ZZZ Assemble matrix", [&] { ZCK(ctx, zzz_matfree_setup(ctx)); });
+  else if (!cgpoisson)
     phase("ZZZ Assemble matrix", [&] { ZCK(ctx, zzz_assemble_matrix(ctx, form)); });
   phase("ZZZ Assemble vector", [&] { ZCK(ctx, zzz_assemble_vector(ctx, form)); });
   if (problem == ZZZH_ELASTICITY)
@@ -469,7 +480,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
     so.norm = o.ksp_norm_type == "unpreconditioned" ? ZZZ_NORM_UNPRECONDITIONED
               : o.ksp_norm_type == "natural"        ? ZZZ_NORM_NATURAL
                                                     : ZZZ_NORM_PRECONDITIONED;
-    so.op = ZZZ_OP_CSR;
+    so.op = matfree_op ? ZZZ_OP_MATFREE : ZZZ_OP_CSR;
     so.max_it = o.ksp_max_it;
     so.rtol = o.ksp_rtol;
     so.atol = o.ksp_atol;
@@ -639,6 +650,13 @@ void solve(int argc, char** argv)
     throw std::runtime_error("--comm " + o.comm + ": rccl or local");
   if (o.allreduce != "peer" && o.allreduce != "comm")
     throw std::runtime_error("--allreduce " + o.allreduce + ": peer or comm");
+  if (o.op != "assembled" && o.op != "matfree")
+    throw std::runtime_error("--operator " + o.op + ": assembled or matfree");
+  if (o.op == "matfree" && o.problem_type != "poisson")
+    throw std::runtime_error("--operator matfree applies to --problem_type poisson (cgpoisson is matrix-free already; the "
+                             "matrix-free kernel holds the Poisson form only)");
+  if (o.op == "matfree" && (o.pc_type == "chebyshev_jacobi" || o.ksp_cg_single_reduction))
+    throw std::runtime_error("--operator matfree: -pc_type jacobi or none, classical CG");
   if (o.ngpus < 1 || (o.comm == "rccl" && o.ngpus > ndev))
     throw std::runtime_error("--ngpus " + std::to_string(o.ngpus) + " but " + std::to_string(ndev) + " GPU(s) visible");
 
@@ -737,7 +755,9 @@ void solve(int argc, char** argv)
               << o.ksp_rtol << ", absolute=" << o.ksp_atol << "\n  using " << o.ksp_norm_type
               << " norm type for convergence test\n"
               << (o.ksp_cg_single_reduction ? "  using single-reduction variant\n" : "") << "PC Object: type: " << o.pc_type
-              << "\n  linear system matrix: type=csr (fp64 values, int32 indices) on " << S.nranks << " MI355X\n"
+              << (o.op == "matfree" ? "\n  linear system matrix: type=shell (matrix-free action, diagonal from the element matrices) on "
+                                    : "\n  linear system matrix: type=csr (fp64 values, int32 indices) on ")
+              << S.nranks << " MI355X\n"
               << (S.nranks > 1 ? (S.p2p_enabled[0] ? "  scalar all-reduces: peer-memory mailboxes; halo: peer-memory window where the plan fits\n"
                                                     : "  scalar all-reduces and halo: communicator\n")
                                : "");

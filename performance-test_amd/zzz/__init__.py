@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
-    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
+    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_matfree_diagonal", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_cg_info", "zzz_internal_order_download", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
@@ -112,6 +112,7 @@ def hip():
         L.zzz_spmv_time.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.zzz_action.argtypes = [C.c_void_p, _f64p, _f64p]
         L.zzz_matfree_setup.argtypes = [C.c_void_p]
+        L.zzz_matfree_diagonal.argtypes = [C.c_void_p, _f64p]
         L.zzz_matfree_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.zzz_action_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.zzz_near_nullspace_build.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -514,6 +515,12 @@ class Context:
 
     def matfree_setup(self):
         self._ck(self.L.zzz_matfree_setup(self.h))
+
+    def matfree_diagonal(self):
+        """diag(A) of the matrix-free operator (1.0 on constrained rows), nothing assembled"""
+        d = np.zeros(self.n_owned * self.bs)
+        self._ck(self.L.zzz_matfree_diagonal(self.h, d))
+        return d
 
     def matfree_info(self):
         a = (C.c_int64 * 8)()

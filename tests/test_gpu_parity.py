@@ -316,6 +316,98 @@ def test_matrix_free_operator_and_cg(ctx, order, dims):
     assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
 
 
+@pytest.mark.parametrize("order,dims", [(1, (9, 8, 10)), (2, (5, 4, 6)), (3, (3, 4, 3))])
+def test_jacobi_pcg_on_the_matrix_free_operator(order, dims):
+    """KSPCG + PCJACOBI with the operator never assembled (op = ZZZ_OP_MATFREE; driver: --operator matfree): the diagonal
+    comes from the element matrices in the matrix-free kernel's pass and must be the assembled matrix's (1.0 on constrained
+    rows); the solve must be the assembled one's -- the oracle's PCG on the oracle's matrix -- to the usual bars."""
+    P = zzz.Part("poisson", order, *dims)
+    bc = P.bc_marker()
+    orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, 1)
+    ov = zo.assemble_matrix(0, order, P.x, P.cells, P.cell_dofs, bc, orp, ocl)
+    ob = zo.assemble_vector(0, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets, bc)
+    odiag = np.array([ov[orp[i]:orp[i + 1]][ocl[orp[i]:orp[i + 1]] == i][0] for i in range(P.n_owned)])
+    oit, ou, orn, or0 = zo.pcg(orp, ocl, ov, ob, rtol=1e-8)
+    with zzz.Context(0) as c:
+        # nothing but mesh, dofmap, Dirichlet set and the right-hand side: no pattern, no matrix
+        c.upload_part(P)
+        d = c.matfree_diagonal()
+        assert np.abs(d - odiag).max() <= 1e-12 * np.abs(odiag).max()
+        assert np.all(d[bc.astype(bool)] == 1.0)
+        np.testing.assert_array_equal(d, c.matfree_diagonal())  # the same bits every time
+        c.vec_upload(zzz.VEC_B, ob)
+        it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, op=zzz.OP_MATFREE, rtol=1e-8)
+        u = c.vec_download(zzz.VEC_U)
+        assert abs(it - oit) <= 2
+        assert np.linalg.norm(u - ou) <= 1e-6 * np.linalg.norm(ou)
+        assert abs(r0 - or0) <= 1e-11 * or0
+        assert np.linalg.norm(ob - zo.spmv(orp, ocl, ov, u)) <= 1e-7 * np.linalg.norm(ob)
+        # ... and against the library's own assembled solve
+        c.pattern_build()
+        c.assemble_matrix(zzz.FORM_POISSON)
+        c.assemble_vector(zzz.FORM_POISSON)
+        ita, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        ua = c.vec_download(zzz.VEC_U)
+        assert abs(it - ita) <= 2 and np.linalg.norm(u - ua) <= 1e-7 * np.linalg.norm(ua)
+        # -pc_type none on the same operator
+        itn, _, _ = c.cg_solve(pc=zzz.PC_NONE, op=zzz.OP_MATFREE, rtol=1e-8)
+        itna, _, _ = c.cg_solve(pc=zzz.PC_NONE, rtol=1e-8)
+        assert abs(itn - itna) <= 2
+        # what stays with the assembled operator says so
+        for bad in (dict(pc=zzz.PC_CHEBYSHEV_JACOBI), dict(single_reduction=True)):
+            with pytest.raises(zzz.ZzzError):
+                c.cg_solve(op=zzz.OP_MATFREE, rtol=1e-8, **bad)
+
+
+def test_jacobi_pcg_on_the_matrix_free_operator_partitioned():
+    """The same across three z-slabs on one GPU (host-mailbox communicator): halo of p before every action, all-reduced
+    scalars; iteration count and solution of the single-rank assembled solve."""
+    import threading
+
+    problem, order, dims, nparts = "poisson", 2, (4, 4, 9), 3
+    G = zzz.Part(problem, order, *dims)
+    with zzz.Context(0) as c0:
+        c0.upload_part(G)
+        c0.pattern_build()
+        c0.assemble_matrix(G.form)
+        c0.assemble_vector(G.form)
+        it0, _, _ = c0.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+        u0 = c0.vec_download(zzz.VEC_U)
+        _, _, v0 = c0.csr_download()
+        rp0, cl0, _ = c0.csr_download()
+    d0 = np.array([v0[rp0[i]:rp0[i + 1]][cl0[rp0[i]:rp0[i + 1]] == i][0] for i in range(G.n_owned)])
+    grp = zzz.LocalGroup(nparts)
+    out = [None] * nparts
+    err = []
+
+    def run(rank):
+        try:
+            P = zzz.Part(problem, order, *dims, nparts, rank)
+            with zzz.Context(0) as c:
+                c.comm_init_local(grp.h, rank)
+                c.upload_part(P)
+                c.upload_halo(P)
+                c.pattern_build()
+                c.assemble_vector(P.form)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, op=zzz.OP_MATFREE, rtol=1e-8)
+                out[rank] = (it, P.own_offset, c.vec_download(zzz.VEC_U), c.matfree_diagonal())
+        except Exception as e:  # noqa: BLE001
+            err.append((rank, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    grp.close()
+    assert not err, err
+    assert len({o[0] for o in out}) == 1 and abs(out[0][0] - it0) <= 2
+    u = np.concatenate([o[2] for o in out])
+    d = np.concatenate([o[3] for o in out])
+    assert np.linalg.norm(u - u0) <= 1e-7 * np.linalg.norm(u0)
+    assert np.abs(d - d0).max() <= 1e-12 * np.abs(d0).max()
+
+
 def test_rccl_path_single_rank(ctx):
     """The multi-GPU code path (reduce -> ncclAllReduce -> scalar kernels, halo with no neighbour)
     on a 1-rank communicator must reproduce the single-GPU solve exactly."""
@@ -465,6 +557,19 @@ def test_driver_binary_surface():
     base = base + ["chebyshev_jacobi"]
     its_s, nrm_s, _ = its_norm(base + ["-ksp_cg_single_reduction"])   # one reduction point per three products
     assert abs(its_s - seen[0]) <= 2 and abs(nrm_s - 47.56358) < 1e-3
+    # --operator matfree (an extension): KSPCG + Jacobi with no matrix, one rank and two; the assembled run's numbers
+    jac = [exe, "--problem_type", "poisson", "--scaling_type", "weak", "--ndofs", "50000", "--order", "2", "-ksp_type", "cg",
+           "-ksp_rtol", "1.0e-8", "-pc_type", "jacobi"]
+    its_a, nrm_a, _ = its_norm(jac)
+    its_m, nrm_m, text = its_norm(jac + ["--operator", "matfree", "-ksp_view"])
+    assert abs(its_m - its_a) <= 2 and abs(nrm_m - nrm_a) < 1e-6 * nrm_a and "type=shell" in text and "ZZZ Assemble matrix" in text
+    two = ["--ngpus", "2", "--comm", "local"]  # (weak scaling: twice the problem)
+    its_a2, nrm_a2, _ = its_norm(jac + two)
+    its_m2, nrm_m2, _ = its_norm(jac + ["--operator", "matfree"] + two)
+    assert abs(its_m2 - its_a2) <= 2 and abs(nrm_m2 - nrm_a2) < 1e-6 * nrm_a2
+    for bad in (["--problem_type", "elasticity"], ["-pc_type", "chebyshev_jacobi"], ["--operator", "sparse"]):
+        o = subprocess.run(jac + ["--operator", "matfree"] + bad, capture_output=True, text=True, timeout=60)
+        assert o.returncode != 0
     # --memory_profiling: the logging thread of src/mem.cpp (VSIZE / RSS in kB every 100 ms, here plus used HBM)
     out = subprocess.run([exe, "--problem_type", "poisson", "--ndofs", "2000000", "--memory_profiling", "-pc_type", "jacobi",
                           "-ksp_rtol", "1e-8"], capture_output=True, text=True, timeout=300)
