@@ -57,7 +57,7 @@ __device__ inline void vstore(T v, T* p)
 __global__ void k_invert(double* __restrict__ d, int64_t n)
 {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
-    d[r] = 1.0 / d[r];
+    d[r] = 1.0 / (d[r] == 0.0 ? 1.0 : d[r]); // PCJACOBI replaces zero diagonal entries by one
 }
 
 __global__ void k_extract_dinv(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,

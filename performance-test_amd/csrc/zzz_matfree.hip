@@ -112,11 +112,13 @@ __global__ __launch_bounds__(256) void k_mf_cell_keys(const double* __restrict__
 // wavefront per block walks the block's cells in 64 interleaved Morton sequences (lane l takes cells l * nbatch, l * nbatch
 // + 1, ...: the 64 cells of a batch lie far apart, consecutive batches are neighbours): every lane prices the steps for its
 // cell -- max over the cell's dofs of the cells a step already holds there, from byte counters per (dof, step) in an LDS hash
-// table keyed by the global dof -- and takes the cheapest step that has room (ties: the emptier step); the lanes that picked
-// one step get consecutive places in it in lane order, those beyond its capacity pick again.  P1, 8 steps: ~4 rounds per
-// step against 6.4 for dealing the cells out in turn; P3, 3 steps: 8.4 against 11.3.  Deterministic: picks depend on the
+// table keyed by the global dof -- and takes the cheapest step that has room (ties: rotated by the lane, so that the lanes of a
+// batch, which cannot see each other's choice, spread over the steps: 4.9 -> 4.5 rounds at P1); the lanes that picked
+// one step get consecutive places in it in lane order, those beyond its capacity pick again.  P1, 8 steps: 4.5 rounds per
+// step against 6.4 for dealing the cells out in turn (4.0 when one cell at a time chooses); P3, 3 steps: 9.5 against 11.3
+// (8.3).  Deterministic: picks depend on the
 // counters at the start of the batch and on lane order only (which hash slot a dof gets does not matter).  A first version
-// walked the cells one by one (57 ms at P1 10 M dofs: a chain of dependent LDS reads per cell); this one takes ~1 ms.
+// walked the cells one by one (36-57 ms at P1 10 M dofs: a chain of dependent LDS reads per cell); this one takes 3.8 ms.
 // More than 16 steps: dealt out in turn.
 __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ sorted, const int32_t* __restrict__ cell_dofs, int nd,
                                                   int64_t ncells, int nc, int T, int nsb, int cw, int H, int W, int64_t nblocks,
@@ -193,14 +195,14 @@ __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ so
       bool placed = !have;
       for (int guard = 0; guard < 64 && __ballot(!placed) != 0ull; ++guard)
       {
-        // cheapest step with room (ties: the emptier, then the lower step)
+        // cheapest step with room (ties: rotated by the lane)
         int best = INT_MAX;
         if (!placed)
         {
 #pragma unroll
           for (int sI = 0; sI < 16; ++sI)
             if (sI < nsb && fill[sI] < T)
-              best = min(best, (cost[sI] << 20) | (fill[sI] << 6) | sI);
+              best = min(best, (cost[sI] << 12) | (((sI + lane) % nsb) << 6) | sI);
         }
         const int want = (!placed && best != INT_MAX) ? (best & 63) : -1;
         __syncthreads();
@@ -1084,6 +1086,26 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   int32_t h_err = 0;
   ZZZ_HIP(ctx, hipMemcpyAsync(&h_err, nlmax.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
+#ifdef ZZZ_EXPERIMENTS
+  if (getenv("ZZZ_MF_PLAN_STATS"))
+  {
+    // quality of the step assignment: rounds per (block, step) = the most cells of the step at one dof
+    std::vector<uint8_t> hr((size_t)(nb * nsb * M.nrw * 4));
+    ZZZ_HIP(ctx, hipMemcpy(hr.data(), M.rmax.p, hr.size(), hipMemcpyDeviceToHost));
+    double sum = 0;
+    int worst = 0;
+    for (int64_t bs_ = 0; bs_ < nb * nsb; ++bs_)
+    {
+      int m = 0;
+      for (int j = 0; j < nd; ++j)
+        m = std::max(m, (int)hr[(size_t)bs_ * M.nrw * 4 + j]);
+      sum += m;
+      worst = std::max(worst, m);
+    }
+    fprintf(stderr, "[zzz] matrix-free plan: %lld blocks x %d steps, rounds per step: mean %.3f, worst %d\n", (long long)nb, nsb,
+            sum / (double)(nb * nsb), worst);
+  }
+#endif
   if (h_err)
     return fail(ctx, ZZZ_ERR_LIMIT, "matrix-free plan: a dof meets more than 254 cells of one step");
 
