@@ -65,6 +65,8 @@ enum
   ZZZH_GLOBAL_CELLS,
   ZZZH_OWNED_CELLS, /* cells of this partition's own layers (sum over parts = global cells) */
   ZZZH_OWN_OFFSET,  /* global block index of local owned dof 0 (owned range is contiguous) */
+  ZZZH_GLOBAL_NBC,  /* constrained scalar dofs of the whole problem (all partitions) */
+  ZZZH_BC_MODE,     /* spoke mesh: the bc_mode in effect (2 resolves to 0 or 1); cube: 0 */
   ZZZH_NSIZES
 };
 
@@ -81,8 +83,15 @@ zzzh_part* zzzh_part_create_native(int problem, int order, int64_t nx, int64_t n
  * bisection, :357-452: same geometry and coarse topology, conforming, not a lattice -- but not the reference's refined
  * mesh entity for entity).  One partition.  Generic dofmaps by sorting (P1-P3, scalar and vector-valued).
  * bc_mode 0: the reference's Dirichlet markers (src/poisson_problem.cpp:60-71, src/elasticity_problem.cpp:127-138) --
- * on this geometry possibly an empty set, as in the reference; 1: every dof of the exterior boundary. */
+ * on this geometry possibly an empty set, as in the reference; 1: every dof of the exterior boundary; 2: the reference's
+ * markers if they select anything, else the whole exterior boundary (sizes[ZZZH_BC_MODE] says which). */
 zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int bc_mode);
+/* Partition `part` of `nparts` of that mesh (mpirun -np N of the reference's CI, .github/workflows/ccpp.yml:102-117): the
+ * dofs cut into nparts sectors of equal size by polar angle about the ring's axis; a partition owns a sector's dofs, holds
+ * every cell touching one of them and the remaining dofs of those cells as ghosts (grouped by owner, ascending).  Global
+ * numbering owner-major (one partition: the generator's, nothing renumbered).  Neighbours are whatever the mesh says --
+ * the ring closes on itself.  Every caller builds the whole mesh and keeps its part. */
+zzzh_part* zzzh_part_create_spoke_part(int problem, int order, int m, int bc_mode, int nparts, int part);
 /* smallest m whose mesh has (about) `target_nodes` nodes of the order-k space: the refinement loop of src/mesh.cpp:357-368 */
 int zzzh_spoke_size(int64_t target_nodes, int order);
 void zzzh_part_destroy(zzzh_part* p);

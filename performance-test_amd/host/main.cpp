@@ -364,31 +364,28 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
       ZCK(ctx, zzz_cube_generate(ctx, form, (int)o.order, S.dims[0] << r, S.dims[1] << r, S.dims[2] << r, S.nranks, rank, info));
     else
     {
-      // create_spoke_mesh (src/mesh.cpp:209-453) through the host feed and the upload entry points (one process).  The
-      // reference's Dirichlet markers (|x| or |x - 1| < 1e-8; |y| < 1e-8) may select nothing on this geometry -- the
-      // reference then solves a singular system; here the whole exterior boundary is constrained instead, and it says so
-      zzzh_part* P = zzzh_part_create_spoke(problem, (int)o.order, S.spoke_m, 0);
+      // create_spoke_mesh (src/mesh.cpp:209-453) through the host feed and the upload entry points; with several ranks each
+      // takes its sector of the cut by polar angle (host/spoke_mesh.cpp).  The reference's Dirichlet markers (|x| or
+      // |x - 1| < 1e-8; |y| < 1e-8) may select nothing on this geometry -- the reference then solves a singular system;
+      // here the whole exterior boundary is constrained instead (bc_mode 2), and it says so
+      zzzh_part* P = zzzh_part_create_spoke_part(problem, (int)o.order, S.spoke_m, 2, S.nranks, rank);
       if (!P)
         throw std::runtime_error(zzzh_last_error());
       std::int64_t sz[ZZZH_NSIZES];
       zzzh_part_sizes(P, sz);
-      if (sz[ZZZH_NBC] == 0)
-      {
-        zzzh_part_destroy(P);
-        P = zzzh_part_create_spoke(problem, (int)o.order, S.spoke_m, 1);
-        if (!P)
-          throw std::runtime_error(zzzh_last_error());
-        zzzh_part_sizes(P, sz);
+      if (root && sz[ZZZH_BC_MODE] == 1)
         std::cout << "Unstructured mesh: the reference's Dirichlet markers select no facet of this geometry; the whole "
-                     "exterior boundary is constrained (" << sz[ZZZH_NBC] << " dofs)" << std::endl;
-      }
+                     "exterior boundary is constrained (" << sz[ZZZH_GLOBAL_NBC] << " dofs)" << std::endl;
       struct Guard
       {
         zzzh_part* p;
         ~Guard() { zzzh_part_destroy(p); }
       } guard{P};
       ZCK(ctx, zzz_mesh_upload(ctx, sz[ZZZH_NVERTS], zzzh_part_x(P), sz[ZZZH_NCELLS], zzzh_part_cells(P)));
-      ZCK(ctx, zzz_dofmap_upload(ctx, (int)o.order, (int)sz[ZZZH_BS], zzzh_part_cell_dofs(P), sz[ZZZH_NOWNED], 0));
+      ZCK(ctx, zzz_dofmap_upload(ctx, (int)o.order, (int)sz[ZZZH_BS], zzzh_part_cell_dofs(P), sz[ZZZH_NOWNED], sz[ZZZH_NGHOST]));
+      if (S.nranks > 1)
+        ZCK(ctx, zzz_halo_upload(ctx, (int)sz[ZZZH_NNEIGH], zzzh_part_neigh(P), zzzh_part_send_off(P), zzzh_part_send_idx(P),
+                                 zzzh_part_recv_cnt(P)));
       ZCK(ctx, zzz_bc_upload(ctx, sz[ZZZH_NBC], zzzh_part_bc_dofs(P)));
       ZCK(ctx, zzz_facets_upload(ctx, sz[ZZZH_NFACETS], zzzh_part_facets(P)));
       ZCK(ctx, zzz_coeff_upload(ctx, ZZZ_COEFF_F, zzzh_part_coeff(P, 0)));
@@ -545,7 +542,7 @@ void run_rank(Shared& S, std::barrier<>& bar, int rank)
       zzzh_part* P = o.mesh_type == "cube"
                          ? zzzh_part_create(problem, (int)o.order, S.dims[0] << S.dims[3], S.dims[1] << S.dims[3],
                                             S.dims[2] << S.dims[3], S.nranks, rank)
-                         : zzzh_part_create_spoke(problem, (int)o.order, S.spoke_m, 1);
+                         : zzzh_part_create_spoke_part(problem, (int)o.order, S.spoke_m, 2, S.nranks, rank);
       if (!P)
         throw std::runtime_error(zzzh_last_error());
       const std::string base = o.output + "/";
@@ -634,8 +631,6 @@ void solve(int argc, char** argv)
   if (o.problem_type != "poisson" && o.problem_type != "cgpoisson" && o.problem_type != "elasticity")
     throw std::runtime_error("Unknown problem type: " + o.problem_type); // src/main.cpp:170
   // src/main.cpp:131-141: "cube", anything else is the unstructured (spoke) mesh
-  if (o.mesh_type != "cube" && o.ngpus != 1)
-    throw std::runtime_error("--mesh_type " + o.mesh_type + ": the unstructured mesh is fed from one process (--ngpus 1)");
   if (o.ksp_type != "cg")
     throw std::runtime_error("-ksp_type " + o.ksp_type + ": only cg is built");
   if (o.pc_type != "jacobi" && o.pc_type != "none" && o.pc_type != "chebyshev_jacobi")

@@ -328,6 +328,9 @@ static zzzh_part* part_create(int problem, int order, int64_t nx, int64_t ny, in
   Sz[ZZZH_GLOBAL_CELLS] = 6 * nx * ny * nz;
   Sz[ZZZH_OWNED_CELLS] = 6 * nx * ny * (ze - zs);
   Sz[ZZZH_OWN_OFFSET] = own_lo;
+  // the marked planes hold every point of the order-k lattice: x = 0 and x = 1 (Poisson), y = 0 (elasticity, 3 components)
+  Sz[ZZZH_GLOBAL_NBC] = problem == ZZZH_POISSON ? 2 * (order * ny + 1) * (order * nz + 1) : 3 * (order * nx + 1) * (order * nz + 1);
+  Sz[ZZZH_BC_MODE] = 0;
   return P;
 }
 

@@ -6,7 +6,15 @@
 // `cube` of :233-235, all six share the diagonal 2-4), so that faces between blocks -- ring/ring and ring/spur -- carry
 // the same diagonals from both sides, as in the reference's coarse mesh: conforming (checked below: every interior face
 // has two cells), same geometry, not a lattice (curved, tapered, valence changes where the spurs meet the ring), but not
-// the reference's refined mesh entity for entity.  One partition only.
+// the reference's refined mesh entity for entity.
+//
+// Partitions (zzzh_part_create_spoke_part): the dofs are cut into `nparts` sectors of equal size by the polar angle of
+// their coordinates about the ring's axis; a partition owns one sector's dofs, holds every cell that touches one of them
+// (owned-row assembly needs no exchange: the ghost-cell layer of the cube feed) and the other dofs of those cells as
+// ghosts, grouped by owner.  Global numbering: owner-major, the generator's order inside an owner -- with one partition
+// nothing is renumbered.  The ring closes on itself, spurs curl across sector borders: neighbour lists are whatever the
+// mesh says, not "rank +- 1".  Every process builds the whole mesh and keeps its own part (a host feed for tests and
+// single-node runs, not a distributed mesh generator: src/mesh.cpp:345-356 does the same on rank 0 before distributing).
 //
 // Dofs: generic, by sorting (vertices; edges as sorted vertex pairs; faces as sorted triples), Basix's local order, cells
 // with their vertices ascending so that a cell's edge directions are the global ones.  Numbering: block by block in
@@ -17,6 +25,7 @@
 
 #include <algorithm>
 #include <array>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -88,7 +97,7 @@ constexpr int EDGE_V[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
 constexpr int FACE_V[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
 } // namespace
 
-extern "C" zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int bc_mode)
+static zzzh_part* spoke_whole(int problem, int order, int m, int bc_mode)
 {
   if (problem != ZZZH_POISSON && problem != ZZZH_ELASTICITY)
   {
@@ -311,32 +320,40 @@ extern "C" zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int 
   // dofs on the closure of the exterior facets (bc_mode 1), or of those exterior facets ALL of whose vertices satisfy the
   // reference's marker (bc_mode 0: mesh::locate_entities(mesh, 2, marker) + locate_dofs_topological,
   // src/poisson_problem.cpp:58-75 -- a line of marked vertices that spans no facet constrains nothing)
-  for (size_t k = 0; k < facets.size() / 2; ++k)
-  {
-    const int64_t c = facets[2 * k];
-    const int f = facets[2 * k + 1];
-    const int32_t* cd = &P->cell_dofs[(size_t)(nd * c)];
-    if (bc_mode != 1)
+  auto mark = [&](int mode) {
+    std::fill(dof_on_boundary.begin(), dof_on_boundary.end(), (uint8_t)0);
+    for (size_t k = 0; k < facets.size() / 2; ++k)
     {
-      bool all = true;
+      const int64_t c = facets[2 * k];
+      const int f = facets[2 * k + 1];
+      const int32_t* cd = &P->cell_dofs[(size_t)(nd * c)];
+      if (mode != 1)
+      {
+        bool all = true;
+        for (int q = 0; q < 3; ++q)
+          all = all && zzzcube::is_dirichlet(problem, &x[3 * (size_t)cells[(size_t)(4 * c + FACE_V[f][q])]]);
+        if (!all)
+          continue;
+      }
       for (int q = 0; q < 3; ++q)
-        all = all && zzzcube::is_dirichlet(problem, &x[3 * (size_t)cells[(size_t)(4 * c + FACE_V[f][q])]]);
-      if (!all)
-        continue;
+        dof_on_boundary[(size_t)cd[FACE_V[f][q]]] = 1;
+      if (order >= 2)
+        for (int e = 0; e < 6; ++e) // edges of the facet: those that do not touch the opposite vertex f
+          if (EDGE_V[e][0] != f && EDGE_V[e][1] != f)
+            for (int k2 = 0; k2 < order - 1; ++k2)
+              dof_on_boundary[(size_t)cd[4 + (order - 1) * e + k2]] = 1;
+      if (order == 3)
+        dof_on_boundary[(size_t)cd[16 + f]] = 1;
     }
-    for (int q = 0; q < 3; ++q)
-      dof_on_boundary[(size_t)cd[FACE_V[f][q]]] = 1;
-    if (order >= 2)
-      for (int e = 0; e < 6; ++e) // edges of the facet: those that do not touch the opposite vertex f
-        if (EDGE_V[e][0] != f && EDGE_V[e][1] != f)
-          for (int k2 = 0; k2 < order - 1; ++k2)
-            dof_on_boundary[(size_t)cd[4 + (order - 1) * e + k2]] = 1;
-    if (order == 3)
-      dof_on_boundary[(size_t)cd[16 + f]] = 1;
-  }
+    return std::count(dof_on_boundary.begin(), dof_on_boundary.end(), (uint8_t)1);
+  };
   // Dirichlet dofs.  bc_mode 0: the reference's markers (src/poisson_problem.cpp:60-71, src/elasticity_problem.cpp:127-138:
   // |x| or |x - 1| < 1e-8, |y| < 1e-8) on whole facets -- on this geometry that set is EMPTY (the reference then solves a
-  // singular system); bc_mode 1: every dof of the exterior boundary (a well-posed problem for tests and measurements)
+  // singular system); bc_mode 1: every dof of the exterior boundary (a well-posed problem for tests and measurements);
+  // bc_mode 2: the markers if they select anything, else the whole boundary
+  int mode_used = bc_mode == 1 ? 1 : 0;
+  if (mark(mode_used) == 0 && bc_mode == 2)
+    mark(mode_used = 1);
   for (int64_t l = 0; l < ndofs; ++l)
   {
     if (dof_on_boundary[(size_t)l])
@@ -374,6 +391,217 @@ extern "C" zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int 
   Sz[ZZZH_GLOBAL_DOFS] = ndofs * bs;
   Sz[ZZZH_GLOBAL_CELLS] = ncells;
   Sz[ZZZH_OWNED_CELLS] = ncells;
+  Sz[ZZZH_GLOBAL_NBC] = (int64_t)P->bc_dofs.size();
+  Sz[ZZZH_BC_MODE] = mode_used;
+  return P;
+}
+
+// partition `part` of `nparts` cut out of the whole mesh G (see the head of this file)
+static zzzh_part* spoke_extract(const zzzh_part& G, int nparts, int part)
+{
+  const int nd = G.nd, bs = G.bs;
+  const int64_t n = G.sizes[ZZZH_NOWNED], ncells = G.sizes[ZZZH_NCELLS], nverts = G.sizes[ZZZH_NVERTS];
+  // owners: equal chunks of the dofs sorted by polar angle (ties: generator order)
+  std::vector<int32_t> owner((size_t)n);
+  {
+    std::vector<std::pair<double, int32_t>> key((size_t)n);
+    for (int64_t l = 0; l < n; ++l)
+      key[(size_t)l] = {std::atan2(G.dof_x[3 * (size_t)l + 1], G.dof_x[3 * (size_t)l]), (int32_t)l};
+    std::sort(key.begin(), key.end());
+    for (int64_t i = 0; i < n; ++i)
+      owner[(size_t)key[(size_t)i].second] = (int32_t)(i * nparts / n);
+  }
+  // global numbering: owner-major, generator order inside an owner
+  std::vector<int64_t> first((size_t)nparts + 1, 0), newg((size_t)n);
+  for (int64_t l = 0; l < n; ++l)
+    ++first[(size_t)owner[(size_t)l] + 1];
+  for (int q = 0; q < nparts; ++q)
+    first[(size_t)q + 1] += first[(size_t)q];
+  {
+    std::vector<int64_t> next(first.begin(), first.end() - 1);
+    for (int64_t l = 0; l < n; ++l)
+      newg[(size_t)l] = next[(size_t)owner[(size_t)l]]++;
+  }
+  // local cells (any dof owned here), ghosts, and what the others ghost from here
+  std::vector<int64_t> lcells;
+  std::vector<std::pair<int32_t, int64_t>> ghosts, wanted; // (owner, new global id) / (ghosting part, new global id of a dof owned here)
+  int64_t owned_cells = 0;
+  for (int64_t c = 0; c < ncells; ++c)
+  {
+    const int32_t* cd = &G.cell_dofs[(size_t)(nd * c)];
+    bool mine = false, mixed = false;
+    for (int i = 0; i < nd; ++i)
+    {
+      mine = mine || owner[(size_t)cd[i]] == part;
+      mixed = mixed || owner[(size_t)cd[i]] != owner[(size_t)cd[0]];
+    }
+    if (!mine)
+      continue;
+    lcells.push_back(c);
+    if (owner[(size_t)cd[0]] == part)
+      ++owned_cells; // (a cell counts where its first dof lives: the parts' counts add up to the mesh)
+    if (!mixed)
+      continue;
+    for (int i = 0; i < nd; ++i)
+    {
+      const int32_t q = owner[(size_t)cd[i]];
+      if (q != part)
+      {
+        ghosts.push_back({q, newg[(size_t)cd[i]]});
+        for (int j = 0; j < nd; ++j) // the cell is local to q as well: q ghosts every dof of it owned here
+          if (owner[(size_t)cd[j]] == part)
+            wanted.push_back({q, newg[(size_t)cd[j]]});
+      }
+    }
+  }
+  auto uniq = [](std::vector<std::pair<int32_t, int64_t>>& v) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
+  uniq(ghosts);
+  uniq(wanted);
+  const int64_t n_owned = first[(size_t)part + 1] - first[(size_t)part], n_ghost = (int64_t)ghosts.size(), nloc = n_owned + n_ghost;
+  // local index of a global (generator-numbered) dof
+  std::vector<int64_t> g_of_newg((size_t)n);
+  for (int64_t l = 0; l < n; ++l)
+    g_of_newg[(size_t)newg[(size_t)l]] = l;
+  std::vector<int32_t> loc((size_t)n, -1);
+  std::vector<int64_t> gen((size_t)nloc); // local -> generator number
+  for (int64_t i = 0; i < n_owned; ++i)
+    gen[(size_t)i] = g_of_newg[(size_t)(first[(size_t)part] + i)];
+  for (int64_t i = 0; i < n_ghost; ++i)
+    gen[(size_t)(n_owned + i)] = g_of_newg[(size_t)ghosts[(size_t)i].second];
+  for (int64_t i = 0; i < nloc; ++i)
+    loc[(size_t)gen[(size_t)i]] = (int32_t)i;
+
+  zzzh_part* P = new zzzh_part();
+  P->problem = G.problem;
+  P->order = G.order;
+  P->bs = bs;
+  P->nd = nd;
+  P->nparts = nparts;
+  P->part = part;
+  P->nx = G.nx;
+  P->ny = G.ny;
+  P->nz = G.nz;
+  // vertices of the local cells, ascending in the global numbering (cells keep their vertices ascending)
+  std::vector<int32_t> vloc((size_t)nverts, -1);
+  for (int64_t c : lcells)
+    for (int k = 0; k < 4; ++k)
+      vloc[(size_t)G.cells[(size_t)(4 * c + k)]] = 0;
+  int64_t nv = 0;
+  for (int64_t v = 0; v < nverts; ++v)
+    if (vloc[(size_t)v] == 0)
+    {
+      vloc[(size_t)v] = (int32_t)nv++;
+      P->global_verts.push_back(v);
+      for (int a = 0; a < 3; ++a)
+        P->x.push_back(G.x[3 * (size_t)v + a]);
+    }
+  std::vector<int32_t> cloc((size_t)ncells, -1);
+  P->cells.reserve(4 * lcells.size());
+  P->cell_dofs.reserve((size_t)nd * lcells.size());
+  for (size_t k = 0; k < lcells.size(); ++k)
+  {
+    const int64_t c = lcells[k];
+    cloc[(size_t)c] = (int32_t)k;
+    for (int q = 0; q < 4; ++q)
+      P->cells.push_back(vloc[(size_t)G.cells[(size_t)(4 * c + q)]]);
+    for (int i = 0; i < nd; ++i)
+      P->cell_dofs.push_back(loc[(size_t)G.cell_dofs[(size_t)(nd * c + i)]]);
+  }
+  for (size_t k = 0; k < G.facets.size() / 2; ++k) // (sorted by cell, and the local cells keep their order)
+    if (cloc[(size_t)G.facets[2 * k]] >= 0)
+    {
+      P->facets.push_back(cloc[(size_t)G.facets[2 * k]]);
+      P->facets.push_back(G.facets[2 * k + 1]);
+    }
+  std::vector<uint8_t> marked((size_t)(n * bs), 0);
+  for (int32_t d : G.bc_dofs)
+    marked[(size_t)d] = 1;
+  P->dof_x.resize((size_t)(3 * nloc));
+  P->global_dofs.resize((size_t)nloc);
+  P->coeff[0].resize((size_t)(nloc * bs));
+  if (G.problem == ZZZH_POISSON)
+    P->coeff[1].resize((size_t)nloc);
+  for (int64_t i = 0; i < nloc; ++i)
+  {
+    const int64_t l = gen[(size_t)i];
+    P->global_dofs[(size_t)i] = newg[(size_t)l];
+    for (int a = 0; a < 3; ++a)
+      P->dof_x[3 * (size_t)i + a] = G.dof_x[3 * (size_t)l + a];
+    for (int k = 0; k < bs; ++k)
+    {
+      P->coeff[0][(size_t)(i * bs + k)] = G.coeff[0][(size_t)(l * bs + k)];
+      if (marked[(size_t)(l * bs + k)])
+        P->bc_dofs.push_back((int32_t)(i * bs + k));
+    }
+    if (G.problem == ZZZH_POISSON)
+      P->coeff[1][(size_t)i] = G.coeff[1][(size_t)l];
+  }
+  // forward-scatter plan: neighbours ascending = the order of the ghost groups; to q go the dofs q ghosts from here, in
+  // q's ghost order (ascending global number inside an owner's group)
+  P->send_off.push_back(0);
+  {
+    size_t ig = 0, iw = 0;
+    while (ig < ghosts.size() || iw < wanted.size())
+    {
+      const int32_t q = std::min(ig < ghosts.size() ? ghosts[ig].first : INT32_MAX, iw < wanted.size() ? wanted[iw].first : INT32_MAX);
+      int64_t nrecv = 0;
+      for (; ig < ghosts.size() && ghosts[ig].first == q; ++ig)
+        ++nrecv;
+      for (; iw < wanted.size() && wanted[iw].first == q; ++iw)
+        P->send_idx.push_back((int32_t)(wanted[iw].second - first[(size_t)part]));
+      P->neigh.push_back(q);
+      P->recv_cnt.push_back(nrecv);
+      P->send_off.push_back((int64_t)P->send_idx.size());
+    }
+  }
+  int64_t* Sz = P->sizes;
+  for (int i = 0; i < ZZZH_NSIZES; ++i)
+    Sz[i] = 0;
+  Sz[ZZZH_NVERTS] = nv;
+  Sz[ZZZH_NCELLS] = (int64_t)lcells.size();
+  Sz[ZZZH_NOWNED] = n_owned;
+  Sz[ZZZH_NGHOST] = n_ghost;
+  Sz[ZZZH_ND] = nd;
+  Sz[ZZZH_BS] = bs;
+  Sz[ZZZH_NFACETS] = (int64_t)P->facets.size() / 2;
+  Sz[ZZZH_NBC] = (int64_t)P->bc_dofs.size();
+  Sz[ZZZH_NNEIGH] = (int64_t)P->neigh.size();
+  Sz[ZZZH_NSEND] = (int64_t)P->send_idx.size();
+  Sz[ZZZH_GLOBAL_DOFS] = n * bs;
+  Sz[ZZZH_GLOBAL_CELLS] = ncells;
+  Sz[ZZZH_OWNED_CELLS] = owned_cells;
+  Sz[ZZZH_OWN_OFFSET] = first[(size_t)part];
+  Sz[ZZZH_GLOBAL_NBC] = G.sizes[ZZZH_GLOBAL_NBC];
+  Sz[ZZZH_BC_MODE] = G.sizes[ZZZH_BC_MODE];
+  return P;
+}
+
+extern "C" zzzh_part* zzzh_part_create_spoke(int problem, int order, int m, int bc_mode)
+{
+  return spoke_whole(problem, order, m, bc_mode);
+}
+
+extern "C" zzzh_part* zzzh_part_create_spoke_part(int problem, int order, int m, int bc_mode, int nparts, int part)
+{
+  if (nparts < 1 || part < 0 || part >= nparts)
+  {
+    zzzh_set_error("spoke mesh: bad partition");
+    return nullptr;
+  }
+  zzzh_part* G = spoke_whole(problem, order, m, bc_mode);
+  if (!G || nparts == 1)
+    return G;
+  if (G->sizes[ZZZH_NOWNED] < nparts)
+  {
+    zzzh_part_destroy(G);
+    zzzh_set_error("spoke mesh: fewer dofs than partitions");
+    return nullptr;
+  }
+  zzzh_part* P = spoke_extract(*G, nparts, part);
+  zzzh_part_destroy(G);
   return P;
 }
 

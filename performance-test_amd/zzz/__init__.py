@@ -33,14 +33,14 @@ ABI_SYMBOLS = [
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
 HOST_SYMBOLS = [
-    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_create_native", "zzzh_part_create_spoke", "zzzh_spoke_size", "zzzh_part_destroy", "zzzh_part_global_verts",
+    "zzzh_num_pdofs", "zzzh_num_entities", "zzzh_mesh_size", "zzzh_count_suffix", "zzzh_part_create", "zzzh_part_create_native", "zzzh_part_create_spoke", "zzzh_part_create_spoke_part", "zzzh_spoke_size", "zzzh_part_destroy", "zzzh_part_global_verts",
     "zzzh_last_error", "zzzh_part_sizes", "zzzh_part_x", "zzzh_part_cells", "zzzh_part_cell_dofs",
     "zzzh_part_facets", "zzzh_part_bc_dofs", "zzzh_part_dof_x", "zzzh_part_global_dofs", "zzzh_part_coeff",
     "zzzh_part_neigh", "zzzh_part_send_off", "zzzh_part_send_idx", "zzzh_part_recv_cnt",
 ]
 
 (NVERTS, NCELLS, NOWNED, NGHOST, ND, BS, NFACETS, NBC, NNEIGH, NSEND, GLOBAL_DOFS, GLOBAL_CELLS, OWNED_CELLS,
- OWN_OFFSET, NSIZES) = range(15)
+ OWN_OFFSET, GLOBAL_NBC, BC_MODE, NSIZES) = range(17)
 
 
 class SolverOpts(C.Structure):
@@ -154,6 +154,8 @@ def host():
         L.zzzh_part_create_native.restype = C.c_void_p
         L.zzzh_part_create_spoke.restype = C.c_void_p
         L.zzzh_part_create_spoke.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.zzzh_part_create_spoke_part.restype = C.c_void_p
+        L.zzzh_part_create_spoke_part.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.zzzh_spoke_size.restype = C.c_int
         L.zzzh_spoke_size.argtypes = [C.c_int64, C.c_int]
         L.zzzh_part_create_native.argtypes = L.zzzh_part_create.argtypes
@@ -217,7 +219,7 @@ class Part:
         pid = FORM_ELASTICITY if problem == "elasticity" else FORM_POISSON
         if spoke is not None:
             # the unstructured ring-with-spurs mesh (host/spoke_mesh.cpp): nx = ny = nz = m sub-blocks per block edge
-            h = H.zzzh_part_create_spoke(pid, order, nx, int(spoke))
+            h = H.zzzh_part_create_spoke_part(pid, order, nx, int(spoke), nparts, part)
         else:
             h = (H.zzzh_part_create_native if native else H.zzzh_part_create)(pid, order, nx, ny, nz, nparts, part)
         if not h:
@@ -235,6 +237,7 @@ class Part:
             self.nloc = self.n_owned + self.n_ghost
             self.global_dofs_total, self.global_cells = int(s[GLOBAL_DOFS]), int(s[GLOBAL_CELLS])
             self.owned_cells, self.own_offset = int(s[OWNED_CELLS]), int(s[OWN_OFFSET])
+            self.global_nbc, self.bc_mode = int(s[GLOBAL_NBC]), int(s[BC_MODE])
             self.x = _arr(H.zzzh_part_x(h), 3 * self.nverts, np.float64, (-1, 3))
             self.cells = _arr(H.zzzh_part_cells(h), 4 * self.ncells, np.int32, (-1, 4))
             self.cell_dofs = _arr(H.zzzh_part_cell_dofs(h), self.nd * self.ncells, np.int32, (-1, self.nd))
@@ -254,10 +257,11 @@ class Part:
             H.zzzh_part_destroy(h)
 
     @classmethod
-    def spoke(cls, problem, order, m, bc_mode=1):
+    def spoke(cls, problem, order, m, bc_mode=1, nparts=1, part=0):
         """`--mesh_type unstructured` (src/mesh.cpp:209-453) with m sub-blocks per block edge; bc_mode 1: the whole exterior
-        boundary is constrained (0: the reference's markers, possibly an empty set on this geometry)"""
-        return cls(problem, order, m, m, m, spoke=bc_mode)
+        boundary is constrained (0: the reference's markers, possibly an empty set on this geometry); nparts > 1: the
+        partition `part` of the cut by polar angle (owner-major global numbering)"""
+        return cls(problem, order, m, m, m, nparts, part, spoke=bc_mode)
 
     def bc_marker(self):
         m = np.zeros(self.nloc * self.bs, np.uint8)

@@ -274,3 +274,67 @@ def test_unstructured_spoke_mesh_feed(order):
     # the reference's own Dirichlet markers select nothing (or nearly nothing) on this geometry
     P0 = zzz.Part("poisson", order, 2, 2, 2, spoke=0)
     assert P0.bc_dofs.size <= P.bc_dofs.size
+
+
+@pytest.mark.parametrize("problem,order,m,nparts", [("poisson", 1, 3, 2), ("poisson", 2, 2, 3), ("poisson", 3, 1, 4),
+                                                    ("elasticity", 1, 2, 5), ("poisson", 1, 2, 8)])
+def test_unstructured_spoke_mesh_partitions(problem, order, m, nparts):
+    """zzzh_part_create_spoke_part: the parts of the cut by polar angle tile the whole mesh -- owned ranges contiguous and
+    disjoint, every dof and cell accounted for once, ghosts grouped by owner, the send list to a neighbour IS that
+    neighbour's ghost group in its order (the one property the forward halo rests on), neighbour relation symmetric -- and
+    the oracle's owned rows of A and b on a part are the whole mesh's rows (matched through the dof coordinates)."""
+    import zzz_oracle as zo
+
+    G = zzz.Part.spoke(problem, order, m)
+    parts = [zzz.Part.spoke(problem, order, m, 1, nparts, r) for r in range(nparts)]
+    bs = G.bs
+    assert sum(P.n_owned for P in parts) == G.n_owned and sum(P.owned_cells for P in parts) == G.ncells
+    off = 0
+    for P in parts:
+        assert P.own_offset == off and P.global_dofs_total == G.n_owned * bs and P.global_cells == G.ncells
+        np.testing.assert_array_equal(P.global_dofs[:P.n_owned], np.arange(off, off + P.n_owned))
+        off += P.n_owned
+        gh = P.global_dofs[P.n_owned:]
+        owner = np.searchsorted(np.cumsum([Q.n_owned for Q in parts]), gh, side="right")
+        assert np.all(owner != P.part)
+        key = owner.astype(np.int64) * (G.n_owned + 1) + gh
+        assert np.all(np.diff(key) > 0)  # grouped by owner, ascending inside a group, no duplicates
+        np.testing.assert_array_equal(np.unique(owner), P.neigh)
+        np.testing.assert_array_equal([np.count_nonzero(owner == q) for q in P.neigh], P.recv_cnt)
+        assert np.all(np.diff(P.cells, axis=1) > 0) and P.cell_dofs.min() == 0 and P.cell_dofs.max() == P.nloc - 1
+        # every local cell touches an owned dof; every local dof is touched
+        assert np.all((P.cell_dofs < P.n_owned).any(axis=1))
+        assert np.unique(P.cell_dofs).size == P.nloc
+    for P in parts:
+        for k, q in enumerate(P.neigh):
+            Q = parts[q]
+            assert P.part in Q.neigh.tolist()
+            sent = P.global_dofs[P.send_idx[P.send_off[k]:P.send_off[k + 1]]]
+            kq = Q.neigh.tolist().index(P.part)
+            g0 = Q.n_owned + int(Q.recv_cnt[:kq].sum())
+            np.testing.assert_array_equal(sent, Q.global_dofs[g0:g0 + int(Q.recv_cnt[kq])])
+    # coordinates identify a dof: the parts' owned dofs are a permutation of the whole mesh's
+    def rows(a):
+        return [tuple(r) for r in a.tolist()]
+    where = {c: i for i, c in enumerate(rows(G.dof_x))}
+    assert len(where) == G.n_owned
+    perm = np.concatenate([[where[c] for c in rows(P.dof_x[:P.n_owned])] for P in parts])
+    np.testing.assert_array_equal(np.sort(perm), np.arange(G.n_owned))
+    # owned rows of the operator and the right-hand side, part by part, against the whole mesh's
+    form = 1 if problem == "elasticity" else 0
+    grp, gcl = zo.pattern(G.n_owned, G.cell_dofs, bs)
+    gv = zo.assemble_matrix(form, order, G.x, G.cells, G.cell_dofs, G.bc_marker(), grp, gcl)
+    gb = zo.assemble_vector(form, order, G.x, G.cells, G.cell_dofs, G.f, G.g, G.facets, G.bc_marker())
+    rng = np.random.default_rng(3)
+    xg = rng.standard_normal(G.n_owned * bs)
+    yg = zo.spmv(grp, gcl, gv, xg)
+    for P in parts:
+        togen = np.array([where[c] for c in rows(P.dof_x)])  # local dof -> the whole mesh's number
+        rp, cl = zo.pattern(P.nloc, P.cell_dofs, bs)
+        v = zo.assemble_matrix(form, order, P.x, P.cells, P.cell_dofs, P.bc_marker(), rp, cl)
+        b = zo.assemble_vector(form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets, P.bc_marker())
+        sc = (togen[:, None] * bs + np.arange(bs)).ravel()
+        no = P.n_owned * bs
+        assert np.abs(b[:no] - gb[sc[:no]]).max() <= 1e-12 * np.abs(gb).max()
+        y = zo.spmv(rp, cl, v, xg[sc])
+        assert np.abs(y[:no] - yg[sc[:no]]).max() <= 1e-11 * np.abs(yg).max()
