@@ -239,9 +239,11 @@ __global__ __launch_bounds__(64) void k_mf_assign(const int32_t* __restrict__ so
   }
 }
 
-// one (block, dof) key per incidence; value = position in the block * nd + local index
+// one key per incidence: the dof (the block is the segment the incidence sits in: nc * nd incidences per block); value =
+// position in the block * nd + local index.  Cells that are not there (the last block's tail): key 0xffffffff, behind
+// everything else of their segment.
 __global__ __launch_bounds__(256) void k_mf_pairs(const int32_t* __restrict__ mf_cell, const int32_t* __restrict__ cell_dofs,
-                                                  int nd, int nc, int64_t total, uint64_t invalid, uint64_t* __restrict__ key,
+                                                  int nd, int nc, int64_t total, uint32_t* __restrict__ key,
                                                   uint32_t* __restrict__ val)
 {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total * nd; i += gridDim.x * 256ll)
@@ -251,30 +253,29 @@ __global__ __launch_bounds__(256) void k_mf_pairs(const int32_t* __restrict__ mf
     const int64_t b = pe / nc;
     const int e = (int)(pe - b * nc);
     const int32_t c = mf_cell[pe];
-    key[i] = c < 0 ? invalid : (((uint64_t)b << 32) | (uint32_t)cell_dofs[(int64_t)c * nd + li]);
+    key[i] = c < 0 ? 0xffffffffu : (uint32_t)cell_dofs[(int64_t)c * nd + li];
     val[i] = (uint32_t)(e * nd + li);
   }
 }
 
-__global__ __launch_bounds__(256) void k_mf_heads(const uint64_t* __restrict__ key, int64_t n, uint64_t invalid,
-                                                  int32_t* __restrict__ flag)
+__global__ __launch_bounds__(256) void k_mf_heads(const uint32_t* __restrict__ key, int64_t n, int seg, int32_t* __restrict__ flag)
 {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
-    flag[i] = (key[i] != invalid && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
+    flag[i] = (key[i] != 0xffffffffu && (i % seg == 0 || key[i] != key[i - 1])) ? 1 : 0;
 }
 
 // at the head of every run: the unique's key and where its run starts; how many blocks hold each dof
-__global__ __launch_bounds__(256) void k_mf_uniques(const uint64_t* __restrict__ key, const int32_t* __restrict__ flag,
-                                                    const int32_t* __restrict__ uidx, int64_t n, uint64_t* __restrict__ ukey,
+__global__ __launch_bounds__(256) void k_mf_uniques(const uint32_t* __restrict__ key, const int32_t* __restrict__ flag,
+                                                    const int32_t* __restrict__ uidx, int64_t n, int seg, uint64_t* __restrict__ ukey,
                                                     int32_t* __restrict__ run_start, int32_t* __restrict__ nblk_of)
 {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
     if (flag[i])
     {
       const int32_t j = uidx[i];
-      ukey[j] = key[i];
+      ukey[j] = ((uint64_t)(i / seg) << 32) | key[i];
       run_start[j] = (int32_t)i;
-      atomicAdd(&nblk_of[(uint32_t)key[i]], 1);
+      atomicAdd(&nblk_of[key[i]], 1);
     }
 }
 
@@ -284,15 +285,31 @@ __global__ __launch_bounds__(256) void k_mf_classify(const uint64_t* __restrict_
                                                      uint64_t* __restrict__ key2, int32_t* __restrict__ val2,
                                                      int32_t* __restrict__ cnt3)
 {
-  for (int64_t j = blockIdx.x * 256ll + threadIdx.x; j < nu; j += gridDim.x * 256ll)
+  for (int64_t j0 = blockIdx.x * 256ll + (threadIdx.x & ~63); j0 < nu; j0 += gridDim.x * 256ll)
   {
-    const uint64_t k = ukey[j];
-    const uint32_t g = (uint32_t)k;
-    const uint64_t b = k >> 32;
-    const int c = (int64_t)g >= n_owned ? 2 : (nblk_of[g] > 1 ? 1 : 0);
-    key2[j] = (b << 34) | ((uint64_t)c << 32) | g;
-    val2[j] = (int32_t)j;
-    atomicAdd(&cnt3[b * 3 + c], 1);
+    const int64_t j = j0 + (threadIdx.x & 63);
+    uint64_t b = ~0ull;
+    int c = -1;
+    if (j < nu)
+    {
+      const uint64_t k = ukey[j];
+      const uint32_t g = (uint32_t)k;
+      b = k >> 32;
+      c = (int64_t)g >= n_owned ? 2 : (nblk_of[g] > 1 ? 1 : 0);
+      key2[j] = (b << 34) | ((uint64_t)c << 32) | g;
+      val2[j] = (int32_t)j;
+    }
+    // the uniques of a block sit side by side: a wavefront counts for its first lane's block together (three counters per
+    // block took the atomics of thousands of uniques one at a time), the few lanes of the next block on their own
+    const uint64_t b0 = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    for (int k = 0; k < 3; ++k)
+    {
+      const unsigned long long m = __ballot(b == b0 && c == k);
+      if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1)
+        atomicAdd(&cnt3[b0 * 3 + k], (int)__popcll(m));
+    }
+    if (c >= 0 && b != b0)
+      atomicAdd(&cnt3[b * 3 + c], 1);
   }
 }
 
@@ -359,35 +376,54 @@ __global__ __launch_bounds__(256) void k_mf_lists(const uint64_t* __restrict__ k
 }
 
 // per incidence (in the order of the sorted pairs): its 16-bit local index and its rank among the incidences of the same
-// dof in the same step (the run of a (block, dof) key holds them by ascending position)
-__global__ __launch_bounds__(256) void k_mf_cells(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
-                                                  const int32_t* __restrict__ uidx, const int32_t* __restrict__ flag, int64_t n,
-                                                  uint64_t invalid, const int32_t* __restrict__ run_start, const int32_t* __restrict__ loc_of, int nd,
+// dof in the same step (the run of a (block, dof) key holds them by ascending position).  One workgroup per block: the
+// block's words are put together in LDS and leave as whole words (the sorted order scatters the 2-byte and 1-byte items
+// over the block's words: written to memory one by one they cost 7 ms at P1 10 M dofs, this way 2).
+__global__ __launch_bounds__(1024) void k_mf_cells(const uint32_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                  const int32_t* __restrict__ uidx, const int32_t* __restrict__ flag, int64_t nb,
+                                                  int seg, const int32_t* __restrict__ run_start, const int32_t* __restrict__ loc_of, int nd,
                                                   int nc, int T, int ndw, int nrw, uint32_t* __restrict__ idxw,
                                                   uint32_t* __restrict__ rnkw, int32_t* __restrict__ err)
 {
-  uint16_t* idx16 = reinterpret_cast<uint16_t*>(idxw);
-  uint8_t* rnk8 = reinterpret_cast<uint8_t*>(rnkw);
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+  extern __shared__ uint32_t cells_lds[]; // [ndw * nc] index words, [nrw * nc] rank words
+  uint32_t* const iw = cells_lds;
+  uint32_t* const rw = cells_lds + ndw * nc;
+  uint16_t* const idx16 = reinterpret_cast<uint16_t*>(iw);
+  uint8_t* const rnk8 = reinterpret_cast<uint8_t*>(rw);
+  for (int64_t b = blockIdx.x; b < nb; b += gridDim.x)
   {
-    const uint64_t k = key[i];
-    if (k == invalid)
-      continue;
-    const int32_t j = uidx[i] - (flag[i] ? 0 : 1); // uidx is the exclusive scan of the head flags
-    const int64_t b = (int64_t)(k >> 32);
-    const uint32_t v = val[i];
-    const int e = (int)(v / (uint32_t)nd), li = (int)(v - (uint32_t)e * nd);
-    const int s = e / T;
-    int rank = 0;
-    for (int64_t p = run_start[j]; p < i; ++p)
-      rank += ((int)(val[p] / (uint32_t)nd) / T == s) ? 1 : 0;
-    if (rank > 254)
+    for (int k = threadIdx.x; k < ndw * nc; k += 1024)
+      iw[k] = 0;
+    for (int k = threadIdx.x; k < nrw * nc; k += 1024)
+      rw[k] = 0xffffffffu; // (a rank byte of 0xff: no cell)
+    __syncthreads();
+    for (int t = threadIdx.x; t < seg; t += 1024)
     {
-      *err = 1;
-      rank = 254;
+      const int64_t i = b * seg + t;
+      if (key[i] == 0xffffffffu)
+        continue;
+      const int32_t j = uidx[i] - (flag[i] ? 0 : 1); // uidx is the exclusive scan of the head flags
+      const uint32_t v = val[i];
+      const int e = (int)(v / (uint32_t)nd), li = (int)(v - (uint32_t)e * nd);
+      const int s = e / T;
+      // (positions ascend inside a run, so the incidences of one step sit side by side: walk back to the step's first)
+      int rank = 0;
+      for (int64_t p = i - 1, p0 = run_start[j]; p >= p0 && (int)(val[p] / (uint32_t)nd) / T == s; --p)
+        ++rank;
+      if (rank > 254)
+      {
+        *err = 1;
+        rank = 254;
+      }
+      idx16[((li >> 1) * nc + e) * 2 + (li & 1)] = (uint16_t)loc_of[j];
+      rnk8[((li >> 2) * nc + e) * 4 + (li & 3)] = (uint8_t)rank;
     }
-    idx16[((b * ndw + (li >> 1)) * nc + e) * 2 + (li & 1)] = (uint16_t)loc_of[j];
-    rnk8[((b * nrw + (li >> 2)) * nc + e) * 4 + (li & 3)] = (uint8_t)rank;
+    __syncthreads();
+    for (int k = threadIdx.x; k < ndw * nc; k += 1024)
+      idxw[b * ndw * nc + k] = iw[k];
+    for (int k = threadIdx.x; k < nrw * nc; k += 1024)
+      rnkw[b * nrw * nc + k] = rw[k];
+    __syncthreads();
   }
 }
 // rounds local dof i needs in every (block, step): 1 + the largest rank among the step's cells
@@ -865,6 +901,12 @@ __global__ __launch_bounds__(256) void k_mf_finish(const int32_t* __restrict__ s
   }
 }
 
+struct SegOffset
+{
+  unsigned seg;
+  __host__ __device__ unsigned operator()(unsigned k) const { return k * seg; }
+};
+
 int grid_for(int64_t n)
 {
   int64_t g = (n + 255) / 256;
@@ -985,28 +1027,35 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   }
   sorted_cells.release();
 
-  // 2. (block, dof) incidences, sorted; their unique keys
+  // 2. the incidences of every block sorted by dof (one segment of nc * nd pairs per block: a block-level sort each, the
+  // data moves once -- the global sort of (block, dof) keys this replaces took six passes over 64-bit keys); unique keys
   const int64_t np = total * nd;
-  const uint64_t invalid = ((uint64_t)nb << 32) | 0xffffffffull;
-  DevBuf<uint64_t> key;
-  DevBuf<uint32_t> val;
+  const int seg = nc * nd;
+  DevBuf<uint32_t> key, val;
   {
-    DevBuf<uint64_t> key0;
-    DevBuf<uint32_t> val0;
+    DevBuf<uint32_t> key0, val0;
     ZZZ_HIP(ctx, key0.alloc((size_t)np));
     ZZZ_HIP(ctx, val0.alloc((size_t)np));
     ZZZ_HIP(ctx, key.alloc((size_t)np));
     ZZZ_HIP(ctx, val.alloc((size_t)np));
-    // (keys of cells that are not there -- the last block's tail -- sort behind everything else)
-    hipLaunchKernelGGL(k_mf_pairs, dim3(grid_for(np)), dim3(256), 0, s, M.mf_cell.p, ctx->cell_dofs.p, nd, nc, total, invalid, key0.p,
-                       val0.p);
-    if (int rc = sort_pairs(ctx, key0, key, val0, val, (size_t)np, 32 + bits_for((uint64_t)nb)))
-      return rc;
+    hipLaunchKernelGGL(k_mf_pairs, dim3(grid_for(np)), dim3(256), 0, s, M.mf_cell.p, ctx->cell_dofs.p, nd, nc, total, key0.p, val0.p);
+    auto begin = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned>(0), SegOffset{(unsigned)seg});
+    auto end = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned>(1), SegOffset{(unsigned)seg});
+    // (one bit above the dofs': the key of a missing cell stays behind every dof)
+    const unsigned end_bit = std::min(32u, bits_for((uint64_t)(ctx->n_owned + ctx->n_ghost)) + 1u);
+    size_t tb = 0;
+    ZZZ_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb, key0.p, key.p, val0.p, val.p, (unsigned)np, (unsigned)nb, begin, end,
+                                                     0u, end_bit, s));
+    DevBuf<unsigned char> tmp;
+    ZZZ_HIP(ctx, tmp.alloc(tb));
+    ZZZ_HIP(ctx, rocprim::segmented_radix_sort_pairs(tmp.p, tb, key0.p, key.p, val0.p, val.p, (unsigned)np, (unsigned)nb, begin, end,
+                                                     0u, end_bit, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
   }
   DevBuf<int32_t> flag, uidx;
   ZZZ_HIP(ctx, flag.alloc((size_t)np + 1));
   ZZZ_HIP(ctx, uidx.alloc((size_t)np + 1));
-  hipLaunchKernelGGL(k_mf_heads, dim3(grid_for(np)), dim3(256), 0, s, key.p, np, invalid, flag.p);
+  hipLaunchKernelGGL(k_mf_heads, dim3(grid_for(np)), dim3(256), 0, s, key.p, np, seg, flag.p);
   ZZZ_HIP(ctx, hipMemsetAsync(flag.p + np, 0, sizeof(int32_t), s));
   if (int rc = scan_excl(ctx, flag.p, uidx.p, (size_t)np + 1))
     return rc;
@@ -1020,7 +1069,7 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   ZZZ_HIP(ctx, run_start.alloc((size_t)nu + 1));
   ZZZ_HIP(ctx, nblk_of.alloc((size_t)nloc_all));
   ZZZ_HIP(ctx, hipMemsetAsync(nblk_of.p, 0, (size_t)nloc_all * sizeof(int32_t), s));
-  hipLaunchKernelGGL(k_mf_uniques, dim3(grid_for(np)), dim3(256), 0, s, key.p, flag.p, uidx.p, np, ukey.p, run_start.p, nblk_of.p);
+  hipLaunchKernelGGL(k_mf_uniques, dim3(grid_for(np)), dim3(256), 0, s, key.p, flag.p, uidx.p, np, seg, ukey.p, run_start.p, nblk_of.p);
 
   // 3. classes, block-local order, headers
   DevBuf<uint64_t> key2, key2s;
@@ -1077,10 +1126,14 @@ int plan_attempt(zzz_ctx* ctx, int nc, int T, int nloc_limit, bool* retry)
   ZZZ_HIP(ctx, M.idxw.alloc((size_t)(nb * M.ndw * nc)));
   ZZZ_HIP(ctx, M.rnkw.alloc((size_t)(nb * M.nrw * nc)));
   ZZZ_HIP(ctx, M.rmax.alloc((size_t)(nb * nsb * M.nrw * 4)));
-  ZZZ_HIP(ctx, hipMemsetAsync(M.idxw.p, 0, (size_t)(nb * M.ndw * nc) * 4, s));
-  ZZZ_HIP(ctx, hipMemsetAsync(M.rnkw.p, 0xff, (size_t)(nb * M.nrw * nc) * 4, s));
-  hipLaunchKernelGGL(k_mf_cells, dim3(grid_for(np)), dim3(256), 0, s, key.p, val.p, uidx.p, flag.p, np, invalid, run_start.p, loc_of.p, nd, nc,
-                     T, M.ndw, M.nrw, M.idxw.p, M.rnkw.p, nlmax.p + 1);
+  {
+    const int lds = (M.ndw + M.nrw) * nc * 4;
+    if (lds > 48 * 1024)
+      ZZZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_cells), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k_mf_cells, dim3((unsigned)std::min<int64_t>(nb, 256ll * std::max(1, std::min(2, (160 * 1024) / (lds + 256))))), dim3(1024), lds,
+                       s, key.p, val.p, uidx.p, flag.p, nb, seg, run_start.p, loc_of.p, nd, nc, T, M.ndw, M.nrw, M.idxw.p, M.rnkw.p,
+                       nlmax.p + 1);
+  }
   hipLaunchKernelGGL(k_mf_rmax, dim3((unsigned)std::min<int64_t>((nb * nsb * M.nrw + 3) / 4, 8192)), dim3(256), 0, s, M.rnkw.p, nb, nc,
                      T, nsb, M.nrw, M.rmax.p);
   int32_t h_err = 0;
