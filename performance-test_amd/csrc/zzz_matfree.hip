@@ -1243,6 +1243,9 @@ int mf_plan_build(zzz_ctx* ctx)
       nc = v;
   }
   nc = std::max(nc, T);
+  // (the plan's own kernels put a block's index and rank words together in LDS: 4 (nd / 2 + (nd + 3) / 4) bytes per cell)
+  while (nc / 2 >= T && (nc / 2) % T == 0 && (nd / 2 + (nd + 3) / 4) * 4 * nc > 150 * 1024)
+    nc /= 2;
   // LDS budget per workgroup: 64 KiB unless ZZZ_MF_LDS_KB says otherwise (160 KiB per CU)
   int lds_kb = nd == 4 ? 40 : 64;
   if (const char* e = getenv("ZZZ_MF_LDS_KB"))
