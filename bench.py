@@ -476,6 +476,10 @@ def main():
 
         import datetime
 
+        if a.force_dist and world == 1:
+            # started by hand, not by torch.distributed.run: the rendezvous of a single rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
         with deadline(600, "gloo process group"):
             dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank,
                                     timeout=datetime.timedelta(seconds=600))
