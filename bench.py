@@ -241,6 +241,7 @@ def run_other_config(name, steps=3, unstructured=None):
         spmv_ms, spmv_n = ctx.profile()
         bytes_pl, sinfo = physical_bytes_per_product(ctx, nrows, nnz)
         ctx_windows = ctx.spmv_x_windows()[0] > 0
+        values = ctx.spmv_values_info()
         unorm = ctx.vec_norm(zzz.VEC_U)
         if unstructured:
             # what the structured feed's luck was worth: entries kept in the stream, and the matrix-free action here
@@ -259,7 +260,9 @@ def run_other_config(name, steps=3, unstructured=None):
             "krylov_iterations": it, "relative_residual": rn / r0 if r0 else 0.0, "solution_norm": unorm,
             "product_ms": spmv_ms, "product_launches_timed": spmv_n, "product_bytes_per_launch": bytes_pl,
             "product_GBs": phys, "roofline_frac": phys / HBM_PEAK_GBS,
-            "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")) if sinfo[5] else "CSR tile kernel",
+            "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")
+                         + (f", values as codes into a {values['form']} of {values['distinct_values']} distinct values"
+                            if values["form"] != "doubles" else "")) if sinfo[5] else "CSR tile kernel",
             **extra}
 
 
@@ -788,6 +791,12 @@ def main():
             out["config"]["spmv_operator"] = (f"sliced-ELL operator stream, {'length-sorted' if sinfo[5] == 2 else 'natural'} row order: "
                                               f"{sinfo[7]} entries ({sinfo[7] / nnz:.3f} of the {nnz}-entry pattern; exact zeros "
                                               f"dropped, chunks of 8 padded), {sinfo[6]} B per product")
+            vi = ctx.spmv_values_info()
+            out["config"]["spmv_values"] = vi
+            if vi["form"] != "doubles":
+                out["config"]["spmv_operator"] += (f"; values as 16-bit codes into a {vi['form']} of the matrix's "
+                                                   f"{vi['distinct_values']} distinct values (bit-identical products; as doubles the "
+                                                   f"stream would be {vi['bytes_per_product_as_doubles']} B per product)")
             xw = ctx.spmv_x_windows()
             if xw[0]:
                 out["config"]["spmv_operator"] += (f"; x windows: per group of 256 rows the columns it reaches are loaded into LDS "

@@ -354,6 +354,13 @@ int zzz_profile_get(zzz_ctx* ctx, double* spmv_avg_ms, int64_t* spmv_count);
  * group, the stream's codes are window indices) info[3] = -(LDS doubles per workgroup) and info[2] = bytes of x those
  * loads move per product. */
 int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
+/* The values of the operator stream (csrc/zzz_sellp.hip): info[0] = 0 when the product reads them as doubles, 1 / 2 when it
+ * reads 16-bit codes into a dictionary of the matrix's DISTINCT values held in memory / copied into LDS by every workgroup
+ * (matrices of regular meshes hold few: ~1 300 at 10 M-dof P1 Poisson; at most 65 535 qualify; same doubles, same
+ * order of operations, bit-identical products); info[1] = distinct values (+0.0 included); info[2] = bytes per product of
+ * the stream in the form in use; info[3] = bytes per product with the values as doubles.  0s when the product does not
+ * run on the stream. */
+int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4]);
 
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */
 

@@ -140,6 +140,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   }
   if (const char* e = getenv("ZZZ_SELLP_DROP"))
     ctx->sellp_drop = atoi(e) != 0;
+  if (const char* e = getenv("ZZZ_SELLP_DICT"))
+    ctx->sellp_dict = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_AFFINE")) // 0: no code-free chunks (column = slot base + lane); A/B knob
     if (atoi(e) == 0)
       ctx->sellp_tail |= 2;
@@ -960,6 +962,21 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   info[5] = sellp_active(ctx) ? (ctx->sp_sorted ? 2 : 1) : 0;
   info[6] = sellp_active(ctx) ? sellp_stream_bytes(ctx) : 0; // bytes of the operator stream read per product
   info[7] = sellp_active(ctx) ? ctx->sp_chunks * 512 : 0;     // its entries, padding included
+  return ZZZ_OK;
+}
+
+int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4])
+{
+  ZZZ_ENTER(ctx);
+  if (!info || !ctx->have_pattern)
+    return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_values_info: no pattern");
+  info[0] = info[1] = info[2] = info[3] = 0;
+  if (!sellp_active(ctx))
+    return ZZZ_OK;
+  info[0] = ctx->sp_dict_on ? (ctx->sp_dict_n <= zzz::SP_DICT_LDS_ENTRIES ? 2 : 1) : 0;
+  info[1] = ctx->sp_dict_on ? ctx->sp_dict_n : 0;
+  info[2] = sellp_stream_bytes(ctx);
+  info[3] = ctx->sp_bytes + ctx->nslices * 8;
   return ZZZ_OK;
 }
 

@@ -251,6 +251,18 @@ struct zzz_ctx
   int64_t nslices = 0, sp_chunks = 0, sp_kept = 0, sp_bytes = 0; // slices, chunks of the stream, matrix entries kept in it,
                                                                  // bytes a product reads from it
   zzz::DevBuf<uint8_t> sp_wlast; // per slice: entries of the longest row in its last chunk (1..8)
+  // value dictionary of the stream (zzz_sellp.hip, sp_dict_build): the matrices of a regular mesh hold a few hundred to a few
+  // ten thousand DISTINCT values (10 M-dof P1 Poisson: ~1 300); where there are at most 65 535 the product reads a 16-bit
+  // code per entry (sp_vcode: [chunk][lane][8]) and looks the value up (sp_dict: code 0 = +0.0) -- the same doubles in the
+  // same order, a quarter of the bytes.  More distinct values (an unstructured mesh): sp_dict_on stays false, sp_vals is read.
+  zzz::DevBuf<uint16_t> sp_vcode;
+  zzz::DevBuf<double> sp_dict;
+  zzz::DevBuf<unsigned long long> sp_dict_table; // open-addressing set of the values' bit patterns (build only)
+  zzz::DevBuf<int32_t> sp_dict_slot;             // table slot -> code (build only)
+  bool sp_dict_done = false, sp_dict_on = false;
+  int sellp_dict = 1;       // ZZZ_SELLP_DICT=0: no value dictionary
+  int sp_dict_n = 0;        // distinct values (with +0.0)
+  int64_t sp_dict_bytes = 0; // bytes a product reads from the stream in dictionary form
   bool sp_sorted = false;    // rows ordered by length inside windows (SELL-C-sigma)
   int sellp_mode = 1;        // ZZZ_SELLP: 0 off, 1 automatic, 2 natural row order always, 3 sorted rows always
   bool sellp_align = true; // scalar rows, one-chunk slices: entries placed by column so that short boundary rows fit the affine form
@@ -376,6 +388,7 @@ int sellp_resolve(zzz_ctx* ctx);
 int sellp_pattern_bounds(zzz_ctx* ctx);
 int sellp_capacity_rows(zzz_ctx* ctx); // sp_crow := capacity-based row starts of the compacted copy (+ its allocation)
 int64_t sellp_stream_bytes(const zzz_ctx* ctx);
+constexpr int SP_DICT_LDS_ENTRIES = 2048; // a value dictionary of at most this many entries is copied into LDS by every workgroup (16 KiB: eight per CU)
 int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr,
                  const ChebEpi* epi = nullptr);
 int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials, int* npartials, const double* rvec,

@@ -952,6 +952,207 @@ __global__ void k_sp_desc(const int32_t* __restrict__ off, const uint8_t* __rest
     desc[s] = make_int2(off[s], (off[s + 1] - off[s]) | ((int)wlast[s] << 24));
 }
 
+// ---- value dictionary -----------------------------------------------------------------------------------
+// The entries of the packed stream as (slice, chunk, lane, slot) with the values the product would load: slots of a
+// slice's last chunk beyond its width and lanes without a row are never loaded (and hold anything).
+constexpr int SP_DICT_BITS = 18;                        // table of 2^18 slots for at most 65 535 values
+constexpr unsigned long long SP_DICT_EMPTY = ~0ull;     // (a NaN pattern no assembled value has; met all the same: no dictionary)
+constexpr int SP_DICT_MAX = 65535;
+constexpr int SP_DICT_LDS_MAX = SP_DICT_LDS_ENTRIES;
+
+__device__ inline unsigned sp_dict_hash(unsigned long long b)
+{
+  b ^= b >> 29;
+  b *= 0x9E3779B97F4A7C15ull;
+  return (unsigned)(b >> (64 - SP_DICT_BITS));
+}
+
+// value of entry (chunk c of width w, lane, slot e) in the value blocks: [4][64 lanes][2]; the last entry of an odd width
+// sits alone, 8 B per lane (emit_chunk)
+__device__ inline unsigned long long sp_value_bits(const double* __restrict__ svals, int64_t c, int w, int lane, int e)
+{
+  const int64_t at = ((w & 1) && e == w - 1) ? 128 * (e >> 1) + lane : 128 * (e >> 1) + 2 * lane + (e & 1);
+  return reinterpret_cast<const unsigned long long*>(svals)[c * 512 + at];
+}
+
+// info[0] distinct values so far, info[1] overflow / unusable
+template <bool PERM>
+__global__ __launch_bounds__(256) void k_sp_dict_insert(const int2* __restrict__ desc, const int32_t* __restrict__ perm,
+                                                         const double* __restrict__ svals, int nrows, int64_t nslices,
+                                                         unsigned long long* __restrict__ table, int* __restrict__ info)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6); s < nslices; s += gridDim.x * 4ll)
+  {
+    const int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
+    if (r < 0 || r >= nrows)
+      continue;
+    const int2 ds = desc[s];
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    unsigned long long last = 0ull; // (+0.0 is code 0 without the table)
+    for (int j = 0; j < nch; ++j)
+    {
+      const int w = j + 1 < nch ? 8 : wl;
+      for (int e = 0; e < w; ++e)
+      {
+        const unsigned long long b = sp_value_bits(svals, c0 + j, w, lane, e);
+        if (b == last || b == 0ull)
+          continue; // (a row repeats its values: the previous one is in the table already)
+        last = b;
+        if (b == SP_DICT_EMPTY)
+        {
+          info[1] = 1;
+          continue;
+        }
+        unsigned h = sp_dict_hash(b);
+        for (int probe = 0; probe < (1 << SP_DICT_BITS); ++probe)
+        {
+          const unsigned long long cur = table[h];
+          if (cur == b)
+            break;
+          if (cur == SP_DICT_EMPTY)
+          {
+            const unsigned long long old = atomicCAS(&table[h], SP_DICT_EMPTY, b);
+            if (old == SP_DICT_EMPTY)
+            {
+              if (atomicAdd(&info[0], 1) >= SP_DICT_MAX - 1)
+                info[1] = 1;
+              break;
+            }
+            if (old == b)
+              break;
+          }
+          h = (h + 1) & ((1u << SP_DICT_BITS) - 1);
+          if (info[1]) // too many distinct values: the table may be filling up, stop looking
+            break;
+        }
+      }
+    }
+  }
+}
+
+// codes in table order: slot -> 1 + the number of occupied slots before it (one workgroup; code 0 = +0.0)
+__global__ __launch_bounds__(1024) void k_sp_dict_number(const unsigned long long* __restrict__ table, int32_t* __restrict__ slot_code,
+                                                         double* __restrict__ dict, int* __restrict__ info)
+{
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  if (threadIdx.x == 0)
+  {
+    base_s = 1;
+    dict[0] = 0.0;
+  }
+  __syncthreads();
+  if (info[1])
+    return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k0 = 0; k0 < (1 << SP_DICT_BITS); k0 += 1024)
+  {
+    const int k = k0 + threadIdx.x;
+    const unsigned long long b = table[k];
+    const bool used = b != SP_DICT_EMPTY;
+    const unsigned long long m = __ballot(used);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0)
+      wsum[wv] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int q = 0; q < wv; ++q)
+      off += wsum[q];
+    if (used)
+    {
+      const int code = off + before;
+      slot_code[k] = code;
+      if (code <= SP_DICT_MAX)
+        dict[code] = __longlong_as_double((long long)b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int t = 0;
+      for (int q = 0; q < 16; ++q)
+        t += wsum[q];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    info[2] = base_s; // entries of the dictionary, +0.0 included
+}
+
+// the stream's values as codes, [chunk][lane][8] (16 B per lane and chunk); info[4..5]: bytes the product reads in this form
+template <bool PERM>
+__global__ __launch_bounds__(256) void k_sp_dict_encode(const int2* __restrict__ desc, const int32_t* __restrict__ perm,
+                                                         const double* __restrict__ svals, const int32_t* __restrict__ meta,
+                                                         int nrows, int64_t nslices, const unsigned long long* __restrict__ table,
+                                                         const int32_t* __restrict__ slot_code, uint16_t* __restrict__ vcode,
+                                                         int* __restrict__ info)
+{
+  if (info[1])
+    return;
+  const int lane = threadIdx.x & 63;
+  unsigned long long bytes = 0;
+  for (int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6); s < nslices; s += gridDim.x * 4ll)
+  {
+    const int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
+    const bool row = r >= 0 && r < nrows;
+    const int2 ds = desc[s];
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    unsigned long long last = 0ull;
+    unsigned last_code = 0;
+    for (int j = 0; j < nch; ++j)
+    {
+      const int w = j + 1 < nch ? 8 : wl;
+      unsigned code[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+      {
+        code[e] = 0;
+        if (row && e < w)
+        {
+          const unsigned long long b = sp_value_bits(svals, c0 + j, w, lane, e);
+          if (b == 0ull)
+            continue;
+          if (b != last)
+          {
+            unsigned h = sp_dict_hash(b);
+            while (table[h] != b)
+              h = (h + 1) & ((1u << SP_DICT_BITS) - 1);
+            last = b;
+            last_code = (unsigned)slot_code[h];
+          }
+          code[e] = last_code;
+        }
+      }
+      uint4v q;
+      q.x = code[0] | (code[1] << 16);
+      q.y = code[2] | (code[3] << 16);
+      q.z = code[4] | (code[5] << 16);
+      q.w = code[6] | (code[7] << 16);
+      reinterpret_cast<uint4v*>(vcode + (size_t)(c0 + j) * 512)[lane] = q;
+      if (lane == 0)
+      {
+        // what the product reads of this chunk: 1 KiB of value codes, the slot bases, the column codes by the chunk's mode
+        const int m0 = meta[(size_t)(c0 + j) * 8];
+        unsigned cb = 0;
+        if (m0 < 0 && (m0 & 0x40000000))
+          cb = 100; // periodic: 25 scalar words
+        else if (m0 < 0)
+          cb = 2048; // int32 columns
+        else if ((m0 & 0x60000000) == 0x20000000)
+          cb = 0; // affine
+        else if (m0 & 0x40000000)
+          cb = 512; // 8-bit codes
+        else
+          cb = 1024; // 16-bit codes
+        bytes += 1024 + 32 + cb;
+      }
+    }
+  }
+  if (lane == 0 && bytes)
+    atomicAdd(reinterpret_cast<unsigned long long*>(info + 4), bytes);
+}
+
 // ---- the product --------------------------------------------------------------------------------------
 template <bool NT, typename T>
 __device__ inline T sp_load(const T* p)
@@ -969,11 +1170,30 @@ __device__ inline double gather(const double* __restrict__ x, int col)
 // Values and columns of chunk c for this lane.  FULL: all eight slots (every chunk but the last of a slice);
 // otherwise only the first w: unused value blocks are not loaded (an odd w loads its last entry with one 8-B load).
 // Columns by the chunk's mode (meta[c][0]: bit 31 int32, bit 30 8-bit codes, else 16-bit codes on the slot bases).
-template <bool NT, bool FULL>
+// DICT: the values are 16-bit codes into the stream's dictionary (vcode: [chunk][lane][8], one 16-B load; code 0 = +0.0,
+// which is also what the slots beyond a last chunk's width hold)
+template <bool NT, bool FULL, int DICT = 0>
 __device__ inline void read_chunk(int c, int w, int lane, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
-                                  const int32_t* __restrict__ c32, const int32_t* __restrict__ meta, dbl2 (&v)[4], int (&cl)[8])
+                                  const int32_t* __restrict__ c32, const int32_t* __restrict__ meta, dbl2 (&v)[4], int (&cl)[8],
+                                  const uint16_t* __restrict__ vcode = nullptr, const double* __restrict__ dict = nullptr)
 {
   const double* __restrict__ sp = svals + (size_t)c * 512;
+  if constexpr (DICT)
+  {
+    const uint4v q = sp_load<NT>(reinterpret_cast<const uint4v*>(vcode + (size_t)c * 512) + lane);
+    // DICT == 2: `dict` is the workgroup's copy in LDS (a small dictionary: the lanes of a slice mostly hold the same
+    // code in a slot -- broadcast reads); DICT == 1: gathers from memory
+    auto look = [&](unsigned code) -> double { return DICT == 2 ? dict[code] : gather(dict, (int)code); };
+    v[0].x = look(q.x & 0xffffu);
+    v[0].y = look(q.x >> 16);
+    v[1].x = look(q.y & 0xffffu);
+    v[1].y = look(q.y >> 16);
+    v[2].x = look(q.z & 0xffffu);
+    v[2].y = look(q.z >> 16);
+    v[3].x = look(q.w & 0xffffu);
+    v[3].y = look(q.w >> 16);
+  }
+  else
 #pragma unroll
   for (int j = 0; j < 4; ++j)
   {
@@ -1055,14 +1275,15 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
 }
 
 // sum += the chunk's products in ascending column order, mul and add rounded separately (the scalar CPU loop's bits)
-template <bool NT, bool FULL, bool LDS = false>
+template <bool NT, bool FULL, bool LDS = false, int DICT = 0>
 __device__ inline void chunk_product(int c, int w, int lane, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
                                      const int32_t* __restrict__ c32, const int32_t* __restrict__ meta,
-                                     const double* __restrict__ x, double& sum)
+                                     const double* __restrict__ x, double& sum, const uint16_t* __restrict__ vcode = nullptr,
+                                     const double* __restrict__ dict = nullptr)
 {
   dbl2 v[4];
   int cl[8];
-  read_chunk<NT, FULL>(c, w, lane, svals, c16, c32, meta, v, cl);
+  read_chunk<NT, FULL, DICT>(c, w, lane, svals, c16, c32, meta, v, cl, vcode, dict);
   double xv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
@@ -1073,7 +1294,7 @@ __device__ inline void chunk_product(int c, int w, int lane, const double* __res
       sum += ((e & 1) ? v[e >> 1].y : v[e >> 1].x) * xv[e];
 }
 
-template <bool DOT, bool NT, bool PERM, bool CHEB = false, bool WIN = false>
+template <bool DOT, bool NT, bool PERM, bool CHEB = false, bool WIN = false, int DICT = 0>
 __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __restrict__ desc,
                                                               const double* __restrict__ svals,
                                                               const uint16_t* __restrict__ c16,
@@ -1086,9 +1307,14 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
                                                               const int32_t* __restrict__ group_list, int64_t nlist,
                                                               const double* __restrict__ rvec, int pstride, int nn_is_rr,
                                                               TailArgs tail, ChebEpi epi, const int2* __restrict__ win_info,
-                                                              const int2* __restrict__ win_seg)
+                                                              const int2* __restrict__ win_seg, const uint16_t* __restrict__ vcode,
+                                                              const double* __restrict__ dict_g, int dict_n)
 {
-  extern __shared__ __attribute__((aligned(16))) double xwin[]; // WIN: the group's x window (launch: sp_win_max doubles)
+  // dynamic LDS: DICT == 2: the value dictionary (dict_n doubles, rounded up to 2); WIN: the group's x window behind it
+  // (launch: sp_win_max doubles)
+  extern __shared__ __attribute__((aligned(16))) double sp_lds[];
+  double* const xwin = sp_lds + (DICT == 2 ? ((dict_n + 1) & ~1) : 0);
+  const double* const dict = DICT == 2 ? sp_lds : dict_g;
   // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
   // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
   // spmv_tile_kernel
@@ -1117,6 +1343,12 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
   int st_n = next_slice(0, s_n, ds_n);
   if (stop_flag && *stop_flag) // CG already converged: the host is a few iterations ahead
     return;
+  if (DICT == 2)
+  {
+    for (int k = threadIdx.x; k < dict_n; k += SP_BLOCK)
+      sp_lds[k] = dict_g[k];
+    __syncthreads();
+  }
   for (int i = 0; st_n >= 0; ++i)
   {
     const int st = st_n, s = s_n;
@@ -1156,25 +1388,25 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     if (WIN && nwin > 0)
     {
       for (int j = 0; j + 1 < nch; ++j)
-        chunk_product<NT, true, true>(c0 + j, 8, lane, svals, c16, c32, meta, xwin, sum);
+        chunk_product<NT, true, true, DICT>(c0 + j, 8, lane, svals, c16, c32, meta, xwin, sum, vcode, dict);
       if (nch)
       {
         if (wl == 8)
-          chunk_product<NT, true, true>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, xwin, sum);
+          chunk_product<NT, true, true, DICT>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, xwin, sum, vcode, dict);
         else
-          chunk_product<NT, false, true>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, xwin, sum);
+          chunk_product<NT, false, true, DICT>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, xwin, sum, vcode, dict);
       }
     }
     else
     {
       for (int j = 0; j + 1 < nch; ++j)
-        chunk_product<NT, true>(c0 + j, 8, lane, svals, c16, c32, meta, x, sum);
+        chunk_product<NT, true, false, DICT>(c0 + j, 8, lane, svals, c16, c32, meta, x, sum, vcode, dict);
       if (nch)
       {
         if (wl == 8)
-          chunk_product<NT, true>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, x, sum);
+          chunk_product<NT, true, false, DICT>(c0 + nch - 1, 8, lane, svals, c16, c32, meta, x, sum, vcode, dict);
         else
-          chunk_product<NT, false>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, x, sum);
+          chunk_product<NT, false, false, DICT>(c0 + nch - 1, wl, lane, svals, c16, c32, meta, x, sum, vcode, dict);
       }
     }
     if (CHEB)
@@ -1648,6 +1880,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
 {
   (void)structure;
   ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
+  ctx->sp_dict_done = ctx->sp_dict_on = false; // (the values changed: the dictionary is rebuilt at the stream's first use)
   ctx->sp_win_max = 0; // (set again by the long-row packer when most groups get an x window)
   ctx->sp_win_bytes = 0;
   const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
@@ -1838,17 +2071,77 @@ int sellp_resolve(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
+// The value dictionary of the finished stream (see zzz_internal.h): distinct values into a hash set, numbered, every
+// value of the stream replaced by its code.  Synchronous (once per assembly, at the first use of the stream): 1-2 ms at
+// 10 M rows.  More than 65 535 distinct values, or ZZZ_SELLP_DICT=0: the stream keeps being read as values.
+static int sp_dict_build(zzz_ctx* ctx)
+{
+  ctx->sp_dict_done = true;
+  ctx->sp_dict_on = false;
+  ctx->sp_dict_n = 0;
+  // ZZZ_SELLP_DICT: 0 never, 2 always (tests at small sizes), 1: for streams of more than 48 MB of values -- below that the
+  // whole loop sits in the Infinity Cache, bytes are not what the product waits for, and building the dictionary (three
+  // passes over the stream and a synchronisation, ~0.4 ms at 500 k rows) costs more than a solve gains
+  if (!ctx->sellp_dict || ctx->sp_chunks <= 0 || (ctx->sellp_dict == 1 && ctx->sp_bytes < 48ll << 20))
+    return ZZZ_OK;
+  hipStream_t s = ctx->stream;
+  const int64_t nsl = ctx->nslices;
+  ZZZ_HIP(ctx, ctx->sp_dict_table.alloc((size_t)1 << SP_DICT_BITS));
+  ZZZ_HIP(ctx, ctx->sp_dict_slot.alloc((size_t)1 << SP_DICT_BITS));
+  ZZZ_HIP(ctx, ctx->sp_dict.alloc((size_t)SP_DICT_MAX + 1));
+  ZZZ_HIP(ctx, ctx->sp_vcode.alloc((size_t)ctx->sp_chunks * 512));
+  DevBuf<int32_t> info;
+  ZZZ_HIP(ctx, info.alloc(8));
+  ZZZ_HIP(ctx, hipMemsetAsync(info.p, 0, 8 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_dict_table.p, 0xff, sizeof(unsigned long long) << SP_DICT_BITS, s));
+  const int2* desc = reinterpret_cast<const int2*>(ctx->sp_desc.p);
+  const unsigned grid = (unsigned)std::min<int64_t>((nsl + 3) / 4, 256 * 16);
+  if (ctx->sp_sorted)
+    hipLaunchKernelGGL(k_sp_dict_insert<true>, dim3(grid), dim3(256), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, (int)ctx->nrows, nsl,
+                       ctx->sp_dict_table.p, info.p);
+  else
+    hipLaunchKernelGGL(k_sp_dict_insert<false>, dim3(grid), dim3(256), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p,
+                       (int)ctx->nrows, nsl, ctx->sp_dict_table.p, info.p);
+  hipLaunchKernelGGL(k_sp_dict_number, dim3(1), dim3(1024), 0, s, ctx->sp_dict_table.p, ctx->sp_dict_slot.p, ctx->sp_dict.p, info.p);
+  if (ctx->sp_sorted)
+    hipLaunchKernelGGL(k_sp_dict_encode<true>, dim3(grid), dim3(256), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, ctx->sp_meta.p,
+                       (int)ctx->nrows, nsl, ctx->sp_dict_table.p, ctx->sp_dict_slot.p, ctx->sp_vcode.p, info.p);
+  else
+    hipLaunchKernelGGL(k_sp_dict_encode<false>, dim3(grid), dim3(256), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p,
+                       ctx->sp_meta.p, (int)ctx->nrows, nsl, ctx->sp_dict_table.p, ctx->sp_dict_slot.p, ctx->sp_vcode.p, info.p);
+  ZZZ_HIP(ctx, hipGetLastError());
+  int32_t h[8];
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (h[1] || h[2] <= 0 || h[2] > SP_DICT_MAX + 1)
+    return ZZZ_OK;
+  unsigned long long bytes = 0;
+  memcpy(&bytes, h + 4, sizeof(bytes));
+  ctx->sp_dict_n = h[2];
+  ctx->sp_dict_bytes = (int64_t)bytes + (int64_t)h[2] * 8;
+  ctx->sp_dict_on = true;
+  return ZZZ_OK;
+}
+
 bool sellp_active(zzz_ctx* ctx)
 {
   if (ctx->sp_pending)
     (void)sellp_resolve(ctx);
   if (!ctx->have_sell || !ctx->sell_current)
     return false;
-  return ctx->spmv_auto || (ctx->spmv_variant & 8) != 0;
+  if (!(ctx->spmv_auto || (ctx->spmv_variant & 8) != 0))
+    return false;
+  if (!ctx->sp_dict_done)
+    (void)sp_dict_build(ctx);
+  return true;
 }
 
-// bytes one product reads from the stream (values + codes + bases; int32 chunks are not counted separately)
-int64_t sellp_stream_bytes(const zzz_ctx* ctx) { return ctx->sp_bytes + ctx->nslices * 8; } // (x windows: sp_win_bytes, reported apart)
+// bytes one product reads from the stream (values or value codes + dictionary, column codes, bases; int32 chunks are not
+// counted separately)
+int64_t sellp_stream_bytes(const zzz_ctx* ctx)
+{
+  return (ctx->sp_dict_on ? ctx->sp_dict_bytes : ctx->sp_bytes) + ctx->nslices * 8; // (x windows: sp_win_bytes, reported apart)
+}
 
 static int sp_grid(int64_t ngroups)
 {
@@ -1874,19 +2167,31 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
   const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
   const int2* winfo = reinterpret_cast<const int2*>(ctx->sp_win_info.p);
   const int2* wseg = reinterpret_cast<const int2*>(ctx->sp_win_seg.p);
-#define ZZZ_SP_GO5(NT, PERM, WIN, LDSB)                                                                                \
+#define ZZZ_SP_GO6(NT, PERM, WIN, LDSB, DICT)                                                                          \
   do                                                                                                                   \
   {                                                                                                                    \
     if (epi)                                                                                                           \
-      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, true, WIN>), dim3(grid), dim3(SP_BLOCK), LDSB, ctx->stream,   \
-                         off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,  \
-                         (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr,   \
-                         TailArgs(), *epi, winfo, wseg);                                                               \
+      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, true, WIN, DICT>), dim3(grid), dim3(SP_BLOCK), LDSB,         \
+                         ctx->stream, off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,           \
+                         ctx->sp_perm.p, x, y, (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec,     \
+                         SPMV_PSTRIDE, nn_is_rr, TailArgs(), *epi, winfo, wseg, ctx->sp_vcode.p, ctx->sp_dict.p,           \
+                         ctx->sp_dict_n);                                                                              \
     else                                                                                                               \
-      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, false, WIN>), dim3(grid), dim3(SP_BLOCK), LDSB, ctx->stream,  \
-                         off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, ctx->sp_perm.p, x, y,  \
-                         (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec, SPMV_PSTRIDE, nn_is_rr,   \
-                         tail, ChebEpi(), winfo, wseg);                                                                \
+      hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, false, WIN, DICT>), dim3(grid), dim3(SP_BLOCK), LDSB,        \
+                         ctx->stream, off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,           \
+                         ctx->sp_perm.p, x, y, (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec,     \
+                         SPMV_PSTRIDE, nn_is_rr, tail, ChebEpi(), winfo, wseg, ctx->sp_vcode.p, ctx->sp_dict.p,            \
+                         ctx->sp_dict_n);                                                                              \
+  } while (0)
+#define ZZZ_SP_GO5(NT, PERM, WIN, LDSB)                                                                                \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (ctx->sp_dict_on && ctx->sp_dict_n <= SP_DICT_LDS_MAX)                                                          \
+      ZZZ_SP_GO6(NT, PERM, WIN, (LDSB) + (size_t)((ctx->sp_dict_n + 1) & ~1) * sizeof(double), 2);                     \
+    else if (ctx->sp_dict_on)                                                                                          \
+      ZZZ_SP_GO6(NT, PERM, WIN, LDSB, 1);                                                                              \
+    else                                                                                                               \
+      ZZZ_SP_GO6(NT, PERM, WIN, LDSB, 0);                                                                              \
   } while (0)
 #define ZZZ_SP_GO(NT, PERM) ZZZ_SP_GO5(NT, PERM, false, 0)
   if (ctx->sp_win_max > 0 && !ctx->sp_sorted)
@@ -1914,6 +2219,7 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
   }
 #undef ZZZ_SP_GO
 #undef ZZZ_SP_GO5
+#undef ZZZ_SP_GO6
 }
 
 int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int* npartials, const double* rvec, int nn_is_rr,

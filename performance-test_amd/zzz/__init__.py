@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
-    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_matfree_diagonal", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
+    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_spmv_values_info", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_matfree_diagonal", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_cg_info", "zzz_internal_order_download", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
@@ -121,6 +121,7 @@ def hip():
         L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.zzz_spmv_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.zzz_spmv_values_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.zzz_internal_order_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.zzz_comm_unique_id.argtypes = [C.c_void_p]
         L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -566,6 +567,14 @@ class Context:
         info = (C.c_int64 * 8)()
         self._ck(self.L.zzz_spmv_info(self.h, info))
         return [int(v) for v in info]
+
+    def spmv_values_info(self):
+        """how the operator stream holds its values: dict(form = 'doubles' | 'dictionary in memory' | 'dictionary in LDS',
+        distinct values, bytes per product in that form, bytes per product as doubles)"""
+        info = (C.c_int64 * 4)()
+        self._ck(self.L.zzz_spmv_values_info(self.h, info))
+        return dict(form=("doubles", "dictionary in memory", "dictionary in LDS")[int(info[0])], distinct_values=int(info[1]),
+                    bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]))
 
     def spmv_x_windows(self):
         """(LDS doubles per workgroup, bytes of x loaded into LDS per product) when the operator stream carries x windows,

@@ -471,6 +471,51 @@ def test_unstructured_spoke_mesh_partitioned_on_one_gpu(problem, order, m, npart
             assert np.abs(a - a0[sc]).max() <= 1e-12 * np.abs(a0).max()
 
 
+@pytest.mark.parametrize("problem,order,dims,form", [("poisson", 1, (24, 22, 23), "dictionary in LDS"),
+                                                     ("elasticity", 1, (10, 9, 11), "dictionary in LDS"),
+                                                     ("poisson", 2, (9, 8, 7), "dictionary in LDS"),
+                                                     ("poisson", 3, (15, 14, 13), "dictionary in memory"),
+                                                     ("spoke", 1, 6, "doubles")])
+def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
+    """The operator stream with its values as 16-bit codes into a dictionary of the matrix's distinct values (LDS copy per
+    workgroup for small dictionaries, memory for larger ones, plain doubles when a matrix has more than 65 535 distinct values:
+    the unstructured mesh): the same doubles in the same order -- the product is the serial CSR loop's bit for bit, the solve
+    is the undictionaried stream's iteration for iteration and bit for bit."""
+    P = zzz.Part.spoke("poisson", order, dims) if problem == "spoke" else zzz.Part(problem, order, *dims)
+    x = np.random.default_rng(4).standard_normal(P.n_owned * P.bs)
+    res = {}
+    old = os.environ.get("ZZZ_SELLP_DICT")
+    try:
+        for knob in ("0", "2"):
+            os.environ["ZZZ_SELLP_DICT"] = knob
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                y = c.spmv(x)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                res[knob] = (y, it, c.vec_download(zzz.VEC_U), c.spmv_values_info(), c.csr_download(), c.spmv_info_raw()[5])
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_SELLP_DICT", None)
+        else:
+            os.environ["ZZZ_SELLP_DICT"] = old
+    assert res["0"][5] and res["2"][5], "the product must run on the operator stream in this test"
+    rp, cl, v = res["2"][4]
+    np.testing.assert_array_equal(res["2"][0], zo.spmv(rp.astype(np.int64), cl, v, x))
+    np.testing.assert_array_equal(res["2"][0], res["0"][0])
+    assert res["2"][1] == res["0"][1]
+    np.testing.assert_array_equal(res["2"][2], res["0"][2])
+    vi = res["2"][3]
+    assert res["0"][3]["form"] == "doubles" and vi["form"] == form, vi
+    if form != "doubles":
+        nd_ = np.unique(v[v != 0.0]).size + 1
+        assert vi["distinct_values"] <= nd_ and vi["distinct_values"] >= 2  # (dropped zeros and padding share code 0)
+        assert vi["bytes_per_product"] < 0.5 * vi["bytes_per_product_as_doubles"]
+        assert (vi["distinct_values"] <= 2048) == (form == "dictionary in LDS")
+
+
 def test_rccl_path_single_rank(ctx):
     """The multi-GPU code path (reduce -> ncclAllReduce -> scalar kernels, halo with no neighbour)
     on a 1-rank communicator must reproduce the single-GPU solve exactly."""
@@ -957,7 +1002,8 @@ def test_knob_combinations_keep_results(seed):
              "ZZZ_SPMV_LPR": ["1", "2", "4"], "ZZZ_COLS16": ["0", "11", "13"],
              "ZZZ_PATTERN": ["host"], "ZZZ_PATTERN_WAVE": ["1"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
              "ZZZ_ADJ_SORT": ["1"], "ZZZ_ASM_SEARCH": ["1"], "ZZZ_ASM_NO_COMPACT": ["1"],
-             "ZZZ_SELLP_WIN": ["0", "1024", "8064"], "ZZZ_MF_NC": ["256", "512"], "ZZZ_MF_T": ["128", "256"]}
+             "ZZZ_SELLP_WIN": ["0", "1024", "8064"], "ZZZ_MF_NC": ["256", "512"], "ZZZ_MF_T": ["128", "256"],
+             "ZZZ_SELLP_DICT": ["0", "2", "2"]}
     names = sorted(knobs)
     chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
     problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4)),
