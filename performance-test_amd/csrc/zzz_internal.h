@@ -259,6 +259,7 @@ struct zzz_ctx
   zzz::DevBuf<double> sp_dict;
   zzz::DevBuf<unsigned long long> sp_dict_table; // open-addressing set of the values' bit patterns (build only)
   zzz::DevBuf<int32_t> sp_dict_slot;             // table slot -> code (build only)
+  zzz::DevBuf<int32_t> sp_dict_info;             // counters of the build
   bool sp_dict_done = false, sp_dict_on = false;
   int sellp_dict = 1;       // ZZZ_SELLP_DICT=0: no value dictionary
   int sp_dict_n = 0;        // distinct values (with +0.0)

@@ -975,18 +975,22 @@ __device__ inline unsigned long long sp_value_bits(const double* __restrict__ sv
   return reinterpret_cast<const unsigned long long*>(svals)[c * 512 + at];
 }
 
-// info[0] distinct values so far, info[1] overflow / unusable
+// info[0] distinct values so far, info[1] overflow / unusable.  The lanes of a slice mostly hold the same value in a slot:
+// one lane per distinct value of the wavefront goes to the table; the table is read past the L1 cache (a line cached as
+// empty before another CU's insertion would send every later occurrence of that value to the atomic: 3.4 ms at 1.25 M rows
+// instead of 0.05).
 template <bool PERM>
 __global__ __launch_bounds__(256) void k_sp_dict_insert(const int2* __restrict__ desc, const int32_t* __restrict__ perm,
                                                          const double* __restrict__ svals, int nrows, int64_t nslices,
-                                                         unsigned long long* __restrict__ table, int* __restrict__ info)
+                                                         unsigned long long* __restrict__ table, int* __restrict__ info, int limit)
 {
   const int lane = threadIdx.x & 63;
   for (int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6); s < nslices; s += gridDim.x * 4ll)
   {
+    if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return; // more distinct values than the dictionary may hold (an unstructured mesh): nothing left to find out
     const int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
-    if (r < 0 || r >= nrows)
-      continue;
+    const bool row = r >= 0 && r < nrows;
     const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     unsigned long long last = 0ull; // (+0.0 is code 0 without the table)
@@ -995,89 +999,99 @@ __global__ __launch_bounds__(256) void k_sp_dict_insert(const int2* __restrict__
       const int w = j + 1 < nch ? 8 : wl;
       for (int e = 0; e < w; ++e)
       {
-        const unsigned long long b = sp_value_bits(svals, c0 + j, w, lane, e);
-        if (b == last || b == 0ull)
-          continue; // (a row repeats its values: the previous one is in the table already)
+        const unsigned long long b = row ? sp_value_bits(svals, c0 + j, w, lane, e) : 0ull;
+        bool need = b != last && b != 0ull; // (a row repeats its values: the previous one is in the table already)
         last = b;
-        if (b == SP_DICT_EMPTY)
+        unsigned long long todo = __ballot(need);
+        while (todo)
         {
-          info[1] = 1;
-          continue;
-        }
-        unsigned h = sp_dict_hash(b);
-        for (int probe = 0; probe < (1 << SP_DICT_BITS); ++probe)
-        {
-          const unsigned long long cur = table[h];
-          if (cur == b)
-            break;
-          if (cur == SP_DICT_EMPTY)
+          if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return; // (the waves in flight when the limit is met would fill the table up otherwise)
+          const int src = __ffsll((long long)todo) - 1;
+          const unsigned long long bb = ((unsigned long long)(unsigned)__shfl((int)(b >> 32), src) << 32)
+                                        | (unsigned)__shfl((int)(unsigned)b, src);
+          if (lane == src)
           {
-            const unsigned long long old = atomicCAS(&table[h], SP_DICT_EMPTY, b);
-            if (old == SP_DICT_EMPTY)
+            if (bb == SP_DICT_EMPTY)
+              info[1] = 1;
+            else
             {
-              if (atomicAdd(&info[0], 1) >= SP_DICT_MAX - 1)
-                info[1] = 1;
-              break;
+              unsigned h = sp_dict_hash(bb);
+              for (int probe = 0; probe < (1 << SP_DICT_BITS); ++probe)
+              {
+                const unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == bb)
+                  break;
+                if (cur == SP_DICT_EMPTY)
+                {
+                  const unsigned long long old = atomicCAS(&table[h], SP_DICT_EMPTY, bb);
+                  if (old == SP_DICT_EMPTY)
+                  {
+                    if (atomicAdd(&info[0], 1) >= limit - 1)
+                      info[1] = 1;
+                    break;
+                  }
+                  if (old == bb)
+                    break;
+                }
+                h = (h + 1) & ((1u << SP_DICT_BITS) - 1);
+                if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                  break; // too many distinct values: the table may be filling up, stop looking
+              }
             }
-            if (old == b)
-              break;
           }
-          h = (h + 1) & ((1u << SP_DICT_BITS) - 1);
-          if (info[1]) // too many distinct values: the table may be filling up, stop looking
-            break;
+          need = need && b != bb;
+          todo = __ballot(need);
         }
       }
     }
   }
 }
 
-// codes in table order: slot -> 1 + the number of occupied slots before it (one workgroup; code 0 = +0.0)
+// codes: every thread numbers the occupied slots it meets (slot = k * 1024 + thread), threads in order; code 0 = +0.0
 __global__ __launch_bounds__(1024) void k_sp_dict_number(const unsigned long long* __restrict__ table, int32_t* __restrict__ slot_code,
-                                                         double* __restrict__ dict, int* __restrict__ info)
+                                                         double* __restrict__ dict, int* __restrict__ info, int lds_max, int forced)
 {
   __shared__ int wsum[16];
-  __shared__ int base_s;
-  if (threadIdx.x == 0)
-  {
-    base_s = 1;
-    dict[0] = 0.0;
-  }
-  __syncthreads();
   if (info[1])
     return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k0 = 0; k0 < (1 << SP_DICT_BITS); k0 += 1024)
+  int mine = 0;
+  for (int k = threadIdx.x; k < (1 << SP_DICT_BITS); k += 1024)
+    mine += table[k] != SP_DICT_EMPTY ? 1 : 0;
+  // exclusive scan of `mine` over the 1024 threads
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1)
   {
-    const int k = k0 + threadIdx.x;
+    const int t = __shfl_up(incl, d);
+    if (lane >= d)
+      incl += t;
+  }
+  if (lane == 63)
+    wsum[wv] = incl;
+  __syncthreads();
+  int off = 1; // (code 0 is +0.0)
+  for (int q = 0; q < wv; ++q)
+    off += wsum[q];
+  int code = off + incl - mine;
+  for (int k = threadIdx.x; k < (1 << SP_DICT_BITS); k += 1024)
+  {
     const unsigned long long b = table[k];
-    const bool used = b != SP_DICT_EMPTY;
-    const unsigned long long m = __ballot(used);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0)
-      wsum[wv] = __popcll(m);
-    __syncthreads();
-    int off = base_s;
-    for (int q = 0; q < wv; ++q)
-      off += wsum[q];
-    if (used)
+    if (b != SP_DICT_EMPTY)
     {
-      const int code = off + before;
       slot_code[k] = code;
       if (code <= SP_DICT_MAX)
         dict[code] = __longlong_as_double((long long)b);
+      ++code;
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      int t = 0;
-      for (int q = 0; q < 16; ++q)
-        t += wsum[q];
-      base_s += t;
-    }
-    __syncthreads();
   }
-  if (threadIdx.x == 0)
-    info[2] = base_s; // entries of the dictionary, +0.0 included
+  if (threadIdx.x == 1023)
+  {
+    dict[0] = 0.0;
+    info[2] = code; // entries of the dictionary, +0.0 included
+    if (code > lds_max && !forced)
+      info[1] = 2; // too large for the LDS copy: the stream stays as doubles, the encoding pass has nothing to do
+  }
 }
 
 // the stream's values as codes, [chunk][lane][8] (16 B per lane and chunk); info[4..5]: bytes the product reads in this form
@@ -2090,19 +2104,22 @@ static int sp_dict_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->sp_dict_slot.alloc((size_t)1 << SP_DICT_BITS));
   ZZZ_HIP(ctx, ctx->sp_dict.alloc((size_t)SP_DICT_MAX + 1));
   ZZZ_HIP(ctx, ctx->sp_vcode.alloc((size_t)ctx->sp_chunks * 512));
-  DevBuf<int32_t> info;
-  ZZZ_HIP(ctx, info.alloc(8));
+  DevBuf<int32_t>& info = ctx->sp_dict_info;
+  ZZZ_HIP(ctx, info.reserve(8));
   ZZZ_HIP(ctx, hipMemsetAsync(info.p, 0, 8 * sizeof(int32_t), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_dict_table.p, 0xff, sizeof(unsigned long long) << SP_DICT_BITS, s));
   const int2* desc = reinterpret_cast<const int2*>(ctx->sp_desc.p);
   const unsigned grid = (unsigned)std::min<int64_t>((nsl + 3) / 4, 256 * 16);
+  // (the search stops at the first value beyond what will be used: the LDS copy's capacity, unless the memory form is forced)
+  const int limit = ctx->sellp_dict == 2 ? SP_DICT_MAX : SP_DICT_LDS_MAX - 1;
   if (ctx->sp_sorted)
     hipLaunchKernelGGL(k_sp_dict_insert<true>, dim3(grid), dim3(256), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, (int)ctx->nrows, nsl,
-                       ctx->sp_dict_table.p, info.p);
+                       ctx->sp_dict_table.p, info.p, limit);
   else
     hipLaunchKernelGGL(k_sp_dict_insert<false>, dim3(grid), dim3(256), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p,
-                       (int)ctx->nrows, nsl, ctx->sp_dict_table.p, info.p);
-  hipLaunchKernelGGL(k_sp_dict_number, dim3(1), dim3(1024), 0, s, ctx->sp_dict_table.p, ctx->sp_dict_slot.p, ctx->sp_dict.p, info.p);
+                       (int)ctx->nrows, nsl, ctx->sp_dict_table.p, info.p, limit);
+  hipLaunchKernelGGL(k_sp_dict_number, dim3(1), dim3(1024), 0, s, ctx->sp_dict_table.p, ctx->sp_dict_slot.p, ctx->sp_dict.p, info.p,
+                     SP_DICT_LDS_MAX, ctx->sellp_dict == 2 ? 1 : 0);
   if (ctx->sp_sorted)
     hipLaunchKernelGGL(k_sp_dict_encode<true>, dim3(grid), dim3(256), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, ctx->sp_meta.p,
                        (int)ctx->nrows, nsl, ctx->sp_dict_table.p, ctx->sp_dict_slot.p, ctx->sp_vcode.p, info.p);
@@ -2114,6 +2131,11 @@ static int sp_dict_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   if (h[1] || h[2] <= 0 || h[2] > SP_DICT_MAX + 1)
+    return ZZZ_OK;
+  // A dictionary too large for the LDS copy is gathered from memory: 2.3x fewer bytes at P3 6.2 M dofs (8 270 values) and the
+  // same 0.61-0.63 ms per product -- the gathers, not the bytes, are what the kernel waits for -- so that form is not used
+  // unless ZZZ_SELLP_DICT=2 asks for it (tests)
+  if (h[2] > SP_DICT_LDS_MAX && ctx->sellp_dict != 2)
     return ZZZ_OK;
   unsigned long long bytes = 0;
   memcpy(&bytes, h + 4, sizeof(bytes));

@@ -121,7 +121,10 @@ def hip():
         L.zzz_cg_history.argtypes = [C.c_void_p, C.c_int, _f64p]
         L.zzz_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.zzz_spmv_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
-        L.zzz_spmv_values_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        # (tools/ab_product.sh loads an older build of the library beside the current one: ZZZ_AB_OLD tolerates the entry
+        # points that build does not have yet; without it a missing symbol is an error, as everywhere)
+        if hasattr(L, "zzz_spmv_values_info") or not os.environ.get("ZZZ_AB_OLD"):
+            L.zzz_spmv_values_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.zzz_internal_order_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.zzz_comm_unique_id.argtypes = [C.c_void_p]
         L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -572,6 +575,8 @@ class Context:
         """how the operator stream holds its values: dict(form = 'doubles' | 'dictionary in memory' | 'dictionary in LDS',
         distinct values, bytes per product in that form, bytes per product as doubles)"""
         info = (C.c_int64 * 4)()
+        if os.environ.get("ZZZ_AB_OLD") and not hasattr(self.L, "zzz_spmv_values_info"):
+            return dict(form="doubles", distinct_values=0, bytes_per_product=0, bytes_per_product_as_doubles=0)
         self._ck(self.L.zzz_spmv_values_info(self.h, info))
         return dict(form=("doubles", "dictionary in memory", "dictionary in LDS")[int(info[0])], distinct_values=int(info[1]),
                     bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]))
