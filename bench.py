@@ -776,7 +776,8 @@ def main():
         }
         # one whole PCG iteration, physically: the product's bytes + the two vector kernels' (k_update_xr, k_update_p: three
         # reads and two writes of a vector each) over solve time / iterations
-        it_bytes = streamed + (96 if single_reduction else 80) * nrows
+        dinv_codes = ctx.cg_info()["dinv_codes"] > 0  # Jacobi's inverse diagonal as 16-bit codes, z recomputed: 68 B per row
+        it_bytes = streamed + (96 if single_reduction else (68 if dinv_codes else 80)) * nrows
         it_s = avg("solve") / max(iters, 1)
         out["roofline"]["iteration"] = {"what": "one whole Jacobi-PCG iteration: bytes its kernels address / (ZZZ Solve / iterations)",
                                         "bytes": it_bytes, "us": it_s * 1e6, "achieved": it_bytes / it_s / 1e9, "unit": "GB/s",

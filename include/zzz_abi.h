@@ -331,7 +331,10 @@ int zzz_cg_solve(zzz_ctx* ctx, const zzz_solver_opts* opts, int* iters, double* 
 int zzz_cg_history(zzz_ctx* ctx, int n, double* out);
 
 /* About the last zzz_cg_solve: info[0] = 1 when the iteration ran as two kernels (product fused with the
- * direction update p = z + b p, x += a p: the A/B variant ZZZ_CG_FUSED=2), 0 for the three-kernel form;
+ * direction update p = z + b p, x += a p: the A/B variant ZZZ_CG_FUSED=2), 0 for the three-kernel form; bit 1 (value 2)
+ * when Jacobi's inverse diagonal was read as 16-bit codes into a table of its distinct values and z = D^-1 r recomputed
+ * instead of stored (68 instead of 80 B per row and iteration in the two vector kernels; the same bits), info[0] >> 8 = those
+ * distinct values;
  * info[1] = its iteration count (same iterates, bit for bit, either way); info[2] = how it ended, in
  * KSPConvergedReason's numbering: 2 KSP_CONVERGED_RTOL, 3 KSP_CONVERGED_ATOL, -3 KSP_DIVERGED_ITS (max_it / kmax
  * reached), -4 KSP_DIVERGED_DTOL, -9 KSP_DIVERGED_NANORINF; info[3] = with ZZZ_PC_CHEBYSHEV_JACOBI the upper bound of

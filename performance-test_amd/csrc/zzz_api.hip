@@ -142,6 +142,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_drop = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_DICT"))
     ctx->sellp_dict = atoi(e);
+  if (const char* e = getenv("ZZZ_CG_DINV_CODES"))
+    ctx->cg_dinv_codes = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_AFFINE")) // 0: no code-free chunks (column = slot base + lane); A/B knob
     if (atoi(e) == 0)
       ctx->sellp_tail |= 2;
@@ -996,7 +998,7 @@ int zzz_cg_info(zzz_ctx* ctx, int64_t info[4])
 {
   if (!ctx || !info)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_cg_info: bad arguments");
-  info[0] = ctx->last_solve_fused ? 1 : 0;
+  info[0] = (ctx->last_solve_fused ? 1 : 0) | (ctx->last_solve_dinv_codes > 0 ? 2 : 0) | ((int64_t)ctx->last_solve_dinv_codes << 8);
   info[1] = ctx->last_iters;
   info[2] = ctx->last_reason;
   info[3] = (int64_t)(ctx->last_pc_bound * 1.0e6); // Chebyshev-Jacobi: spectrum bound x 1e6

@@ -92,6 +92,127 @@ __global__ void k_extract_dinv(const rp_t* __restrict__ rowptr, const int32_t* _
   }
 }
 
+// ---- the inverse diagonal as 16-bit codes (DinvCodes below): distinct values of d[0..n) into a small open-addressing set
+constexpr int DD_BITS = 14; // 16 384 slots for at most DZ_MAX = 2 048 values
+constexpr unsigned long long DD_EMPTY = ~0ull;
+__device__ inline unsigned dd_hash(unsigned long long b)
+{
+  b ^= b >> 29;
+  b *= 0x9E3779B97F4A7C15ull;
+  return (unsigned)(b >> (64 - DD_BITS));
+}
+// info[0] distinct values, info[1] too many (or a value with the bit pattern of the empty marker)
+__global__ __launch_bounds__(256) void k_dd_insert(const double* __restrict__ d, int64_t n, unsigned long long* __restrict__ table,
+                                                   int* __restrict__ info, int limit)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t span = (n + 63) & ~(int64_t)63;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < span; i += gridDim.x * 256ll)
+  {
+    if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return;
+    const bool have = i < n;
+    const unsigned long long b = have ? (unsigned long long)__double_as_longlong(d[i]) : 0ull;
+    bool need = have;
+    unsigned long long todo = __ballot(need);
+    while (todo) // one lane per distinct value of the wavefront goes to the table
+    {
+      const int src = __ffsll((long long)todo) - 1;
+      const unsigned long long bb = ((unsigned long long)(unsigned)__shfl((int)(b >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)b, src);
+      if (lane == src)
+      {
+        if (bb == DD_EMPTY)
+          info[1] = 1;
+        else
+        {
+          unsigned h = dd_hash(bb);
+          for (int probe = 0; probe < (1 << DD_BITS); ++probe)
+          {
+            const unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == bb)
+              break;
+            if (cur == DD_EMPTY)
+            {
+              const unsigned long long old = atomicCAS(&table[h], DD_EMPTY, bb);
+              if (old == DD_EMPTY)
+              {
+                if (atomicAdd(&info[0], 1) >= limit)
+                  info[1] = 1;
+                break;
+              }
+              if (old == bb)
+                break;
+            }
+            h = (h + 1) & ((1u << DD_BITS) - 1);
+          }
+        }
+      }
+      need = need && b != bb;
+      todo = __ballot(need);
+      if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        return;
+    }
+  }
+}
+// codes in slot order (one workgroup); dict[code] = value
+__global__ __launch_bounds__(1024) void k_dd_number(const unsigned long long* __restrict__ table, int32_t* __restrict__ slot_code,
+                                                    double* __restrict__ dict, int* __restrict__ info)
+{
+  __shared__ int wsum[16];
+  if (info[1])
+    return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int mine = 0;
+  for (int k = threadIdx.x; k < (1 << DD_BITS); k += 1024)
+    mine += table[k] != DD_EMPTY ? 1 : 0;
+  int incl = mine;
+  for (int dd = 1; dd < 64; dd <<= 1)
+  {
+    const int t = __shfl_up(incl, dd);
+    if (lane >= dd)
+      incl += t;
+  }
+  if (lane == 63)
+    wsum[wv] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int q = 0; q < wv; ++q)
+    off += wsum[q];
+  int code = off + incl - mine;
+  for (int k = threadIdx.x; k < (1 << DD_BITS); k += 1024)
+  {
+    const unsigned long long b = table[k];
+    if (b != DD_EMPTY)
+    {
+      slot_code[k] = code;
+      dict[code] = __longlong_as_double((long long)b);
+      ++code;
+    }
+  }
+  if (threadIdx.x == 1023)
+    info[2] = code;
+}
+__global__ __launch_bounds__(256) void k_dd_encode(const double* __restrict__ d, int64_t n, int64_t npad,
+                                                   const unsigned long long* __restrict__ table, const int32_t* __restrict__ slot_code,
+                                                   uint16_t* __restrict__ codes, const int* __restrict__ info)
+{
+  if (info[1])
+    return;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < npad; i += gridDim.x * 256ll)
+  {
+    uint16_t c = 0;
+    if (i < n)
+    {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(d[i]);
+      unsigned h = dd_hash(b);
+      while (table[h] != b)
+        h = (h + 1) & ((1u << DD_BITS) - 1);
+      c = (uint16_t)slot_code[h];
+    }
+    codes[i] = c;
+  }
+}
+
 // r = b - w (w = A x0, or nothing when x0 == 0); z = dinv r; partials: pa = <r,z>, pb = test norm^2
 __global__ __launch_bounds__(VB) void k_init_residual(const double* __restrict__ b, const double* __restrict__ w,
                                                       const double* __restrict__ dinv, double* __restrict__ r,
@@ -135,15 +256,35 @@ __device__ inline int block_flag(int f)
 // anyway) instead of in k_update_xr: one vector read less per iteration, same operations on the same
 // operands, so x is bit-identical.  It must be applied by the launch that detects convergence too; only
 // launches enqueued after that one skip it (conv_it1).  update_dir == 0: the final test after max_it.
-template <bool NT>
+// DZ (round 4): no z vector.  Jacobi's inverse diagonal holds few distinct values on a regular mesh (a subset of the
+// matrix's: section 3 of DESIGN.md); as 16-bit codes into a table in LDS it costs 2 B per row instead of 8, and with it
+// z = D^-1 r is cheaper to RECOMPUTE here from r (the same product of the same two doubles: the same bits) than to
+// write in k_update_xr and read back: 80 -> 68 B per row and iteration for the two kernels.  dz.codes = nullptr: off.
+struct DinvCodes
+{
+  const uint32_t* codes; // two 16-bit codes per word, entry pairs as the dbl2 accesses take them
+  const double* dict;
+  const double* r;
+  int ndict;
+};
+constexpr int DZ_MAX = 2048;
+
+template <bool NT, bool DZ = false>
 __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, double* __restrict__ beta_hist,
                                                  double* __restrict__ dp_hist, const double* __restrict__ alpha_hist,
                                                  int it, CgParams P, const double* __restrict__ pa,
                                                  const double* __restrict__ pb, int np, const double* __restrict__ z,
                                                  double* __restrict__ p, double* __restrict__ x, int64_t n,
-                                                 int update_dir)
+                                                 int update_dir, DinvCodes dz = DinvCodes())
 {
   __shared__ double sh[VB / 64];
+  __shared__ double dtab[DZ ? DZ_MAX : 1];
+  if (DZ)
+  {
+    for (int k = threadIdx.x; k < dz.ndict; k += VB)
+      dtab[k] = dz.dict[k];
+    __syncthreads();
+  }
   // The first entries of this thread are requested BEFORE the scalar prologue (flag, partial sums, convergence logic: a
   // chain of dependent loads and barriers of 3-5 us that every workgroup walks): at the 8-GPU per-rank size a thread
   // has one or two entries in all, so the kernel was prologue + one memory round trip in sequence (11-12 us for 50 MB
@@ -152,14 +293,17 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
   const int64_t i0 = blockIdx.x * (int64_t)VB + threadIdx.x;
   dbl2* __restrict__ p2 = reinterpret_cast<dbl2*>(p);
   dbl2* __restrict__ x2 = reinterpret_cast<dbl2*>(x);
-  const dbl2* __restrict__ z2 = reinterpret_cast<const dbl2*>(z);
+  const dbl2* __restrict__ z2 = reinterpret_cast<const dbl2*>(DZ ? dz.r : z);
   const int64_t c0 = (i0 < n2) ? i0 : 0;
   dbl2 pi0 = {0, 0}, xi0 = {0, 0}, zi0 = {0, 0};
+  uint32_t dc0 = 0;
   if (n2 > 0)
   {
     pi0 = p2[c0];
     xi0 = vload<NT>(x2 + c0);
-    zi0 = vload<NT>(z2 + c0);
+    zi0 = vload<NT>(z2 + c0); // DZ: r
+    if (DZ)
+      dc0 = dz.codes[c0];
   }
   const double alpha_h = it > 0 ? alpha_hist[it - 1] : 0.0; // requested with the rest of the prologue's inputs
   DirScalars S;
@@ -172,7 +316,7 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
   {
     if (dir)
       for (int64_t i = blockIdx.x * (int64_t)VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
-        p[i] = z[i];
+        p[i] = DZ ? dtab[reinterpret_cast<const uint16_t*>(dz.codes)[i]] * dz.r[i] : z[i];
     return;
   }
   const double alpha = alpha_h;
@@ -193,6 +337,12 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
       xi = vload<NT>(x2 + i);
       zi = vload<NT>(z2 + i);
     }
+    if (DZ)
+    {
+      const uint32_t dc = i == i0 ? dc0 : dz.codes[i];
+      zi.x = dtab[dc & 0xffffu] * zi.x; // z = D^-1 r, as k_update_xr formed it for its sums
+      zi.y = dtab[dc >> 16] * zi.y;
+    }
     xi.x = alpha * pi.x + xi.x; // src/cg.h:68, one kernel late
     xi.y = alpha * pi.y + xi.y;
     vstore<NT>(xi, x2 + i);
@@ -210,19 +360,26 @@ __global__ __launch_bounds__(VB) void k_update_p(CgState* __restrict__ st, doubl
     const double pi = p[i];
     x[i] = alpha * pi + x[i];
     if (dir)
-      p[i] = bcoef * pi + z[i];
+      p[i] = bcoef * pi + (DZ ? dtab[reinterpret_cast<const uint16_t*>(dz.codes)[i]] * dz.r[i] : z[i]);
   }
 }
 
-template <bool NT>
+template <bool NT, bool DZ = false>
 __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, const double* __restrict__ beta_hist,
                                                   double* __restrict__ alpha_hist, int it,
                                                   const double* __restrict__ pw_parts, int npw,
                                                   const double* __restrict__ w, const double* __restrict__ dinv,
                                                   double* __restrict__ r, double* __restrict__ z, int64_t n, int norm,
                                                   double* __restrict__ pa, double* __restrict__ pb, int variant,
-                                                  TailArgs tail)
+                                                  TailArgs tail, DinvCodes dz = DinvCodes())
 {
+  __shared__ double dtab[DZ ? DZ_MAX : 1];
+  if (DZ)
+  {
+    for (int k = threadIdx.x; k < dz.ndict; k += VB)
+      dtab[k] = dz.dict[k];
+    __syncthreads();
+  }
   // first entries requested before the scalar prologue (see k_update_p)
   const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * VB;
   const int64_t i0 = blockIdx.x * (int64_t)VB + threadIdx.x;
@@ -232,11 +389,15 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   dbl2* __restrict__ z2 = reinterpret_cast<dbl2*>(z);
   const int64_t c0 = (i0 < n2) ? i0 : 0;
   dbl2 wi0 = {0, 0}, di0 = {0, 0}, ri0 = {0, 0};
+  uint32_t dc0 = 0;
   // (the scalar inputs of the prologue are requested in the same breath, below: flag, beta, <p,w>)
   if (n2 > 0)
   {
     wi0 = vload<NT>(w2 + c0); // last use of w
-    di0 = vload<NT>(d2 + c0);
+    if (DZ)
+      dc0 = dz.codes[c0];
+    else
+      di0 = vload<NT>(d2 + c0);
     ri0 = vload<NT>(r2 + c0); // r and D^-1 are touched once per iteration
   }
   const int f0 = st->converged;
@@ -274,15 +435,27 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
     else
     {
       wi = vload<NT>(w2 + i);
-      di = vload<NT>(d2 + i);
+      if (!DZ)
+        di = vload<NT>(d2 + i);
       ri = vload<NT>(r2 + i);
+    }
+    if (DZ)
+    {
+      const uint32_t dc = i == i0 ? dc0 : dz.codes[i];
+      di.x = dtab[dc & 0xffffu];
+      di.y = dtab[dc >> 16];
     }
     ri.x = -alpha * wi.x + ri.x; // src/cg.h:71
     ri.y = -alpha * wi.y + ri.y;
     zi.x = di.x * ri.x;
     zi.y = di.y * ri.y;
-    vstore<NT>(ri, r2 + i);
-    z2[i] = zi;
+    if (DZ)
+      r2[i] = ri; // (read again by k_update_p: left in the cache)
+    else
+    {
+      vstore<NT>(ri, r2 + i);
+      z2[i] = zi;
+    }
     sa += ri.x * zi.x;
     sa += ri.y * zi.y;
     if (norm == ZZZ_NORM_UNPRECONDITIONED)
@@ -300,9 +473,10 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
   {
     const int64_t i = n - 1;
     const double ri = -alpha * w[i] + r[i];
-    const double zi = dinv[i] * ri;
+    const double zi = (DZ ? dtab[reinterpret_cast<const uint16_t*>(dz.codes)[i]] : dinv[i]) * ri;
     r[i] = ri;
-    z[i] = zi;
+    if (!DZ)
+      z[i] = zi;
     sa += ri * zi;
     sb += (norm == ZZZ_NORM_UNPRECONDITIONED) ? ri * ri : zi * zi;
   }
@@ -632,8 +806,9 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   const int g = vgrid(n);
   hipStream_t s = ctx->stream;
   const bool nt = loop_exceeds_cache(ctx, 6);
-  auto kern_update_p = nt ? k_update_p<true> : k_update_p<false>;
-  auto kern_update_xr = nt ? k_update_xr<true> : k_update_xr<false>;
+  // (kernels by load policy and by whether z is recomputed from the coded inverse diagonal: chosen where dz is known)
+  auto pick_update_p = [&](bool dzf) { return dzf ? (nt ? k_update_p<true, true> : k_update_p<false, true>) : (nt ? k_update_p<true, false> : k_update_p<false, false>); };
+  auto pick_update_xr = [&](bool dzf) { return dzf ? (nt ? k_update_xr<true, true> : k_update_xr<false, true>) : (nt ? k_update_xr<true, false> : k_update_xr<false, false>); };
   // A/B knob ZZZ_CG_FUSED=2: two kernels per iteration (product fused with the direction update, zzz_sellp.hip).
   // Bit-identical, but MEASURED slower wherever it was tried: at the 8-GPU per-rank size (1.25 M rows, loop resident
   // in the Infinity Cache) the fused kernel takes 39-41 us against 14.7 + 19.6 us for k_update_p + product (the
@@ -672,6 +847,36 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   else
     hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, (const rp_t*)nullptr, (const int32_t*)nullptr,
                        (const double*)nullptr, ctx->dinv.p, n, 0);
+
+  // Jacobi's inverse diagonal as 16-bit codes and no z vector (DinvCodes, k_update_p): KSPCG + PCJACOBI, vectors too large for
+  // the Infinity Cache to make their bytes irrelevant (ZZZ_CG_DINV_CODES: 0 never, 2 at any size), at most 2 048 values
+  DinvCodes dzc{nullptr, nullptr, nullptr, 0};
+  if (o->variant == ZZZ_CG_PETSC && o->pc == ZZZ_PC_JACOBI && !fused && ctx->cg_dinv_codes != 0
+      && (ctx->cg_dinv_codes == 2 || n * 8 >= (32ll << 20)))
+  {
+    const int64_t npad = (n + 1) & ~(int64_t)1;
+    ZZZ_HIP(ctx, ctx->dd_table.reserve((size_t)1 << DD_BITS));
+    ZZZ_HIP(ctx, ctx->dd_slot.reserve((size_t)1 << DD_BITS));
+    ZZZ_HIP(ctx, ctx->dd_dict.reserve((size_t)DZ_MAX));
+    ZZZ_HIP(ctx, ctx->dd_codes.reserve((size_t)npad));
+    ZZZ_HIP(ctx, ctx->dd_info.reserve(8));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->dd_info.p, 0, 8 * sizeof(int32_t), s));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->dd_table.p, 0xff, sizeof(unsigned long long) << DD_BITS, s));
+    const unsigned gd = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_dd_insert, dim3(gd), dim3(256), 0, s, ctx->dinv.p, n, ctx->dd_table.p, ctx->dd_info.p, DZ_MAX);
+    hipLaunchKernelGGL(k_dd_number, dim3(1), dim3(1024), 0, s, ctx->dd_table.p, ctx->dd_slot.p, ctx->dd_dict.p, ctx->dd_info.p);
+    hipLaunchKernelGGL(k_dd_encode, dim3(gd), dim3(256), 0, s, ctx->dinv.p, n, npad, ctx->dd_table.p, ctx->dd_slot.p, ctx->dd_codes.p,
+                       ctx->dd_info.p);
+    int32_t h[4] = {0, 1, 0, 0};
+    ZZZ_HIP(ctx, hipMemcpyAsync(h, ctx->dd_info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    if (!h[1] && h[2] > 0 && h[2] <= DZ_MAX)
+      dzc = DinvCodes{reinterpret_cast<const uint32_t*>(ctx->dd_codes.p), ctx->dd_dict.p, ctx->r.p, h[2]};
+  }
+  ctx->last_solve_dinv_codes = dzc.codes ? dzc.ndict : 0;
+  const bool dz = dzc.codes != nullptr;
+  auto kern_update_p = pick_update_p(dz);
+  auto kern_update_xr = pick_update_xr(dz);
 
   auto apply = [&](double* x, double* y, double* parts, int* np) -> int {
     // partitioned CSR operator: halo of x overlapped with the interior tiles
@@ -752,7 +957,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     // convergence test of iteration `it` and the new search direction
     if (!fused)
       hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
-                         ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1);
+                         ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, ctx->p.p, ctx->u.p, n, 1, dzc);
     int np = 0;
     const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
     ctx->prof_now = timed;
@@ -801,7 +1006,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
       Txr.base = 0;
     }
     hipLaunchKernelGGL(kern_update_xr, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->alpha_hist.p, it, pw_src,
-                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb, P.variant, Txr);
+                       np, ctx->w.p, ctx->dinv.p, ctx->r.p, ctx->z.p, n, P.norm, pa, pb, P.variant, Txr, dzc);
     if (!folded_xr)
     {
       int rc = allreduce_beta();
@@ -826,7 +1031,7 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   // the test of the last completed iteration (it == max_it when the loop ran out) and its pending
   // solution update; no new direction
   hipLaunchKernelGGL(kern_update_p, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dp_hist.p,
-                     ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, pbuf[it & 1], ctx->u.p, n, 0);
+                     ctx->alpha_hist.p, it, P, rz_src, nn_src, n_rz, ctx->z.p, pbuf[it & 1], ctx->u.p, n, 0, dzc);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));

@@ -262,6 +262,13 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> sp_dict_info;             // counters of the build
   bool sp_dict_done = false, sp_dict_on = false;
   int sellp_dict = 1;       // ZZZ_SELLP_DICT=0: no value dictionary
+  // Jacobi's inverse diagonal as 16-bit codes (zzz_cg.hip, DinvCodes)
+  zzz::DevBuf<unsigned long long> dd_table;
+  zzz::DevBuf<int32_t> dd_slot, dd_info;
+  zzz::DevBuf<double> dd_dict;
+  zzz::DevBuf<uint16_t> dd_codes;
+  int cg_dinv_codes = 1;          // ZZZ_CG_DINV_CODES: 0 never, 1 for vectors of 32 MB and more, 2 always
+  int last_solve_dinv_codes = 0;  // distinct values of the inverse diagonal when the last solve ran on codes, else 0
   int sp_dict_n = 0;        // distinct values (with +0.0)
   int64_t sp_dict_bytes = 0; // bytes a product reads from the stream in dictionary form
   bool sp_sorted = false;    // rows ordered by length inside windows (SELL-C-sigma)

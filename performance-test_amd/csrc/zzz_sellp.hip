@@ -2168,6 +2168,10 @@ int64_t sellp_stream_bytes(const zzz_ctx* ctx)
 static int sp_grid(int64_t ngroups)
 {
   int64_t gs = 256 * 8; // (1024 or 1536 workgroups at the per-rank size: no faster)
+#ifdef ZZZ_EXPERIMENTS
+  if (const char* e = getenv("ZZZ_SP_WGS_PER_CU")) // how the product's time depends on the wavefronts in flight
+    gs = 256 * std::max(1, std::min(8, atoi(e)));
+#endif
   const int64_t need = (ngroups + 7) / 8 * 8;
   if (gs > need)
     gs = need;

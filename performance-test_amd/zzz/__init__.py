@@ -620,7 +620,8 @@ class Context:
     def cg_info(self):
         info = (C.c_int64 * 4)()
         self._ck(self.L.zzz_cg_info(self.h, info))
-        return {"fused": bool(info[0]), "reason": int(info[2]), "pc_spectrum_bound": info[3] * 1.0e-6}
+        return {"fused": bool(info[0] & 1), "dinv_codes": int(info[0] >> 8) if info[0] & 2 else 0, "reason": int(info[2]),
+                "pc_spectrum_bound": info[3] * 1.0e-6}
 
     def profile(self):
         ms, n = C.c_double(), C.c_int64()

@@ -516,6 +516,42 @@ def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
         assert (vi["distinct_values"] <= 2048) == (form == "dictionary in LDS")
 
 
+@pytest.mark.parametrize("problem,order,dims", [("poisson", 1, (20, 18, 19)), ("elasticity", 1, (8, 7, 9)), ("poisson", 3, (5, 4, 6))])
+def test_inverse_diagonal_as_codes_keeps_every_bit(problem, order, dims):
+    """KSPCG + PCJACOBI with Jacobi's inverse diagonal read as 16-bit codes into a table of its distinct values and
+    z = D^-1 r recomputed where it is used instead of stored (ZZZ_CG_DINV_CODES; default for vectors of 32 MB and more):
+    the same doubles multiplied in the same places -- iteration count, residual norms and solution identical bit for bit
+    to the run on the plain array; an odd number of rows and a partitioned run (all-reduced scalars) included."""
+    P = zzz.Part(problem, order, *dims)
+    res = {}
+    old = os.environ.get("ZZZ_CG_DINV_CODES")
+    try:
+        for knob in ("0", "2"):
+            os.environ["ZZZ_CG_DINV_CODES"] = knob
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                out = []
+                for norm in (zzz.NORM_PRECONDITIONED, zzz.NORM_UNPRECONDITIONED, zzz.NORM_NATURAL):
+                    it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, norm=norm, rtol=1e-9)
+                    out.append((it, rn, r0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"]))
+                # what does not take the coded path says so in cg_info and still works
+                itn, _, _ = c.cg_solve(pc=zzz.PC_NONE, rtol=1e-9)
+                out.append((itn, 0.0, 0.0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"]))
+                res[knob] = out
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_CG_DINV_CODES", None)
+        else:
+            os.environ["ZZZ_CG_DINV_CODES"] = old
+    for a, b in zip(res["0"], res["2"]):
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3])
+    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res["2"][:3]) and res["2"][3][4] == 0
+
+
 def test_rccl_path_single_rank(ctx):
     """The multi-GPU code path (reduce -> ncclAllReduce -> scalar kernels, halo with no neighbour)
     on a 1-rank communicator must reproduce the single-GPU solve exactly."""
@@ -1003,7 +1039,7 @@ def test_knob_combinations_keep_results(seed):
              "ZZZ_PATTERN": ["host"], "ZZZ_PATTERN_WAVE": ["1"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
              "ZZZ_ADJ_SORT": ["1"], "ZZZ_ASM_SEARCH": ["1"], "ZZZ_ASM_NO_COMPACT": ["1"],
              "ZZZ_SELLP_WIN": ["0", "1024", "8064"], "ZZZ_MF_NC": ["256", "512"], "ZZZ_MF_T": ["128", "256"],
-             "ZZZ_SELLP_DICT": ["0", "2", "2"]}
+             "ZZZ_SELLP_DICT": ["0", "2", "2"], "ZZZ_CG_DINV_CODES": ["0", "2", "2"]}
     names = sorted(knobs)
     chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
     problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4)),
