@@ -848,11 +848,11 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
     hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, (const rp_t*)nullptr, (const int32_t*)nullptr,
                        (const double*)nullptr, ctx->dinv.p, n, 0);
 
-  // Jacobi's inverse diagonal as 16-bit codes and no z vector (DinvCodes, k_update_p): KSPCG + PCJACOBI, vectors too large for
-  // the Infinity Cache to make their bytes irrelevant (ZZZ_CG_DINV_CODES: 0 never, 2 at any size), at most 2 048 values
+  // Jacobi's inverse diagonal as 16-bit codes and no z vector (DinvCodes, k_update_p): KSPCG + PCJACOBI, a loop too large for
+  // the Infinity Cache (where bytes are what the vector kernels wait for: the criterion of their load policy;
+  // ZZZ_CG_DINV_CODES: 0 never, 2 at any size), at most 2 048 values
   DinvCodes dzc{nullptr, nullptr, nullptr, 0};
-  if (o->variant == ZZZ_CG_PETSC && o->pc == ZZZ_PC_JACOBI && !fused && ctx->cg_dinv_codes != 0
-      && (ctx->cg_dinv_codes == 2 || n * 8 >= (32ll << 20)))
+  if (o->variant == ZZZ_CG_PETSC && o->pc == ZZZ_PC_JACOBI && !fused && ctx->cg_dinv_codes != 0 && (ctx->cg_dinv_codes == 2 || nt))
   {
     const int64_t npad = (n + 1) & ~(int64_t)1;
     ZZZ_HIP(ctx, ctx->dd_table.reserve((size_t)1 << DD_BITS));

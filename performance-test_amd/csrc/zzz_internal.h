@@ -267,7 +267,7 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> dd_slot, dd_info;
   zzz::DevBuf<double> dd_dict;
   zzz::DevBuf<uint16_t> dd_codes;
-  int cg_dinv_codes = 1;          // ZZZ_CG_DINV_CODES: 0 never, 1 for vectors of 32 MB and more, 2 always
+  int cg_dinv_codes = 1;          // ZZZ_CG_DINV_CODES: 0 never, 1 when the CG loop exceeds the Infinity Cache, 2 always
   int last_solve_dinv_codes = 0;  // distinct values of the inverse diagonal when the last solve ran on codes, else 0
   int sp_dict_n = 0;        // distinct values (with +0.0)
   int64_t sp_dict_bytes = 0; // bytes a product reads from the stream in dictionary form
