@@ -552,6 +552,27 @@ def test_inverse_diagonal_as_codes_keeps_every_bit(problem, order, dims):
     assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res["2"][:3]) and res["2"][3][4] == 0
 
 
+@pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (10, 9, 12), 2), ("poisson", 3, (3, 3, 6), 3),
+                                                       ("elasticity", 1, (5, 5, 8), 2)])
+def test_partitioned_solve_with_coded_values(problem, order, dims, nparts):
+    """The partitioned solve (ghost columns, interior / boundary groups of the halo overlap, all-reduced scalars, the
+    single-reduction form) with the stream's values and Jacobi's inverse diagonal as codes at sizes where the defaults would
+    not switch them on: every assertion of test_partitioned_solve_on_one_gpu, and of the Chebyshev-Jacobi one, holds."""
+    saved = {k: os.environ.get(k) for k in ("ZZZ_SELLP_DICT", "ZZZ_CG_DINV_CODES")}
+    try:
+        os.environ["ZZZ_SELLP_DICT"] = "2"
+        os.environ["ZZZ_CG_DINV_CODES"] = "2"
+        test_partitioned_solve_on_one_gpu(problem, order, dims, nparts, False)
+        if problem == "poisson" and order == 1:
+            test_chebyshev_jacobi_partitioned_on_one_gpu(problem, order, dims, nparts, False)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_rccl_path_single_rank(ctx):
     """The multi-GPU code path (reduce -> ncclAllReduce -> scalar kernels, halo with no neighbour)
     on a 1-rank communicator must reproduce the single-GPU solve exactly."""
