@@ -496,6 +496,9 @@ def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
                 y = c.spmv(x)
                 it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
                 res[knob] = (y, it, c.vec_download(zzz.VEC_U), c.spmv_values_info(), c.csr_download(), c.spmv_info_raw()[5])
+                # new values on the same pattern (MatSetValues + assembly again): the dictionary follows them
+                c.csr_upload_values(2.0 * res[knob][4][2])
+                np.testing.assert_array_equal(c.spmv(x), 2.0 * y)
     finally:
         if old is None:
             os.environ.pop("ZZZ_SELLP_DICT", None)
