@@ -261,7 +261,8 @@ def run_other_config(name, steps=3, unstructured=None):
             "product_ms": spmv_ms, "product_launches_timed": spmv_n, "product_bytes_per_launch": bytes_pl,
             "product_GBs": phys, "roofline_frac": phys / HBM_PEAK_GBS,
             "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")
-                         + (f", values as codes into a {values['form']} of {values['distinct_values']} distinct values"
+                         + (", values as 16-bit codes into per-slice dictionaries" if values["form"] == "slice dictionaries" else
+                            f", values as codes into a {values['form']} of {values['distinct_values']} distinct values"
                             if values["form"] != "doubles" else "")) if sinfo[5] else "CSR tile kernel",
             **extra}
 
@@ -794,7 +795,10 @@ def main():
                                               f"dropped, chunks of 8 padded), {sinfo[6]} B per product")
             vi = ctx.spmv_values_info()
             out["config"]["spmv_values"] = vi
-            if vi["form"] != "doubles":
+            if vi["form"] == "slice dictionaries":
+                out["config"]["spmv_operator"] += ("; values as 16-bit codes into per-slice dictionaries (bit-identical products; as doubles "
+                                                   f"the stream would be {vi['bytes_per_product_as_doubles']} B per product)")
+            elif vi["form"] != "doubles":
                 out["config"]["spmv_operator"] += (f"; values as 16-bit codes into a {vi['form']} of the matrix's "
                                                    f"{vi['distinct_values']} distinct values (bit-identical products; as doubles the "
                                                    f"stream would be {vi['bytes_per_product_as_doubles']} B per product)")

@@ -975,7 +975,7 @@ int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4])
   info[0] = info[1] = info[2] = info[3] = 0;
   if (!sellp_active(ctx))
     return ZZZ_OK;
-  info[0] = ctx->sp_dict_on ? (ctx->sp_dict_n <= zzz::SP_DICT_LDS_ENTRIES ? 2 : 1) : 0;
+  info[0] = ctx->sp_sd_on ? 3 : (ctx->sp_dict_on ? (ctx->sp_dict_n <= zzz::SP_DICT_LDS_ENTRIES ? 2 : 1) : 0);
   info[1] = ctx->sp_dict_on ? ctx->sp_dict_n : 0;
   info[2] = sellp_stream_bytes(ctx);
   info[3] = ctx->sp_bytes + ctx->nslices * 8;

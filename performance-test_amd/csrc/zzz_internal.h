@@ -260,6 +260,12 @@ struct zzz_ctx
   zzz::DevBuf<unsigned long long> sp_dict_table; // open-addressing set of the values' bit patterns (build only)
   zzz::DevBuf<int32_t> sp_dict_slot;             // table slot -> code (build only)
   zzz::DevBuf<int32_t> sp_dict_info;             // counters of the build
+  // per-slice dictionaries (long rows: k_sp_sd_build): 16-bit codes [chunk][lane][8], tables [slice][1024], entries per slice
+  zzz::DevBuf<uint16_t> sp_vcode8;
+  zzz::DevBuf<double> sp_sd_vals;
+  zzz::DevBuf<int32_t> sp_sd_info;
+  bool sp_sd_on = false;
+  int64_t sp_sd_bytes = 0;
   bool sp_dict_done = false, sp_dict_on = false;
   int sellp_dict = 1;       // ZZZ_SELLP_DICT=0: no value dictionary
   // Jacobi's inverse diagonal as 16-bit codes (zzz_cg.hip, DinvCodes)

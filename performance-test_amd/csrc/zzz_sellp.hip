@@ -1167,6 +1167,154 @@ __global__ __launch_bounds__(256) void k_sp_dict_encode(const int2* __restrict__
     atomicAdd(reinterpret_cast<unsigned long long*>(info + 4), bytes);
 }
 
+// ---- per-slice value dictionaries (long rows: P3) ----------------------------------------------------------------
+// A slice of 64 rows of one entity type holds a few hundred distinct values even where the whole matrix holds thousands
+// (P3 at 30^3 sub-cubes: median 296 per slice, all slices below 1 024; 7 400 in the matrix; 8 270 at 61^3).  One wavefront
+// per slice: the slice's distinct values into a hash set in LDS (at most 1 023 besides +0.0), numbered as they arrive; then
+// every value of the slice as a 16-bit code in the layout of the matrix-wide dictionary's codes ([chunk][lane][8], 16 B per
+// lane and chunk), and the table beside it (sd_vals[slice][1024], sd_info[slice] = entries, 0 = this slice stays doubles).
+// The product copies a slice's table into its wavefront's part of LDS (8 KiB per wavefront: five workgroups per CU).
+// Tried: 8-bit codes and tables of 256 (a third of P3's slices qualify: product 0.67 -> 0.54 ms at 6.2 M dofs), tables of 512
+// (0.46 ms there, 4.19 ms at 49.8 M dofs), tables of 1 024 (0.47 / 3.68 ms: kept).
+constexpr int SD_SLOTS = 2048, SD_MAX = 1024;
+template <bool PERM>
+__global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ desc, const int32_t* __restrict__ perm,
+                                                      const double* __restrict__ svals, const int32_t* __restrict__ meta,
+                                                      int nrows, int64_t nslices, uint16_t* __restrict__ vcode8,
+                                                      double* __restrict__ sd_vals, int32_t* __restrict__ sd_info,
+                                                      unsigned long long* __restrict__ bytes_out)
+{
+  __shared__ unsigned long long keys_s[2][SD_SLOTS];
+  __shared__ uint16_t code_s[2][SD_SLOTS];
+  __shared__ int cnt_s[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long* const keys = keys_s[wv];
+  uint16_t* const codes = code_s[wv];
+  unsigned long long bytes = 0;
+  for (int64_t s = blockIdx.x * 2ll + wv; s < nslices; s += gridDim.x * 2ll)
+  {
+    for (int k = lane; k < SD_SLOTS; k += 64)
+      keys[k] = ~0ull;
+    if (lane == 0)
+      cnt_s[wv] = 1; // (entry 0 is +0.0)
+    __builtin_amdgcn_wave_barrier();
+    const int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
+    const bool row = r >= 0 && r < nrows;
+    const int2 ds = desc[s];
+    const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
+    double* const tab = sd_vals + s * SD_MAX;
+    if (lane == 0)
+      tab[0] = 0.0;
+    unsigned long long last = 0ull;
+    for (int j = 0; j < nch; ++j)
+    {
+      if (cnt_s[wv] > SD_MAX)
+        break; // (more values than the table holds: this slice stays doubles)
+      const int w = j + 1 < nch ? 8 : wl;
+      for (int e = 0; e < w; ++e)
+      {
+        const unsigned long long b = row ? sp_value_bits(svals, c0 + j, w, lane, e) : 0ull;
+        if (b != 0ull && b != last && b != ~0ull)
+        {
+          unsigned h = sp_dict_hash(b) & (SD_SLOTS - 1);
+          for (int probe = 0; probe < SD_SLOTS; ++probe)
+          {
+            const unsigned long long cur = keys[h];
+            if (cur == b)
+              break;
+            if (cur == ~0ull)
+            {
+              const unsigned long long old = atomicCAS(&keys[h], ~0ull, b);
+              if (old == ~0ull)
+              {
+                const int c = atomicAdd(&cnt_s[wv], 1);
+                codes[h] = (uint16_t)c;
+                if (c < SD_MAX)
+                  tab[c] = __longlong_as_double((long long)b);
+                break;
+              }
+              if (old == b)
+                break;
+            }
+            h = (h + 1) & (SD_SLOTS - 1);
+            if (cnt_s[wv] > SD_MAX)
+              break;
+          }
+        }
+        if (b == ~0ull)
+          cnt_s[wv] = SD_MAX + 1;
+        last = b;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n = cnt_s[wv];
+    const bool ok = n <= SD_MAX;
+    if (lane == 0)
+      sd_info[s] = ok ? n : 0;
+    if (ok)
+    {
+      last = 0ull;
+      unsigned last_code = 0;
+      for (int j = 0; j < nch; ++j)
+      {
+        const int w = j + 1 < nch ? 8 : wl;
+        unsigned code[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+        {
+          code[e] = 0;
+          if (row && e < w)
+          {
+            const unsigned long long b = sp_value_bits(svals, c0 + j, w, lane, e);
+            if (b == 0ull)
+              continue;
+            if (b != last)
+            {
+              unsigned h = sp_dict_hash(b) & (SD_SLOTS - 1);
+              while (keys[h] != b)
+                h = (h + 1) & (SD_SLOTS - 1);
+              last = b;
+              last_code = codes[h];
+            }
+            code[e] = last_code;
+          }
+        }
+        uint4v q;
+        q.x = code[0] | (code[1] << 16);
+        q.y = code[2] | (code[3] << 16);
+        q.z = code[4] | (code[5] << 16);
+        q.w = code[6] | (code[7] << 16);
+        reinterpret_cast<uint4v*>(vcode8 + (size_t)(c0 + j) * 512)[lane] = q;
+      }
+    }
+    if (lane == 0)
+    {
+      // what the product reads of this slice: the table and per chunk 512 B of codes, or the values as before
+      for (int j = 0; j < nch; ++j)
+      {
+        const int w = j + 1 < nch ? 8 : wl;
+        const int m0 = meta[(size_t)(c0 + j) * 8];
+        unsigned cb = 0;
+        if (m0 < 0 && (m0 & 0x40000000))
+          cb = 100;
+        else if (m0 < 0)
+          cb = 2048;
+        else if ((m0 & 0x60000000) == 0x20000000)
+          cb = 0;
+        else if (m0 & 0x40000000)
+          cb = 512;
+        else
+          cb = 1024;
+        bytes += 32 + cb + (ok ? 1024 : (unsigned)((w >> 1) * 1024 + (w & 1) * 512));
+      }
+      bytes += ok ? (unsigned)n * 8 + 4 : 4;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0 && bytes)
+    atomicAdd(bytes_out, bytes);
+}
+
 // ---- the product --------------------------------------------------------------------------------------
 template <bool NT, typename T>
 __device__ inline T sp_load(const T* p)
@@ -1192,12 +1340,13 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
                                   const uint16_t* __restrict__ vcode = nullptr, const double* __restrict__ dict = nullptr)
 {
   const double* __restrict__ sp = svals + (size_t)c * 512;
-  if constexpr (DICT)
+  if (DICT == 1 || DICT == 2 || (DICT == 3 && dict != nullptr))
   {
     const uint4v q = sp_load<NT>(reinterpret_cast<const uint4v*>(vcode + (size_t)c * 512) + lane);
     // DICT == 2: `dict` is the workgroup's copy in LDS (a small dictionary: the lanes of a slice mostly hold the same
-    // code in a slot -- broadcast reads); DICT == 1: gathers from memory
-    auto look = [&](unsigned code) -> double { return DICT == 2 ? dict[code] : gather(dict, (int)code); };
+    // code in a slot -- broadcast reads); DICT == 1: gathers from memory; DICT == 3: the slice's own table in the
+    // wavefront's LDS (dict == nullptr: this slice stays doubles, below)
+    auto look = [&](unsigned code) -> double { return DICT == 1 ? gather(dict, (int)code) : dict[code]; };
     v[0].x = look(q.x & 0xffffu);
     v[0].y = look(q.x >> 16);
     v[1].x = look(q.y & 0xffffu);
@@ -1322,13 +1471,16 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
                                                               const double* __restrict__ rvec, int pstride, int nn_is_rr,
                                                               TailArgs tail, ChebEpi epi, const int2* __restrict__ win_info,
                                                               const int2* __restrict__ win_seg, const uint16_t* __restrict__ vcode,
-                                                              const double* __restrict__ dict_g, int dict_n)
+                                                              const double* __restrict__ dict_g, int dict_n,
+                                                              const int32_t* __restrict__ sd_info)
 {
   // dynamic LDS: DICT == 2: the value dictionary (dict_n doubles, rounded up to 2); WIN: the group's x window behind it
   // (launch: sp_win_max doubles)
   extern __shared__ __attribute__((aligned(16))) double sp_lds[];
   double* const xwin = sp_lds + (DICT == 2 ? ((dict_n + 1) & ~1) : 0);
-  const double* const dict = DICT == 2 ? sp_lds : dict_g;
+  // DICT == 3: dict_g holds the slices' tables (SD_MAX entries each), sp_lds one table per wavefront
+  double* const sdl = sp_lds + (threadIdx.x >> 6) * SD_MAX;
+  const double* dict = DICT == 2 ? sp_lds : dict_g;
   // group_list != nullptr: only the listed groups of 4 slices (interior or boundary subset of a partitioned
   // matrix); rvec != nullptr: also the partials of <r,x> and of the test norm (single-reduction CG), as in
   // spmv_tile_kernel
@@ -1393,6 +1545,21 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     }
     if (st == 0)
       continue;
+    if (DICT == 3)
+    {
+      // the slice's table into the wavefront's LDS (entries 0 .. n - 1; n == 0: the slice's values are doubles)
+      const int n_sd = __builtin_amdgcn_readfirstlane(sd_info[s]);
+      if (n_sd > 0)
+      {
+        __builtin_amdgcn_wave_barrier(); // (the previous slice's lookups are done)
+        for (int k = lane; k < n_sd; k += 64)
+          sdl[k] = dict_g[(int64_t)s * SD_MAX + k];
+        __builtin_amdgcn_wave_barrier();
+        dict = sdl;
+      }
+      else
+        dict = nullptr;
+    }
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
     int r = PERM ? perm[(int64_t)s * 64 + lane] : s * 64 + lane;
     if (!PERM && r >= nrows)
@@ -1894,7 +2061,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
 {
   (void)structure;
   ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
-  ctx->sp_dict_done = ctx->sp_dict_on = false; // (the values changed: the dictionary is rebuilt at the stream's first use)
+  ctx->sp_dict_done = ctx->sp_dict_on = ctx->sp_sd_on = false; // (the values changed: the dictionaries are rebuilt at the stream's first use)
   ctx->sp_win_max = 0; // (set again by the long-row packer when most groups get an x window)
   ctx->sp_win_bytes = 0;
   const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
@@ -2145,6 +2312,44 @@ static int sp_dict_build(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
+// Per-slice dictionaries (k_sp_sd_build) for streams whose global dictionary does not fit LDS: long rows (P3).  Kept when
+// they take the stream below 60 % of its bytes.  ZZZ_SELLP_DICT: 0 none of this, 3 slice dictionaries whenever they apply.
+static int sp_sd_build(zzz_ctx* ctx)
+{
+  ctx->sp_sd_on = false;
+  if (!ctx->sellp_dict || ctx->sp_dict_on || ctx->sp_chunks <= 0 || ctx->sp_win_max > 0)
+    return ZZZ_OK;
+  if (ctx->sellp_dict != 3 && (ctx->sp_bytes < 48ll << 20 || ctx->sp_chunks < 4 * ctx->nslices))
+    return ZZZ_OK; // (small streams: bytes do not matter; short rows -- P1: the table would cost as much as it saves)
+  hipStream_t s = ctx->stream;
+  const int64_t nsl = ctx->nslices;
+  ZZZ_HIP(ctx, ctx->sp_vcode8.alloc((size_t)ctx->sp_chunks * 512));
+  ZZZ_HIP(ctx, ctx->sp_sd_vals.alloc((size_t)nsl * SD_MAX));
+  ZZZ_HIP(ctx, ctx->sp_sd_info.alloc((size_t)nsl));
+  ZZZ_HIP(ctx, ctx->sp_dict_info.reserve(8));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_dict_info.p, 0, 8 * sizeof(int32_t), s));
+  const int2* desc = reinterpret_cast<const int2*>(ctx->sp_desc.p);
+  const unsigned grid = (unsigned)std::min<int64_t>((nsl + 1) / 2, 256 * 8);
+  unsigned long long* bytes = reinterpret_cast<unsigned long long*>(ctx->sp_dict_info.p + 4);
+  if (ctx->sp_sorted)
+    hipLaunchKernelGGL(k_sp_sd_build<true>, dim3(grid), dim3(128), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, ctx->sp_meta.p,
+                       (int)ctx->nrows, nsl, ctx->sp_vcode8.p, ctx->sp_sd_vals.p, ctx->sp_sd_info.p, bytes);
+  else
+    hipLaunchKernelGGL(k_sp_sd_build<false>, dim3(grid), dim3(128), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p, ctx->sp_meta.p,
+                       (int)ctx->nrows, nsl, ctx->sp_vcode8.p, ctx->sp_sd_vals.p, ctx->sp_sd_info.p, bytes);
+  ZZZ_HIP(ctx, hipGetLastError());
+  int32_t h[8];
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, ctx->sp_dict_info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  unsigned long long b = 0;
+  memcpy(&b, h + 4, sizeof(b));
+  if (ctx->sellp_dict != 3 && (double)b > 0.6 * (double)ctx->sp_bytes)
+    return ZZZ_OK;
+  ctx->sp_sd_bytes = (int64_t)b;
+  ctx->sp_sd_on = true;
+  return ZZZ_OK;
+}
+
 bool sellp_active(zzz_ctx* ctx)
 {
   if (ctx->sp_pending)
@@ -2154,7 +2359,10 @@ bool sellp_active(zzz_ctx* ctx)
   if (!(ctx->spmv_auto || (ctx->spmv_variant & 8) != 0))
     return false;
   if (!ctx->sp_dict_done)
+  {
     (void)sp_dict_build(ctx);
+    (void)sp_sd_build(ctx);
+  }
   return true;
 }
 
@@ -2162,7 +2370,7 @@ bool sellp_active(zzz_ctx* ctx)
 // counted separately)
 int64_t sellp_stream_bytes(const zzz_ctx* ctx)
 {
-  return (ctx->sp_dict_on ? ctx->sp_dict_bytes : ctx->sp_bytes) + ctx->nslices * 8; // (x windows: sp_win_bytes, reported apart)
+  return (ctx->sp_sd_on ? ctx->sp_sd_bytes : (ctx->sp_dict_on ? ctx->sp_dict_bytes : ctx->sp_bytes)) + ctx->nslices * 8; // (x windows: sp_win_bytes, reported apart)
 }
 
 // Load policy of the product: non-temporal stream loads when one CG iteration (the stream and six vectors) cannot stay in
@@ -2205,23 +2413,27 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
 #define ZZZ_SP_GO6(NT, PERM, WIN, LDSB, DICT)                                                                          \
   do                                                                                                                   \
   {                                                                                                                    \
+    const uint16_t* VC_ = (DICT) == 3 ? ctx->sp_vcode8.p : ctx->sp_vcode.p;         \
+    const double* DG_ = (DICT) == 3 ? ctx->sp_sd_vals.p : ctx->sp_dict.p;                                               \
     if (epi)                                                                                                           \
       hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, true, WIN, DICT>), dim3(grid), dim3(SP_BLOCK), LDSB,         \
                          ctx->stream, off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,           \
                          ctx->sp_perm.p, x, y, (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec,     \
-                         SPMV_PSTRIDE, nn_is_rr, TailArgs(), *epi, winfo, wseg, ctx->sp_vcode.p, ctx->sp_dict.p,           \
-                         ctx->sp_dict_n);                                                                              \
+                         SPMV_PSTRIDE, nn_is_rr, TailArgs(), *epi, winfo, wseg, VC_, DG_, ctx->sp_dict_n,                  \
+                         ctx->sp_sd_info.p);                                                                           \
     else                                                                                                               \
       hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, false, WIN, DICT>), dim3(grid), dim3(SP_BLOCK), LDSB,        \
                          ctx->stream, off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,           \
                          ctx->sp_perm.p, x, y, (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec,     \
-                         SPMV_PSTRIDE, nn_is_rr, tail, ChebEpi(), winfo, wseg, ctx->sp_vcode.p, ctx->sp_dict.p,            \
-                         ctx->sp_dict_n);                                                                              \
+                         SPMV_PSTRIDE, nn_is_rr, tail, ChebEpi(), winfo, wseg, VC_, DG_, ctx->sp_dict_n,                   \
+                         ctx->sp_sd_info.p);                                                                           \
   } while (0)
 #define ZZZ_SP_GO5(NT, PERM, WIN, LDSB)                                                                                \
   do                                                                                                                   \
   {                                                                                                                    \
-    if (ctx->sp_dict_on && ctx->sp_dict_n <= SP_DICT_LDS_MAX)                                                          \
+    if (ctx->sp_sd_on && !(WIN))                                                                                       \
+      ZZZ_SP_GO6(NT, PERM, false, (size_t)4 * SD_MAX * sizeof(double), 3);                                             \
+    else if (ctx->sp_dict_on && ctx->sp_dict_n <= SP_DICT_LDS_MAX)                                                     \
       ZZZ_SP_GO6(NT, PERM, WIN, (LDSB) + (size_t)((ctx->sp_dict_n + 1) & ~1) * sizeof(double), 2);                     \
     else if (ctx->sp_dict_on)                                                                                          \
       ZZZ_SP_GO6(NT, PERM, WIN, LDSB, 1);                                                                              \

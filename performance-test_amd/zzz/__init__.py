@@ -578,7 +578,7 @@ class Context:
         if os.environ.get("ZZZ_AB_OLD") and not hasattr(self.L, "zzz_spmv_values_info"):
             return dict(form="doubles", distinct_values=0, bytes_per_product=0, bytes_per_product_as_doubles=0)
         self._ck(self.L.zzz_spmv_values_info(self.h, info))
-        return dict(form=("doubles", "dictionary in memory", "dictionary in LDS")[int(info[0])], distinct_values=int(info[1]),
+        return dict(form=("doubles", "dictionary in memory", "dictionary in LDS", "slice dictionaries")[int(info[0])], distinct_values=int(info[1]),
                     bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]))
 
     def spmv_x_windows(self):

@@ -475,18 +475,22 @@ def test_unstructured_spoke_mesh_partitioned_on_one_gpu(problem, order, m, npart
                                                      ("elasticity", 1, (10, 9, 11), "dictionary in LDS"),
                                                      ("poisson", 2, (9, 8, 7), "dictionary in LDS"),
                                                      ("poisson", 3, (15, 14, 13), "dictionary in memory"),
+                                                     ("poisson", 3, (15, 14, 13), "slice dictionaries"),
+                                                     ("elasticity", 3, (5, 4, 5), "slice dictionaries"),
                                                      ("spoke", 1, 6, "doubles")])
 def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
     """The operator stream with its values as 16-bit codes into a dictionary of the matrix's distinct values (LDS copy per
     workgroup for small dictionaries, memory for larger ones, plain doubles when a matrix has more than 65 535 distinct values:
-    the unstructured mesh): the same doubles in the same order -- the product is the serial CSR loop's bit for bit, the solve
-    is the undictionaried stream's iteration for iteration and bit for bit."""
+    the unstructured mesh) or into per-slice dictionaries (long rows whose matrix-wide dictionary does not fit LDS): the same
+    doubles in the same order -- the product is the serial CSR loop's bit for bit, the solve is the undictionaried stream's
+    iteration for iteration and bit for bit."""
     P = zzz.Part.spoke("poisson", order, dims) if problem == "spoke" else zzz.Part(problem, order, *dims)
     x = np.random.default_rng(4).standard_normal(P.n_owned * P.bs)
     res = {}
     old = os.environ.get("ZZZ_SELLP_DICT")
     try:
-        for knob in ("0", "2"):
+        forced = "3" if form == "slice dictionaries" else "2"
+        for knob in ("0", forced):
             os.environ["ZZZ_SELLP_DICT"] = knob
             with zzz.Context(0) as c:
                 c.upload_part(P)
@@ -504,15 +508,17 @@ def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
             os.environ.pop("ZZZ_SELLP_DICT", None)
         else:
             os.environ["ZZZ_SELLP_DICT"] = old
-    assert res["0"][5] and res["2"][5], "the product must run on the operator stream in this test"
-    rp, cl, v = res["2"][4]
-    np.testing.assert_array_equal(res["2"][0], zo.spmv(rp.astype(np.int64), cl, v, x))
-    np.testing.assert_array_equal(res["2"][0], res["0"][0])
-    assert res["2"][1] == res["0"][1]
-    np.testing.assert_array_equal(res["2"][2], res["0"][2])
-    vi = res["2"][3]
+    assert res["0"][5] and res[forced][5], "the product must run on the operator stream in this test"
+    rp, cl, v = res[forced][4]
+    np.testing.assert_array_equal(res[forced][0], zo.spmv(rp.astype(np.int64), cl, v, x))
+    np.testing.assert_array_equal(res[forced][0], res["0"][0])
+    assert res[forced][1] == res["0"][1]
+    np.testing.assert_array_equal(res[forced][2], res["0"][2])
+    vi = res[forced][3]
     assert res["0"][3]["form"] == "doubles" and vi["form"] == form, vi
-    if form != "doubles":
+    if form == "slice dictionaries":
+        assert vi["bytes_per_product"] < vi["bytes_per_product_as_doubles"]  # (slices of more than 1 023 values stay doubles)
+    elif form != "doubles":
         nd_ = np.unique(v[v != 0.0]).size + 1
         assert vi["distinct_values"] <= nd_ and vi["distinct_values"] >= 2  # (dropped zeros and padding share code 0)
         assert vi["bytes_per_product"] < 0.5 * vi["bytes_per_product_as_doubles"]
@@ -549,10 +555,10 @@ def test_inverse_diagonal_as_codes_keeps_every_bit(problem, order, dims):
             os.environ.pop("ZZZ_CG_DINV_CODES", None)
         else:
             os.environ["ZZZ_CG_DINV_CODES"] = old
-    for a, b in zip(res["0"], res["2"]):
+    for a, b in zip(res["0"], res[forced]):
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3])
-    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res["2"][:3]) and res["2"][3][4] == 0
+    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res[forced][:3]) and res[forced][3][4] == 0
 
 
 @pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (10, 9, 12), 2), ("poisson", 3, (3, 3, 6), 3),
@@ -1063,7 +1069,7 @@ def test_knob_combinations_keep_results(seed):
              "ZZZ_PATTERN": ["host"], "ZZZ_PATTERN_WAVE": ["1"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
              "ZZZ_ADJ_SORT": ["1"], "ZZZ_ASM_SEARCH": ["1"], "ZZZ_ASM_NO_COMPACT": ["1"],
              "ZZZ_SELLP_WIN": ["0", "1024", "8064"], "ZZZ_MF_NC": ["256", "512"], "ZZZ_MF_T": ["128", "256"],
-             "ZZZ_SELLP_DICT": ["0", "2", "2"], "ZZZ_CG_DINV_CODES": ["0", "2", "2"]}
+             "ZZZ_SELLP_DICT": ["0", "2", "3"], "ZZZ_CG_DINV_CODES": ["0", "2", "2"]}
     names = sorted(knobs)
     chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
     problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4)),

@@ -55,7 +55,7 @@ def test_operator_stream_kernel_keeps_full_occupancy(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if not re.match(r"_ZN3zzz17spmv_sellp_kernelILb[01]ELb[01]ELb[01]ELb[01]ELb[01]ELi[012]EEE", name):
+        if not re.match(r"_ZN3zzz17spmv_sellp_kernelILb[01]ELb[01]ELb[01]ELb[01]ELb[01]ELi[0123]EEE", name):
             continue
         vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
@@ -67,5 +67,6 @@ def test_operator_stream_kernel_keeps_full_occupancy(tmp_path):
         assert vgprs <= 64 and occ == 8 and scratch <= 64 and lds <= 512 and sgprs <= 80, (name, vgprs, occ, scratch, lds, sgprs)
         seen += 1
     # (dot products, load policy, row permutation, Chebyshev-term epilogue) + x windows (natural order), each with the
-    # values as doubles, as codes into a dictionary in memory, as codes into a dictionary in LDS
-    assert seen == 72
+    # values as doubles, as codes into a dictionary in memory, as codes into a dictionary in LDS, as 8-bit codes into
+    # per-slice dictionaries
+    assert seen == 88  # (slice dictionaries and x windows exclude each other)
