@@ -555,10 +555,10 @@ def test_inverse_diagonal_as_codes_keeps_every_bit(problem, order, dims):
             os.environ.pop("ZZZ_CG_DINV_CODES", None)
         else:
             os.environ["ZZZ_CG_DINV_CODES"] = old
-    for a, b in zip(res["0"], res[forced]):
+    for a, b in zip(res["0"], res["2"]):
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3])
-    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res[forced][:3]) and res[forced][3][4] == 0
+    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res["2"][:3]) and res["2"][3][4] == 0
 
 
 @pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (10, 9, 12), 2), ("poisson", 3, (3, 3, 6), 3),
