@@ -142,6 +142,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_drop = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_DICT"))
     ctx->sellp_dict = atoi(e);
+  if (const char* e = getenv("ZZZ_SELLP_PIPE")) // 0: the generic product kernel always (A/B against the pipelined one)
+    ctx->sellp_pipe = atoi(e);
   if (const char* e = getenv("ZZZ_CG_DINV_CODES"))
     ctx->cg_dinv_codes = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_AFFINE")) // 0: no code-free chunks (column = slot base + lane); A/B knob

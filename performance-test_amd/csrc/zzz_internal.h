@@ -248,6 +248,10 @@ struct zzz_ctx
   int64_t sp_chunk_bound = 0; // chunks of the natural-order stream if no entry were zero
   zzz::DevBuf<uint16_t> sp_codes16;
   zzz::DevBuf<double> sp_vals;
+  zzz::DevBuf<unsigned long long> sp_smode; // per slice: two bits per chunk, what a product loads for its columns (zzz_sellp.h)
+  bool sp_pipe_ok = false;                  // every chunk is described by its slice's mode word: the pipelined product may run
+  bool sp_one_chunk = false;                // ... and no slice has more than one chunk (scalar P1 on a regular mesh)
+  int sellp_pipe = 1;                       // ZZZ_SELLP_PIPE=0: the generic product always
   int64_t nslices = 0, sp_chunks = 0, sp_kept = 0, sp_bytes = 0; // slices, chunks of the stream, matrix entries kept in it,
                                                                  // bytes a product reads from it
   zzz::DevBuf<uint8_t> sp_wlast; // per slice: entries of the longest row in its last chunk (1..8)
@@ -265,6 +269,7 @@ struct zzz_ctx
   zzz::DevBuf<double> sp_sd_vals;
   zzz::DevBuf<int32_t> sp_sd_info;
   bool sp_sd_on = false;
+  bool sp_sd_all = false; // every slice has its table (none stays doubles)
   int64_t sp_sd_bytes = 0;
   bool sp_dict_done = false, sp_dict_on = false;
   int sellp_dict = 1;       // ZZZ_SELLP_DICT=0: no value dictionary

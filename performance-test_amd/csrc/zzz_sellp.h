@@ -1,0 +1,62 @@
+// Shared declarations of the operator-stream translation units (zzz_sellp.hip: packer, dictionaries, the generic
+// product; zzz_sellp_pipe.hip: the software-pipelined product).  Not part of the ABI.
+#pragma once
+#include <climits>
+#include <cstdint>
+
+#include "zzz_device.h"
+#include "zzz_internal.h"
+
+namespace zzz
+{
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+constexpr int SP_BLOCK = 256;
+constexpr int SP_SIGMA = 512; // sorting window (rows) of the sorted form: one workgroup
+
+// x windows (k_sp_windows)
+constexpr int SP_WIN_NSEG = 24;    // segments per group at most
+constexpr int SP_WIN_GAP = 8;      // gaps of up to this many columns are filled (fewer segments, a few unused slots)
+constexpr int SP_WIN_WORDS = 8192; // bitmap words of k_sp_windows (32 KiB of LDS): two mesh planes of up to 131 k entries each
+constexpr int SP_WIN_SPAN = (SP_WIN_WORDS - 2) * 32; // columns between a group's smallest and largest at most
+
+// per-slice value dictionaries (k_sp_sd_build)
+constexpr int SD_SLOTS = 2048, SD_MAX = 1024;
+
+// Column-code class of a chunk, two bits per chunk in the slice's mode word (sp_smode: chunk j of a slice at bits 2 j, 2 j + 1;
+// written by the packers from emit_chunk's mode).  What the pipelined product has to LOAD per lane for the chunk's columns:
+constexpr int SP_CLS_NONE = 0;  // affine or periodic chunk: nothing
+constexpr int SP_CLS_C8 = 1;    // 8-bit codes, first half of the chunk's code block
+constexpr int SP_CLS_C16 = 2;   // 16-bit codes, the chunk's code block
+constexpr int SP_CLS_C8T = 3;   // 8-bit codes in the free tail of the chunk's value block
+constexpr int SP_SMODE_CHUNKS = 32; // chunks per slice the mode word describes (longer slices: the generic product)
+
+// tile index for (workgroup b, step i): XCD x = b % 8 owns items [x*T/8, (x+1)*T/8)   (as in zzz_spmv.hip)
+__device__ inline int64_t sp_xcd_item(int64_t n, int b, int nb, int i)
+{
+  const int xcd = b & 7;
+  const int64_t lo = n * xcd / 8, hi = n * (xcd + 1) / 8;
+  const int wg_in_xcd = b >> 3, n_in_xcd = (nb + 7 - xcd) >> 3;
+  const int64_t t = lo + wg_in_xcd + (int64_t)i * n_in_xcd;
+  return t < hi ? t : -1;
+}
+
+// x[col] with a 32-bit byte offset: one shift per gather instead of a 64-bit address computation
+// (the launcher guarantees 8 * ncols < 2^32)
+__device__ inline double gather(const double* __restrict__ x, int col)
+{
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
+}
+
+// workgroups per CU of the pipelined product (its register budget: <= 96 per lane); sp_grid sizes the persistent grid by it
+constexpr int SP_PIPE_WGS = 5;
+constexpr int SP_ONE_WGS = 6; // ... of the kernel for streams of one-chunk slices (<= 80 registers per lane)
+constexpr int SP_ONE_WGS_SR = 5; // ... with the single-reduction form's extra sums (<= 96)
+int sellp_pipe_wgs(const zzz_ctx* ctx, bool sr); // workgroups per CU of the kernel of zzz_sellp_pipe.hip that serves the context's stream; 0: none does
+// The software-pipelined product (zzz_sellp_pipe.hip).  Returns false when this stream / launch is not one it serves (the
+// caller then launches the generic kernel); true after launching.
+bool launch_sellp_pipe(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
+                       const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr);
+} // namespace zzz

@@ -28,31 +28,13 @@
 #include <cstdlib>
 #include <vector>
 
-#include "zzz_device.h"
-#include "zzz_internal.h"
+#include "zzz_sellp.h"
 #include "zzz_cg_device.h"
 
 #include <rocprim/rocprim.hpp>
 
 namespace zzz
 {
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-typedef int int4v __attribute__((ext_vector_type(4)));
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-constexpr int SP_BLOCK = 256;
-constexpr int SP_SIGMA = 512; // sorting window (rows) of the sorted form: one workgroup
-
-// tile index for (workgroup b, step i): XCD x = b % 8 owns items [x*T/8, (x+1)*T/8)   (as in zzz_spmv.hip)
-__device__ inline int64_t sp_xcd_item(int64_t n, int b, int nb, int i)
-{
-  const int xcd = b & 7;
-  const int64_t lo = n * xcd / 8, hi = n * (xcd + 1) / 8;
-  const int wg_in_xcd = b >> 3, n_in_xcd = (nb + 7 - xcd) >> 3;
-  const int64_t t = lo + wg_in_xcd + (int64_t)i * n_in_xcd;
-  return t < hi ? t : -1;
-}
-
 // ---- build ------------------------------------------------------------------------------------------
 // entries of each row that the stream keeps
 // The same counts with dense loads: one wavefront sweeps the CSR range of its 64 rows 64 entries at a time; every lane
@@ -169,8 +151,9 @@ __global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict_
 // meta[c][0] carries the mode: bit 31 int32 columns, bit 30 8-bit codes.  Returns the bytes a product reads.
 __device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl)[8], int lane, int nrows, bool& gh,
                                  double* __restrict__ svals, uint16_t* __restrict__ c16, int32_t* __restrict__ c32,
-                                 int32_t* __restrict__ meta, int tail_codes)
+                                 int32_t* __restrict__ meta, int tail_codes, int& cls)
 {
+  // cls: what a product loads per lane for the chunk's columns (SP_CLS_*, zzz_sellp.h; -1: int32 columns)
   const bool affine_ok = (tail_codes & 2) == 0; // knob ZZZ_SELLP_AFFINE=0 sets bit 1
   double v[8];
 #pragma unroll
@@ -336,6 +319,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl
       tp[24] = (tail_codes >> 8) & 3;
     mode = (int)0xC0000000;
     code_bytes = 128;
+    cls = SP_CLS_NONE;
   }
   else if (all_affine)
   {
@@ -343,6 +327,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl
     // 56 instead of 64 B per row)
     mode = 0x20000000;
     code_bytes = 0;
+    cls = SP_CLS_NONE;
   }
   else if (range > 65535)
   {
@@ -354,6 +339,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl
     cp[1] = q1;
     mode = (int)0x80000000;
     code_bytes = 2048;
+    cls = -1;
   }
   else if (range > 255)
   {
@@ -364,6 +350,7 @@ __device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl
     q.w = (unsigned)(cl[6] - base[6]) | ((unsigned)(cl[7] - base[7]) << 16);
     reinterpret_cast<uint4v*>(c16 + (size_t)c * 512)[lane] = q;
     code_bytes = 1024;
+    cls = SP_CLS_C16;
   }
   else
   {
@@ -377,11 +364,13 @@ __device__ inline int emit_chunk(int c, int w, const double (&v_in)[8], int (&cl
       // the chunk's value block has a free last 512 B: codes there, and the chunk is ONE contiguous 4-KiB read
       reinterpret_cast<uint2v*>(sp + 448)[lane] = q;
       mode = 0x60000000;
+      cls = SP_CLS_C8T;
     }
     else
     {
       reinterpret_cast<uint2v*>(c16 + (size_t)c * 512)[lane] = q; // first half of the chunk's code block
       mode = 0x40000000;
+      cls = SP_CLS_C8;
     }
     code_bytes = 512;
   }
@@ -401,7 +390,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
                                                  const int32_t* __restrict__ perm, const int2* __restrict__ desc,
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
                                                  int32_t* __restrict__ c32, int32_t* __restrict__ meta,
-                                                 uint8_t* __restrict__ ghost_flag, unsigned long long* __restrict__ bytes, int tail_codes)
+                                                 uint8_t* __restrict__ ghost_flag, unsigned long long* __restrict__ bytes, int tail_codes,
+                                                 unsigned long long* __restrict__ smode, int* __restrict__ nopipe)
 {
   const int lane = threadIdx.x & 63;
   unsigned long long mine = 0;
@@ -410,6 +400,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
     int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
     if (!PERM && r >= nrows)
       r = -1;
+    unsigned long long sm = 0; // the slice's mode word (zzz_sellp.h)
+    bool sm_bad = false;
     int64_t k = r >= 0 ? rowptr[r] : 0;
     const int64_t end = r >= 0 ? rowptr[r + 1] : 0;
     const int2 ds = desc[s];
@@ -439,7 +431,17 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
           }
         }
       }
-      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc);
+      int cls = 0;
+      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc, cls);
+      sm_bad |= cls < 0 || j >= SP_SMODE_CHUNKS;
+      if (cls > 0 && j < SP_SMODE_CHUNKS)
+        sm |= (unsigned long long)cls << (2 * j);
+    }
+    if (lane == 0)
+    {
+      smode[s] = sm;
+      if (sm_bad)
+        *nopipe = 1;
     }
     if (ghost_flag)
     {
@@ -530,10 +532,7 @@ __global__ __launch_bounds__(256) void k_sp_compact(const rp_t* __restrict__ row
 // product loads those segments once per group with wide coalesced loads and gathers from LDS.  The stream's column
 // codes of such a group are LDS indices: the map column -> index is monotone and a translation inside a segment, so the
 // chunk encodings (affine, periodic, 8- / 16-bit) and the ascending-column summation order are what they were.
-constexpr int SP_WIN_NSEG = 24;      // segments per group at most
-constexpr int SP_WIN_GAP = 8;        // gaps of up to this many columns are filled (fewer segments, a few unused slots)
-constexpr int SP_WIN_WORDS = 8192;   // bitmap words of k_sp_windows (32 KiB of LDS): two mesh planes of up to 131 k entries each
-constexpr int SP_WIN_SPAN = (SP_WIN_WORDS - 2) * 32; // columns between a group's smallest and largest at most
+// (SP_WIN_NSEG, SP_WIN_GAP, SP_WIN_WORDS, SP_WIN_SPAN: zzz_sellp.h)
 
 // One workgroup per group of four slices (256 rows, natural order).  The group's kept columns (its CSR range swept with
 // coalesced loads; entries that are exactly zero do not count when the stream drops them) are looked at as a set --
@@ -707,7 +706,8 @@ __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ c
                                                    const int2* __restrict__ desc, double* __restrict__ svals,
                                                    uint16_t* __restrict__ c16, int32_t* __restrict__ c32,
                                                    int32_t* __restrict__ meta, uint8_t* __restrict__ ghost_flag,
-                                                   unsigned long long* __restrict__ bytes, int tail_codes)
+                                                   unsigned long long* __restrict__ bytes, int tail_codes,
+                                                   unsigned long long* __restrict__ smode, int* __restrict__ nopipe)
 {
   const int lane = threadIdx.x & 63;
   unsigned long long mine = 0;
@@ -716,6 +716,8 @@ __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ c
     int r = PERM ? perm[s * 64 + lane] : (int)(s * 64 + lane);
     if (!PERM && r >= nrows)
       r = -1;
+    unsigned long long sm = 0;
+    bool sm_bad = false;
     const int n = r >= 0 ? rownnz[r] : 0;
     const int64_t base = r >= 0 ? crow[r] : 0;
     const int2 ds = desc[s];
@@ -744,7 +746,17 @@ __global__ __launch_bounds__(256) void k_sp_fill_c(const int64_t* __restrict__ c
           v[e] = 0.0;
           cl[e] = INT_MAX;
         }
-      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc);
+      int cls = 0;
+      mine += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, nrows, gh, svals, c16, c32, meta, tc, cls);
+      sm_bad |= cls < 0 || j >= SP_SMODE_CHUNKS;
+      if (cls > 0 && j < SP_SMODE_CHUNKS)
+        sm |= (unsigned long long)cls << (2 * j);
+    }
+    if (lane == 0)
+    {
+      smode[s] = sm;
+      if (sm_bad)
+        *nopipe = 1;
     }
     if (ghost_flag)
     {
@@ -811,7 +823,8 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
                                                  double* __restrict__ svals, uint16_t* __restrict__ c16,
                                                  int32_t* __restrict__ c32, int32_t* __restrict__ meta,
                                                  uint8_t* __restrict__ ghost_flag, int tail_codes,
-                                                 const int2* __restrict__ win_info, const int2* __restrict__ win_seg)
+                                                 const int2* __restrict__ win_info, const int2* __restrict__ win_seg,
+                                                 unsigned long long* __restrict__ smode)
 {
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
 
@@ -912,6 +925,8 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
       desc[s] = make_int2(c0, nch | (wl << 24));
     kept_w += (unsigned long long)running;
     const int tc = ((tail_codes & 4) ? (tail_codes | ((int)((s * 64) % 3) << 8)) : tail_codes) | (((tail_codes & 16) && nch == 1) ? 8 : 0);
+    unsigned long long sm = 0; // the slice's mode word (zzz_sellp.h)
+    bool sm_bad = false;
     for (int j = 0; j < nch; ++j)
     {
       double v[8];
@@ -925,8 +940,20 @@ __global__ __launch_bounds__(256) void k_sp_pack(const rp_t* __restrict__ rowptr
         cl[e] = has ? lc[cstart + q] : INT_MAX;
       }
       bool gh2 = false; // (windowed: the ghost test was made on the columns themselves, above)
+      int cls = 0;
       bytes_w += (unsigned long long)emit_chunk(c0 + j, j + 1 < nch ? 8 : wl, v, cl, lane, limit, (WINB && limit != nrows) ? gh2 : gh,
-                                                svals, c16, c32, meta, tc);
+                                                svals, c16, c32, meta, tc, cls);
+      sm_bad |= cls < 0 || j >= SP_SMODE_CHUNKS;
+      if (cls > 0 && j < SP_SMODE_CHUNKS)
+        sm |= (unsigned long long)cls << (2 * j);
+    }
+    if (lane == 0)
+    {
+      smode[s] = sm;
+      if (sm_bad)
+        counter[14] = 1; // a chunk with int32 columns or a slice of more than 32 chunks: the generic product
+      if (nch > 1)
+        counter[15] = 1; // not a stream of one-chunk slices (spmv_one_kernel serves those)
     }
     if (ghost_flag)
     {
@@ -1176,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_sp_dict_encode(const int2* __restrict__
 // The product copies a slice's table into its wavefront's part of LDS (8 KiB per wavefront: five workgroups per CU).
 // Tried: 8-bit codes and tables of 256 (a third of P3's slices qualify: product 0.67 -> 0.54 ms at 6.2 M dofs), tables of 512
 // (0.46 ms there, 4.19 ms at 49.8 M dofs), tables of 1 024 (0.47 / 3.68 ms: kept).
-constexpr int SD_SLOTS = 2048, SD_MAX = 1024;
+// (SD_SLOTS = 2048, SD_MAX = 1024: zzz_sellp.h)
 template <bool PERM>
 __global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ desc, const int32_t* __restrict__ perm,
                                                       const double* __restrict__ svals, const int32_t* __restrict__ meta,
@@ -1250,7 +1277,11 @@ __global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ de
     const int n = cnt_s[wv];
     const bool ok = n <= SD_MAX;
     if (lane == 0)
+    {
       sd_info[s] = ok ? n : 0;
+      if (!ok)
+        atomicAdd(reinterpret_cast<int*>(bytes_out) + 2, 1); // slices that stay doubles (the pipelined product wants none)
+    }
     if (ok)
     {
       last = 0ull;
@@ -1320,13 +1351,6 @@ template <bool NT, typename T>
 __device__ inline T sp_load(const T* p)
 {
   return NT ? __builtin_nontemporal_load(p) : *p;
-}
-
-// x[col] with a 32-bit byte offset: one shift per gather instead of a 64-bit address computation
-// (the launcher guarantees 8 * ncols < 2^32)
-__device__ inline double gather(const double* __restrict__ x, int col)
-{
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
 }
 
 // Values and columns of chunk c for this lane.  FULL: all eight slots (every chunk but the last of a slice);
@@ -1844,6 +1868,7 @@ static int sp_alloc_stream(zzz_ctx* ctx, int64_t total)
   ZZZ_HIP(ctx, ctx->sp_codes16.alloc(ne));
   ZZZ_HIP(ctx, ctx->sp_codes32.alloc(ne)); // touched only by chunks that need int32 columns
   ZZZ_HIP(ctx, ctx->sp_meta.alloc((size_t)total * 8 + 8));
+  ZZZ_HIP(ctx, ctx->sp_smode.alloc((size_t)ctx->nslices + 1)); // the slices' mode words (zzz_sellp.h)
   return ZZZ_OK;
 }
 
@@ -1945,6 +1970,8 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
   hipLaunchKernelGGL(k_sp_desc, dim3(grid_cap(nsl, 256, 4096)), dim3(256), 0, s, ctx->sp_chunk_off.p, ctx->sp_wlast.p, nsl, desc);
   unsigned long long* bytes = reinterpret_cast<unsigned long long*>(ctx->sp_counter.p + 8);
   ZZZ_HIP(ctx, hipMemsetAsync(bytes, 0, sizeof(unsigned long long), s));
+  int* nopipe = ctx->sp_counter.p + 14; // set by a chunk with int32 columns or a slice of more than 32 chunks
+  ZZZ_HIP(ctx, hipMemsetAsync(nopipe, 0, sizeof(int), s));
   if (ctx->nnz >= 16 * ctx->nrows && ctx->nnz + 8 * ctx->nrows < ((int64_t)1 << 40))
   {
     // long rows: through the compacted copy (crow = scan of the kept counts padded to 8)
@@ -1970,25 +1997,29 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
     if (sorted)
       hipLaunchKernelGGL(k_sp_fill_c<true>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
+                         ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0), ctx->sp_smode.p, nopipe);
     else
       hipLaunchKernelGGL(k_sp_fill_c<false>, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->sp_crow.p, ctx->sp_rownnz.p,
                          ctx->sp_cvals.p, ctx->sp_ccols.p, nrows, nsl, (const int32_t*)nullptr, desc, ctx->sp_vals.p,
-                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
+                         ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0), ctx->sp_smode.p, nopipe);
   }
   else if (sorted)
     hipLaunchKernelGGL(k_sp_fill<true>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, ctx->sp_perm.p, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0), ctx->sp_smode.p, nopipe);
   else
     hipLaunchKernelGGL(k_sp_fill<false>, dim3(grid_cap(nsl, 4, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                        nrows, nsl, ctx->sellp_drop ? 1 : 0, (const int32_t*)nullptr, desc, ctx->sp_vals.p, ctx->sp_codes16.p,
-                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0));
+                       ctx->sp_codes32.p, ctx->sp_meta.p, gflag, bytes, ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0), ctx->sp_smode.p, nopipe);
   ZZZ_HIP(ctx, hipGetLastError());
   unsigned long long hb = 0;
+  int hnp = 0;
   ZZZ_HIP(ctx, hipMemcpyAsync(&hb, bytes, sizeof(hb), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(&hnp, nopipe, sizeof(hnp), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   ctx->sp_bytes = (int64_t)hb;
+  ctx->sp_pipe_ok = hnp == 0;
+  ctx->sp_one_chunk = false; // (the synchronous builds serve long rows)
   ctx->sp_sorted = sorted;
   ctx->sp_chunks = total;
   return sp_group_split(ctx, gflag);
@@ -2156,9 +2187,10 @@ int sell_update(zzz_ctx* ctx, bool structure)
   // nonzeros) the two barriers and the window load per group cost more than the gathers they replace (product 34.5 ->
   // 37.9 us), so without the knob windows are built for matrices beyond ~300 MB of values only
   const char* win_env = getenv("ZZZ_SELLP_WIN");
-  // (at most 8064 doubles: the product's dynamic LDS plus its static words must stay inside the 64 KiB a launch gets
-  // without raising the kernel's limit -- a window of 8192 would fail at the first product, after the stream was packed)
-  const int win_knob = win_env ? std::min(atoi(win_env), 8064) : 2048;
+  // (at most 6136 doubles: the product's dynamic LDS -- the window AND the value dictionary's copy of up to
+  // SP_DICT_LDS_ENTRIES doubles -- plus its static words must stay inside the 64 KiB a launch gets without raising the
+  // kernel's limit; a larger window would fail at the first product, after the stream was packed)
+  const int win_knob = win_env ? std::min(atoi(win_env), (64 * 1024 - SP_DICT_LDS_ENTRIES * 8 - 64) / 8) : 2048;
   const bool winb = ctx->bs == 3 && win_knob >= 256 && (win_env || (double)ctx->nnz * 8.0 > 300.0e6);
   if (lds * waves > 64 * 1024 && !ctx->sp_lds_attr)
   {
@@ -2169,7 +2201,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
     ctx->sp_lds_attr = true;
   }
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p, 0, 4 * sizeof(int), s));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p + 8, 0, 4 * sizeof(int), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_counter.p + 8, 0, 8 * sizeof(int), s)); // ([14]: "not for the pipelined product")
   const int cap = (ctx->sp_max_range + 63) & ~63;
   const int tcodes = ctx->sellp_tail | ((ctx->bs == 3 && ctx->sellp_periodic) ? 4 : 0) | ((ctx->bs == 1 && ctx->sellp_align) ? 16 : 0);
   // workgroups of the packer take slices in fours only when they have four wavefronts: the group of a slice is s >> 2
@@ -2185,19 +2217,20 @@ int sell_update(zzz_ctx* ctx, bool structure)
     hipLaunchKernelGGL(k_sp_pack<true>, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p,
                        ctx->cols.p, ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p,
                        reinterpret_cast<int2*>(ctx->sp_desc.p), ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,
-                       gflag, tcodes, reinterpret_cast<const int2*>(ctx->sp_win_info.p), reinterpret_cast<const int2*>(ctx->sp_win_seg.p));
+                       gflag, tcodes, reinterpret_cast<const int2*>(ctx->sp_win_info.p), reinterpret_cast<const int2*>(ctx->sp_win_seg.p),
+                       ctx->sp_smode.p);
     ctx->sp_win_max = win_knob; // the product reads win_info per group; a group without a window gathers from memory
   }
   else
     hipLaunchKernelGGL(k_sp_pack<false>, dim3(grid_cap(nsl, waves, 256 * 12)), dim3(64 * waves), lds * waves, s, ctx->rowptr.p,
                        ctx->cols.p, ctx->vals.p, nrows, nsl, ctx->sellp_drop ? 1 : 0, cap, ctx->sp_counter.p,
                        reinterpret_cast<int2*>(ctx->sp_desc.p), ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,
-                       gflag, tcodes, (const int2*)nullptr, (const int2*)nullptr);
+                       gflag, tcodes, (const int2*)nullptr, (const int2*)nullptr, ctx->sp_smode.p);
   ZZZ_HIP(ctx, hipGetLastError());
   if (!ctx->sp_event)
     ZZZ_HIP(ctx, hipEventCreateWithFlags(&ctx->sp_event, hipEventDisableTiming));
   int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 5); // pinned
-  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 12 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(tot, ctx->sp_counter.p, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipEventRecord(ctx->sp_event, s));
   ctx->sp_sorted = false;
   ctx->sp_pending = true;
@@ -2226,6 +2259,8 @@ int sellp_resolve(zzz_ctx* ctx)
   unsigned long long hw = 0;
   memcpy(&hw, hc + 10, sizeof(hw));
   ctx->sp_win_bytes = ctx->sp_win_max > 0 ? (int64_t)hw * 8 : 0;
+  ctx->sp_pipe_ok = hc[14] == 0;
+  ctx->sp_one_chunk = hc[14] == 0 && hc[15] == 0;
   const double full = (double)ctx->nnz + 64.0 * 512.0;
   const bool always = ctx->sellp_mode == 2 || ctx->sp_forced;
   // Natural row order unless its padding makes it slower than the alternatives: the length-sorted form (priced only
@@ -2316,7 +2351,7 @@ static int sp_dict_build(zzz_ctx* ctx)
 // they take the stream below 60 % of its bytes.  ZZZ_SELLP_DICT: 0 none of this, 3 slice dictionaries whenever they apply.
 static int sp_sd_build(zzz_ctx* ctx)
 {
-  ctx->sp_sd_on = false;
+  ctx->sp_sd_on = ctx->sp_sd_all = false;
   if (!ctx->sellp_dict || ctx->sp_dict_on || ctx->sp_chunks <= 0 || ctx->sp_win_max > 0)
     return ZZZ_OK;
   if (ctx->sellp_dict != 3 && (ctx->sp_bytes < 48ll << 20 || ctx->sp_chunks < 4 * ctx->nslices))
@@ -2347,6 +2382,7 @@ static int sp_sd_build(zzz_ctx* ctx)
     return ZZZ_OK;
   ctx->sp_sd_bytes = (int64_t)b;
   ctx->sp_sd_on = true;
+  ctx->sp_sd_all = h[6] == 0;
   return ZZZ_OK;
 }
 
@@ -2382,9 +2418,11 @@ static bool sp_stream_nt(const zzz_ctx* ctx)
   return (double)sellp_stream_bytes(ctx) + 48.0 * (double)(ctx->n_owned + ctx->n_ghost) * ctx->bs > 200.0e6;
 }
 
-static int sp_grid(int64_t ngroups)
+static int sp_grid(const zzz_ctx* ctx, int64_t ngroups, bool sr)
 {
-  int64_t gs = 256 * 8; // (1024 or 1536 workgroups at the per-rank size: no faster)
+  // persistent workgroups: as many as are resident at once (a second round of a grid that is not would run on part of the chip)
+  const int pw = sellp_pipe_wgs(ctx, sr);
+  int64_t gs = 256 * (pw ? pw : 8); // (1024 or 1536 workgroups at the per-rank size: no faster)
 #ifdef ZZZ_EXPERIMENTS
   if (const char* e = getenv("ZZZ_SP_WGS_PER_CU")) // how the product's time depends on the wavefronts in flight
     gs = 256 * std::max(1, std::min(8, atoi(e)));
@@ -2407,6 +2445,8 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
   bool nt = sp_stream_nt(ctx);
   if (!ctx->spmv_auto)
     nt = (ctx->spmv_variant & 1) != 0;
+  if (!epi && !tail.parts && launch_sellp_pipe(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
+    return;
   const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
   const int2* winfo = reinterpret_cast<const int2*>(ctx->sp_win_info.p);
   const int2* wseg = reinterpret_cast<const int2*>(ctx->sp_win_seg.p);
@@ -2473,7 +2513,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
                  const ChebEpi* epi)
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
-  const int gs = sp_grid((ctx->nslices + 3) / 4);
+  const int gs = sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec));
 #ifdef ZZZ_EXPERIMENTS
   const char* e = ctx->timing_only ? getenv("ZZZ_EXP_WIN") : nullptr; // timing probe, wrong results by construction (see
   if (e)                                                               // the kernel): inside zzz_spmv_time only
@@ -2529,10 +2569,12 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
-  int g_in = gi ? sp_grid(gi) : 0;
-  if (g_in > 256 * 7 && ctx->nneigh > 0)
-    g_in = 256 * 7;
-  const int g_bd = gb ? sp_grid(gb) : 0;
+  int g_in = gi ? sp_grid(ctx, gi, (partials && rvec)) : 0;
+  const int pw = sellp_pipe_wgs(ctx, partials && rvec);
+  const int room = 256 * ((pw ? pw : 8) - 1); // (one workgroup slot per CU left to the exchange's kernel)
+  if (g_in > room && ctx->nneigh > 0)
+    g_in = room;
+  const int g_bd = gb ? sp_grid(ctx, gb, (partials && rvec)) : 0;
   if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
     return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
   TailArgs Ti, Tb;
@@ -2607,10 +2649,10 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
   if (overlap && ctx->have_group_split)
   {
     const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
-    int g_in = gi ? sp_grid(gi) : 0;
+    int g_in = gi ? sp_grid(ctx, gi, false) : 0;
     if (g_in > 256 * 7 && ctx->nneigh > 0)
       g_in = 256 * 7; // room for the exchange's kernel beside the persistent workgroups (launch_spmv_overlapped)
-    const int g_bd = gb ? sp_grid(gb) : 8;
+    const int g_bd = gb ? sp_grid(ctx, gb, false) : 8;
     if ((size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
       return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
     int rc = comm_halo_begin(ctx, z);
@@ -2632,7 +2674,7 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
       if (rc)
         return rc;
     }
-    const int gs = sp_grid((ctx->nslices + 3) / 4);
+    const int gs = sp_grid(ctx, (ctx->nslices + 3) / 4, false);
     go(gs, nullptr, 0, partials, ctx->n_ghost > 0 ? 1 : 0);
     *npartials = gs;
   }
