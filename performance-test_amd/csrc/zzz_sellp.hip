@@ -1406,18 +1406,24 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
     // the 25 words are wave-uniform: pinned into scalar registers, the selects below stay register selects.  (Left to
     // itself the compiler folds them into a per-lane ADDRESS select, tp + 3 e + k, behind divergent branches -- and
     // that code decoded slot 0 of the third class wrongly when the chunk sits inside the chunk loop.)
+    // (All 25 requested first, pinned after: pinning each word as it is loaded made 25 DEPENDENT scalar round trips of
+    // them -- `s_load_dword; s_waitcnt lgkmcnt(0)` 25 times per periodic chunk, 2-3 us of a 3.5-us chunk at C4.)
     int t[25];
 #pragma unroll
     for (int i = 0; i < 25; ++i)
-    {
       t[i] = tp[i];
+#pragma unroll
+    for (int i = 0; i < 25; ++i)
       asm volatile("" : "+s"(t[i]));
-    }
     const int l = lane + t[24];
     const int q = l / 3, k = l - 3 * q, q3 = 3 * q;
+    // T[slot][k] without a select per class: T0 + (k >= 1) (T1 - T0) + (k == 2) (T2 - T1), the brackets as masks.  (The nested
+    // selects compiled into divergent control flow, ~15 scalar instructions per slot: 163 scalar instructions per chunk at C4,
+    // more than the CU's scalar unit issues in the time the chunk's bytes take.)
+    const int k1 = k >= 1 ? -1 : 0, k2 = k == 2 ? -1 : 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      cl[e] = (k == 0 ? t[3 * e] : (k == 1 ? t[3 * e + 1] : t[3 * e + 2])) + q3;
+      cl[e] = (t[3 * e] + q3) + (k1 & (t[3 * e + 1] - t[3 * e])) + (k2 & (t[3 * e + 2] - t[3 * e + 1]));
   }
   else if (m0 < 0)
   {

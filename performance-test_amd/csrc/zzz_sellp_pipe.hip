@@ -27,6 +27,7 @@
 // Serves: natural row order, the value dictionary in LDS (DICT = 2) or per-slice tables (DICT = 3), x windows (block size 3),
 // group lists of a partitioned matrix, the single-reduction form's extra sums.  Everything else (sorted rows, doubles, int32
 // columns, slices of more than 32 chunks, the Chebyshev epilogue, the folded all-reduce) stays on the generic kernel.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -58,7 +59,22 @@ struct PipeArgs
   const int2* win_info;
   const int2* win_seg;
   int dbg; // TEMPORARY timing probe
+  unsigned long long* stamps; // ZZZ_PIPE_STAMPS build: per-segment cycle sums
 };
+#ifdef ZZZ_PIPE_STAMPS
+#define ZZZ_STAMP(i)                                                                                                              \
+  do                                                                                                                             \
+  {                                                                                                                              \
+    unsigned long long t_;                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    seg[i] += t_ - t_prev;                                                                                                       \
+    t_prev = t_;                                                                                                                 \
+  } while (0)
+#else
+#define ZZZ_STAMP(i)
+#endif
 
 // stream registers of one chunk
 struct Stage
@@ -521,6 +537,10 @@ __global__ __launch_bounds__(SP_BLOCK, SR ? SP_ONE_WGS_SR : SP_ONE_WGS) void spm
 
   double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
   int regs_base = 0;
+#ifdef ZZZ_PIPE_STAMPS
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
   auto step_scalars = [&](int i, int& info, int& s) {
     if (i >= n_steps)
     {
@@ -541,7 +561,12 @@ __global__ __launch_bounds__(SP_BLOCK, SR ? SP_ONE_WGS_SR : SP_ONE_WGS) void spm
   // one slice: consume stage S (scalars info, s), request the stream of the step two places on into stage N
   auto body = [&](One& S, int info, int s, One& N, int info_n, int s_n) {
     const int w = (info >> 25) & 15, cls = (info >> 29) & 3;
+    ZZZ_STAMP(0); // loop overhead, the step's scalars
     const uint4v vq = S.vq, cq = S.cq;
+#ifdef ZZZ_PIPE_STAMPS
+    asm volatile("" ::"v"(vq.x), "v"(cq.x), "s"(S.b[0]));
+    ZZZ_STAMP(1); // waiting for the stage's stream data
+#endif
     const double xr = DOT ? S.xr : 0.0, rr = (DOT && SR) ? S.rr : 0.0;
     double sum = 0.0;
     // W entries per row: W gathers, W dictionary look-ups (waited for before the scalar loads of the next stage are requested:
@@ -578,11 +603,17 @@ __global__ __launch_bounds__(SP_BLOCK, SR ? SP_ONE_WGS_SR : SP_ONE_WGS) void spm
         v[e] = dict[vc[e]];
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+      ZZZ_STAMP(2); // decode, gathers and look-ups issued, look-ups back
       prefetch(N, info_n, s_n);
       __builtin_amdgcn_sched_barrier(0);
+      ZZZ_STAMP(3); // requesting the stream two steps on
 #pragma unroll
       for (int e = 0; e < W; ++e)
         sum += v[e] * xv[e];
+#ifdef ZZZ_PIPE_STAMPS
+      asm volatile("" ::"v"(sum));
+      ZZZ_STAMP(4); // the gathers' round trip and the products
+#endif
     };
     if (w == 7) // (an interior P1 row of the Kuhn mesh)
       run(std::integral_constant<int, 7>());
@@ -640,6 +671,7 @@ __global__ __launch_bounds__(SP_BLOCK, SR ? SP_ONE_WGS_SR : SP_ONE_WGS) void spm
         }
       }
     }
+    ZZZ_STAMP(5); // store, the sums
   };
 
   // three stages in rotation: consume A (step i) and refill C's successor ... no register that a load is still writing is
@@ -665,6 +697,13 @@ __global__ __launch_bounds__(SP_BLOCK, SR ? SP_ONE_WGS_SR : SP_ONE_WGS) void spm
     ++i;
   }
 
+#ifdef ZZZ_PIPE_STAMPS
+  if (lane == 0 && a.stamps)
+    for (int q = 0; q < 6; ++q)
+      atomicAdd(&a.stamps[q], seg[q]);
+  if (threadIdx.x == 0 && a.stamps)
+    atomicAdd(&a.stamps[7], (unsigned long long)n_steps);
+#endif
   if (DOT)
   {
     const double sres = block_reduce_sum(dot, red);
@@ -738,6 +777,27 @@ bool launch_sellp_pipe(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* 
   a.win_info = reinterpret_cast<const int2*>(ctx->sp_win_info.p);
   a.win_seg = reinterpret_cast<const int2*>(ctx->sp_win_seg.p);
   a.dbg = getenv("ZZZ_PIPE_DBG") ? atoi(getenv("ZZZ_PIPE_DBG")) : 0;
+  a.stamps = nullptr;
+#ifdef ZZZ_PIPE_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  static int stamps_launches = 0;
+  if (!stamps_dev)
+  {
+    (void)hipMalloc((void**)&stamps_dev, 64);
+    (void)hipMemset(stamps_dev, 0, 64);
+  }
+  a.stamps = stamps_dev;
+  if (++stamps_launches % 32 == 0)
+  {
+    unsigned long long h[8];
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(h, stamps_dev, 64, hipMemcpyDeviceToHost);
+    (void)hipMemset(stamps_dev, 0, 64);
+    const double n = (double)h[7] * 4.0; // wavefront-steps
+    fprintf(stderr, "STAMPS per slice and wavefront (clk): overhead %.0f  stream wait %.0f  decode+issue+lookups %.0f  prefetch issue %.0f  gathers+products %.0f  store %.0f  | steps %llu\n",
+            h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[7]);
+  }
+#endif
   const size_t lds = d3 ? (size_t)4 * SD_MAX * sizeof(double)
                         : (size_t)((ctx->sp_dict_n + 1) & ~1) * sizeof(double) + (win ? (size_t)ctx->sp_win_max * sizeof(double) : 0);
   const bool bs3 = ctx->bs == 3;
