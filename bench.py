@@ -166,6 +166,28 @@ def cpu_baseline(P, ctx, iters_gpu):
     zo.set_num_threads(cores)
     t_total = (t2 - t0) + t_solve
     n = P.n_owned * P.bs
+    # BASELINE configs[0]: "--ndofs 500000, CPU reference path, 1 MPI rank" -- the whole of it on ONE thread (~10 s)
+    c1 = None
+    try:
+        zo.set_num_threads(1)
+        nx1, ny1, nz1, r1 = zzz.mesh_size(500000, True, 1, 1, 1)
+        P1 = zzz.Part("poisson", 1, nx1 << r1, ny1 << r1, nz1 << r1)
+        ta = time.perf_counter()
+        rp1, cl1 = zo.pattern(P1.n_owned, P1.cell_dofs, 1)
+        tb = time.perf_counter()
+        bc1 = P1.bc_marker()
+        v1 = zo.assemble_matrix(0, 1, P1.x, P1.cells, P1.cell_dofs, bc1, rp1, cl1)
+        b1 = zo.assemble_vector(0, 1, P1.x, P1.cells, P1.cell_dofs, P1.f, P1.g, P1.facets, bc1)
+        tc = time.perf_counter()
+        it1 = zo.pcg(rp1, cl1, v1, b1, rtol=1e-8, max_it=10000)[0]
+        td = time.perf_counter()
+        c1 = {"dofs": int(P1.n_owned), "threads": 1, "create_matrix_s": tb - ta, "assemble_s": tc - tb, "solve_s": td - tc,
+              "krylov_iterations": int(it1), "dofs_per_s": P1.n_owned / (td - tb),
+              "dofs_per_s_with_create_matrix": P1.n_owned / (td - ta)}
+        del P1, rp1, cl1, v1, b1
+    except Exception as e:  # noqa: BLE001 -- a baseline beside the baseline must not cost the line
+        c1 = {"error": repr(e)}
+    zo.set_num_threads(cores)
     return {
         "value": n / t_total, "unit": "DoF/s", "cores": cores, "kind": "port",
         "sample": (f"oracle/zzz_oracle.c with OpenMP on {cores} threads, same {n}-dof problem, the whole of it: matrix "
@@ -173,6 +195,8 @@ def cpu_baseline(P, ctx, iters_gpu):
                    f"({t_solve:.2f} s, {t_iter * 1e3:.1f} ms per iteration; the GPU solve took {iters_gpu})"),
         "assemble_s": t2 - t0, "ms_per_cg_iteration": t_iter * 1e3, "solve_s": t_solve, "krylov_iterations": it_cpu,
         "ms_per_cg_iteration_1_thread": t_iter1 * 1e3,
+        # BASELINE configs[0] on this box's CPU, one thread: DoF/s of ZZZ Assemble matrix + vector + ZZZ Solve
+        "c1_1_thread_dofs_per_s": (c1 or {}).get("dofs_per_s"), "c1_1_thread": c1,
     }
 
 
@@ -364,6 +388,40 @@ def run_cgpoisson(order, ndofs, note, solves=3):
             "frac_of_peak_addressed": plan["bytes_per_action"] / (act_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if act_ms > 0 else None,
             "plan": plan, "setup_ms": setup_warm * 1e3, "setup_ms_cold": setup_cold * 1e3,
             "kernel": "k_mf_action + k_mf_finish (one pass over cell blocks in LDS; csrc/zzz_matfree.hip)"}
+
+
+def run_rank_size(problem, order, nx, ny, nz, what):
+    """One rank's share of a multi-GPU BASELINE configuration as a problem of its own on ONE GPU, with the multi-GPU code path
+    attached (1-rank communicator, peer-memory mailboxes: every scalar all-reduce and the halo entry points run, over no
+    links): the slab's mesh, nz / N layers of the cube (no ghost columns: the slab's neighbours are not there).  What a rank's
+    kernels take per Krylov iteration -- an UPPER bound on what N GPUs can gain: xGMI latency comes on top."""
+    form = zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON
+    zzz.comm_load()
+    with zzz.Context(0) as ctx:
+        ctx.comm_init(1, 0, zzz.comm_unique_id())
+        p2p = os.environ.get("ZZZ_P2P", "1") != "0" and ctx.comm_p2p_attach(ctx.comm_p2p_export())
+        info = ctx.cube_generate(problem, order, nx, ny, nz, 1, 0)
+        ctx.pattern_build()
+        ctx.assemble_matrix(form)
+        ctx.assemble_vector(form)
+        best = None
+        for sr in (True, False):
+            ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_JACOBI, rtol=1e-8, max_it=10000, single_reduction=sr)
+            ts = []
+            for _ in range(2):
+                ctx.sync()
+                t0 = time.perf_counter()
+                it, rn, r0 = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_JACOBI, rtol=1e-8, max_it=10000, single_reduction=sr)
+                ctx.sync()
+                ts.append(time.perf_counter() - t0)
+            t = min(ts)
+            if best is None or t < best[0]:
+                best = (t, it, "single_reduction" if sr else "classical")
+        nrows = ctx.csr_sizes()[0]
+    t, it, form_name = best
+    return {"what": what, "mesh": f"{nx}x{ny}x{nz} sub-cubes", "rows": nrows, "dofs": int(info[0]), "krylov_iterations": it,
+            "solve_ms": t * 1e3, "us_per_iteration": t / max(it, 1) * 1e6, "cg_form": form_name,
+            "scalar_allreduce": "peer-memory mailboxes" if p2p else "ncclAllReduce"}
 
 
 def full_pattern_product(a, nx, ny, nz):
@@ -728,8 +786,10 @@ def main():
         alg_bytes = spmv_algorithmic_bytes(nrows, nnz) + (8 * nrows if single_reduction else 0)  # + read of r
         achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         streamed, sinfo = physical_bytes_per_product(ctx, nrows, nnz, single_reduction)
-        kernel_name = ("spmv_sellp_kernel (CG SpMV on the sliced-ELL operator stream + <p,Ap> partials)" if sinfo[5]
-                       else "spmv_tile_kernel (CG SpMV + <p,Ap> partials)")
+        kernel_name = ("spmv_tile_kernel (CG SpMV + <p,Ap> partials)" if not sinfo[5] else
+                       "spmv_one_kernel (CG SpMV on the operator stream's one-chunk slices, two rows per lane, + <p,Ap> partials)"
+                       if ctx.spmv_values_info()["one_chunk_kernel"] else
+                       "spmv_sellp_kernel (CG SpMV on the sliced-ELL operator stream + <p,Ap> partials)")
         traffic, traffic_src = pmc_traffic(nrows, nnz, streamed)
         phys = streamed / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
@@ -783,6 +843,9 @@ def main():
         out["roofline"]["iteration"] = {"what": "one whole Jacobi-PCG iteration: bytes its kernels address / (ZZZ Solve / iterations)",
                                         "bytes": it_bytes, "us": it_s * 1e6, "achieved": it_bytes / it_s / 1e9, "unit": "GB/s",
                                         "frac": it_bytes / it_s / 1e9 / HBM_PEAK_GBS}
+        # (the same as scalars: a record that keeps scalar keys only still carries them)
+        out["roofline"]["iteration_frac"] = out["roofline"]["iteration"]["frac"]
+        out["roofline"]["iteration_us"] = out["roofline"]["iteration"]["us"]
         if out["roofline"]["frac"] > 1.0:
             # a stream that stays in L2 / the Infinity Cache between launches can be read faster than HBM delivers: said,
             # not asserted (the line and the other ranks' barrier must not die of it)
@@ -889,6 +952,8 @@ def main():
         # the other BASELINE configs, compactly, so that the driver's record (not only builder-run profiles) has them
         try:
             out["roofline"]["full_pattern"] = full_pattern_product(a, nx, ny, nz)
+            out["roofline"]["full_pattern_frac"] = out["roofline"]["full_pattern"]["frac"]
+            out["roofline"]["full_pattern_ms"] = out["roofline"]["full_pattern"]["avg_launch_ms"]
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             out["roofline"]["full_pattern"] = {"error": repr(e)}
         out["other_configs"] = {}
@@ -912,6 +977,36 @@ def main():
                 out["other_configs"][key] = run_matfree_operator(name, steps=st)
             except Exception as e:  # noqa: BLE001
                 out["other_configs"][key] = {"error": repr(e)}
+        # what ONE rank of the multi-GPU configurations does per Krylov iteration (no 8-GPU node is needed to know the bound)
+        rs = {}
+        lay = lambda n_, parts: -(-n_ // parts)  # noqa: E731 -- layers of the thickest z-slab
+        mx4 = zzz.mesh_size(500000, False, 8, 3, 1)
+        mx5 = zzz.mesh_size(50000000, True, 1, 1, 3)
+        for key, prob, order, mesh, single_ms, what in (
+                ("c3_n2", "poisson", 1, (nx, ny, lay(nz, 2)), avg("solve") * 1e3, "BASELINE configs[2] on 2 GPUs: one z-slab"),
+                ("c3_n4", "poisson", 1, (nx, ny, lay(nz, 4)), avg("solve") * 1e3, "BASELINE configs[2] on 4 GPUs: one z-slab"),
+                ("c3_n8", "poisson", 1, (nx, ny, lay(nz, 8)), avg("solve") * 1e3, "BASELINE configs[2] on 8 GPUs: one z-slab"),
+                ("c4_n8", "elasticity", 1, (mx4[0] << mx4[3], mx4[1] << mx4[3], lay(mx4[2] << mx4[3], 8)),
+                 (out["other_configs"].get("c4_total", {}).get("phases_ms") or {}).get("solve"), "BASELINE configs[3]: one of 8 z-slabs"),
+                ("c5_n8", "poisson", 3, (mx5[0] << mx5[3], mx5[1] << mx5[3], lay(mx5[2] << mx5[3], 8)),
+                 (out["other_configs"].get("c5_whole", {}).get("phases_ms") or {}).get("solve"), "BASELINE configs[4]: one of 8 z-slabs")):
+            try:
+                rec = run_rank_size(prob, order, mesh[0], mesh[1], mesh[2], what)
+                nr = int(key.split("_n")[1])
+                if single_ms:
+                    rec["single_gpu_solve_ms"] = single_ms
+                    # strong scaling: one GPU's solve over one rank's; weak (c4): the total problem's solve over one rank's x N
+                    rec["projected_speedup_upper_bound"] = single_ms / rec["solve_ms"]
+                    rec["projected_speedup_note"] = (f"single-GPU ZZZ Solve / one rank's ZZZ Solve at N = {nr}: kernels only, no xGMI "
+                                                     "latency, no load imbalance -- a bound, not a measurement of N GPUs")
+                rs[key] = rec
+            except Exception as e:  # noqa: BLE001
+                rs[key] = {"error": repr(e)}
+        rs["scalar_allreduce_default"] = ("peer-memory mailboxes over xGMI (one kernel: reduce the workgroups' partials, store {values, tag} "
+                                          "into every peer's mailbox, poll the own one); ncclAllReduce is the fallback, chosen per node by "
+                                          "bench.py's warm-up tuning: an RCCL all-reduce of 1-3 doubles is two extra launches and ~20 us on "
+                                          "one node, the mailbox kernel ~6 us (DESIGN.md section 5)")
+        out["other_configs"]["rank_sizes"] = rs
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -361,9 +361,10 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
  * reads 16-bit codes into a dictionary of the matrix's DISTINCT values held in memory / copied into LDS by every workgroup
  * (matrices of regular meshes hold few: ~1 300 at 10 M-dof P1 Poisson; at most 65 535 qualify; same doubles, same
  * order of operations, bit-identical products); info[1] = distinct values (+0.0 included); info[2] = bytes per product of
- * the stream in the form in use; info[3] = bytes per product with the values as doubles.  0s when the product does not
- * run on the stream. */
-int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4]);
+ * the stream in the form in use; info[3] = bytes per product with the values as doubles; info[4] = 1 when the stream is
+ * one of one-chunk slices and the product runs on the kernel for those (csrc/zzz_sellp_pipe.hip: two rows per lane), else 0;
+ * info[5] = workgroups per CU of the product's persistent grid.  0s when the product does not run on the stream. */
+int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[6]);
 
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */
 

@@ -1,6 +1,7 @@
 // C-ABI entry points of libzzz_hip.so (declared, with the reference interfaces they replace, in
 // include/zzz_abi.h).  There is no CPU fallback: without a usable GPU every entry point fails.
 #include "zzz_internal.h"
+#include "zzz_sellp.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -969,14 +970,16 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   return ZZZ_OK;
 }
 
-int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4])
+int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[6])
 {
   ZZZ_ENTER(ctx);
   if (!info || !ctx->have_pattern)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_values_info: no pattern");
-  info[0] = info[1] = info[2] = info[3] = 0;
+  info[0] = info[1] = info[2] = info[3] = info[4] = info[5] = 0;
   if (!sellp_active(ctx))
     return ZZZ_OK;
+  info[4] = zzz::sellp_pipe_wgs(ctx, false) ? 1 : 0;
+  info[5] = info[4] ? zzz::sellp_pipe_wgs(ctx, false) : 8;
   info[0] = ctx->sp_sd_on ? 3 : (ctx->sp_dict_on ? (ctx->sp_dict_n <= zzz::SP_DICT_LDS_ENTRIES ? 2 : 1) : 0);
   info[1] = ctx->sp_dict_on ? ctx->sp_dict_n : 0;
   info[2] = sellp_stream_bytes(ctx);

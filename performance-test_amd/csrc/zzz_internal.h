@@ -251,6 +251,8 @@ struct zzz_ctx
   zzz::DevBuf<unsigned long long> sp_smode; // per slice: two bits per chunk, what a product loads for its columns (zzz_sellp.h)
   bool sp_pipe_ok = false;                  // every chunk is described by its slice's mode word: the pipelined product may run
   bool sp_one_chunk = false;                // ... and no slice has more than one chunk (scalar P1 on a regular mesh)
+  zzz::DevBuf<uint8_t> sp_pairs;            // one-chunk streams: slices 2 p and 2 p + 1 form an affine pair (zzz_sellp_pipe.hip)
+  bool sp_pairs_ok = false;
   int sellp_pipe = 1;                       // ZZZ_SELLP_PIPE=0: the generic product always
   int64_t nslices = 0, sp_chunks = 0, sp_kept = 0, sp_bytes = 0; // slices, chunks of the stream, matrix entries kept in it,
                                                                  // bytes a product reads from it

@@ -50,13 +50,12 @@ __device__ inline double gather(const double* __restrict__ x, int col)
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
 }
 
-// workgroups per CU of the pipelined product (its register budget: <= 96 per lane); sp_grid sizes the persistent grid by it
-constexpr int SP_PIPE_WGS = 5;
-constexpr int SP_ONE_WGS = 6; // ... of the kernel for streams of one-chunk slices (<= 80 registers per lane)
-constexpr int SP_ONE_WGS_SR = 5; // ... with the single-reduction form's extra sums (<= 96)
-int sellp_pipe_wgs(const zzz_ctx* ctx, bool sr); // workgroups per CU of the kernel of zzz_sellp_pipe.hip that serves the context's stream; 0: none does
-// The software-pipelined product (zzz_sellp_pipe.hip).  Returns false when this stream / launch is not one it serves (the
-// caller then launches the generic kernel); true after launching.
+// workgroups per CU of the product for streams of one-chunk slices (zzz_sellp_pipe.hip: two rows per lane, <= 96 registers per
+// lane); sp_grid sizes the persistent grid by it
+constexpr int SP_ONE_WGS = 4;
+constexpr int SP_ONE_WGS_SR = 4; // ... with the single-reduction form's extra sums
+int sellp_pipe_wgs(const zzz_ctx* ctx, bool sr); // workgroups per CU if spmv_one_kernel serves the context's stream; 0: it does not
+int sellp_pairs_build(zzz_ctx* ctx); // marks the affine slice pairs of a stream of one-chunk slices (spmv_one_kernel)
 bool launch_sellp_pipe(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
                        const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr);
 } // namespace zzz

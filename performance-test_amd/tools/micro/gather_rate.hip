@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k_gather(const double* __restrict__ x, lo
 {
   const int lane = threadIdx.x & 63;
   const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const unsigned mask = (unsigned)(nelem / 64 / 2 - 1); // (a power of two: the lower half of the buffer, room for the shifted runs)
+  const unsigned mask = (unsigned)(nelem / 64 / 4 - 1); // (a power of two: the lower half of the buffer, room for the shifted runs)
   double acc = 0.0;
   for (int it = 0; it < iters; ++it)
   {
@@ -54,8 +54,25 @@ __global__ __launch_bounds__(256) void k_gather(const double* __restrict__ x, lo
       }
       else if (PAT == 9)
         v[e] = b[0];
-      else
+      else if (PAT == 10)
         v[e] = lane < 2 ? b[lane * 65] : 0.0;
+      else if (PAT == 11)
+      {
+        dbl2 q;
+        __builtin_memcpy(&q, b + 1 + 2 * lane, 16); // 16 B per lane at an address that is 8-B aligned only
+        v[e] = q.x + q.y;
+      }
+      else if (PAT == 12)
+      {
+        dbl2 q;
+        __builtin_memcpy(&q, b + 1 + 2 * (lane & 31) + (lane >> 5) * 4096, 16); // two 512-B runs, 8-B aligned, 32 KB apart
+        v[e] = q.x + q.y;
+      }
+      else
+      {
+        dbl2 q = reinterpret_cast<const dbl2*>(b + (lane >> 5) * 4096)[lane & 31]; // two 512-B runs, 16-B aligned
+        v[e] = q.x + q.y;
+      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -102,5 +119,8 @@ int main()
   run<8>("dwordx4, lanes 0..31 only (512 B)", x, nelem, out);
   run<9>("dwordx2, one address for every lane", x, nelem, out);
   run<10>("dwordx2, two lanes only", x, nelem, out);
+  run<11>("dwordx4, contiguous 1 KiB, 8-B aligned only", x, nelem, out);
+  run<12>("dwordx4, two 512-B runs, 8-B aligned only", x, nelem, out);
+  run<13>("dwordx4, two 512-B runs, 16-B aligned", x, nelem, out);
   return 0;
 }

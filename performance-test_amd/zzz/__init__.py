@@ -574,12 +574,14 @@ class Context:
     def spmv_values_info(self):
         """how the operator stream holds its values: dict(form = 'doubles' | 'dictionary in memory' | 'dictionary in LDS',
         distinct values, bytes per product in that form, bytes per product as doubles)"""
-        info = (C.c_int64 * 4)()
+        info = (C.c_int64 * 6)()
         if os.environ.get("ZZZ_AB_OLD") and not hasattr(self.L, "zzz_spmv_values_info"):
-            return dict(form="doubles", distinct_values=0, bytes_per_product=0, bytes_per_product_as_doubles=0)
+            return dict(form="doubles", distinct_values=0, bytes_per_product=0, bytes_per_product_as_doubles=0,
+                        one_chunk_kernel=False, workgroups_per_cu=8)
         self._ck(self.L.zzz_spmv_values_info(self.h, info))
         return dict(form=("doubles", "dictionary in memory", "dictionary in LDS", "slice dictionaries")[int(info[0])], distinct_values=int(info[1]),
-                    bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]))
+                    bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]),
+                    one_chunk_kernel=bool(info[4]), workgroups_per_cu=int(info[5]))
 
     def spmv_x_windows(self):
         """(LDS doubles per workgroup, bytes of x loaded into LDS per product) when the operator stream carries x windows,

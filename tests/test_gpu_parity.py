@@ -513,8 +513,15 @@ def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
     np.testing.assert_array_equal(res[forced][0], zo.spmv(rp.astype(np.int64), cl, v, x))
     np.testing.assert_array_equal(res[forced][0], res["0"][0])
     assert res[forced][1] == res["0"][1]
-    np.testing.assert_array_equal(res[forced][2], res["0"][2])
     vi = res[forced][3]
+    if vi["one_chunk_kernel"]:
+        # a stream of one-chunk slices on coded values runs on its own kernel (zzz_sellp_pipe.hip: two rows per lane) with
+        # another persistent grid: the products keep their bits (above), the workgroups' partial sums of <p, A p> are added
+        # in another order -- as MPI_Allreduce's order is the run's (src/cg.h:65); the solve agrees to rounding
+        assert vi["workgroups_per_cu"] < 8
+        np.testing.assert_allclose(res[forced][2], res["0"][2], rtol=0, atol=1e-12 * np.abs(res["0"][2]).max())
+    else:
+        np.testing.assert_array_equal(res[forced][2], res["0"][2])
     assert res["0"][3]["form"] == "doubles" and vi["form"] == form, vi
     if form == "slice dictionaries":
         assert vi["bytes_per_product"] < vi["bytes_per_product_as_doubles"]  # (slices of more than 1 023 values stay doubles)
