@@ -427,7 +427,13 @@ int zzz_comm_p2p_enable(zzz_ctx* ctx, int* enabled);
  * loop at all (a peer-only communicator becomes a complete transport).  Plans that do not fit the window (more than 32
  * neighbours, or a message beyond window / 2 / ranks) keep the communicator's send / recv.  on = 0 keeps the halo on
  * the communicator while the all-reduces stay on the mailboxes (A/B; every rank must make the same call);
- * *in_use = 1 when the next exchange goes through the window. */
+ * *in_use = 1 when the next exchange goes through the window.
+ * COLLECTIVE, all four: with the mailboxes attached, zzz_comm_p2p_attach, zzz_comm_p2p_enable, zzz_comm_p2p_halo and
+ * zzz_halo_upload end in one agreement of all ranks on the exchange's transport (both ends of an exchange must use the
+ * same one).  Every rank of the communicator must make the same calls the same number of times, in the same order -- as
+ * MPI ranks must for MPI_Comm_dup; the agreement goes through the communicator's own all-reduce (blocking, no time-out)
+ * and, on a peer-only communicator, through the mailboxes (a rank that waits ten minutes for the others gives up with
+ * ZZZ_ERR_RCCL). */
 int zzz_comm_p2p_halo(zzz_ctx* ctx, int on, int* in_use);
 
 /* The forward scatter of common::Scatterer / IndexMap (src/cgpoisson_problem.cpp:187-190,

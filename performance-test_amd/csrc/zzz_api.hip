@@ -244,7 +244,7 @@ int zzz_mesh_upload(zzz_ctx* ctx, int64_t nverts, const double* x, int64_t ncell
   rc = upload(ctx, ctx->cell_verts, cell_verts, (size_t)(4 * ncells));
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
-  ctx->mf.valid = false;
+  ctx->mf.valid = ctx->mf.failed = false;
   return rc;
 }
 
@@ -286,7 +286,7 @@ int zzz_dofmap_upload(zzz_ctx* ctx, int order, int bs, const int32_t* cell_dofs,
   ctx->have_coeff[0] = ctx->have_coeff[1] = false;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
-  ctx->mf.valid = false;
+  ctx->mf.valid = ctx->mf.failed = false;
   ctx->near_null_ld = 0;
   // the library's own locality order of the owned dofs (zzz_renumber.hip): from here on the device connectivity is in
   // internal numbering and every entry point below translates at the boundary
@@ -318,7 +318,7 @@ int zzz_bc_upload(zzz_ctx* ctx, int64_t nbc, const int32_t* bc_dofs)
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->bc.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_bc = true;
-  ctx->mf.valid = false; // the plan of the matrix-free action carries the Dirichlet markers of its dof lists
+  ctx->mf.valid = ctx->mf.failed = false; // the plan of the matrix-free action carries the Dirichlet markers of its dof lists
   return ZZZ_OK;
 }
 

@@ -1081,9 +1081,23 @@ int zzz::halo_peer_agree(zzz_ctx* ctx)
     P->halo_agreed = (nb[0] == 0.0 && nb[1] > 0.0) ? 1 : 0;
     return ZZZ_OK;
   }
+  if (ctx->comm->comm)
+  {
+    // A communicator with a transport of its own: the verdict travels through IT -- a blocking collective without a clock.
+    // (The mailbox kernel below gives up after its time-out; ranks reach set-up calls minutes apart when one of them builds
+    // a mesh on the host, and a rank that gave up would be out of step with the mailboxes' round numbers for good.)
+    if (int rc = comm_allreduce_sum(ctx, tv.p, 2))
+      return rc;
+    double nb[2] = {1.0, 0.0};
+    ZZZ_HIP(ctx, hipMemcpyAsync(nb, tv.p, sizeof(nb), hipMemcpyDeviceToHost, ctx->stream));
+    ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P->halo_agreed = (nb[0] == 0.0 && nb[1] > 0.0) ? 1 : 0;
+    return ZZZ_OK;
+  }
+  // peer-only communicator: the mailboxes are all there is; a set-up call may wait long for the slowest rank (ten minutes)
   const long long seq = ++P->seq;
   hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(1024), 0, ctx->stream, (const int*)nullptr, tv.p, tv.p + 1, tv.p + 2, 1, 3,
-                     tv.p + 4, P->peer_dev.p, P->box, P->nranks, P->rank, seq, P->fail.p, 10 * P2P_TIMEOUT_TICKS);
+                     tv.p + 4, P->peer_dev.p, P->box, P->nranks, P->rank, seq, P->fail.p, 200 * P2P_TIMEOUT_TICKS);
   double nbad[2] = {1.0, 0.0};
   ZZZ_HIP(ctx, hipMemcpyAsync(nbad, tv.p + 4, sizeof(nbad), hipMemcpyDeviceToHost, ctx->stream));
   ZZZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -143,7 +143,7 @@ extern "C" int zzz_cube_generate(zzz_ctx* ctx, int problem, int order, int64_t n
   ctx->have_coeff[1] = problem == ZZZ_FORM_POISSON;
   ctx->have_pattern = ctx->have_matrix = false;
   ctx->xq_valid = false;
-  ctx->mf.valid = false;
+  ctx->mf.valid = ctx->mf.failed = false;
   ctx->adj_runs_n = -1;
   pattern_reserve(ctx);
   rc = ensure_p1_coords(ctx);

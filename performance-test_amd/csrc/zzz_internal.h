@@ -270,6 +270,7 @@ struct zzz_ctx
   zzz::DevBuf<uint16_t> sp_vcode8;
   zzz::DevBuf<double> sp_sd_vals;
   zzz::DevBuf<int32_t> sp_sd_info;
+  zzz::DevBuf<int64_t> sp_sd_off; // where slice s's table starts in sp_sd_vals (the tables back to back, at even entries)
   bool sp_sd_on = false;
   bool sp_sd_all = false; // every slice has its table (none stays doubles)
   int64_t sp_sd_bytes = 0;

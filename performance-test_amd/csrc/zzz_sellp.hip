@@ -464,6 +464,10 @@ __global__ __launch_bounds__(256) void k_sp_fill(const rp_t* __restrict__ rowptr
 // 6.2 M P3 dofs, 7.6 ms).  Instead: (1) k_sp_compact sweeps each slice's CSR range with dense loads and writes the kept
 // entries row by row into a copy whose rows start at multiples of 8 entries (crow, from a scan of the padded counts);
 // (2) k_sp_fill_c reads a lane's next eight entries as 64 + 32 contiguous, aligned bytes (four 16-B and two 16-B loads).
+struct Even2
+{
+  __host__ __device__ int64_t operator()(int32_t n) const { return ((int64_t)n + 1) & ~(int64_t)1; }
+};
 struct Pad8
 {
   __host__ __device__ int64_t operator()(int32_t n) const { return ((int64_t)n + 7) & ~(int64_t)7; }
@@ -1199,17 +1203,19 @@ __global__ __launch_bounds__(256) void k_sp_dict_encode(const int2* __restrict__
 // (P3 at 30^3 sub-cubes: median 296 per slice, all slices below 1 024; 7 400 in the matrix; 8 270 at 61^3).  One wavefront
 // per slice: the slice's distinct values into a hash set in LDS (at most 1 023 besides +0.0), numbered as they arrive; then
 // every value of the slice as a 16-bit code in the layout of the matrix-wide dictionary's codes ([chunk][lane][8], 16 B per
-// lane and chunk), and the table beside it (sd_vals[slice][1024], sd_info[slice] = entries, 0 = this slice stays doubles).
+// lane and chunk), and the table beside it (sd_info[slice] = entries, 0 = this slice stays doubles; the tables back to back in
+// sd_vals, slice s at sd_off[s]: a first pass (COUNT) finds the sizes, a scan the offsets -- 1 024 doubles reserved per slice
+// were 6.4 GB at 49.8 M rows for 1.8 GB of tables).
 // The product copies a slice's table into its wavefront's part of LDS (8 KiB per wavefront: five workgroups per CU).
 // Tried: 8-bit codes and tables of 256 (a third of P3's slices qualify: product 0.67 -> 0.54 ms at 6.2 M dofs), tables of 512
 // (0.46 ms there, 4.19 ms at 49.8 M dofs), tables of 1 024 (0.47 / 3.68 ms: kept).
 // (SD_SLOTS = 2048, SD_MAX = 1024: zzz_sellp.h)
-template <bool PERM>
+template <bool PERM, bool COUNT>
 __global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ desc, const int32_t* __restrict__ perm,
                                                       const double* __restrict__ svals, const int32_t* __restrict__ meta,
                                                       int nrows, int64_t nslices, uint16_t* __restrict__ vcode8,
-                                                      double* __restrict__ sd_vals, int32_t* __restrict__ sd_info,
-                                                      unsigned long long* __restrict__ bytes_out)
+                                                      double* __restrict__ sd_vals, const int64_t* __restrict__ sd_off,
+                                                      int32_t* __restrict__ sd_info, unsigned long long* __restrict__ bytes_out)
 {
   __shared__ unsigned long long keys_s[2][SD_SLOTS];
   __shared__ uint16_t code_s[2][SD_SLOTS];
@@ -1229,8 +1235,24 @@ __global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ de
     const bool row = r >= 0 && r < nrows;
     const int2 ds = desc[s];
     const int c0 = ds.x, nch = ds.y & 0xffffff, wl = ds.y >> 24;
-    double* const tab = sd_vals + s * SD_MAX;
-    if (lane == 0)
+    if (!COUNT && sd_info[s] == 0) // (the first pass found more values than a table holds: this slice stays doubles)
+    {
+      if (lane == 0)
+      {
+        for (int j = 0; j < nch; ++j)
+        {
+          const int w = j + 1 < nch ? 8 : wl;
+          const int m0 = meta[(size_t)(c0 + j) * 8];
+          const unsigned cb = (m0 < 0 && (m0 & 0x40000000)) ? 100u : (m0 < 0 ? 2048u : ((m0 & 0x60000000) == 0x20000000 ? 0u : ((m0 & 0x40000000) ? 512u : 1024u)));
+          bytes += 32 + cb + (unsigned)((w >> 1) * 1024 + (w & 1) * 512);
+        }
+        bytes += 4;
+        atomicAdd(reinterpret_cast<int*>(bytes_out) + 2, 1); // slices that stay doubles
+      }
+      continue;
+    }
+    double* const tab = COUNT ? nullptr : sd_vals + sd_off[s];
+    if (!COUNT && lane == 0)
       tab[0] = 0.0;
     unsigned long long last = 0ull;
     for (int j = 0; j < nch; ++j)
@@ -1256,7 +1278,7 @@ __global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ de
               {
                 const int c = atomicAdd(&cnt_s[wv], 1);
                 codes[h] = (uint16_t)c;
-                if (c < SD_MAX)
+                if (!COUNT && c < SD_MAX)
                   tab[c] = __longlong_as_double((long long)b);
                 break;
               }
@@ -1276,11 +1298,12 @@ __global__ __launch_bounds__(128) void k_sp_sd_build(const int2* __restrict__ de
     __builtin_amdgcn_wave_barrier();
     const int n = cnt_s[wv];
     const bool ok = n <= SD_MAX;
-    if (lane == 0)
+    if (COUNT)
     {
-      sd_info[s] = ok ? n : 0;
-      if (!ok)
-        atomicAdd(reinterpret_cast<int*>(bytes_out) + 2, 1); // slices that stay doubles (the pipelined product wants none)
+      if (lane == 0)
+        sd_info[s] = ok ? n : 0;
+      __builtin_amdgcn_wave_barrier();
+      continue;
     }
     if (ok)
     {
@@ -1502,7 +1525,8 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
                                                               TailArgs tail, ChebEpi epi, const int2* __restrict__ win_info,
                                                               const int2* __restrict__ win_seg, const uint16_t* __restrict__ vcode,
                                                               const double* __restrict__ dict_g, int dict_n,
-                                                              const int32_t* __restrict__ sd_info)
+                                                              const int32_t* __restrict__ sd_info,
+                                                              const int64_t* __restrict__ sd_off)
 {
   // dynamic LDS: DICT == 2: the value dictionary (dict_n doubles, rounded up to 2); WIN: the group's x window behind it
   // (launch: sp_win_max doubles)
@@ -1593,11 +1617,12 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
     {
       // the slice's table into the wavefront's LDS (entries 0 .. n - 1; n == 0: the slice's values are doubles)
       const int n_sd = __builtin_amdgcn_readfirstlane(sd_info[s]);
+      const int64_t sd_tab = sd_off[s];
       if (n_sd > 0)
       {
         __builtin_amdgcn_wave_barrier(); // (the previous slice's lookups are done)
         for (int k = lane; k < n_sd; k += 64)
-          sdl[k] = dict_g[(int64_t)s * SD_MAX + k];
+          sdl[k] = dict_g[sd_tab + k];
         __builtin_amdgcn_wave_barrier();
         dict = sdl;
       }
@@ -2379,19 +2404,40 @@ static int sp_sd_build(zzz_ctx* ctx)
   hipStream_t s = ctx->stream;
   const int64_t nsl = ctx->nslices;
   ZZZ_HIP(ctx, ctx->sp_vcode8.alloc((size_t)ctx->sp_chunks * 512));
-  ZZZ_HIP(ctx, ctx->sp_sd_vals.alloc((size_t)nsl * SD_MAX));
-  ZZZ_HIP(ctx, ctx->sp_sd_info.alloc((size_t)nsl));
+  ZZZ_HIP(ctx, ctx->sp_sd_info.alloc((size_t)nsl + 1));
+  ZZZ_HIP(ctx, ctx->sp_sd_off.alloc((size_t)nsl + 1));
   ZZZ_HIP(ctx, ctx->sp_dict_info.reserve(8));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_dict_info.p, 0, 8 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->sp_sd_info.p + nsl, 0, sizeof(int32_t), s)); // closes the scan
   const int2* desc = reinterpret_cast<const int2*>(ctx->sp_desc.p);
   const unsigned grid = (unsigned)std::min<int64_t>((nsl + 1) / 2, 256 * 8);
   unsigned long long* bytes = reinterpret_cast<unsigned long long*>(ctx->sp_dict_info.p + 4);
+  // first pass: the tables' sizes; scan: where each starts; second pass: tables and codes
   if (ctx->sp_sorted)
-    hipLaunchKernelGGL(k_sp_sd_build<true>, dim3(grid), dim3(128), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, ctx->sp_meta.p,
-                       (int)ctx->nrows, nsl, ctx->sp_vcode8.p, ctx->sp_sd_vals.p, ctx->sp_sd_info.p, bytes);
+    hipLaunchKernelGGL((k_sp_sd_build<true, true>), dim3(grid), dim3(128), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, ctx->sp_meta.p,
+                       (int)ctx->nrows, nsl, (uint16_t*)nullptr, (double*)nullptr, (const int64_t*)nullptr, ctx->sp_sd_info.p, bytes);
   else
-    hipLaunchKernelGGL(k_sp_sd_build<false>, dim3(grid), dim3(128), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p, ctx->sp_meta.p,
-                       (int)ctx->nrows, nsl, ctx->sp_vcode8.p, ctx->sp_sd_vals.p, ctx->sp_sd_info.p, bytes);
+    hipLaunchKernelGGL((k_sp_sd_build<false, true>), dim3(grid), dim3(128), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p,
+                       ctx->sp_meta.p, (int)ctx->nrows, nsl, (uint16_t*)nullptr, (double*)nullptr, (const int64_t*)nullptr,
+                       ctx->sp_sd_info.p, bytes);
+  {
+    const auto even = rocprim::make_transform_iterator(ctx->sp_sd_info.p, Even2{}); // (tables start at even entries: 16-B aligned)
+    size_t tb = 0;
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, even, ctx->sp_sd_off.p, (int64_t)0, (size_t)nsl + 1, rocprim::plus<int64_t>(), s));
+    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, even, ctx->sp_sd_off.p, (int64_t)0, (size_t)nsl + 1, rocprim::plus<int64_t>(), s));
+  }
+  int64_t total = 0;
+  ZZZ_HIP(ctx, hipMemcpyAsync(&total, ctx->sp_sd_off.p + nsl, sizeof(total), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  ZZZ_HIP(ctx, ctx->sp_sd_vals.alloc((size_t)total + 2));
+  if (ctx->sp_sorted)
+    hipLaunchKernelGGL((k_sp_sd_build<true, false>), dim3(grid), dim3(128), 0, s, desc, ctx->sp_perm.p, ctx->sp_vals.p, ctx->sp_meta.p,
+                       (int)ctx->nrows, nsl, ctx->sp_vcode8.p, ctx->sp_sd_vals.p, ctx->sp_sd_off.p, ctx->sp_sd_info.p, bytes);
+  else
+    hipLaunchKernelGGL((k_sp_sd_build<false, false>), dim3(grid), dim3(128), 0, s, desc, (const int32_t*)nullptr, ctx->sp_vals.p,
+                       ctx->sp_meta.p, (int)ctx->nrows, nsl, ctx->sp_vcode8.p, ctx->sp_sd_vals.p, ctx->sp_sd_off.p, ctx->sp_sd_info.p,
+                       bytes);
   ZZZ_HIP(ctx, hipGetLastError());
   int32_t h[8];
   ZZZ_HIP(ctx, hipMemcpyAsync(h, ctx->sp_dict_info.p, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -2416,8 +2462,31 @@ bool sellp_active(zzz_ctx* ctx)
     return false;
   if (!ctx->sp_dict_done)
   {
-    (void)sp_dict_build(ctx);
-    (void)sp_sd_build(ctx);
+    // a failed build (a hipMalloc that did not fit) leaves the stream on doubles -- valid -- but must not leave its partial
+    // allocations or HIP's sticky last error behind (the next hipGetLastError after a product launch would report it)
+    if (sp_dict_build(ctx) != ZZZ_OK)
+    {
+      ctx->sp_dict_on = false;
+      (void)hipGetLastError();
+    }
+    if (!ctx->sp_dict_on)
+    {
+      ctx->sp_vcode.release();
+      ctx->sp_dict_table.release();
+      ctx->sp_dict_slot.release();
+    }
+    if (sp_sd_build(ctx) != ZZZ_OK)
+    {
+      ctx->sp_sd_on = ctx->sp_sd_all = false;
+      (void)hipGetLastError();
+    }
+    if (!ctx->sp_sd_on)
+    {
+      ctx->sp_vcode8.release();
+      ctx->sp_sd_vals.release();
+      ctx->sp_sd_info.release();
+      ctx->sp_sd_off.release();
+    }
     ctx->sp_pairs_ok = false;
     if (ctx->sp_one_chunk && ctx->sp_dict_on && ctx->bs == 1 && !ctx->sp_sorted)
       ctx->sp_pairs_ok = sellp_pairs_build(ctx) == ZZZ_OK;
@@ -2483,13 +2552,13 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
                          ctx->stream, off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,           \
                          ctx->sp_perm.p, x, y, (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec,     \
                          SPMV_PSTRIDE, nn_is_rr, TailArgs(), *epi, winfo, wseg, VC_, DG_, ctx->sp_dict_n,                  \
-                         ctx->sp_sd_info.p);                                                                           \
+                         ctx->sp_sd_info.p, ctx->sp_sd_off.p);                                                         \
     else                                                                                                               \
       hipLaunchKernelGGL((spmv_sellp_kernel<DOT, NT, PERM, false, WIN, DICT>), dim3(grid), dim3(SP_BLOCK), LDSB,        \
                          ctx->stream, off, ctx->sp_vals.p, ctx->sp_codes16.p, ctx->sp_codes32.p, ctx->sp_meta.p,           \
                          ctx->sp_perm.p, x, y, (int)ctx->nrows, ctx->nslices, partials, stop, group_list, nlist, rvec,     \
                          SPMV_PSTRIDE, nn_is_rr, tail, ChebEpi(), winfo, wseg, VC_, DG_, ctx->sp_dict_n,                   \
-                         ctx->sp_sd_info.p);                                                                           \
+                         ctx->sp_sd_info.p, ctx->sp_sd_off.p);                                                         \
   } while (0)
 #define ZZZ_SP_GO5(NT, PERM, WIN, LDSB)                                                                                \
   do                                                                                                                   \
