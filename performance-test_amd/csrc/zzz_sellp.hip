@@ -1599,14 +1599,49 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
       {
         const int2* __restrict__ sg = win_seg + (int64_t)(s >> 2) * SP_WIN_NSEG;
         __syncthreads(); // the previous group's window is done with
-        int off = 0;
-        for (int q = 0; q < nwin; ++q)
+        // Every entry of the window is REQUESTED before any is stored (a loop of load -> store per segment was five to
+        // seven dependent round trips per group, a quarter of the group's time at C4): the segments are cut into blocks of
+        // 256 entries, block i is thread-uniformly one segment's, thread t takes entry t of each; at most WIN_BLOCKS blocks
+        // in registers at a time.
+        constexpr int WIN_BLOCKS = 12;
+        int q = 0, seg_first = 0, off = 0; // the segment of the current block, the first block of it, where it starts in the window
+        int2 sq = sg[0];
+        int c0s = __builtin_amdgcn_readfirstlane(sq.x), len = __builtin_amdgcn_readfirstlane(sq.y);
+        for (int b0 = 0; q < nwin; b0 += WIN_BLOCKS)
         {
-          const int2 sq = sg[q];
-          const int c0s = __builtin_amdgcn_readfirstlane(sq.x), len = __builtin_amdgcn_readfirstlane(sq.y);
-          for (int k = threadIdx.x; k < len; k += SP_BLOCK)
-            xwin[off + k] = x[c0s + k];
-          off += len;
+          double t[WIN_BLOCKS];
+          int at[WIN_BLOCKS]; // where the entry goes (-1: none)
+#pragma unroll
+          for (int i = 0; i < WIN_BLOCKS; ++i)
+          {
+            at[i] = -1;
+            t[i] = 0.0;
+            while (q < nwin && (b0 + i - seg_first) * SP_BLOCK >= len) // (uniform: on to the segment this block belongs to)
+            {
+              off += len;
+              seg_first = b0 + i;
+              ++q;
+              if (q < nwin)
+              {
+                sq = sg[q];
+                c0s = __builtin_amdgcn_readfirstlane(sq.x);
+                len = __builtin_amdgcn_readfirstlane(sq.y);
+              }
+            }
+            if (q < nwin)
+            {
+              const int k = (b0 + i - seg_first) * SP_BLOCK + (int)threadIdx.x;
+              if (k < len)
+              {
+                t[i] = x[c0s + k];
+                at[i] = off + k;
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < WIN_BLOCKS; ++i)
+            if (at[i] >= 0)
+              xwin[at[i]] = t[i];
         }
         __syncthreads();
       }
@@ -1621,8 +1656,21 @@ __global__ __launch_bounds__(SP_BLOCK, 8) void spmv_sellp_kernel(const int2* __r
       if (n_sd > 0)
       {
         __builtin_amdgcn_wave_barrier(); // (the previous slice's lookups are done)
-        for (int k = lane; k < n_sd; k += 64)
-          sdl[k] = dict_g[sd_tab + k];
+        // the table requested 512 entries at a time before any of them is stored, 16 B per lane and request (the tables start
+        // at even entries) -- not one dependent round trip per 64 entries (five for a median table of 296)
+        const dbl2* __restrict__ tsrc = reinterpret_cast<const dbl2*>(dict_g + sd_tab);
+        const int n2 = (n_sd + 1) >> 1;
+        for (int b0 = 0; b0 * 64 < n2; b0 += 4) // (four requests = 512 entries at a time: registers)
+        {
+          dbl2 t[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            t[i] = lane + 64 * (b0 + i) < n2 ? tsrc[lane + 64 * (b0 + i)] : dbl2{0.0, 0.0};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (lane + 64 * (b0 + i) < n2)
+              reinterpret_cast<dbl2*>(sdl)[lane + 64 * (b0 + i)] = t[i];
+        }
         __builtin_amdgcn_wave_barrier();
         dict = sdl;
       }

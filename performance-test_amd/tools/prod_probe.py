@@ -22,7 +22,7 @@ with zzz.Context(0) as ctx:
     ctx.assemble_matrix(form)
     ctx.assemble_vector(form)
     ctx.cg_solve(max_it=3)  # p, w hold something non-trivial; builds the stream and its dictionaries
-    t = [ctx.spmv_time(reps=reps) for _ in range(rounds)]
+    t = [ctx.spmv_time(reps=reps, variant=int(os.environ.get("PROBE_VARIANT", "-1"))) for _ in range(rounds)]
     info = ctx.spmv_info_raw()
     vi = ctx.spmv_values_info()
     nrows, _, nnz = ctx.csr_sizes()
