@@ -94,7 +94,9 @@ def pmc_traffic(nrows, nnz, streamed=None):
             # ... and of the same operator stream: a profile taken before the stream's format changed does not count
             if streamed is not None and k.get("bytes_streamed") != streamed:
                 continue
-            best = (2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024, os.path.relpath(path, ROOT))
+            # (traffic_bytes: the calibrated count of tools/profile_summarise.py -- the x2 of FETCH_SIZE does not hold for
+            # every access pattern; older profiles carry the two counters only)
+            best = (k.get("traffic_bytes", 2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024), os.path.relpath(path, ROOT))
         except Exception:
             continue
     return best

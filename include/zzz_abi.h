@@ -237,7 +237,7 @@ int zzz_vec_norm(zzz_ctx* ctx, int which, double* out);
  * this product yields NaN in every row with a NONZERO entry there, may miss rows whose only coupling to that column
  * is an exact zero, and may add rows of the same 64-row slice through a padding entry.  The CG iterations see a
  * non-finite vector only after they have broken down (reported as KSP_DIVERGED_NANORINF either way).  ZZZ_SELLP_DROP=0
- * with ZZZ_SELLP_ALIGN=0 keeps every structural entry and no padding on a real column: NaN then propagates exactly
+ * with ZZZ_SELLP_FORMS=5 (no aligned slices) keeps every structural entry and no padding on a real column: NaN then propagates exactly
  * as in the serial CSR loop (tested). */
 int zzz_spmv(zzz_ctx* ctx, const double* x, double* y);
 

@@ -137,7 +137,10 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   if (const char* e = getenv("ZZZ_SELLP")) // operator stream: 0 off, 1 automatic, 2 natural row order, 3 sorted rows
   {
     const int v = atoi(e);
-    ctx->sellp_mode = v >= 0 && v <= 3 ? v : 1;
+    ctx->sellp_mode = v >= 0 && v <= 4 ? v : 1; // (4: natural row order through the long-row packer whatever the row lengths: tests)
+    ctx->sellp_long_rows = v == 4;
+    if (v == 4)
+      ctx->sellp_mode = 2;
   }
   if (const char* e = getenv("ZZZ_SELLP_DROP"))
     ctx->sellp_drop = atoi(e) != 0;
@@ -147,13 +150,14 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_pipe = atoi(e);
   if (const char* e = getenv("ZZZ_CG_DINV_CODES"))
     ctx->cg_dinv_codes = atoi(e);
-  if (const char* e = getenv("ZZZ_SELLP_AFFINE")) // 0: no code-free chunks (column = slot base + lane); A/B knob
-    if (atoi(e) == 0)
+  if (const char* e = getenv("ZZZ_SELLP_FORMS")) // A/B knob, a mask of the code-free chunk forms (default 7): 1 affine chunks
+  {                                              // (column = slot base + lane), 2 one-chunk slices placed by column so that
+    const int v = atoi(e);                       // short boundary rows fit the affine form, 4 periodic chunks (block size 3)
+    if (!(v & 1))
       ctx->sellp_tail |= 2;
-  if (const char* e = getenv("ZZZ_SELLP_ALIGN")) // 0: entries always placed by rank (no aligned one-chunk slices); A/B knob
-    ctx->sellp_align = atoi(e) != 0;
-  if (const char* e = getenv("ZZZ_SELLP_PERIODIC")) // 0: no periodic chunks for block size 3 (elasticity); A/B knob
-    ctx->sellp_periodic = atoi(e) != 0;
+    ctx->sellp_align = (v & 2) != 0;
+    ctx->sellp_periodic = (v & 4) != 0;
+  }
   if (const char* e = getenv("ZZZ_SPMV_LPR")) // lanes per row of the SpMV row phase: 1, 2, 4, 8, 16
   {
     const int v = atoi(e);

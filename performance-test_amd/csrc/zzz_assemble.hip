@@ -1207,7 +1207,12 @@ static int launch_matrix_pk_pos(zzz_ctx* ctx)
   (void)hipGetLastError();
   // long rows (the packer's synchronous path): the compacted copy of the kept entries is written from here as well
   const int64_t* crow = nullptr;
-  if (rownnz && ctx->nnz >= 16 * ctx->nrows && ctx->nnz + 8 * ctx->nrows < ((int64_t)1 << 40) && !getenv("ZZZ_ASM_NO_COMPACT"))
+#ifdef ZZZ_EXPERIMENTS
+  const bool compact_here = !getenv("ZZZ_ASM_NO_COMPACT"); // A/B knob (tools build)
+#else
+  const bool compact_here = true;
+#endif
+  if (rownnz && ctx->nnz >= 16 * ctx->nrows && ctx->nnz + 8 * ctx->nrows < ((int64_t)1 << 40) && compact_here)
   {
     if (int rc = sellp_capacity_rows(ctx))
       return rc;

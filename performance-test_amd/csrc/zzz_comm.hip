@@ -1044,7 +1044,7 @@ int zzz_comm_init(zzz_ctx* ctx, int nranks, int rank, const void* id)
     r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
     // second communicator over the same ranks for the halo stream (collective: every rank calls it);
     // without it the halo stays on the main stream and is simply not overlapped
-    if (r == 0 && g_rccl.CommSplit && !getenv("ZZZ_NO_COMM_SPLIT"))
+    if (r == 0 && g_rccl.CommSplit)
       if (g_rccl.CommSplit(c->comm, 0, rank, &c->comm_halo, nullptr) != 0)
         c->comm_halo = nullptr;
   }

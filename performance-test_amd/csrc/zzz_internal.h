@@ -287,6 +287,7 @@ struct zzz_ctx
   int64_t sp_dict_bytes = 0; // bytes a product reads from the stream in dictionary form
   bool sp_sorted = false;    // rows ordered by length inside windows (SELL-C-sigma)
   int sellp_mode = 1;        // ZZZ_SELLP: 0 off, 1 automatic, 2 natural row order always, 3 sorted rows always
+  bool sellp_long_rows = false; // ZZZ_SELLP=4: natural order, always through the long-row packer (count / compact / fill)
   bool sellp_align = true; // scalar rows, one-chunk slices: entries placed by column so that short boundary rows fit the affine form
   bool sellp_periodic = true; // block size 3: chunks whose columns are T[slot][row mod 3] + 3 (row div 3) carry no codes
   int sellp_tail = 1;        // bit 0: 8-bit codes of a narrow chunk go into the free tail of its value block; bit 1: no affine chunks

@@ -1248,8 +1248,10 @@ int mf_plan_build(zzz_ctx* ctx)
     nc /= 2;
   // LDS budget per workgroup: 64 KiB unless ZZZ_MF_LDS_KB says otherwise (160 KiB per CU)
   int lds_kb = nd == 4 ? 40 : 64;
-  if (const char* e = getenv("ZZZ_MF_LDS_KB"))
+#ifdef ZZZ_EXPERIMENTS
+  if (const char* e = getenv("ZZZ_MF_LDS_KB")) // measurement knob, tools build only
     lds_kb = std::min(160, std::max(8, atoi(e)));
+#endif
   const int nloc_limit = std::min(65535, lds_kb * 1024 / (nd == 4 ? 40 : (nd == 20 ? 8 : 16)));
   for (;;)
   {

@@ -1023,8 +1023,10 @@ __global__ __launch_bounds__(ADJ_W) void k_adj_window(const int32_t* __restrict_
 static void adjacency_find_runs(zzz_ctx* ctx)
 {
   ctx->adj_runs_n = 0;
-  if (getenv("ZZZ_ADJ_SORT")) // A/B knob: always the radix sort
+#ifdef ZZZ_EXPERIMENTS
+  if (getenv("ZZZ_ADJ_SORT")) // A/B knob (tools build): always the radix sort
     return;
+#endif
   const int nd = ctx->nd;
   const int64_t nc = ctx->ncells;
   if (nc >= INT32_MAX)
@@ -1233,7 +1235,12 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   bool counted = false;
   // (called after a device wait) a window of the sort-free adjacency did not fit: build again, sorting
   auto adjacency_overflowed = [&]() { return by_runs && ctx->adj_flag_host && *ctx->adj_flag_host != 0; };
-  if (nd == 4 && stage && !getenv("ZZZ_PATTERN_WAVE"))
+#ifdef ZZZ_EXPERIMENTS
+  const bool p1_thread_rows = !getenv("ZZZ_PATTERN_WAVE"); // A/B knob (tools build): P1 rows by wavefronts like P2 / P3
+#else
+  const bool p1_thread_rows = true;
+#endif
+  if (nd == 4 && stage && p1_thread_rows)
   {
     // P1: one thread per row; scal[2] = "a row has more than ROW_T_CAP unique columns"
     int rc = build_adjT_offsets(ctx);

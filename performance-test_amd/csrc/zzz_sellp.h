@@ -50,6 +50,21 @@ __device__ inline double gather(const double* __restrict__ x, int col)
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + ((unsigned)col << 3));
 }
 
+// a grid of at most `cap` workgroups for `items` items at `per` each
+inline int grid_cap(int64_t items, int per, int cap)
+{
+  int64_t g = (items + per - 1) / per;
+  if (g > cap)
+    g = cap;
+  if (g < 1)
+    g = 1;
+  return (int)g;
+}
+
+// the stream's value dictionaries (zzz_sellp_dict.hip), built at the stream's first use after an assembly
+int sp_dict_build(zzz_ctx* ctx);
+int sp_sd_build(zzz_ctx* ctx);
+
 // workgroups per CU of the product for streams of one-chunk slices (zzz_sellp_pipe.hip: two rows per lane, <= 96 registers per
 // lane); sp_grid sizes the persistent grid by it
 constexpr int SP_ONE_WGS = 4;

@@ -14,7 +14,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(lambda:[0.0,0]))
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
-        k="spmv" if ("spmv_tile" in n or "spmv_sellp" in n) else "update_p" if "k_update_p" in n else "update_xr" if "k_update_xr" in n else None
+        k="spmv" if ("spmv_tile" in n or "spmv_sellp" in n or "spmv_one" in n) else "update_p" if "k_update_p" in n else "update_xr" if "k_update_xr" in n else None
         if not k: continue
         if int(r["End_Timestamp"])-int(r["Start_Timestamp"])<30000: continue
         a=acc[k][r["Counter_Name"]]; a[0]+=float(r["Counter_Value"]); a[1]+=1

@@ -14,7 +14,7 @@ import os
 import re
 import sys
 
-KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel"), ("k_sp_pack", r"k_sp_pack"), ("k_sp_fill", r"k_sp_fill"), ("k_sp_count", r"k_sp_count"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
+KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel|spmv_one_kernel"), ("k_sp_pack", r"k_sp_pack"), ("k_sp_fill", r"k_sp_fill"), ("k_sp_count", r"k_sp_count"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
         ("k_sr_update", r"k_sr_update"), ("asm_matrix", r"asm_matrix"), ("asm_vector", r"asm_vector"),
         ("k_row_pattern", r"k_row_pattern"), ("k_row_copy", r"k_row_copy"), ("k_tile_encode_cols", r"k_tile_encode_cols"),
         ("k_adjT_fill", r"k_adjT_fill"), ("k_make_pairs", r"k_make_pairs"), ("radix_sort", r"radix_sort_onesweep_iteration"),
@@ -88,6 +88,18 @@ def merge(pdir, tag, cfg="c2"):
         if st:
             kern["spmv"]["bytes_streamed"] = st
             kern["spmv"]["corrected_over_streamed"] = kern["spmv"]["hbm_bytes_corrected"] / st
+            # The x2 of FETCH_SIZE holds for wide coalesced streams whose requests leave L2 as 128-B fetches tallied at 64 B
+            # (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern").  It does NOT hold for
+            # spmv_one_kernel's loads (32 contiguous bytes per lane in two instructions, 16-B loads from 8-B aligned runs):
+            # there FETCH_SIZE + WRITE_SIZE equals the bytes the kernel addresses within a few per cent, and twice the fetch
+            # count would be more than the kernel's time allows at the rate HBM delivers.  traffic_bytes = the calibrated one.
+            raw = (kern["spmv"]["FETCH_SIZE_KiB"] + kern["spmv"]["WRITE_SIZE_KiB"]) * 1024.0
+            kern["spmv"]["hbm_bytes_uncorrected"] = raw
+            kern["spmv"]["uncorrected_over_streamed"] = raw / st
+            one = "spmv_one_kernel" in (bench["roofline"].get("kernel") or "")
+            kern["spmv"]["traffic_bytes"] = raw if one else kern["spmv"]["hbm_bytes_corrected"]
+            kern["spmv"]["traffic_basis"] = ("FETCH_SIZE + WRITE_SIZE (no x2: calibrated on this kernel's access pattern)" if one
+                                             else "2 x FETCH_SIZE + WRITE_SIZE (wide coalesced streams)")
     # P1 assembly kernels against the minimum they must move: connectivity, coordinates, adjacency,
     # coefficients in; values / vector out.  (Scattered accesses: the x2 FETCH correction is uncalibrated there.)
     wl = cfg.get("workload", "")

@@ -934,8 +934,8 @@ def test_library_is_independent_of_the_callers_numbering(problem, order, dims, k
 
 def test_non_finite_vector_through_the_product():
     """Inf/NaN in x (include/zzz_abi.h, zzz_spmv): the operator stream drops exact zeros and pads aligned slices, so
-    NaN propagates through NONZERO couplings always, through exact-zero couplings only with ZZZ_SELLP_DROP=0 +
-    ZZZ_SELLP_ALIGN=0 -- and then exactly as in the serial CSR loop."""
+    NaN propagates through NONZERO couplings always, through exact-zero couplings only with ZZZ_SELLP_DROP=0 and
+    without the aligned placement (ZZZ_SELLP_FORMS=5) -- and then exactly as in the serial CSR loop."""
     zo.set_num_threads(1)
     P = zzz.Part("poisson", 1, 150, 4, 3)
     rng = np.random.default_rng(21)
@@ -943,12 +943,12 @@ def test_non_finite_vector_through_the_product():
     bad = rng.choice(P.n_owned, size=25, replace=False)
     xv[bad[:15]] = np.nan
     xv[bad[15:]] = np.inf
-    saved = {k: os.environ.get(k) for k in ("ZZZ_SELLP_DROP", "ZZZ_SELLP_ALIGN")}
+    saved = {k: os.environ.get(k) for k in ("ZZZ_SELLP_DROP", "ZZZ_SELLP_FORMS")}
     try:
         for exact in (False, True):
             for k in saved:
                 if exact:
-                    os.environ[k] = "0"
+                    os.environ[k] = "0" if k == "ZZZ_SELLP_DROP" else "5"  # (forms: affine and periodic, not aligned)
                 else:
                     os.environ.pop(k, None)
             with zzz.Context(0) as c:
@@ -1070,11 +1070,12 @@ def test_knob_combinations_keep_results(seed):
     rng = np.random.default_rng(1000 + seed)
     # (the knobs of the PRODUCT library; the tools build's extra ones -- ZZZ_CG_FUSED, ZZZ_SPMV_TILE, pipelined tiles,
     # ZZZ_ASM_LPR, ZZZ_VGRID_PER, ZZZ_TAIL -- have tests of their own that load that build)
-    knobs = {"ZZZ_SPMV_VARIANT": ["1", "8", "9", "16", "17"], "ZZZ_SELLP": ["0", "2", "3"], "ZZZ_SELLP_DROP": ["0"],
-             "ZZZ_SELLP_AFFINE": ["0"], "ZZZ_SELLP_PERIODIC": ["0"], "ZZZ_SELLP_ALIGN": ["0"], "ZZZ_SELLP_SYNC": ["1"],
+    # (ZZZ_SELLP_FORMS: a mask of the code-free chunk forms, 1 affine, 2 aligned, 4 periodic; ZZZ_SELLP=4: the long-row packer)
+    knobs = {"ZZZ_SPMV_VARIANT": ["1", "8", "9", "16", "17"], "ZZZ_SELLP": ["0", "2", "3", "4"], "ZZZ_SELLP_DROP": ["0"],
+             "ZZZ_SELLP_FORMS": ["0", "1", "3", "4", "5", "6"], "ZZZ_SELLP_PIPE": ["0"],
              "ZZZ_SPMV_LPR": ["1", "2", "4"], "ZZZ_COLS16": ["0", "11", "13"],
-             "ZZZ_PATTERN": ["host"], "ZZZ_PATTERN_WAVE": ["1"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
-             "ZZZ_ADJ_SORT": ["1"], "ZZZ_ASM_SEARCH": ["1"], "ZZZ_ASM_NO_COMPACT": ["1"],
+             "ZZZ_PATTERN": ["host"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
+             "ZZZ_ASM_SEARCH": ["1"],
              "ZZZ_SELLP_WIN": ["0", "1024", "8064"], "ZZZ_MF_NC": ["256", "512"], "ZZZ_MF_T": ["128", "256"],
              "ZZZ_SELLP_DICT": ["0", "2", "3"], "ZZZ_CG_DINV_CODES": ["0", "2", "2"]}
     names = sorted(knobs)
@@ -2442,12 +2443,11 @@ def test_operator_stream_forms_are_bit_exact(mode, drop):
                 os.environ[k] = val
 
 
-@pytest.mark.parametrize("problem,dims,knob", [("poisson", (200, 3, 3), "ZZZ_SELLP_AFFINE"),
-                                               ("poisson", (150, 4, 3), "ZZZ_SELLP_ALIGN"),
-                                               ("elasticity", (100, 3, 3), "ZZZ_SELLP_PERIODIC")])
+@pytest.mark.parametrize("problem,dims,knob", [("poisson", (200, 3, 3), 1), ("poisson", (150, 4, 3), 2), ("elasticity", (100, 3, 3), 4)],
+                         ids=["affine", "aligned", "periodic"])
 def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, knob):
     """Chunks whose columns are base + lane in every slot (scalar rows), or T[slot][row mod 3] + 3 (row div 3) (block
-    size 3), carry no column codes (zzz_sellp.hip); with ZZZ_SELLP_ALIGN the entries of a one-chunk slice are placed by
+    size 3), carry no column codes (zzz_sellp.hip); with the aligned placement the entries of a one-chunk slice are placed by
     column, so that the short boundary rows at the end of a mesh line fit that form too (holes of value +0.0 inside a
     row).  The small boxes of the tests above have mesh lines shorter than a
     64-row slice, so none of their chunks qualifies; a long thin box has many.  Same bits as the serial CSR loop with and
@@ -2455,14 +2455,12 @@ def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, k
     zo.set_num_threads(1)
     rng = np.random.default_rng(77)
     P = zzz.Part(problem, 1, *dims)
-    knobs = ("ZZZ_SELLP_AFFINE", "ZZZ_SELLP_ALIGN", "ZZZ_SELLP_PERIODIC")
+    knobs = ("ZZZ_SELLP_FORMS",)  # a mask: 1 affine chunks, 2 aligned one-chunk slices, 4 periodic chunks (default 7)
     saved = {k: os.environ.get(k) for k in knobs}
     res = {}
     try:
-        for k in knobs:
-            os.environ[k] = "1"  # the form under test builds on the others being at their defaults
         for on in ("0", "1"):
-            os.environ[knob] = on
+            os.environ["ZZZ_SELLP_FORMS"] = str(7 if on == "1" else 7 & ~knob)  # the form under test builds on the others
             with zzz.Context(0) as c:
                 c.upload_part(P)
                 c.pattern_build()
@@ -2488,12 +2486,12 @@ def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, k
 
 def test_long_row_packing_path_keeps_every_bit():
     """Rows too long for the one-pass LDS packer (P3 at scale) are packed through a compacted copy (k_sp_count_sweep,
-    k_sp_compact, k_sp_fill_c).  ZZZ_SELLP_SYNC=1 sends small matrices down that path: same bits as the serial CSR
+    k_sp_compact, k_sp_fill_c).  ZZZ_SELLP=4 sends small matrices down that path: same bits as the serial CSR
     loop, also with whole zero rows and scattered zeros (values uploaded by the caller)."""
     zo.set_num_threads(1)
     rng = np.random.default_rng(78)
-    old = {k: os.environ.get(k) for k in ("ZZZ_SELLP", "ZZZ_SELLP_SYNC")}
-    os.environ["ZZZ_SELLP"], os.environ["ZZZ_SELLP_SYNC"] = "2", "1"
+    old = {k: os.environ.get(k) for k in ("ZZZ_SELLP",)}
+    os.environ["ZZZ_SELLP"] = "4"
     try:
         for problem, order, dims in (("poisson", 3, (4, 5, 3)), ("elasticity", 2, (3, 4, 3)), ("elasticity", 3, (2, 3, 2)),
                                      ("poisson", 1, (70, 3, 3))):
@@ -2933,3 +2931,70 @@ def test_near_nullspace_against_oracle(ctx, order, dims, numbering):
     ctx.upload_part(Q)
     with pytest.raises(zzz.ZzzError):
         ctx.near_nullspace()
+
+
+# (problem, order, n): cubes of n^3 cells either side of every size rule that picks a form of the product by itself
+_SWEEP = [("poisson", 1, 40), ("poisson", 1, 56), ("poisson", 1, 66), ("poisson", 1, 84), ("poisson", 1, 100), ("poisson", 1, 132),
+          ("elasticity", 1, 30), ("elasticity", 1, 50), ("elasticity", 1, 56), ("elasticity", 1, 66),
+          ("poisson", 2, 16), ("poisson", 2, 24), ("poisson", 2, 32), ("poisson", 3, 8), ("poisson", 3, 12), ("poisson", 3, 18)]
+_sweep_seen = {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem,order,n", _SWEEP, ids=[f"{p}-P{o}-{n}" for p, o, n in _SWEEP])
+def test_size_sweep_across_the_form_selection_rules(problem, order, n):
+    """The library picks the product's form from sizes: value dictionary from 48 MB of stream, slice dictionaries for long rows
+    when they take the stream below 60 %, x windows for block size 3 beyond 300 MB of values, the kernel for one-chunk slices,
+    non-temporal loads and the coded inverse diagonal once an iteration's bytes exceed the Infinity Cache.  Every rule has a size either side of it here (the last case asserts that both sides were seen); at
+    every size the default product is the serial CSR loop's bit for bit (zo.spmv on the assembled matrix the library holds)
+    and the default solve is that of the plain stream (no dictionaries, no windows, generic kernel) iteration for iteration,
+    to rounding in the solution (the persistent grids differ, so do the orders of the partial sums: src/cg.h:65)."""
+    knobs = {"ZZZ_SELLP_DICT": "0", "ZZZ_SELLP_WIN": "0", "ZZZ_SELLP_PIPE": "0", "ZZZ_CG_DINV_CODES": "0"}
+    saved = {k: os.environ.get(k) for k in knobs}
+    res = {}
+    try:
+        for which in ("default", "plain"):
+            for k, v in knobs.items():
+                if which == "plain":
+                    os.environ[k] = v
+                else:
+                    os.environ.pop(k, None)
+            with zzz.Context(0) as c:
+                info = c.cube_generate(problem, order, n, n - 1, n + 1, 1, 0)
+                c.pattern_build()
+                c.assemble_matrix(zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON)
+                c.assemble_vector(zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON)
+                nrows = (c.n_owned) * c.bs
+                x = np.random.default_rng(n).standard_normal(nrows)
+                y = c.spmv(x)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-30, max_it=40)
+                vi, cg = c.spmv_values_info(), c.cg_info()
+                res[which] = dict(y=y, it=it, rn=rn, u=c.vec_download(zzz.VEC_U), values=vi["form"], one=vi["one_chunk_kernel"],
+                                  windows=c.spmv_x_windows()[0] > 0, fused=cg["fused"], dinv=cg["dinv_codes"] > 0,
+                                  stream=bool(c.spmv_info_raw()[5]))
+                if which == "default":
+                    rp, cl, v = c.csr_download()
+                    np.testing.assert_array_equal(y, zo.spmv_chunked(rp.astype(np.int64), cl, v, x, c.spmv_lanes_per_row()))
+                    del rp, cl, v
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    d, p = res["default"], res["plain"]
+    assert p["values"] in ("doubles",) and not p["one"] and not p["windows"] and not p["dinv"]
+    np.testing.assert_array_equal(d["y"], p["y"])
+    assert d["it"] == p["it"] == 40
+    assert abs(d["rn"] - p["rn"]) <= 1e-10 * p["rn"], (d["rn"], p["rn"])
+    np.testing.assert_allclose(d["u"], p["u"], rtol=0, atol=1e-11 * np.abs(p["u"]).max())
+    _sweep_seen[(problem, order, n)] = {k: d[k] for k in ("values", "one", "windows", "fused", "dinv", "stream")}
+    if (problem, order, n) == _SWEEP[-1] and len(_sweep_seen) == len(_SWEEP):
+        # the sweep straddles the rules: each choice was taken at some sizes and not at others
+        seen = lambda key, pred=lambda k: True: {s[key] for k, s in _sweep_seen.items() if pred(k)}
+        assert seen("values", lambda k: k[1] == 1 and k[0] == "poisson") >= {"doubles", "dictionary in LDS"}, _sweep_seen
+        assert "slice dictionaries" in seen("values", lambda k: k[1] == 3) and len(seen("values", lambda k: k[1] == 3)) >= 2, _sweep_seen
+        assert seen("one", lambda k: k[1] == 1 and k[0] == "poisson") == {False, True}, _sweep_seen
+        assert seen("windows", lambda k: k[0] == "elasticity") == {False, True}, _sweep_seen
+        assert seen("fused") == {False} and seen("dinv") == {False, True}, _sweep_seen  # (the fused direction kernel: by knob only)
+        assert seen("stream") == {True}, _sweep_seen
