@@ -131,6 +131,52 @@ __device__ inline int find_pos(const int32_t* __restrict__ c, int len, int32_t c
   return lo;
 }
 
+// The positions of four columns in a row's sorted columns c[0 .. len): four lower-bound searches side by side, without
+// branches -- pos = number of entries below the column, found bit by bit from the top.  (One after the other, as loops
+// around find_pos, the four searches of a P1 cell were twenty dependent LDS round trips per (row, cell) pair, half of
+// asm_matrix_p1's time; side by side they are five.)
+__device__ inline void find_pos4(const int32_t* __restrict__ c, int len, const int (&col)[4], int (&pos)[4])
+{
+  // byte offsets from c: q = 4 pos; an entry is read at q + 4 step - 4 whether or not it lies in the row (the arrays this is
+  // called on are 32 entries longer than the rows they hold) and counts only if it does
+  const char* __restrict__ cb = reinterpret_cast<const char*>(c);
+  const int end = 4 * len;
+  int q[4] = {0, 0, 0, 0};
+  int top = 16;
+  while (top * 2 <= len) // (not taken on a P1 lattice: 27 columns at most)
+    top *= 2;
+  for (; top > 16; top >>= 1)
+  {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      const int t = q[j] + 4 * top;
+      const int v = t <= end ? *reinterpret_cast<const int32_t*>(cb + t - 4) : INT_MAX;
+      q[j] = v < col[j] ? t : q[j];
+    }
+  }
+  const bool short_rows = __all(len < 16); // (a P1 lattice of Kuhn simplices: 15 columns per row)
+#pragma unroll
+  for (int step = 64; step >= 4; step >>= 1) // 16 entries, 8, ... 1
+  {
+    if (step == 64 && short_rows)
+      continue;
+    int v[4], t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      t[j] = q[j] + step;
+      v[j] = *reinterpret_cast<const int32_t*>(cb + q[j] + (step - 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      q[j] = ((int)(t[j] <= end) & (int)(v[j] < col[j])) ? t[j] : q[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    pos[j] = q[j] >> 2;
+}
+
 // Adjacency transposed in slices of 64 rows: entry a of row (64 s + lane) sits at off[s] + 64 a + lane
 // (cell index, -1 = padding) with the dof's local index in that cell beside it.  A wavefront owns a
 // slice, so "the a-th cell of my row" is one dense 256-B read instead of 64 reads 96 B apart.
@@ -199,7 +245,7 @@ struct AdjIter
 };
 
 // ---- matrix, P1, BS = 1 (Poisson a1, src/Poisson.py:31) or 3 (Elasticity a1, src/Elasticity.py:39)
-template <int BS, int NNZ, int BLK>
+template <int BS, int NNZ, int BLK, int PROBE = 0> // PROBE: timing ablations of the tools build (wrong results)
 __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ xq,
                                                            const int32_t* __restrict__ cell_dofs,
                                                            const int32_t* __restrict__ adjT_off,
@@ -211,7 +257,7 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
                                                            const int32_t* __restrict__ tiles, int64_t ntiles)
 {
   __shared__ double vals_s[NNZ];
-  __shared__ int32_t cols_s[NNZ];
+  __shared__ int32_t cols_s[NNZ + 32]; // (+ 32: find_pos4 reads past a row's end)
   // (Handing the tiles out in the Morton order of their middle vertex instead of row order -- so that the rows that
   // visit a cell would be in flight on one XCD at about the same time -- was measured in round 4: a tile is a stick of
   // ~126 rows along a mesh line, and the fabric-side fetch counter went UP, 5.1 -> 9.3 GB here and 4.6 -> 12.1 GB in the
@@ -243,6 +289,13 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
     // is evaluated the coordinates of a+1, the connectivity of a+2 and the adjacency entry a+3 are in flight, so an
     // iteration waits for one memory round trip, not three (the workgroup's CSR segment in LDS leaves 3-4 wavefronts
     // per SIMD: occupancy alone does not hide the chain).
+    // (profiles/r05_pmc_asm_c2.json, 10 M dofs: 296 VALU + 44 SALU + 26 LDS + 17 VMEM instructions per (row, cell) pair,
+    // VALU busy 78 % of the kernel's cycles, L2 hit rate 80 %: the kernel is bound by the instructions it issues -- with
+    // every gather, the search and the geometry removed (ZZZ_ASM_PROBE=15 of the tools build) it still takes 1.55 of its
+    // 2.65 ms: three wavefronts per SIMD, 24 dependent round trips per row.)
+    // The walk has no branches: every lane runs the slice's `alen` iterations (the transposed adjacency pads shorter
+    // rows with -1), a padding entry loads and evaluates cell 0 and only its update of the row is masked; the
+    // coordinate stages alternate between two register sets (DA, DB: no copies of 25 registers per cell).
     struct Conn
     {
       int cell, li;
@@ -253,23 +306,39 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
       double p[4][3];
       uint8_t bcj[4 * BS];
     };
+    const int alen = adj.len;
     auto adj_at = [&](int a, int& cell, int& li) {
-      const bool in = a < adj.len;
-      cell = in ? adj.cell(a) : -1;
-      li = in ? adj.li(a) : 0;
+      const int ac = min(a, alen - 1);
+      const int cc = adj.cell(ac);
+      cell = a < alen ? cc : -1;
+      li = adj.li(ac);
     };
     auto conn_at = [&](int cell, int li, Conn& K) {
       K.cell = cell;
       K.li = li;
-      if (cell < 0)
-        return;
-      K.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
+      K.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)max(cell, 0));
     };
     auto data_at = [&](const Conn& K, Data& D) {
-      if (K.cell < 0)
-        return;
-      load_cell_q(xq, K.dd, D.p); // (skipping the row's own vertex, as asm_vector_p1 does, made this kernel 3 % slower)
+      if (PROBE & 2) // no coordinate gathers
+      {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          D.p[k][0] = (double)(K.dd.x + k * k);
+          D.p[k][1] = (double)(K.dd.y - k);
+          D.p[k][2] = (double)(K.dd.z + 3 * k);
+        }
+      }
+      else
+        load_cell_q(xq, K.dd, D.p); // (skipping the row's own vertex, as asm_vector_p1 does, made this kernel 3 % slower)
       const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
+      if (PROBE & 4) // no flag gathers
+      {
+#pragma unroll
+        for (int j = 0; j < 4 * BS; ++j)
+          D.bcj[j] = 0;
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -277,20 +346,9 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
           D.bcj[j * BS + d] = bc[dj[j] * BS + d];
     };
     Conn K0, K1;
-    Data D0;
+    Data DA, DB;
     int c2, l2;
-    {
-      int ca, la;
-      adj_at(0, ca, la);
-      conn_at(ca, la, K0);
-      data_at(K0, D0);
-      adj_at(1, ca, la);
-      conn_at(ca, la, K1);
-      adj_at(2, c2, l2);
-    }
-    for (int a = 0; K0.cell >= 0; ++a)
-    {
-      Data D1;
+    auto iter = [&](int a, const Data& D0, Data& D1) {
       Conn K2;
       int c3, l3;
       data_at(K1, D1);
@@ -300,7 +358,15 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
       const int dofs[4] = {K0.dd.x, K0.dd.y, K0.dd.z, K0.dd.w};
       double g[4][3];
       Geom G;
-      geometry(D0.p, G);
+      if (PROBE & 8) // no geometry
+      {
+        G.adet = D0.p[0][0];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          G.K[k / 3][k % 3] = D0.p[1 + k / 4][k % 3];
+      }
+      else
+        geometry(D0.p, G);
       p1_grads(G, g);
       const double w = G.adet / 6.0; // reference volume
 
@@ -313,37 +379,75 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
           gi[1] = g[k][1];
           gi[2] = g[k][2];
         }
+      int pos4[4];
+      {
+        const int col4[4] = {dofs[0] * BS, dofs[1] * BS, dofs[2] * BS, dofs[3] * BS};
+        if (PROBE & 1) // no column search
+        {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            pos4[j] = (col4[j] + j) & 7;
+        }
+        else
+          find_pos4(cols_s + a0, len, col4, pos4);
+      }
+      double val[4][BS];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
       {
-        const int pos = find_pos(cols_s + a0, len, dofs[j] * BS);
         const double gg = gi[0] * g[j][0] + gi[1] * g[j][1] + gi[2] * g[j][2];
         if (BS == 1)
-        {
-          double val = w * gg;
-          if (bcr || D0.bcj[j])
-            val = 0.0;
-          vals_s[a0 + pos] += val;
-        }
+          val[j][0] = (bcr || D0.bcj[j]) ? 0.0 : w * gg;
         else
         {
           const double gic = sel3(gi[0], gi[1], gi[2], c), gjc = sel3(g[j][0], g[j][1], g[j][2], c);
 #pragma unroll
-          for (int d = 0; d < 3; ++d)
+          for (int d = 0; d < BS; ++d)
           {
             // mu (delta_cd g_i.g_j + d_d phi_i d_c phi_j) + lambda d_c phi_i d_d phi_j
-            double val = w * (mu * ((c == d ? gg : 0.0) + gi[d] * gjc) + lmbda * gic * g[j][d]);
-            if (bcr || D0.bcj[j * BS + d])
-              val = 0.0;
-            vals_s[a0 + pos + d] += val;
+            const double v = w * (mu * ((c == d ? gg : 0.0) + gi[d] * gjc) + lmbda * gic * g[j][d]);
+            val[j][d] = (bcr || D0.bcj[j * BS + d]) ? 0.0 : v;
           }
         }
       }
+      if (K0.cell >= 0) // the cell's four (block) columns are distinct entries of the row: read all, add, write all
+      {
+        double acc[4][BS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int d = 0; d < BS; ++d)
+            acc[j][d] = vals_s[a0 + pos4[j] + d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int d = 0; d < BS; ++d)
+            vals_s[a0 + pos4[j] + d] = acc[j][d] + val[j][d];
+      }
       K0 = K1;
-      D0 = D1;
       K1 = K2;
       c2 = c3;
       l2 = l3;
+    };
+    if (alen > 0)
+    {
+      {
+        int ca, la;
+        adj_at(0, ca, la);
+        conn_at(ca, la, K0);
+        data_at(K0, DA);
+        adj_at(1, ca, la);
+        conn_at(ca, la, K1);
+        adj_at(2, c2, l2);
+      }
+      int a = 0;
+      for (; a + 1 < alen; a += 2)
+      {
+        iter(a, DA, DB);
+        iter(a + 1, DB, DA);
+      }
+      if (a < alen)
+        iter(a, DA, DB);
     }
     if (bcr) // fem::set_diagonal: 1.0 on constrained rows
       vals_s[a0 + find_pos(cols_s + a0, len, r)] = 1.0;
@@ -378,6 +482,12 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   // connectivity -> coordinates and coefficients); each link is issued one iteration ahead of the next, so that while
   // cell a is summed the coordinates of a+1, the connectivity of a+2 and the adjacency entry a+3 are in flight and an
   // iteration waits for one memory round trip instead of three.
+  // (Round 5, measured at 10 M dofs: the branch-free walk with alternating register sets that took asm_matrix_p1 from
+  // 3.05 to 2.65 ms makes THIS kernel slower, 1.85 -> 2.22 ms with and 2.16 ms without the own-vertex skip (142 registers
+  // instead of 129, the padding entries' loads issued instead of masked); four wavefronts per SIMD by __launch_bounds__
+  // spill four registers into the loop: 2.38 ms.  profiles/r05_pmc_asm_c2.json: 135 VALU + 14 VMEM instructions per
+  // (row, cell) pair, VALU busy 51 %, 2.6 of 3 wavefronts per SIMD resident, half of their cycles waiting: the kernel is
+  // bound by its dependent loads at the occupancy 129 registers allow.)
   struct Conn
   {
     int cell, li;
@@ -1269,10 +1379,25 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
   if (ctx->order == 1)
   {
     if (bs == 1)
+    {
+#ifdef ZZZ_EXPERIMENTS
+      const int probe = getenv("ZZZ_ASM_PROBE") ? atoi(getenv("ZZZ_ASM_PROBE")) & 15 : 0; // timing ablations (wrong results)
+#define ZZZ_P1_PROBE(P)                                                                                                        \
+  if (probe == P)                                                                                                              \
+  {                                                                                                                            \
+    hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_P1, 128, P>), grid, dim3(128), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,     \
+                       ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,  \
+                       ctx->asm_tile.p, ctx->n_asm_tiles);                                                                     \
+    return ZZZ_OK;                                                                                                             \
+  }
+      ZZZ_P1_PROBE(1) ZZZ_P1_PROBE(6) ZZZ_P1_PROBE(8) ZZZ_P1_PROBE(15)
+#undef ZZZ_P1_PROBE
+#endif
       // one thread per row: a 1920-nonzero tile holds ~126 rows of 15, so 128 threads leave no lane idle
       hipLaunchKernelGGL((asm_matrix_p1<1, ASM_NNZ_P1, 128>), grid, dim3(128), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
+    }
     else
       hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ, ASM_BLOCK>), grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,

@@ -2934,7 +2934,7 @@ def test_near_nullspace_against_oracle(ctx, order, dims, numbering):
 
 
 # (problem, order, n): cubes of n^3 cells either side of every size rule that picks a form of the product by itself
-_SWEEP = [("poisson", 1, 40), ("poisson", 1, 56), ("poisson", 1, 66), ("poisson", 1, 84), ("poisson", 1, 100), ("poisson", 1, 132),
+_SWEEP = [("poisson", 1, 40), ("poisson", 1, 56), ("poisson", 1, 66), ("poisson", 1, 84), ("poisson", 1, 124), ("poisson", 1, 150),
           ("elasticity", 1, 30), ("elasticity", 1, 50), ("elasticity", 1, 56), ("elasticity", 1, 66),
           ("poisson", 2, 16), ("poisson", 2, 24), ("poisson", 2, 32), ("poisson", 3, 8), ("poisson", 3, 12), ("poisson", 3, 18)]
 _sweep_seen = {}
@@ -2948,7 +2948,7 @@ def test_size_sweep_across_the_form_selection_rules(problem, order, n):
     non-temporal loads and the coded inverse diagonal once an iteration's bytes exceed the Infinity Cache.  Every rule has a size either side of it here (the last case asserts that both sides were seen); at
     every size the default product is the serial CSR loop's bit for bit (zo.spmv on the assembled matrix the library holds)
     and the default solve is that of the plain stream (no dictionaries, no windows, generic kernel) iteration for iteration,
-    to rounding in the solution (the persistent grids differ, so do the orders of the partial sums: src/cg.h:65)."""
+    to rounding in the solution; the default product takes no more than 1.15 x the plain stream's time (the persistent grids differ, so do the orders of the partial sums: src/cg.h:65)."""
     knobs = {"ZZZ_SELLP_DICT": "0", "ZZZ_SELLP_WIN": "0", "ZZZ_SELLP_PIPE": "0", "ZZZ_CG_DINV_CODES": "0"}
     saved = {k: os.environ.get(k) for k in knobs}
     res = {}
@@ -2969,7 +2969,8 @@ def test_size_sweep_across_the_form_selection_rules(problem, order, n):
                 y = c.spmv(x)
                 it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-30, max_it=40)
                 vi, cg = c.spmv_values_info(), c.cg_info()
-                res[which] = dict(y=y, it=it, rn=rn, u=c.vec_download(zzz.VEC_U), values=vi["form"], one=vi["one_chunk_kernel"],
+                t_ms = min(c.spmv_time(100) for _ in range(3))
+                res[which] = dict(t=t_ms, y=y, it=it, rn=rn, u=c.vec_download(zzz.VEC_U), values=vi["form"], one=vi["one_chunk_kernel"],
                                   windows=c.spmv_x_windows()[0] > 0, fused=cg["fused"], dinv=cg["dinv_codes"] > 0,
                                   stream=bool(c.spmv_info_raw()[5]))
                 if which == "default":
@@ -2988,6 +2989,9 @@ def test_size_sweep_across_the_form_selection_rules(problem, order, n):
     assert d["it"] == p["it"] == 40
     assert abs(d["rn"] - p["rn"]) <= 1e-10 * p["rn"], (d["rn"], p["rn"])
     np.testing.assert_allclose(d["u"], p["u"], rtol=0, atol=1e-11 * np.abs(p["u"]).max())
+    # the form the size rules pick is no slower than the plain one beyond noise (a rule on the wrong side of its threshold
+    # would show here; + 2 us: launches of 10 us at the small end)
+    assert d["t"] <= 1.15 * p["t"] + 0.002, (d["t"], p["t"], d["values"], d["one"], d["windows"])
     _sweep_seen[(problem, order, n)] = {k: d[k] for k in ("values", "one", "windows", "fused", "dinv", "stream")}
     if (problem, order, n) == _SWEEP[-1] and len(_sweep_seen) == len(_SWEEP):
         # the sweep straddles the rules: each choice was taken at some sizes and not at others
