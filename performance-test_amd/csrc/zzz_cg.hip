@@ -502,7 +502,10 @@ __global__ __launch_bounds__(VB) void k_update_xr(CgState* __restrict__ st, cons
 // pa/pb/pc: partials (or the single all-reduced values) of <r,z>, the test norm^2 and <z,s>.
 // CHEB (Chebyshev-Jacobi preconditioner, cg_solve_single_reduction): z = D^-1 r becomes the polynomial's first term --
 // g = D^-1 r, d = g / theta, z = d (k_cheb_xr's tail) -- and its further terms follow as product epilogues.
-template <bool NT, bool CHEB = false>
+// DZ (round 5): as in k_update_p -- Jacobi's inverse diagonal as 16-bit codes into a table in LDS, and z = D^-1 r of the
+// LAST iteration recomputed from the r this kernel reads anyway (the same product of the same two doubles: the same bits)
+// instead of read back: 96 -> 82 B per row and iteration.  z is still written: the product gathers it.
+template <bool NT, bool CHEB = false, bool DZ = false>
 __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, double* __restrict__ beta_hist,
                                                   double* __restrict__ dpi_hist, double* __restrict__ dp_hist, int it,
                                                   CgParams P, const double* __restrict__ pa, const double* __restrict__ pb,
@@ -510,8 +513,16 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
                                                   const double* __restrict__ s, double* __restrict__ z, double* __restrict__ p,
                                                   double* __restrict__ w, double* __restrict__ x, double* __restrict__ r,
                                                   int64_t n, int scalars_only, double theta = 0.0, double* __restrict__ chg = nullptr,
-                                                  double* __restrict__ chd = nullptr)
+                                                  double* __restrict__ chd = nullptr, DinvCodes dz = DinvCodes())
 {
+  static_assert(!(CHEB && DZ), "the polynomial's first term is not D^-1 r alone");
+  __shared__ double dtab[DZ ? DZ_MAX : 1];
+  if (DZ)
+  {
+    for (int k = threadIdx.x; k < dz.ndict; k += VB)
+      dtab[k] = dz.dict[k];
+    __syncthreads();
+  }
   // first entries requested before the scalar prologue (see k_update_p): seven 16-B loads in flight per thread while
   // the workgroup walks the flag, the three partial sums and the convergence logic
   const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * VB;
@@ -523,11 +534,17 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
                      *__restrict__ r2 = reinterpret_cast<dbl2*>(r);
   const int64_t c0 = (i0 < n2) ? i0 : 0;
   dbl2 zi0 = {0, 0}, si0 = {0, 0}, di0 = {0, 0}, xi0 = {0, 0}, ri0 = {0, 0}, po0 = {0, 0}, wo0 = {0, 0};
+  uint32_t dc0 = 0;
   if (n2 > 0 && !scalars_only)
   {
-    zi0 = z2[c0];
+    if (DZ)
+      dc0 = dz.codes[c0];
+    else
+    {
+      zi0 = z2[c0];
+      di0 = vload<NT>(d2 + c0);
+    }
     si0 = vload<NT>(s2 + c0);
-    di0 = vload<NT>(d2 + c0);
     xi0 = vload<NT>(x2 + c0);
     ri0 = vload<NT>(r2 + c0);
     po0 = vload<NT>(p2 + c0); // zero before the first iteration (cg_solve_single_reduction clears p and w)
@@ -593,14 +610,16 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
   if (conv || scalars_only)
     return;
   auto one = [&](int64_t i) {
-    const double pn = (it == 0) ? z[i] : b * p[i] + z[i];
+    const double dv = DZ ? dtab[reinterpret_cast<const uint16_t*>(dz.codes)[i]] : dinv[i];
+    const double zo = DZ ? dv * r[i] : z[i];
+    const double pn = (it == 0) ? zo : b * p[i] + zo;
     const double wn = (it == 0) ? s[i] : b * w[i] + s[i];
     p[i] = pn;
     w[i] = wn;
     x[i] = a * pn + x[i];
     const double ri = -a * wn + r[i];
     r[i] = ri;
-    const double zi = dinv[i] * ri;
+    const double zi = dv * ri;
     if (CHEB)
     {
       chg[i] = zi;
@@ -615,15 +634,27 @@ __global__ __launch_bounds__(VB) void k_sr_update(CgState* __restrict__ st, doub
     // cache policy: only z (gathered by the next SpMV) and s (its output) are worth keeping; p, w, x, r, D^-1
     // are touched by this kernel alone, once per iteration
     dbl2 zi, si, di, xi, ri, po, wo;
+    uint32_t dc = dc0;
     if (i == i0)
     {
       zi = zi0, si = si0, di = di0, xi = xi0, ri = ri0, po = po0, wo = wo0;
     }
     else
     {
-      zi = z2[i], si = vload<NT>(s2 + i), di = vload<NT>(d2 + i), xi = vload<NT>(x2 + i), ri = vload<NT>(r2 + i);
+      if (DZ)
+        dc = dz.codes[i];
+      else
+        zi = z2[i], di = vload<NT>(d2 + i);
+      si = vload<NT>(s2 + i), xi = vload<NT>(x2 + i), ri = vload<NT>(r2 + i);
       if (it != 0)
         po = vload<NT>(p2 + i), wo = vload<NT>(w2 + i);
+    }
+    if (DZ)
+    {
+      di.x = dtab[dc & 0xffffu];
+      di.y = dtab[dc >> 16];
+      zi.x = di.x * ri.x; // z = D^-1 r as the last iteration (or k_init_residual) formed it
+      zi.y = di.y * ri.y;
     }
     dbl2 pn = zi, wn = si, zn;
     if (it != 0)
@@ -708,6 +739,32 @@ struct EventRing
   }
   hipEvent_t& operator[](int i) { return ev[i]; }
 };
+
+// The inverse diagonal (ctx->dinv, n entries) as 16-bit codes into a table of its distinct values, for the kernels that take
+// DinvCodes: dzc.codes stays null when there are more than DZ_MAX values.  Synchronises the stream once (the count).
+static int dinv_codes_build(zzz_ctx* ctx, int64_t n, DinvCodes& dzc)
+{
+  hipStream_t s = ctx->stream;
+    const int64_t npad = (n + 1) & ~(int64_t)1;
+    ZZZ_HIP(ctx, ctx->dd_table.reserve((size_t)1 << DD_BITS));
+    ZZZ_HIP(ctx, ctx->dd_slot.reserve((size_t)1 << DD_BITS));
+    ZZZ_HIP(ctx, ctx->dd_dict.reserve((size_t)DZ_MAX));
+    ZZZ_HIP(ctx, ctx->dd_codes.reserve((size_t)npad));
+    ZZZ_HIP(ctx, ctx->dd_info.reserve(8));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->dd_info.p, 0, 8 * sizeof(int32_t), s));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->dd_table.p, 0xff, sizeof(unsigned long long) << DD_BITS, s));
+    const unsigned gd = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_dd_insert, dim3(gd), dim3(256), 0, s, ctx->dinv.p, n, ctx->dd_table.p, ctx->dd_info.p, DZ_MAX);
+    hipLaunchKernelGGL(k_dd_number, dim3(1), dim3(1024), 0, s, ctx->dd_table.p, ctx->dd_slot.p, ctx->dd_dict.p, ctx->dd_info.p);
+    hipLaunchKernelGGL(k_dd_encode, dim3(gd), dim3(256), 0, s, ctx->dinv.p, n, npad, ctx->dd_table.p, ctx->dd_slot.p, ctx->dd_codes.p,
+                       ctx->dd_info.p);
+    int32_t h[4] = {0, 1, 0, 0};
+    ZZZ_HIP(ctx, hipMemcpyAsync(h, ctx->dd_info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    if (!h[1] && h[2] > 0 && h[2] <= DZ_MAX)
+      dzc = DinvCodes{reinterpret_cast<const uint32_t*>(ctx->dd_codes.p), ctx->dd_dict.p, ctx->r.p, h[2]};
+    return ZZZ_OK;
+}
 
 // bytes one CG iteration touches (operator + `nvec` vectors) against the Infinity Cache
 static bool loop_exceeds_cache(zzz_ctx* ctx, int nvec)
@@ -853,26 +910,8 @@ int cg_solve(zzz_ctx* ctx, const zzz_solver_opts* o, int* iters, double* rnorm)
   // ZZZ_CG_DINV_CODES: 0 never, 2 at any size), at most 2 048 values
   DinvCodes dzc{nullptr, nullptr, nullptr, 0};
   if (o->variant == ZZZ_CG_PETSC && o->pc == ZZZ_PC_JACOBI && !fused && ctx->cg_dinv_codes != 0 && (ctx->cg_dinv_codes == 2 || nt))
-  {
-    const int64_t npad = (n + 1) & ~(int64_t)1;
-    ZZZ_HIP(ctx, ctx->dd_table.reserve((size_t)1 << DD_BITS));
-    ZZZ_HIP(ctx, ctx->dd_slot.reserve((size_t)1 << DD_BITS));
-    ZZZ_HIP(ctx, ctx->dd_dict.reserve((size_t)DZ_MAX));
-    ZZZ_HIP(ctx, ctx->dd_codes.reserve((size_t)npad));
-    ZZZ_HIP(ctx, ctx->dd_info.reserve(8));
-    ZZZ_HIP(ctx, hipMemsetAsync(ctx->dd_info.p, 0, 8 * sizeof(int32_t), s));
-    ZZZ_HIP(ctx, hipMemsetAsync(ctx->dd_table.p, 0xff, sizeof(unsigned long long) << DD_BITS, s));
-    const unsigned gd = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_dd_insert, dim3(gd), dim3(256), 0, s, ctx->dinv.p, n, ctx->dd_table.p, ctx->dd_info.p, DZ_MAX);
-    hipLaunchKernelGGL(k_dd_number, dim3(1), dim3(1024), 0, s, ctx->dd_table.p, ctx->dd_slot.p, ctx->dd_dict.p, ctx->dd_info.p);
-    hipLaunchKernelGGL(k_dd_encode, dim3(gd), dim3(256), 0, s, ctx->dinv.p, n, npad, ctx->dd_table.p, ctx->dd_slot.p, ctx->dd_codes.p,
-                       ctx->dd_info.p);
-    int32_t h[4] = {0, 1, 0, 0};
-    ZZZ_HIP(ctx, hipMemcpyAsync(h, ctx->dd_info.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    ZZZ_HIP(ctx, hipStreamSynchronize(s));
-    if (!h[1] && h[2] > 0 && h[2] <= DZ_MAX)
-      dzc = DinvCodes{reinterpret_cast<const uint32_t*>(ctx->dd_codes.p), ctx->dd_dict.p, ctx->r.p, h[2]};
-  }
+    if (int rc = dinv_codes_build(ctx, n, dzc))
+      return rc;
   ctx->last_solve_dinv_codes = dzc.codes ? dzc.ndict : 0;
   const bool dz = dzc.codes != nullptr;
   auto kern_update_p = pick_update_p(dz);
@@ -1686,7 +1725,6 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
     if (int rc = chebyshev_setup(ctx, o, C))
       return rc;
   const bool ntv = loop_exceeds_cache(ctx, 8);
-  auto kern_sr_update = cheb ? (ntv ? k_sr_update<true, true> : k_sr_update<false, true>) : (ntv ? k_sr_update<true> : k_sr_update<false>);
   ctx->last_solve_fused = false;
 
   ZZZ_HIP(ctx, ctx->beta_hist.reserve((size_t)max_it + 2));
@@ -1700,6 +1738,17 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ctx->u.n, s)); // KSP zero initial guess
   hipLaunchKernelGGL(k_extract_dinv, dim3(g), dim3(VB), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, ctx->dinv.p, n,
                      o->pc != ZZZ_PC_NONE ? 1 : 0);
+  // Jacobi's inverse diagonal as 16-bit codes, z of the last iteration recomputed from r (k_sr_update<.., DZ>): under the
+  // rule of the classical form (a loop too large for the Infinity Cache; ZZZ_CG_DINV_CODES: 0 never, 2 at any size)
+  DinvCodes dzc{nullptr, nullptr, nullptr, 0};
+  if (!cheb && o->pc == ZZZ_PC_JACOBI && ctx->cg_dinv_codes != 0 && (ctx->cg_dinv_codes == 2 || ntv))
+    if (int rc = dinv_codes_build(ctx, n, dzc))
+      return rc;
+  ctx->last_solve_dinv_codes = dzc.codes ? dzc.ndict : 0;
+  const bool dz = dzc.codes != nullptr;
+  auto kern_sr_update = cheb ? (ntv ? k_sr_update<true, true> : k_sr_update<false, true>)
+                             : (dz ? (ntv ? k_sr_update<true, false, true> : k_sr_update<false, false, true>)
+                                   : (ntv ? k_sr_update<true> : k_sr_update<false>));
   // r = b, z = D^-1 r (the partials of this kernel are not used: the SpMV below leaves all three)
   hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(VB), 0, s, ctx->b.p, (const double*)nullptr, ctx->dinv.p, ctx->r.p,
                      ctx->z.p, n, P.norm, ctx->part_b.p, ctx->part_b.p + VGRID_MAX);
@@ -1790,7 +1839,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   {
     hipLaunchKernelGGL(kern_sr_update, dim3(g), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p,
                        it, P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p,
-                       ctx->r.p, n, 0, C.theta, C.g, C.d);
+                       ctx->r.p, n, 0, C.theta, C.g, C.d, dzc);
     if (int rc = polynomial(false))
       return rc;
     const bool timed = nprof < max_prof && it % PROF_STRIDE == 0;
@@ -1826,7 +1875,7 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
   // convergence test of the last completed iteration: scalars only
   hipLaunchKernelGGL(kern_sr_update, dim3(1), dim3(VB), 0, s, ctx->state.p, ctx->beta_hist.p, ctx->dpi_hist.p, ctx->dp_hist.p, it,
                      P, rz_src, nn_src, zs_src, np, ctx->dinv.p, ctx->sr_s.p, ctx->z.p, ctx->p.p, ctx->w.p, ctx->u.p, ctx->r.p,
-                     n, 1, C.theta, C.g, C.d);
+                     n, 1, C.theta, C.g, C.d, dzc);
   ZZZ_HIP(ctx, hipGetLastError());
   CgState fin;
   ZZZ_HIP(ctx, hipMemcpyAsync(&fin, ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));

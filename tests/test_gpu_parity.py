@@ -550,12 +550,16 @@ def test_inverse_diagonal_as_codes_keeps_every_bit(problem, order, dims):
                 c.assemble_matrix(P.form)
                 c.assemble_vector(P.form)
                 out = []
-                for norm in (zzz.NORM_PRECONDITIONED, zzz.NORM_UNPRECONDITIONED, zzz.NORM_NATURAL):
-                    it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, norm=norm, rtol=1e-9)
-                    out.append((it, rn, r0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"]))
+                for sr in (False, True):  # (-ksp_cg_single_reduction: k_sr_update with the codes, round 5)
+                    for norm in (zzz.NORM_PRECONDITIONED, zzz.NORM_UNPRECONDITIONED, zzz.NORM_NATURAL):
+                        it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, norm=norm, rtol=1e-9, single_reduction=sr)
+                        out.append((it, rn, r0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"], c.cg_history(it + 1)))
                 # what does not take the coded path says so in cg_info and still works
-                itn, _, _ = c.cg_solve(pc=zzz.PC_NONE, rtol=1e-9)
-                out.append((itn, 0.0, 0.0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"]))
+                for sr in (False, True):
+                    itn, _, _ = c.cg_solve(pc=zzz.PC_NONE, rtol=1e-9, single_reduction=sr)
+                    out.append((itn, 0.0, 0.0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"], c.cg_history(itn + 1)))
+                itn, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9, single_reduction=True)
+                out.append((itn, 0.0, 0.0, c.vec_download(zzz.VEC_U), c.cg_info()["dinv_codes"], c.cg_history(itn + 1)))
                 res[knob] = out
     finally:
         if old is None:
@@ -565,7 +569,8 @@ def test_inverse_diagonal_as_codes_keeps_every_bit(problem, order, dims):
     for a, b in zip(res["0"], res["2"]):
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3])
-    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res["2"][:3]) and res["2"][3][4] == 0
+        np.testing.assert_array_equal(a[5], b[5])  # the residual history, every iteration
+    assert all(o[4] == 0 for o in res["0"]) and all(o[4] > 0 for o in res["2"][:6]) and all(o[4] == 0 for o in res["2"][6:])
 
 
 @pytest.mark.parametrize("problem,order,dims,nparts", [("poisson", 1, (10, 9, 12), 2), ("poisson", 3, (3, 3, 6), 3),
