@@ -823,7 +823,18 @@ __global__ __launch_bounds__(T, (ND == 20 ? 3 : 1)) void k_mf_action(const MfArg
             Rc[c] = max(Rc[c], (int)((m >> (8 * k)) & 255u));
           }
       }
-      const int R2 = Rc[2], R1 = max(R2, Rc[1]), R0 = MF_DBG(2) ? 1 : max(R1, Rc[0]);
+      const int R2 = Rc[2], R1 = max(R2, Rc[1]), R0 = MF_DBG(2) ? 1 : (MF_DBG(32) ? 0 : max(R1, Rc[0]));
+      if (MF_DBG(32)) // timing probe: one unconditional addition per local dof, a barrier before each (wrong results)
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __syncthreads();
+          const int i = (iw[j >> 1] >> (16 * (j & 1))) & 0xffff;
+          __hip_atomic_fetch_add(&ys[i], ye[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       for (int r = 0; r < R0; ++r)
       {
         // hipcc (ROCm 7.2) emitted this loop's s_barrier WITHOUT a wait for the LDS store of the round before (seen in
