@@ -23,11 +23,16 @@ __device__ inline T sp_load(const T* p)
 // Columns by the chunk's mode (meta[c][0]: bit 31 int32, bit 30 8-bit codes, else 16-bit codes on the slot bases).
 // DICT: the values are 16-bit codes into the stream's dictionary (vcode: [chunk][lane][8], one 16-B load; code 0 = +0.0,
 // which is also what the slots beyond a last chunk's width hold)
-template <bool NT, bool FULL, int DICT = 0>
+// FOLD (the x window in LDS): a periodic chunk leaves the lane's own part of its columns, 3 (row div 3 - first), in `loff`
+// instead of adding it to each of the eight: the caller adds it to the window's address once.
+template <bool NT, bool FULL, int DICT = 0, bool FOLD = false>
 __device__ inline void read_chunk(int c, int w, int lane, const double* __restrict__ svals, const uint16_t* __restrict__ c16,
                                   const int32_t* __restrict__ c32, const int32_t* __restrict__ meta, dbl2 (&v)[4], int (&cl)[8],
-                                  const uint16_t* __restrict__ vcode = nullptr, const double* __restrict__ dict = nullptr)
+                                  const uint16_t* __restrict__ vcode = nullptr, const double* __restrict__ dict = nullptr,
+                                  int* __restrict__ loff = nullptr)
 {
+  if (FOLD)
+    *loff = 0;
   const double* __restrict__ sp = svals + (size_t)c * 512;
   if (DICT == 1 || DICT == 2 || (DICT == 3 && dict != nullptr))
   {
@@ -85,10 +90,19 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
     // T[slot][k] without a select per class: T0 + (k >= 1) (T1 - T0) + (k == 2) (T2 - T1), the brackets as masks.  (The nested
     // selects compiled into divergent control flow, ~15 scalar instructions per slot: 163 scalar instructions per chunk at C4,
     // more than the CU's scalar unit issues in the time the chunk's bytes take.)
-    const int k1 = k >= 1 ? -1 : 0, k2 = k == 2 ? -1 : 0;
+    int k1 = k >= 1 ? -1 : 0, k2 = k == 2 ? -1 : 0;
+    // (the masks made opaque: left visible, the compiler turns `mask & scalar` back into a select, which needs the scalar
+    // in a vector register first -- two moves, two selects and two adds per slot; this way it is two `v_and` with a scalar
+    // operand and one three-operand add: 48 -> 24 vector instructions per periodic chunk, a quarter of all it issues at C4)
+    asm volatile("" : "+v"(k1), "+v"(k2));
+    if (FOLD)
+      *loff = q3;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      cl[e] = (t[3 * e] + q3) + (k1 & (t[3 * e + 1] - t[3 * e])) + (k2 & (t[3 * e + 2] - t[3 * e + 1]));
+    {
+      const int a = k1 & (t[3 * e + 1] - t[3 * e]), b = k2 & (t[3 * e + 2] - t[3 * e + 1]);
+      cl[e] = FOLD ? (t[3 * e] + a) + b : ((t[3 * e] + q3) + a) + b;
+    }
   }
   else if (m0 < 0)
   {
@@ -141,11 +155,13 @@ __device__ inline void chunk_product(int c, int w, int lane, const double* __res
 {
   dbl2 v[4];
   int cl[8];
-  read_chunk<NT, FULL, DICT>(c, w, lane, svals, c16, c32, meta, v, cl, vcode, dict);
+  int loff = 0;
+  read_chunk<NT, FULL, DICT, LDS>(c, w, lane, svals, c16, c32, meta, v, cl, vcode, dict, &loff);
+  const double* __restrict__ xl = LDS ? x + loff : x;
   double xv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    xv[e] = (FULL || e < w) ? (LDS ? x[cl[e]] : gather(x, cl[e])) : 0.0; // LDS: x is the group's window, cl its index
+    xv[e] = (FULL || e < w) ? (LDS ? xl[cl[e]] : gather(x, cl[e])) : 0.0; // LDS: x is the group's window, cl its index
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     if (FULL || e < w)
