@@ -73,6 +73,8 @@ __device__ inline void read_chunk(int c, int w, int lane, const double* __restri
   {
     // periodic chunk (block size 3): column = T[slot][row mod 3] + 3 (row div 3 - first), nothing per lane to load
     const int32_t* __restrict__ tp = reinterpret_cast<const int32_t*>(c16 + (size_t)c * 512);
+    // (round 5 probe: with every chunk reading the table of one of eight chunks -- scalar-cache hits -- C4's product takes the
+    // same 123-124 us: it does not wait for these loads)
     // the 25 words are wave-uniform: pinned into scalar registers, the selects below stay register selects.  (Left to
     // itself the compiler folds them into a per-lane ADDRESS select, tp + 3 e + k, behind divergent branches -- and
     // that code decoded slot 0 of the third class wrongly when the chunk sits inside the chunk loop.)
