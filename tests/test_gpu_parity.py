@@ -1528,11 +1528,26 @@ def test_bench_contract_line():
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
         it = r["iteration"]
         assert it["bytes"] > r["bytes_per_launch"] and abs(it["frac"] - it["achieved"] / r["peak"]) < 1e-12
+        # the scalar copies the driver's parser keeps (round 5): the same numbers as the nested records
+        assert r["iteration_frac"] == it["frac"] and r["iteration_us"] > 0
+        assert ("full_pattern" in r) == ("full_pattern_frac" in r)
         if not extra:
             c = d["cpu_baseline"]
             assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
             # the CPU leg solves the whole problem (nothing extrapolated) and reports its own iteration count
             assert abs(c["krylov_iterations"] - d["config"]["krylov_iterations"]) <= 2 and c["solve_s"] > 0
+            # BASELINE configs[0] on one host thread, and what one rank of the multi-GPU configurations does per iteration
+            assert c["c1_1_thread_dofs_per_s"] > 0 and c["c1_1_thread"]["threads"] == 1
+            # (other_configs.rank_sizes exists for the default 10 M-dof run only: its record is checked below at a small size)
+    # one record of other_configs.rank_sizes (a rank's share as a problem of its own, communication path attached), in a child
+    # process as bench.py runs it
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench; "
+            "print(json.dumps(bench.run_rank_size('poisson', 1, 20, 18, 7, 'test')))" % (root, zzz.PKG))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["rows"] == 21 * 19 * 8 and rec["us_per_iteration"] > 0 and rec["krylov_iterations"] > 0 and rec["solve_ms"] > 0
+    assert rec["cg_form"] in ("classical", "single_reduction") and rec["scalar_allreduce"] in ("peer-memory mailboxes", "ncclAllReduce")
     # the N > 1 machinery on one GPU (1-rank communicator): mailbox attach, warm-up probe, CG-form tuning
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ndofs", "60000", "--steps", "2", "--warmup", "1",
                           "--no_cpu_baseline", "--force_comm"], capture_output=True, text=True, timeout=600)
