@@ -138,6 +138,10 @@ int zzz_ctx_create(int device, zzz_ctx** out)
   {
     const int v = atoi(e);
     ctx->sellp_mode = v >= 0 && v <= 4 ? v : 1; // (4: natural row order through the long-row packer whatever the row lengths: tests)
+#ifdef ZZZ_EXPERIMENTS
+    if (v == 5) // experiment: component-major slices for block size 3 (zzz_sellp_pack.hip: k_sp_cm)
+      ctx->sellp_mode = 5;
+#endif
     ctx->sellp_long_rows = v == 4;
     if (v == 4)
       ctx->sellp_mode = 2;

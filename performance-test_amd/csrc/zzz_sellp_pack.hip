@@ -143,6 +143,35 @@ __global__ __launch_bounds__(SP_SIGMA) void k_sp_sort(const int32_t* __restrict_
     nch[nslices] = 0;
 }
 
+#ifdef ZZZ_EXPERIMENTS
+// EXPERIMENT (ZZZ_SELLP=5, tools build): block size 3 with the rows of a slice all of ONE component -- slice 3 u + k holds
+// rows 3 (64 u + lane) + k -- so that a slot's 64 columns are 64 consecutive blocks' (stride 3: 8-bit codes on one base, no
+// per-lane decode of a periodic table).  Rides on the sorted form's machinery (perm, synchronous build).
+__global__ __launch_bounds__(192) void k_sp_cm(const int32_t* __restrict__ rownnz, int nrows, int64_t nslices,
+                                               int32_t* __restrict__ perm, int32_t* __restrict__ nch, uint8_t* __restrict__ wlast)
+{
+  __shared__ int mx[3];
+  const int64_t u = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t < 3)
+    mx[t] = 0;
+  __syncthreads();
+  const int64_t r = u * 192 + t;
+  const int k = t % 3, q = t / 3;
+  atomicMax(&mx[k], r < nrows ? rownnz[r] : 0);
+  perm[(3 * u + k) * 64 + q] = r < nrows ? (int32_t)r : -1;
+  __syncthreads();
+  if (t < 3 && 3 * u + t < nslices)
+  {
+    const int m = mx[t];
+    nch[3 * u + t] = (m + 7) >> 3;
+    wlast[3 * u + t] = (uint8_t)(m ? m - 8 * ((m - 1) >> 3) : 8);
+  }
+  if (u == 0 && t == 0)
+    nch[nslices] = 0;
+}
+#endif
+
 // Write chunk c of a slice from the lanes' next eight kept entries (v, cl; cl == INT_MAX: no entry).  Only the first
 // w <= 8 slots are in use by any lane (w < 8: the last chunk of a slice): unused value blocks and the unused half of a
 // code block are neither written nor ever read, so a narrow chunk costs its used bytes only -- an interior P1 row
@@ -1057,6 +1086,12 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out, bool sorted = true)
     hipLaunchKernelGGL(k_sp_count, dim3(grid_cap(nrows, 256, 16384)), dim3(256), 0, s, ctx->rowptr.p, ctx->vals.p, nrows, drop,
                        ctx->sp_rownnz.p);
   const int64_t nwin = (ctx->nrows + SP_SIGMA - 1) / SP_SIGMA;
+#ifdef ZZZ_EXPERIMENTS
+  if (sorted && ctx->sellp_mode == 5)
+    hipLaunchKernelGGL(k_sp_cm, dim3((unsigned)(nsl / 3)), dim3(192), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p, ctx->sp_nch.p,
+                       ctx->sp_wlast.p);
+  else
+#endif
   if (sorted)
     hipLaunchKernelGGL(k_sp_sort, dim3((unsigned)nwin), dim3(SP_SIGMA), 0, s, ctx->sp_rownnz.p, nrows, nsl, ctx->sp_perm.p,
                        ctx->sp_nch.p, ctx->sp_wlast.p);
@@ -1237,9 +1272,15 @@ int sell_update(zzz_ctx* ctx, bool structure)
   hipStream_t s = ctx->stream;
   const int nrows = (int)ctx->nrows;
   const int64_t nsl = ctx->nslices;
-  ZZZ_HIP(ctx, ctx->sp_desc.alloc(2 * (size_t)nsl + 2));
+#ifdef ZZZ_EXPERIMENTS
+  if (ctx->sellp_mode == 5 && ctx->bs == 3) // (experiment: slices of one component, k_sp_cm)
+    ctx->nslices = 3 * ((ctx->nrows + 191) / 192);
+  else if (ctx->sellp_mode == 5)
+    ctx->sellp_mode = 1;
+#endif
+  ZZZ_HIP(ctx, ctx->sp_desc.alloc(2 * (size_t)ctx->nslices + 2));
   ctx->sp_forced = forced;
-  if (ctx->sellp_mode == 3)
+  if (ctx->sellp_mode == 3 || ctx->sellp_mode == 5)
   {
     int64_t t1 = 0;
     int rc = sp_build_sorted(ctx, &t1);
