@@ -458,6 +458,86 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
 }
 
 // ---- vector, P1: Poisson L1 = f v dx + g v ds (src/Poisson.py:32), Elasticity L1 = f.v dx (:40)
+// Round 5: two passes.  What a (row, cell) pair of the cell term needs from its cell is the same for the cell's four rows:
+// |det J| and the sum of the coefficient over the cell's vertices (per component).  k_cell_load_p1 evaluates both once per
+// cell (dense, one thread per cell: connectivity, four vertices, four coefficients, one determinant) into a record of
+// 1 + BS doubles; the row walk then fetches ONE record per pair -- a chain of two dependent loads (adjacency -> record)
+// at 40 registers instead of three (adjacency -> connectivity -> coordinates and coefficients) at 129, no geometry in
+// the walk.  The same operations on the same operands in the same order as the one-pass kernel of rounds 1-4 (the sum
+// over the vertices was formed in vertex order there too): b is bit-identical.  10 M dofs: 1.85 -> 0.88 + 0.74 ms for the two
+// passes; elasticity at 1 M nodes 0.45 -> 0.12 + 0.13 ms.
+// The exterior-facet term (cells with a boundary facet: few) is evaluated in the walk as before.
+// The record's |det J| carries the cell's "has a boundary facet" bit in its SIGN (|det J| >= 0: the walk takes the absolute value
+// and looks the facet mask up only where the sign is set -- one load less per (row, cell) pair).
+// (Measured and dropped: vertices as 32-B records {x, y, z, f}, two aligned 16-B loads each, instead of 24-B coordinates plus
+// the coefficient -- the pass took the same 0.88-0.90 ms at 10 M dofs: it is bound by what it moves, connectivity in,
+// records out and the vertex array once per simplex type of the type-major cell order, not by its 14 loads per cell.)
+template <int BS>
+__global__ __launch_bounds__(256) void k_cell_load_p1(const double* __restrict__ xq, const int32_t* __restrict__ cell_dofs,
+                                                      const double* __restrict__ f, const uint8_t* __restrict__ facet_mask,
+                                                      int64_t ncells, double* __restrict__ rec)
+{
+  // U cells per thread and round, a workgroup's 256 U cells side by side: the U connectivity records are requested together,
+  // then the U x 4 vertices and coefficients (two dependent round trips per U cells, not per cell)
+  constexpr int U = BS == 1 ? 4 : 1; // (block size 3: twelve coefficient loads per cell already; 0.116 ms at 1, 0.132 at 4)
+  auto block = [&](int64_t blk) {
+    const int64_t c0 = blk * (256ll * U) + threadIdx.x;
+    int4 dd[U];
+    unsigned fm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const int64_t c = min(c0 + 256ll * u, ncells - 1);
+      dd[u] = *reinterpret_cast<const int4*>(cell_dofs + 4 * c);
+      fm[u] = (BS == 1) ? facet_mask[c] : 0u;
+    }
+    double p[U][4][3], fl[U][4][BS];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const int dj[4] = {dd[u].x, dd[u].y, dd[u].z, dd[u].w};
+      load_cell_q(xq, dd[u], p[u]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < BS; ++d)
+          fl[u][j][d] = f[(int64_t)dj[j] * BS + d];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const int64_t c = c0 + 256ll * u;
+      if (c >= ncells)
+        break;
+      Geom G;
+      geometry(p[u], G);
+      double* __restrict__ o = rec + c * (BS == 1 ? 2 : 4);
+      double out[1 + BS];
+      out[0] = (BS == 1 && fm[u]) ? -G.adet : G.adet;
+#pragma unroll
+      for (int d = 0; d < BS; ++d)
+      {
+        double fs = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fs += fl[u][j][d];
+        out[1 + d] = fs;
+      }
+      *reinterpret_cast<double2*>(o) = make_double2(out[0], out[1]);
+      if (BS != 1)
+        *reinterpret_cast<double2*>(o + 2) = make_double2(out[2], out[BS]);
+    }
+  };
+  // The blocks of 256 U cells are walked SIX-WAY INTERLEAVED: block q of the walk is block (q mod 6) nb / 6 + q / 6 of the cell
+  // array.  The structured feeds number cells simplex type by simplex type: in array order the pass streamed the vertex array
+  // once per type (0.88 ms at 10 M dofs); interleaved, the six types of one region are in flight together and their vertices
+  // come out of the caches (0.74 ms).  Any other cell order is just walked in another order.  (A region's six blocks pinned to
+  // ONE XCD -- regions x, x + 8, ... on XCD x -- took 0.82 ms: neighbouring regions share vertices too.)
+  const int64_t nb = (ncells + 256 * U - 1) / (256 * U), nb6 = nb / 6;
+  for (int64_t q = blockIdx.x; q < nb; q += gridDim.x)
+    block(q < 6 * nb6 ? (q % 6) * nb6 + q / 6 : q);
+}
+
 template <int BS>
 __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restrict__ xq,
                                                            const int32_t* __restrict__ cell_dofs,
@@ -467,7 +547,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
                                                            const uint8_t* __restrict__ bc,
                                                            const uint8_t* __restrict__ facet_mask,
                                                            const double* __restrict__ f, const double* __restrict__ gc,
-                                                           double* __restrict__ b, int64_t nrows)
+                                                           const double* __restrict__ rec, double* __restrict__ b, int64_t nrows)
 {
   const int64_t blk = xcd_item((nrows + ASM_BLOCK - 1) / ASM_BLOCK);
   const int64_t r = blk * (int64_t)ASM_BLOCK + threadIdx.x;
@@ -476,123 +556,94 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_p1(const double* __restr
   const int i = (int)(r / BS), c = (int)(r % BS);
   double sum = 0.0;
   const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
-  const double own[3] = {xq[3 * (int64_t)i], xq[3 * (int64_t)i + 1], xq[3 * (int64_t)i + 2]}; // the row's own vertex
   const double own_f = f[r];
-  // Three-stage software pipeline over the row's cells.  A cell needs a chain of three dependent loads (adjacency ->
-  // connectivity -> coordinates and coefficients); each link is issued one iteration ahead of the next, so that while
-  // cell a is summed the coordinates of a+1, the connectivity of a+2 and the adjacency entry a+3 are in flight and an
-  // iteration waits for one memory round trip instead of three.
-  // (Round 5, measured at 10 M dofs: the branch-free walk with alternating register sets that took asm_matrix_p1 from
-  // 3.05 to 2.65 ms makes THIS kernel slower, 1.85 -> 2.22 ms with and 2.16 ms without the own-vertex skip (142 registers
-  // instead of 129, the padding entries' loads issued instead of masked); four wavefronts per SIMD by __launch_bounds__
-  // spill four registers into the loop: 2.38 ms.  profiles/r05_pmc_asm_c2.json: 135 VALU + 14 VMEM instructions per
-  // (row, cell) pair, VALU busy 51 %, 2.6 of 3 wavefronts per SIMD resident, half of their cycles waiting: the kernel is
-  // bound by its dependent loads at the occupancy 129 registers allow.)
-  struct Conn
+  const int alen = adj.len;
+  // the walk: the adjacency entry of cell a + 2 and the record (and facet mask) of cell a + 1 are in flight while cell a is
+  // added; every lane runs the slice's alen iterations (padding entries: cell 0's record, not added)
+  struct Rec
   {
-    int cell, li;
+    int cell;
     unsigned mask;
-    int4 dd;
+    double adet, fs;
   };
-  struct Data
-  {
-    double p[4][3], fl[4];
+  auto adj_at = [&](int a) -> int {
+    const int cc = adj.cell(min(a, alen - 1));
+    return a < alen ? cc : -1;
   };
-  auto adj_at = [&](int a, int& cell, int& li) {
-    const bool in = a < adj.len;
-    cell = in ? adj.cell(a) : -1;
-    li = in ? adj.li(a) : 0;
-  };
-  auto conn_at = [&](int cell, int li, Conn& K) {
-    K.cell = cell;
-    K.li = li;
-    if (cell < 0)
-      return;
-    K.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)cell);
-    K.mask = BS == 1 ? facet_mask[cell] : 0u;
-  };
-  auto data_at = [&](const Conn& K, Data& D) {
-    if (K.cell < 0)
-      return;
-    load_cell_q3(xq, K.dd, K.li, own, D.p);
-    const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      D.fl[j] = j != K.li ? f[(int64_t)dj[j] * BS + c] : own_f;
-  };
-  Conn K0, K1;
-  Data D0;
-  int c2, l2;
-  {
-    int ca, la;
-    adj_at(0, ca, la);
-    conn_at(ca, la, K0);
-    data_at(K0, D0);
-    adj_at(1, ca, la);
-    conn_at(ca, la, K1);
-    adj_at(2, c2, l2);
-  }
-  for (int a = 0; K0.cell >= 0; ++a)
-  {
-    Data D1;
-    Conn K2;
-    int c3, l3;
-    data_at(K1, D1);
-    conn_at(c2, l2, K2);
-    adj_at(a + 3, c3, l3);
-    const int li = K0.li;
-    const int dofs[4] = {K0.dd.x, K0.dd.y, K0.dd.z, K0.dd.w};
-    double (&p)[4][3] = D0.p;
-    Geom G;
-    geometry(p, G);
-    double fs = 0.0, fi = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-    {
-      fs += D0.fl[j];
-      if (j == li)
-        fi = D0.fl[j];
-    }
-    sum += G.adet * ((fs + fi) / 120.0); // |detJ| * sum_j (1+delta_ij)/120 f_j
+  auto rec_at = [&](int cell, Rec& R) {
+    R.cell = cell;
+    const int64_t cz = max(cell, 0);
     if (BS == 1)
     {
-      const unsigned m = K0.mask;
-      if (m)
-      {
-        double gl[4], gi = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-          gl[j] = gc[dofs[j]];
-          if (j == li)
-            gi = gl[j];
-        }
-#pragma unroll
-        for (int lf = 0; lf < 4; ++lf)
-          if (((m >> lf) & 1u) && lf != li)
-          {
-            // facet lf = the three vertices other than lf
-            const int q0 = lf == 0 ? 1 : 0, q1 = lf <= 1 ? 2 : 1, q2 = lf == 3 ? 2 : 3;
-            double e1[3], e2[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-            {
-              e1[k] = p[q1][k] - p[q0][k];
-              e2[k] = p[q2][k] - p[q0][k];
-            }
-            const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2],
-                         cz = e1[0] * e2[1] - e1[1] * e2[0];
-            const double scale = sqrt(cx * cx + cy * cy + cz * cz); // 2 * area
-            const double gs = gl[q0] + gl[q1] + gl[q2];
-            sum += scale * ((gs + gi) / 24.0); // 2 area * sum_j (1+delta_ij)/24 g_j
-          }
-      }
+      const double2 q = *reinterpret_cast<const double2*>(rec + 2 * cz);
+      R.adet = fabs(q.x);
+      R.fs = q.y;
+      R.mask = __builtin_signbit(q.x) ? 1u : 0u; // the cell has a boundary facet: which, is looked up where it is used
     }
-    K0 = K1;
-    D0 = D1;
-    K1 = K2;
-    c2 = c3;
-    l2 = l3;
+    else
+    {
+      R.adet = rec[4 * cz];
+      R.fs = rec[4 * cz + 1 + c];
+      R.mask = 0u;
+    }
+  };
+  if (alen > 0)
+  {
+    Rec R0, R1;
+    int c2;
+    rec_at(adj_at(0), R0);
+    int c1 = adj_at(1);
+    for (int a = 0; a < alen; ++a)
+    {
+      rec_at(c1, R1);
+      c2 = adj_at(a + 2);
+      const bool live = R0.cell >= 0;
+      const double term = R0.adet * ((R0.fs + own_f) / 120.0); // |detJ| * sum_j (1+delta_ij)/120 f_j
+      if (live)
+        sum += term;
+      if (BS == 1)
+      {
+        if (live && R0.mask)
+        {
+          // a cell with boundary facets (few): its facet mask, vertices and the boundary coefficient, here
+          const unsigned m = facet_mask[R0.cell];
+          const int li = adj.li(a);
+          const int4 dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)R0.cell);
+          const int dofs[4] = {dd.x, dd.y, dd.z, dd.w};
+          double p[4][3];
+          load_cell_q(xq, dd, p);
+          double gl[4], gi = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+          {
+            gl[j] = gc[dofs[j]];
+            if (j == li)
+              gi = gl[j];
+          }
+#pragma unroll
+          for (int lf = 0; lf < 4; ++lf)
+            if (((m >> lf) & 1u) && lf != li)
+            {
+              // facet lf = the three vertices other than lf
+              const int q0 = lf == 0 ? 1 : 0, q1 = lf <= 1 ? 2 : 1, q2 = lf == 3 ? 2 : 3;
+              double e1[3], e2[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+              {
+                e1[k] = p[q1][k] - p[q0][k];
+                e2[k] = p[q2][k] - p[q0][k];
+              }
+              const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2],
+                           cz = e1[0] * e2[1] - e1[1] * e2[0];
+              const double scale = sqrt(cx * cx + cy * cy + cz * cz); // 2 * area
+              const double gs = gl[q0] + gl[q1] + gl[q2];
+              sum += scale * ((gs + gi) / 24.0); // 2 area * sum_j (1+delta_ij)/24 g_j
+            }
+        }
+      }
+      R0 = R1;
+      c1 = c2;
+    }
   }
   b[r] = bc[r] ? 0.0 : sum; // bc->set(b), u0 == 0
 }
@@ -1450,14 +1501,26 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
     return rc;
   if (ctx->order == 1)
   {
+    // the cells' records first (|det J| and the coefficient's vertex sum: k_cell_load_p1), then the row walk
+    ZZZ_HIP(ctx, ctx->cell_geom.alloc((size_t)(ctx->ncells * (bs == 1 ? 2 : 4))));
+    const int cper = bs == 1 ? 1024 : 256; // cells per workgroup and round (k_cell_load_p1: U)
+    const dim3 cgrid((unsigned)std::min<int64_t>((ctx->ncells + cper - 1) / cper, 16384));
     if (bs == 1)
-      hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
-                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
-                         ctx->coeff[1].p, ctx->b.p, nrows);
+    {
+      hipLaunchKernelGGL(k_cell_load_p1<1>, cgrid, dim3(256), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->coeff[0].p,
+                         ctx->facet_mask.p, ctx->ncells, ctx->cell_geom.p);
+      hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p,
+                         ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p, ctx->coeff[1].p, ctx->cell_geom.p, ctx->b.p,
+                         nrows);
+    }
     else
-      hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
-                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p,
-                         (const double*)nullptr, ctx->b.p, nrows);
+    {
+      hipLaunchKernelGGL(k_cell_load_p1<3>, cgrid, dim3(256), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->coeff[0].p,
+                         (const uint8_t*)nullptr, ctx->ncells, ctx->cell_geom.p);
+      hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p,
+                         ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p, (const double*)nullptr, ctx->cell_geom.p,
+                         ctx->b.p, nrows);
+    }
   }
   else
   {

@@ -13,7 +13,7 @@ import csv,glob,json
 f=glob.glob("$OUT/p/**/*kernel_stats.csv",recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n=r["Name"]
-    if "asm_matrix" in n or "asm_vector" in n or "k_cell_geom" in n: print(f'{float(r["AverageNs"])/1e3:10.1f} us x {r["Calls"]:>4}  {n[:60]}')
+    if "asm_matrix" in n or "asm_vector" in n or "k_cell_" in n: print(f'{float(r["AverageNs"])/1e3:10.1f} us x {r["Calls"]:>4}  {n[:60]}')
 d=json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1]); print({k[:16]:round(v,2) for k,v in d["phases_ms"].items()})
 PY
   rm -rf $OUT

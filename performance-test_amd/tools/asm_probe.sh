@@ -13,7 +13,7 @@ import csv,glob
 f=glob.glob("$OUT/p/**/*kernel_stats.csv",recursive=True)
 for r in csv.DictReader(open(f[0])) if f else []:
     n=r["Name"]
-    if "asm_matrix" in n or "asm_vector" in n or "k_cell_geom" in n: print(f'{float(r["AverageNs"])/1e3:10.1f} us x {r["Calls"]:>4}  {n[:60]}')
+    if "asm_matrix" in n or "asm_vector" in n or "k_cell_" in n: print(f'{float(r["AverageNs"])/1e3:10.1f} us x {r["Calls"]:>4}  {n[:60]}')
 PY
   rm -rf $OUT
 done
