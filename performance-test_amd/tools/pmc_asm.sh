@@ -28,7 +28,7 @@ for d in sorted(glob.glob(f"{root}/pmcasm_{tag}_*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            k = next((x for x in ("asm_matrix_p1", "asm_vector_p1", "asm_matrix_pk_pos", "asm_vector_pk", "k_cell_geom") if x in n), None)
+            k = next((x for x in ("asm_matrix_p1", "asm_vector_p1", "asm_matrix_pk_pos", "asm_vector_pk", "k_cell_geom", "k_cell_load_p1") if x in n), None)
             if not k:
                 continue
             a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1

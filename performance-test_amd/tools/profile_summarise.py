@@ -19,7 +19,7 @@ KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel|spmv_one_kernel"), ("k_sp_
         ("k_row_pattern", r"k_row_pattern"), ("k_row_copy", r"k_row_copy"), ("k_tile_encode_cols", r"k_tile_encode_cols"),
         ("k_adjT_fill", r"k_adjT_fill"), ("k_make_pairs", r"k_make_pairs"), ("radix_sort", r"radix_sort_onesweep_iteration"),
         ("k_cube_cells", r"k_cube_cells"), ("k_extract_dinv", r"k_extract_dinv"), ("k_adj_window", r"k_adj_window"),
-        ("k_cell_geom", r"k_cell_geom"), ("k_sp_compact", r"k_sp_compact"), ("k_mf_action", r"k_mf_action"),
+        ("k_cell_geom", r"k_cell_geom"), ("k_cell_load_p1", r"k_cell_load_p1"), ("k_sp_compact", r"k_sp_compact"), ("k_mf_action", r"k_mf_action"),
         ("k_mf_finish", r"k_mf_finish")]
 
 
