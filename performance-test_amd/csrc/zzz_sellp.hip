@@ -607,15 +607,16 @@ bool sellp_active(zzz_ctx* ctx)
     return false;
   if (!ctx->sp_dict_done)
   {
-    // a failed build (a hipMalloc that did not fit) leaves the stream on doubles -- valid -- but must not leave its partial
-    // allocations or HIP's sticky last error behind (the next hipGetLastError after a product launch would report it)
+    // a FAILED build (a hipMalloc that did not fit) leaves the stream on doubles -- valid -- but must not leave its partial
+    // allocations or HIP's sticky last error behind (the next hipGetLastError after a product launch would report it).
+    // A build that was DECLINED (too many distinct values, the 60 % rule) keeps its buffers for the next assembly: this runs
+    // at the first product of a solve, and hipFree waits for the whole device -- with two ranks on ONE GPU (the tests' and
+    // the driver's --comm local) the other rank may already be polling its all-reduce mailbox for this one: a release here
+    // was a dead wait until the poll's time-out (round 5, found by tools/soak_driver.sh: elasticity P2, two ranks).
     if (sp_dict_build(ctx) != ZZZ_OK)
     {
       ctx->sp_dict_on = false;
       (void)hipGetLastError();
-    }
-    if (!ctx->sp_dict_on)
-    {
       ctx->sp_vcode.release();
       ctx->sp_dict_table.release();
       ctx->sp_dict_slot.release();
@@ -624,9 +625,6 @@ bool sellp_active(zzz_ctx* ctx)
     {
       ctx->sp_sd_on = ctx->sp_sd_all = false;
       (void)hipGetLastError();
-    }
-    if (!ctx->sp_sd_on)
-    {
       ctx->sp_vcode8.release();
       ctx->sp_sd_vals.release();
       ctx->sp_sd_info.release();

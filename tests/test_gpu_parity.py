@@ -1443,6 +1443,13 @@ def test_driver_multi_rank_threads_on_one_gpu():
     assert m1.returncode == 0 and m2.returncode == 0, m2.stderr
     (j1, q1), (j2, q2) = parse(m1.stdout), parse(m2.stdout)
     assert j1 == j2 == 100 and abs(q2 - q1) <= 1e-9 * q1
+    # two ranks on ONE GPU, peer-memory all-reduce, a stream whose slice dictionaries are built and DECLINED at the first
+    # product of the solve (elasticity P2: the 60 % rule): nothing on that path may free device memory -- hipFree waits for
+    # the whole device, i.e. for the other rank's kernel that polls its mailbox for this rank (round 5: a 3-s time-out)
+    e2 = subprocess.run([exe, "--problem_type", "elasticity", "--order", "2", "--scaling_type", "strong", "--ndofs", "150000",
+                         "--ngpus", "2", "--comm", "local", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-8"],
+                        capture_output=True, text=True, timeout=300)
+    assert e2.returncode == 0 and "timed out" not in e2.stderr and "Num processes:   2" in e2.stdout, e2.stderr[-1500:]
 
 
 def test_run_to_run_reproducibility(ctx):
