@@ -67,7 +67,7 @@ int sp_sd_build(zzz_ctx* ctx);
 
 // workgroups per CU of the product for streams of one-chunk slices (zzz_sellp_pipe.hip: two rows per lane, <= 96 registers per
 // lane); sp_grid sizes the persistent grid by it
-constexpr int SP_ONE_WGS = 4;
+constexpr int SP_ONE_WGS = 4; // (five fit its 89 registers: 73.4 us against 70-72.5 at C2 -- more wavefronts in flight do not help)
 constexpr int SP_ONE_WGS_SR = 4; // ... with the single-reduction form's extra sums
 int sellp_pipe_wgs(const zzz_ctx* ctx, bool sr); // workgroups per CU if spmv_one_kernel serves the context's stream; 0: it does not
 int sellp_pairs_build(zzz_ctx* ctx); // marks the affine slice pairs of a stream of one-chunk slices (spmv_one_kernel)

@@ -322,18 +322,48 @@ __global__ __launch_bounds__(SP_BLOCK, SR ? SP_ONE_WGS_SR : SP_ONE_WGS) void spm
       auto pair = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
         dbl2u xq[W];
+        // Two loads saved per pair where the slots allow it (all conditions are on the slots' bases: scalars).  (i) Three
+        // slots whose runs start at consecutive columns (c - 1, c, c + 1: the mesh line's own neighbours) -- the middle run
+        // is the outer two's inner halves, x[c + 2 l] = .y of the first, x[c + 2 l + 1] = .x of the third: not loaded.
+        // (ii) The slot of the diagonal (its run starts at the pair's first row) IS the rows' own x for <x, A x>: the
+        // 16-B load of x at the rows themselves is issued only where no slot is the diagonal's.
+        unsigned bs_[W];
+        bool mid[W];
 #pragma unroll
         for (int e = 0; e < W; ++e)
-        {
-          const unsigned base = e == 0 ? (unsigned)(S.ba[0] & 0x1fffffff) : ((W == 8 && e >= w) ? 0u : (unsigned)S.ba[e]);
-          xq[e] = *reinterpret_cast<const dbl2u*>(reinterpret_cast<const char*>(p_x) + ((base << 3) + lane16));
-        }
+          bs_[e] = e == 0 ? (unsigned)(S.ba[0] & 0x1fffffff) : ((W == 8 && e >= w) ? 0u : (unsigned)S.ba[e]);
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+          mid[e] = e >= 1 && e + 1 < W && bs_[e - 1] + 1u == bs_[e] && bs_[e] + 1u == bs_[e + 1] && !mid[e >= 1 ? e - 1 : 0];
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+          if (!mid[e])
+            xq[e] = *reinterpret_cast<const dbl2u*>(reinterpret_cast<const char*>(p_x) + ((bs_[e] << 3) + lane16));
+#pragma unroll
+        for (int e = 1; e + 1 < W; ++e)
+          if (mid[e])
+          {
+            xq[e].x = xq[e - 1].y;
+            xq[e].y = xq[e + 1].x;
+          }
         double xr0 = 0.0, xr1 = 0.0, rr0 = 0.0, rr1 = 0.0;
         if (DOT)
         {
-          const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane16, sa << 9, 0);
-          xr0 = __hiloint2double((int)u[1], (int)u[0]);
-          xr1 = __hiloint2double((int)u[3], (int)u[2]);
+          bool have_diag = false;
+#pragma unroll
+          for (int e = 0; e < W; ++e)
+            if (bs_[e] == ((unsigned)sa << 6) && (W < 8 || e < w))
+            {
+              xr0 = xq[e].x;
+              xr1 = xq[e].y;
+              have_diag = true;
+            }
+          if (!have_diag)
+          {
+            const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane16, sa << 9, 0);
+            xr0 = __hiloint2double((int)u[1], (int)u[0]);
+            xr1 = __hiloint2double((int)u[3], (int)u[2]);
+          }
           if (SR)
           {
             const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_r, lane16, sa << 9, 0);
