@@ -20,6 +20,7 @@ CASES = {
     "c5": ("poisson", 3, 50000000, 1),
     "p2": ("poisson", 2, 5000000, 1),
     "e3": ("elasticity", 3, 1000000, 3),
+    "e2": ("elasticity", 2, 2000000, 3),
 }
 
 
