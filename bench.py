@@ -426,6 +426,42 @@ def run_rank_size(problem, order, nx, ny, nz, what):
             "scalar_allreduce": "peer-memory mailboxes" if p2p else "ncclAllReduce"}
 
 
+def run_driver_one_shot(args, timeout=900):
+    """ONE run of the drop-in driver binary (performance-test_amd/dolfinx-scaling-test: the reference's CLI and timer surface,
+    src/main.cpp:57-74,152-211): every phase once, as the reference runs them, its "Summary of timings" parsed.  A child
+    process (this one's GPU context stays as it is), outside every timed region."""
+    import re
+    import subprocess
+
+    exe = os.path.join(zzz.PKG, "dolfinx-scaling-test")
+    if not os.path.exists(exe):
+        return {"error": "driver binary not built"}
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        return {"error": f"exit status {r.returncode}: {r.stderr[-300:]}"}
+    rec = {"command": "dolfinx-scaling-test " + " ".join(args), "timers_ms": {}}
+    for line in r.stdout.splitlines():
+        m = re.match(r"^(ZZZ [^|]+?)\s*\|\s*(\d+)\s+([0-9.eE+-]+)\s+([0-9.eE+-]+)\s*$", line)
+        if m:
+            rec["timers_ms"][m.group(1)] = float(m.group(4)) * 1e3
+        m = re.match(r"^\*\*\* Number of Krylov iterations: (\d+)", line)
+        if m:
+            rec["krylov_iterations"] = int(m.group(1))
+        m = re.match(r"^\*\*\* Solution norm:\s+([0-9.eE+-]+)", line)
+        if m:
+            rec["solution_norm"] = float(m.group(1))
+        m = re.match(r"^\s*Total degrees of freedom:\s+(\d+)", line)
+        if m:
+            rec["dofs"] = int(m.group(1))
+    t = rec["timers_ms"]
+    if "dofs" in rec and t.get("ZZZ Solve"):
+        rec["dofs_per_s"] = {k: rec["dofs"] / (v * 1e-3) for k, v in t.items()
+                             if k in ("ZZZ Assemble", "ZZZ Assemble matrix", "ZZZ Assemble vector", "ZZZ Solve") and v > 0}
+    rec["note"] = ("one process, every phase ONCE (first-time allocations, code objects loaded at zzz_ctx_create); the `ZZZ Assemble` "
+                   "umbrella holds create_matrix + matrix + vector (src/poisson_problem.cpp:49,122-157)")
+    return rec
+
+
 def full_pattern_product(a, nx, ny, nz):
     """The product on the FULL pattern (ZZZ_SELLP_DROP=0: every structural entry of the reference's matrix streamed, exact
     zeros included), so that the kernel's share of `roofline.frac` can be told from the mesh's: 46 % of C2's entries are
@@ -959,6 +995,15 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             out["roofline"]["full_pattern"] = {"error": repr(e)}
         out["other_configs"] = {}
+        # the drop-in surface as a user of dolfinx-scaling-test sees it: one-shot runs of the driver binary
+        for key, dargs in (("driver_one_shot", ["--problem_type", "poisson", "--order", "1", "--scaling_type", "strong", "--ndofs", "10000000",
+                                                "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-8"]),
+                           ("driver_one_shot_c4_total", ["--problem_type", "elasticity", "--order", "1", "--scaling_type", "strong", "--ndofs",
+                                                         "4000000", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-8"])):
+            try:
+                out["other_configs"][key] = run_driver_one_shot(dargs)
+            except Exception as e:  # noqa: BLE001
+                out["other_configs"][key] = {"error": repr(e)}
         for name in ("c1", "c4_total", "c5_rank", "c5"):
             try:
                 out["other_configs"]["c5_whole" if name == "c5" else name] = run_other_config(name, steps=2 if name == "c5" else 3)

@@ -363,8 +363,17 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
  * order of operations, bit-identical products); info[1] = distinct values (+0.0 included); info[2] = bytes per product of
  * the stream in the form in use; info[3] = bytes per product with the values as doubles; info[4] = 1 when the stream is
  * one of one-chunk slices and the product runs on the kernel for those (csrc/zzz_sellp_pipe.hip: two rows per lane), else 0;
- * info[5] = workgroups per CU of the product's persistent grid.  0s when the product does not run on the stream. */
-int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[6]);
+ * info[5] = workgroups per CU of the product's persistent grid.  0s when the product does not run on the stream.
+ * zzz_spmv_values_info writes info[0..3] only (its signature of round 4: a caller built against that header passes four
+ * entries); everything from info[4] on comes through zzz_spmv_values_info2, which writes the first min(n, 10) entries:
+ * info[6] = 1 when the product of a block-size-3 matrix runs in block-row form (csrc/zzz_sellp_blk.hip: one lane per node,
+ * 16-bit codes into a table of the matrix's distinct 3 x 3 blocks in LDS), info[7] = entries of that table (zero block
+ * included), info[8] = chunks of 16 block slots per node, info[9] = reserved (0); info[2] is then the bytes of THAT form. */
+int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4]);
+int zzz_spmv_values_info2(zzz_ctx* ctx, int n, int64_t* info);
+/* Version of this header's ABI: bumped whenever an existing entry point changes what it reads or writes (6: round 6). */
+#define ZZZ_ABI_VERSION 6
+int zzz_abi_version(void);
 
 /* ---- multi-GPU (one context per GPU; RCCL over xGMI) --------------------------------------- */
 

@@ -124,6 +124,30 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     return fail(nullptr, ZZZ_ERR_HIP, "context allocation failed");
   }
   memset(ctx->h_state, 0, 8 * sizeof(zzz::CgState));
+  // the code objects of every translation unit, now (see ZZZ_PRELOAD_TU); once per process and device is enough, and a
+  // failure here is not an error: the launch that needs the unit would report it
+  {
+    static bool loaded[64] = {};
+    if (device < 64 && !loaded[device])
+    {
+      loaded[device] = true;
+      zzz::preload_cubegen();
+      zzz::preload_renumber();
+      zzz::preload_pattern();
+      zzz::preload_assemble();
+      zzz::preload_sellp_pack();
+      zzz::preload_sellp_dict();
+      zzz::preload_sellp_pipe();
+      zzz::preload_sellp_blk();
+      zzz::preload_sellp();
+      zzz::preload_spmv();
+      zzz::preload_cg();
+      zzz::preload_comm();
+      zzz::preload_matfree();
+      zzz::preload_nullspace();
+      (void)hipGetLastError();
+    }
+  }
   // tuning knobs for A/B measurements (defaults are the measured best)
 #ifdef ZZZ_EXPERIMENTS
   if (const char* e = getenv("ZZZ_SPMV_TILE")) // (tools build only: the 4096-nonzero tiles lost)
@@ -150,6 +174,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_drop = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_DICT"))
     ctx->sellp_dict = atoi(e);
+  if (const char* e = getenv("ZZZ_SELLP_BLK")) // 0: block size 3 stays on the generic product (A/B against the block-row form)
+    ctx->sellp_blk = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_PIPE")) // 0: the generic product kernel always (A/B against the pipelined one)
     ctx->sellp_pipe = atoi(e);
   if (const char* e = getenv("ZZZ_CG_DINV_CODES"))
@@ -978,22 +1004,33 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8])
   return ZZZ_OK;
 }
 
-int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[6])
+int zzz_spmv_values_info2(zzz_ctx* ctx, int n, int64_t* out)
 {
   ZZZ_ENTER(ctx);
-  if (!info || !ctx->have_pattern)
+  if (!out || n < 0 || !ctx->have_pattern)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_spmv_values_info: no pattern");
-  info[0] = info[1] = info[2] = info[3] = info[4] = info[5] = 0;
-  if (!sellp_active(ctx))
-    return ZZZ_OK;
-  info[4] = zzz::sellp_pipe_wgs(ctx, false) ? 1 : 0;
-  info[5] = info[4] ? zzz::sellp_pipe_wgs(ctx, false) : 8;
-  info[0] = ctx->sp_sd_on ? 3 : (ctx->sp_dict_on ? (ctx->sp_dict_n <= zzz::SP_DICT_LDS_ENTRIES ? 2 : 1) : 0);
-  info[1] = ctx->sp_dict_on ? ctx->sp_dict_n : 0;
-  info[2] = sellp_stream_bytes(ctx);
-  info[3] = ctx->sp_bytes + ctx->nslices * 8;
+  int64_t info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (sellp_active(ctx))
+  {
+    const bool blk = zzz::sellp_blk_serves(ctx);
+    info[4] = !blk && zzz::sellp_pipe_wgs(ctx, false) ? 1 : 0;
+    info[5] = blk ? 1 : (info[4] ? zzz::sellp_pipe_wgs(ctx, false) : 8);
+    info[0] = ctx->sp_sd_on ? 3 : (ctx->sp_dict_on ? (ctx->sp_dict_n <= zzz::SP_DICT_LDS_ENTRIES ? 2 : 1) : 0);
+    info[1] = ctx->sp_dict_on ? ctx->sp_dict_n : 0;
+    info[2] = sellp_stream_bytes(ctx);
+    info[3] = ctx->sp_bytes + ctx->nslices * 8;
+    info[6] = blk ? 1 : 0;
+    info[7] = blk ? ctx->bk_entries : 0;
+    info[8] = blk ? ctx->bk_chunks : 0;
+  }
+  for (int i = 0; i < std::min(n, 10); ++i)
+    out[i] = info[i];
   return ZZZ_OK;
 }
+
+int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4]) { return zzz_spmv_values_info2(ctx, 4, info); }
+
+int zzz_abi_version(void) { return ZZZ_ABI_VERSION; }
 
 int zzz_internal_order_download(zzz_ctx* ctx, int32_t* perm, int32_t* kind)
 {

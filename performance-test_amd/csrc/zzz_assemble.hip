@@ -1822,4 +1822,5 @@ int launch_matfree_legacy(zzz_ctx* ctx, const double* u, double* y, double* part
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
+ZZZ_PRELOAD_TU(assemble)
 } // namespace zzz

@@ -1926,4 +1926,5 @@ static int cg_solve_single_reduction(zzz_ctx* ctx, const zzz_solver_opts* o, int
     ctx->last_pc_bound = C.hi;
   return finish_reason(ctx, o, fin, its);
 }
+ZZZ_PRELOAD_TU(cg)
 } // namespace zzz

@@ -965,6 +965,7 @@ void comm_destroy(zzz_ctx* ctx)
     ctx->comm = nullptr;
   }
 }
+ZZZ_PRELOAD_TU(comm)
 } // namespace zzz
 
 using namespace zzz;

@@ -86,6 +86,7 @@ static int gridfor(int64_t n)
     g = 1;
   return (int)g;
 }
+ZZZ_PRELOAD_TU(cubegen)
 } // namespace zzz
 
 using namespace zzz;

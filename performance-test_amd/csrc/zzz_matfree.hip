@@ -1363,4 +1363,5 @@ static int mf_run(zzz_ctx* ctx, bool diag, const double* u, double* y, double* p
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
+ZZZ_PRELOAD_TU(matfree)
 } // namespace zzz

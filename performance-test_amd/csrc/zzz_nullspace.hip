@@ -140,6 +140,7 @@ int nn_dot(zzz_ctx* ctx, const double* a, const double* b, int64_t n_owned_scala
   return ZZZ_OK;
 }
 } // namespace
+ZZZ_PRELOAD_TU(nullspace)
 } // namespace zzz
 
 using namespace zzz;

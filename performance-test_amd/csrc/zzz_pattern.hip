@@ -937,7 +937,10 @@ __global__ __launch_bounds__(ADJ_W) void k_adj_window(const int32_t* __restrict_
   for (int r = tid; r < nruns; r += ADJ_W)
   {
     const int a = lo[(int64_t)r * (nwin + 1) + w], b = lo[(int64_t)r * (nwin + 1) + w + 1];
-    seg0[r] = a;
+    // (an empty range may start at the run's END, i.e. at cell `ncells` for the last run: the sweeps below load the first
+    // cell of every range unconditionally -- one entry past the connectivity, a memory fault when the array ends on a
+    // page boundary: 2^k cells, found in round 6 at 64 x 32 x 32 sub-cubes.  An empty range points at the run's first cell.)
+    seg0[r] = b > a ? a : runs[3 * r + 1];
     segn[r] = b - a; // <= 256: the keys of a run grow strictly
     segk[r] = runs[3 * r];
   }
@@ -1080,6 +1083,16 @@ static void adjacency_find_runs(zzz_ctx* ctx)
   ctx->adj_runs_n = nruns;
 }
 
+#define ZZZ_DBG(name)                                                                                                  \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (getenv("ZZZ_DEBUG_SYNC"))                                                                                      \
+    {                                                                                                                  \
+      hipError_t e_ = hipStreamSynchronize(ctx->stream);                                                               \
+      fprintf(stderr, "[zzz dbg] %s: %s\n", name, hipGetErrorString(e_));                                              \
+      fflush(stderr);                                                                                                  \
+    }                                                                                                                  \
+  } while (0)
 // adjacency through the runs, enqueued without a host wait: whether every window fitted arrives in
 // ctx->adj_flag_host behind these kernels and is looked at the next time the build waits for the device anyway
 static int adjacency_by_runs(zzz_ctx* ctx)
@@ -1094,8 +1107,13 @@ static int adjacency_by_runs(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_run_window_bounds, dim3(grid_for((int64_t)nruns * (nwin + 1), 256, 16384)), dim3(256), 0, s,
                      ctx->cell_dofs.p, nd, ctx->adj_runs.p, nruns, nwin, ctx->adj_run_lo.p);
+  if (getenv("ZZZ_DEBUG_SYNC"))
+    fprintf(stderr, "[zzz dbg] nruns %d nwin %d nb %d\n", nruns, nwin, nb);
+  ZZZ_DBG("k_run_window_bounds");
   hipLaunchKernelGGL(k_window_tot, dim3(grid_for(nwin)), dim3(256), 0, s, ctx->adj_run_lo.p, nruns, nwin, ctx->adj_win_base.p);
+  ZZZ_DBG("k_window_tot");
   hipLaunchKernelGGL(k_window_base, dim3(1), dim3(1024), 0, s, nwin, ctx->adj_win_base.p, flag);
+  ZZZ_DBG("k_window_base");
   hipLaunchKernelGGL(k_adj_window, dim3(nwin), dim3(ADJ_W), 0, s, ctx->cell_dofs.p, nd, ctx->adj_runs.p, nruns, ctx->adj_run_lo.p,
                      nwin, ctx->adj_win_base.p, nb, ctx->adj_off.p, ctx->adj_cells.p);
   ZZZ_HIP(ctx, hipMemcpyAsync(ctx->adj_flag_host, flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1215,12 +1233,14 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
   {
     if (int rc = adjacency_by_runs(ctx))
       return rc;
+    ZZZ_DBG("adjacency_by_runs");
   }
   else
   {
     ZZZ_HIP(ctx, rocprim::radix_sort_pairs<AdjSortConfig>(tmp.p, tb, ctx->cell_dofs.p, keys_out.p, cell_of.p, ctx->adj_cells.p, (size_t)N,
                                            0, (unsigned)end_bit, s));
     hipLaunchKernelGGL(k_adj_bounds, dim3(grid_for((N + 4) / 4)), dim3(256), 0, s, keys_out.p, N, nb, ctx->adj_off.p);
+    ZZZ_DBG("radix sort + k_adj_bounds");
   }
 
   // 2. pattern: count, scan, fill
@@ -1246,6 +1266,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
     int rc = build_adjT_offsets(ctx);
     if (rc)
       return rc;
+    ZZZ_DBG("build_adjT_offsets");
     // 8 workgroups per CU = 4 wavefronts per SIMD, what the kernel's 108 registers allow (a cap of 4 left half of that
     // occupancy unused: 2.98 -> ~2.0 ms)
     const dim3 tg((grid_for((int64_t)nb, ROW_T_BLOCK, 256 * 8) + 7) / 8 * 8);
@@ -1258,6 +1279,7 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
       else
         hipLaunchKernelGGL((k_row_pattern_thread4<32, 4096>), tg, dim3(ROW_T_BLOCK), 0, s, ctx->cell_dofs.p, ctx->adj_off.p,
                            ctx->adj_cells.p, nb, cnt.p, scal.p, scal.p + 2, stage, ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p);
+      ZZZ_DBG("k_row_pattern_thread4");
       ZZZ_HIP(ctx, hipMemcpyAsync(h, scal.p, sizeof(h), hipMemcpyDeviceToHost, s));
       ZZZ_HIP(ctx, hipStreamSynchronize(s));
       if (adjacency_overflowed())
@@ -1324,10 +1346,12 @@ int pattern_build_device(zzz_ctx* ctx, bool* fallback)
                        ctx->adj_cells.p, nb, cnt.p, scal.p, bptr.p, ctx->cols.p, scal.p + 1, (int32_t*)nullptr, (uint16_t*)nullptr,
                        (int32_t*)nullptr);
   ZZZ_HIP(ctx, hipGetLastError());
+  ZZZ_DBG("k_row_copy");
   // 3. tiles
   int rc = build_tiles_device(ctx, h[0]);
   if (rc)
     return rc;
+  ZZZ_DBG("build_tiles_device");
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   return ZZZ_OK;
 }
@@ -1377,4 +1401,5 @@ int build_tile_split(zzz_ctx* ctx)
   ctx->have_tile_split = true;
   return ZZZ_OK;
 }
+ZZZ_PRELOAD_TU(pattern)
 } // namespace zzz

@@ -642,4 +642,5 @@ int csr_values_to_internal(zzz_ctx* ctx, const double* vals_c, std::vector<doubl
   }
   return ZZZ_OK;
 }
+ZZZ_PRELOAD_TU(renumber)
 } // namespace zzz

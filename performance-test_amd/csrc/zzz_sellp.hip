@@ -633,6 +633,12 @@ bool sellp_active(zzz_ctx* ctx)
     ctx->sp_pairs_ok = false;
     if (ctx->sp_one_chunk && ctx->sp_dict_on && ctx->bs == 1 && !ctx->sp_sorted)
       ctx->sp_pairs_ok = sellp_pairs_build(ctx) == ZZZ_OK;
+    // block size 3: the block-row form beside the stream (zzz_sellp_blk.hip); a failed build leaves the stream as it is
+    if (sellp_blk_build(ctx) != ZZZ_OK)
+    {
+      ctx->bk_on = false;
+      (void)hipGetLastError();
+    }
   }
   return true;
 }
@@ -641,6 +647,8 @@ bool sellp_active(zzz_ctx* ctx)
 // counted separately)
 int64_t sellp_stream_bytes(const zzz_ctx* ctx)
 {
+  if (sellp_blk_serves(ctx))
+    return ctx->bk_bytes; // (descriptors and table included)
   return (ctx->sp_sd_on ? ctx->sp_sd_bytes : (ctx->sp_dict_on ? ctx->sp_dict_bytes : ctx->sp_bytes)) + ctx->nslices * 8; // (x windows: sp_win_bytes, reported apart)
 }
 
@@ -653,10 +661,12 @@ static bool sp_stream_nt(const zzz_ctx* ctx)
   return (double)sellp_stream_bytes(ctx) + 48.0 * (double)(ctx->n_owned + ctx->n_ghost) * ctx->bs > 200.0e6;
 }
 
-static int sp_grid(const zzz_ctx* ctx, int64_t ngroups, bool sr)
+// plain: the launch carries no Chebyshev epilogue and no folded all-reduce, so the specialised kernels (one-chunk slices,
+// block rows) may serve it; otherwise the generic kernel runs and keeps its eight workgroups per CU
+static int sp_grid(const zzz_ctx* ctx, int64_t ngroups, bool sr, bool plain)
 {
   // persistent workgroups: as many as are resident at once (a second round of a grid that is not would run on part of the chip)
-  const int pw = sellp_pipe_wgs(ctx, sr);
+  const int pw = plain ? sellp_pipe_wgs(ctx, sr) : 0;
   int64_t gs = 256 * (pw ? pw : 8); // (1024 or 1536 workgroups at the per-rank size: no faster)
 #ifdef ZZZ_EXPERIMENTS
   if (const char* e = getenv("ZZZ_SP_WGS_PER_CU")) // how the product's time depends on the wavefronts in flight
@@ -673,13 +683,16 @@ static int sp_grid(const zzz_ctx* ctx, int64_t ngroups, bool sr)
 template <bool DOT>
 static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
                        const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr,
-                       const TailArgs& tail = TailArgs(), const ChebEpi* epi = nullptr)
+                       const TailArgs& tail = TailArgs(), const ChebEpi* epi = nullptr, bool blk = false)
 {
   // load policy by stream size, as for the tile kernel: a stream that stays in the 256 MiB Infinity Cache from
   // one CG iteration to the next is read with plain loads, a larger one with non-temporal loads
   bool nt = sp_stream_nt(ctx);
   if (!ctx->spmv_auto)
     nt = (ctx->spmv_variant & 1) != 0;
+  // blk: the caller sized the grid and chose the slice list for the block-row kernel (block size 3)
+  if (blk && launch_sellp_blk(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
+    return;
   if (!epi && !tail.parts && launch_sellp_pipe(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
     return;
   const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
@@ -748,7 +761,9 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
                  const ChebEpi* epi)
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
-  const int gs = sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec));
+  const bool plain = !epi && !(partials && ctx->tail_armed);
+  const bool blk = plain && sellp_blk_serves(ctx);
+  const int gs = blk ? sellp_blk_grid(ctx, ctx->bk_slices) : sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec), plain);
 #ifdef ZZZ_EXPERIMENTS
   const char* e = ctx->timing_only ? getenv("ZZZ_EXP_WIN") : nullptr; // timing probe, wrong results by construction (see
   if (e)                                                               // the kernel): inside zzz_spmv_time only
@@ -787,12 +802,12 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
       ctx->tail_armed = false;
       ctx->tail_used = true;
     }
-    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr, T, epi);
+    launch_one<true>(ctx, gs, x, y, partials, stop, nullptr, 0, rvec, nn_is_rr, T, epi, blk);
     if (npartials)
       *npartials = gs;
   }
   else
-    launch_one<false>(ctx, gs, x, y, nullptr, stop, nullptr, 0, nullptr, 0, TailArgs(), epi);
+    launch_one<false>(ctx, gs, x, y, nullptr, stop, nullptr, 0, nullptr, 0, TailArgs(), epi, blk);
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
@@ -803,13 +818,17 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
                             int nn_is_rr, const ChebEpi* epi)
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
-  const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
-  int g_in = gi ? sp_grid(ctx, gi, (partials && rvec)) : 0;
-  const int pw = sellp_pipe_wgs(ctx, partials && rvec);
-  const int room = 256 * ((pw ? pw : 8) - 1); // (one workgroup slot per CU left to the exchange's kernel)
-  if (g_in > room && ctx->nneigh > 0)
+  const bool plain = !epi && !(partials && ctx->tail_armed);
+  const bool blk = plain && sellp_blk_serves(ctx) && ctx->bk_have_split;
+  const int64_t gi = blk ? ctx->bk_n_interior : ctx->n_groups_interior, gb = blk ? ctx->bk_n_boundary : ctx->n_groups_boundary;
+  const int32_t* list_in = blk ? ctx->bk_list_interior.p : ctx->groups_interior.p;
+  const int32_t* list_bd = blk ? ctx->bk_list_boundary.p : ctx->groups_boundary.p;
+  int g_in = gi ? (blk ? sellp_blk_grid(ctx, gi) : sp_grid(ctx, gi, (partials && rvec), plain)) : 0;
+  const int pw = plain ? sellp_pipe_wgs(ctx, partials && rvec) : 0;
+  const int room = 256 * ((pw ? pw : 8) - 1); // (one workgroup slot per CU left to the exchange's kernel; the block-row
+  if (!blk && g_in > room && ctx->nneigh > 0) //  kernel's one workgroup per CU leaves half the CU's wavefront slots free)
     g_in = room;
-  const int g_bd = gb ? sp_grid(ctx, gb, (partials && rvec)) : 0;
+  const int g_bd = gb ? (blk ? sellp_blk_grid(ctx, gb) : sp_grid(ctx, gb, (partials && rvec), plain)) : 0;
   if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
     return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
   TailArgs Ti, Tb;
@@ -831,9 +850,9 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   if (gi)
   {
     if (partials)
-      launch_one<true>(ctx, g_in, x, y, partials, stop, ctx->groups_interior.p, gi, rvec, nn_is_rr, Ti, epi);
+      launch_one<true>(ctx, g_in, x, y, partials, stop, list_in, gi, rvec, nn_is_rr, Ti, epi, blk);
     else
-      launch_one<false>(ctx, g_in, x, y, nullptr, stop, ctx->groups_interior.p, gi, nullptr, 0, TailArgs(), epi);
+      launch_one<false>(ctx, g_in, x, y, nullptr, stop, list_in, gi, nullptr, 0, TailArgs(), epi, blk);
   }
   rc = comm_halo_end(ctx);
   if (rc)
@@ -841,9 +860,9 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   if (gb)
   {
     if (partials)
-      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, ctx->groups_boundary.p, gb, rvec, nn_is_rr, Tb, epi);
+      launch_one<true>(ctx, g_bd, x, y, partials + g_in, stop, list_bd, gb, rvec, nn_is_rr, Tb, epi, blk);
     else
-      launch_one<false>(ctx, g_bd, x, y, nullptr, stop, ctx->groups_boundary.p, gb, nullptr, 0, TailArgs(), epi);
+      launch_one<false>(ctx, g_bd, x, y, nullptr, stop, list_bd, gb, nullptr, 0, TailArgs(), epi, blk);
   }
   if (npartials)
     *npartials = g_in + g_bd;
@@ -884,10 +903,10 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
   if (overlap && ctx->have_group_split)
   {
     const int64_t gi = ctx->n_groups_interior, gb = ctx->n_groups_boundary;
-    int g_in = gi ? sp_grid(ctx, gi, false) : 0;
+    int g_in = gi ? sp_grid(ctx, gi, false, false) : 0;
     if (g_in > 256 * 7 && ctx->nneigh > 0)
       g_in = 256 * 7; // room for the exchange's kernel beside the persistent workgroups (launch_spmv_overlapped)
-    const int g_bd = gb ? sp_grid(ctx, gb, false) : 8;
+    const int g_bd = gb ? sp_grid(ctx, gb, false, false) : 8;
     if ((size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
       return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
     int rc = comm_halo_begin(ctx, z);
@@ -909,7 +928,7 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
       if (rc)
         return rc;
     }
-    const int gs = sp_grid(ctx, (ctx->nslices + 3) / 4, false);
+    const int gs = sp_grid(ctx, (ctx->nslices + 3) / 4, false, false);
     go(gs, nullptr, 0, partials, ctx->n_ghost > 0 ? 1 : 0);
     *npartials = gs;
   }
@@ -917,4 +936,5 @@ int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new
   return ZZZ_OK;
 }
 #endif // ZZZ_EXPERIMENTS
+ZZZ_PRELOAD_TU(sellp)
 } // namespace zzz

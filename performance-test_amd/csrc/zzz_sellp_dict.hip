@@ -520,4 +520,5 @@ int sp_sd_build(zzz_ctx* ctx)
   ctx->sp_sd_all = h[6] == 0;
   return ZZZ_OK;
 }
+ZZZ_PRELOAD_TU(sellp_dict)
 } // namespace zzz

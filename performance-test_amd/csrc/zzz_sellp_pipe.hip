@@ -552,4 +552,5 @@ bool launch_sellp_pipe(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* 
 #undef ZZZ_ONE_GO
   return true;
 }
+ZZZ_PRELOAD_TU(sellp_pipe)
 } // namespace zzz

@@ -416,4 +416,5 @@ int launch_spmv_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials,
   ZZZ_HIP(ctx, hipGetLastError());
   return ZZZ_OK;
 }
+ZZZ_PRELOAD_TU(spmv)
 } // namespace zzz

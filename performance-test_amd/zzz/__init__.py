@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "zzz_dofmap_upload", "zzz_bc_upload", "zzz_facets_upload", "zzz_coeff_upload", "zzz_cube_generate",
     "zzz_csr_pattern_build",
     "zzz_csr_sizes", "zzz_csr_download", "zzz_csr_rowptr64_download", "zzz_csr_upload_values", "zzz_assemble_matrix", "zzz_assemble_vector",
-    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_spmv_values_info", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_matfree_diagonal", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
+    "zzz_vec_download", "zzz_vec_upload", "zzz_vec_norm", "zzz_spmv", "zzz_spmv_time", "zzz_spmv_values_info", "zzz_spmv_values_info2", "zzz_abi_version", "zzz_action", "zzz_matfree_setup", "zzz_matfree_info", "zzz_matfree_diagonal", "zzz_action_time", "zzz_near_nullspace_build", "zzz_near_nullspace_download", "zzz_cg_solve", "zzz_cg_history",
     "zzz_profile_get", "zzz_cg_info", "zzz_internal_order_download", "zzz_global_ids_upload", "zzz_global_ids_download", "zzz_ghost_layer_build", "zzz_local_sizes", "zzz_spmv_info", "zzz_comm_load", "zzz_comm_library_path", "zzz_comm_info", "zzz_comm_unique_id", "zzz_comm_init", "zzz_halo_upload", "zzz_local_group_create",
     "zzz_local_group_destroy", "zzz_local_group_abort", "zzz_comm_init_local", "zzz_comm_init_peer_only", "zzz_comm_p2p_export", "zzz_comm_p2p_attach", "zzz_comm_p2p_disable", "zzz_comm_p2p_enable", "zzz_comm_p2p_halo",
 ]
@@ -125,6 +125,8 @@ def hip():
         # points that build does not have yet; without it a missing symbol is an error, as everywhere)
         if hasattr(L, "zzz_spmv_values_info") or not os.environ.get("ZZZ_AB_OLD"):
             L.zzz_spmv_values_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        if hasattr(L, "zzz_spmv_values_info2") or not os.environ.get("ZZZ_AB_OLD"):
+            L.zzz_spmv_values_info2.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.zzz_internal_order_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.zzz_comm_unique_id.argtypes = [C.c_void_p]
         L.zzz_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -574,14 +576,15 @@ class Context:
     def spmv_values_info(self):
         """how the operator stream holds its values: dict(form = 'doubles' | 'dictionary in memory' | 'dictionary in LDS',
         distinct values, bytes per product in that form, bytes per product as doubles)"""
-        info = (C.c_int64 * 6)()
-        if os.environ.get("ZZZ_AB_OLD") and not hasattr(self.L, "zzz_spmv_values_info"):
+        info = (C.c_int64 * 10)()
+        if os.environ.get("ZZZ_AB_OLD") and not hasattr(self.L, "zzz_spmv_values_info2"):
             return dict(form="doubles", distinct_values=0, bytes_per_product=0, bytes_per_product_as_doubles=0,
-                        one_chunk_kernel=False, workgroups_per_cu=8)
-        self._ck(self.L.zzz_spmv_values_info(self.h, info))
+                        one_chunk_kernel=False, workgroups_per_cu=8, block_rows=False, block_table_entries=0, block_chunks=0)
+        self._ck(self.L.zzz_spmv_values_info2(self.h, 10, info))
         return dict(form=("doubles", "dictionary in memory", "dictionary in LDS", "slice dictionaries")[int(info[0])], distinct_values=int(info[1]),
                     bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]),
-                    one_chunk_kernel=bool(info[4]), workgroups_per_cu=int(info[5]))
+                    one_chunk_kernel=bool(info[4]), workgroups_per_cu=int(info[5]), block_rows=bool(info[6]),
+                    block_table_entries=int(info[7]), block_chunks=int(info[8]))
 
     def spmv_x_windows(self):
         """(LDS doubles per workgroup, bytes of x loaded into LDS per product) when the operator stream carries x windows,
