@@ -368,7 +368,9 @@ int zzz_spmv_info(zzz_ctx* ctx, int64_t info[8]);
  * entries); everything from info[4] on comes through zzz_spmv_values_info2, which writes the first min(n, 10) entries:
  * info[6] = 1 when the product of a block-size-3 matrix runs in block-row form (csrc/zzz_sellp_blk.hip: one lane per node,
  * 16-bit codes into a table of the matrix's distinct 3 x 3 blocks in LDS), info[7] = entries of that table (zero block
- * included), info[8] = chunks of 16 block slots per node, info[9] = reserved (0); info[2] is then the bytes of THAT form. */
+ * included), info[8] = chunks of 16 block slots per node, info[9] = 1 when the table's rows (nine doubles each) sit in LDS, 2 when
+ * they are rows of nine 16-bit value offsets in memory and the VALUES sit in LDS (more than 2 200 distinct blocks; then
+ * info[7] still counts the blocks); info[2] is then the bytes of THAT form. */
 int zzz_spmv_values_info(zzz_ctx* ctx, int64_t info[4]);
 int zzz_spmv_values_info2(zzz_ctx* ctx, int n, int64_t* info);
 /* Version of this header's ABI: bumped whenever an existing entry point changes what it reads or writes (6: round 6). */

@@ -1022,6 +1022,7 @@ int zzz_spmv_values_info2(zzz_ctx* ctx, int n, int64_t* out)
     info[6] = blk ? 1 : 0;
     info[7] = blk ? ctx->bk_entries : 0;
     info[8] = blk ? ctx->bk_chunks : 0;
+    info[9] = blk ? ctx->bk_form : 0;
   }
   for (int i = 0; i < std::min(n, 10); ++i)
     out[i] = info[i];

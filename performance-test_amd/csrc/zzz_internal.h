@@ -298,7 +298,11 @@ struct zzz_ctx
   // block-row form of the product for block size 3 (zzz_sellp_blk.hip): one lane per node, 16-bit codes into a table of the
   // matrix's distinct 3 x 3 blocks (copied into LDS by every workgroup), 16 block slots per node and chunk
   zzz::DevBuf<int32_t> bk_desc, bk_meta, bk_flags, bk_nch, bk_c0, bk_slot_code, bk_info, bk_list_interior, bk_list_boundary;
-  zzz::DevBuf<uint16_t> bk_code, bk_ccode;
+  zzz::DevBuf<uint16_t> bk_code, bk_ccode, bk_rows16;
+  zzz::DevBuf<unsigned long long> bk_vset;
+  zzz::DevBuf<int32_t> bk_vcode;
+  zzz::DevBuf<double> bk_vdict;
+  int bk_form = 1, bk_ndict = 0; // 1: the table's rows (nine doubles) in LDS; 2: rows of value offsets in memory, the values in LDS
   zzz::DevBuf<double> bk_tab;
   zzz::DevBuf<unsigned long long> bk_hash_tag, bk_hash_owner;
   zzz::DevBuf<uint8_t> bk_gflag;

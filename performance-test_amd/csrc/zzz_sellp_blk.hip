@@ -23,7 +23,7 @@
 //
 // When it applies: block size 3, natural row order, at most BK_TAB_MAX distinct blocks (the LDS copy), 16-bit column codes
 // suffice, no Chebyshev epilogue / folded all-reduce on the launch (those stay on the generic kernel, like spmv_one_kernel's
-// exceptions).  Otherwise nothing changes.  ZZZ_SELLP_BLK=0 switches it off (A/B, parity tests).
+// exceptions).  Otherwise nothing changes.  ZZZ_SELLP_BLK=0 switches it off (A/B, parity tests), 2 forces it below 100 000 nodes.
 // Built at the stream's first use after an assembly (sellp_active), from the CSR matrix of record, on the device.
 #include <algorithm>
 #include <cstdlib>
@@ -38,9 +38,13 @@ namespace zzz
 {
 constexpr int BK_SLOTS = 16;             // block slots per node and chunk
 constexpr int BK_META = 32;              // ints of meta per chunk: [0..15] slot bases, [16] width | affine << 8
-constexpr int BK_HASH_BITS = 15;         // open-addressing set of the distinct blocks (build only)
+constexpr int BK_HASH_BITS = 18;         // open-addressing set of the distinct blocks (build only)
 constexpr int BK_HASH = 1 << BK_HASH_BITS;
-constexpr int BK_TAB_MAX = 2200;         // entries of the block table incl. the zero block: 2200 x 72 B = 158 400 B of LDS
+constexpr int BK_TAB_MAX = 2200;         // form 1: entries of the block table incl. the zero block: 2200 x 72 B = 158 400 B of LDS
+constexpr int BK_CODE_MAX = 65536;       // form 2: entries of the block table (16-bit codes), rows of nine value offsets in memory
+constexpr int BK_VAL_BITS = 13;          // form 2: set of the table's distinct VALUES (build only)
+constexpr int BK_VAL_HASH = 1 << BK_VAL_BITS;
+constexpr int BK_VAL_MAX = 2048;         // ... at most this many (the dictionary every workgroup copies into LDS: 16 KiB)
 constexpr int BK_THREADS = 1024;         // one workgroup per CU (the table takes its LDS), sixteen wavefronts
 
 // the nine values of block k of node r: rows 3 r + a at rp[a], block k of a row at entries 3 k .. 3 k + 2
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_bk_number(const unsigned long long* __
     if (tag[h] == 0ull)
       continue;
     slot_code[h] = code;
-    if (code < BK_TAB_MAX)
+    if (code < BK_CODE_MAX)
     {
       const unsigned long long o = owner[h];
       const int64_t r = (int64_t)(o >> 10);
@@ -226,8 +230,131 @@ __global__ __launch_bounds__(1024) void k_bk_number(const unsigned long long* __
   if (threadIdx.x == 1023)
   {
     info[2] = code;
-    if (code > BK_TAB_MAX)
+    if (code > BK_CODE_MAX)
       info[1] = 2;
+  }
+}
+
+// form 2 (more distinct blocks than the LDS table holds): the DISTINCT VALUES of the table's rows into a set, numbered in
+// slot order; then every row as nine byte offsets (value code x 8, 16 bits each) into that dictionary, 32 B per row
+__device__ inline unsigned bk_val_hash(unsigned long long b)
+{
+  b ^= b >> 29;
+  b *= 0x9E3779B97F4A7C15ull;
+  return (unsigned)(b >> (64 - BK_VAL_BITS));
+}
+
+__global__ __launch_bounds__(256) void k_bk_val_insert(const unsigned long long* __restrict__ tab, int n9,
+                                                       unsigned long long* __restrict__ vset, int* __restrict__ info)
+{
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n9; k += gridDim.x * blockDim.x)
+  {
+    const unsigned long long b = tab[k];
+    if (b == 0ull)
+      continue; // +0.0 is offset 0 without the set
+    if (b == ~0ull)
+    {
+      info[1] = 5; // (the empty marker: no assembled value has this NaN pattern; met all the same: no dictionary)
+      continue;
+    }
+    unsigned h = bk_val_hash(b);
+    for (int probe = 0; probe < BK_VAL_HASH; ++probe)
+    {
+      unsigned long long cur = __hip_atomic_load(&vset[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == ~0ull)
+      {
+        cur = atomicCAS(&vset[h], ~0ull, b);
+        if (cur == ~0ull)
+        {
+          if (atomicAdd(&info[3], 1) >= BK_VAL_MAX - 2)
+            info[1] = 5;
+          cur = b;
+        }
+      }
+      if (cur == b)
+        break;
+      h = (h + 1) & (BK_VAL_HASH - 1);
+      if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        return;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_bk_val_number(const unsigned long long* __restrict__ vset, int32_t* __restrict__ vcode,
+                                                        unsigned long long* __restrict__ dict, int* __restrict__ info)
+{
+  __shared__ int wsum[16];
+  if (info[1])
+    return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int PER = BK_VAL_HASH / 1024;
+  int mine = 0;
+  for (int k = 0; k < PER; ++k)
+    mine += vset[threadIdx.x * PER + k] != ~0ull ? 1 : 0;
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d)
+      incl += t;
+  }
+  if (lane == 63)
+    wsum[wv] = incl;
+  __syncthreads();
+  int off = 1; // (entry 0 is +0.0)
+  for (int q = 0; q < wv; ++q)
+    off += wsum[q];
+  int code = off + incl - mine;
+  for (int k = 0; k < PER; ++k)
+  {
+    const int h = threadIdx.x * PER + k;
+    const unsigned long long b = vset[h];
+    if (b == ~0ull)
+      continue;
+    vcode[h] = code;
+    if (code < BK_VAL_MAX)
+      dict[code] = b;
+    ++code;
+  }
+  if (threadIdx.x == 0)
+    dict[0] = 0ull;
+  if (threadIdx.x == 1023)
+  {
+    info[3] = code; // entries of the dictionary, +0.0 included
+    if (code > BK_VAL_MAX)
+      info[1] = 5;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bk_rows16(const unsigned long long* __restrict__ tab, int nent,
+                                                   const unsigned long long* __restrict__ vset, const int32_t* __restrict__ vcode,
+                                                   uint16_t* __restrict__ rows16, const int* __restrict__ info)
+{
+  if (info[1])
+    return;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nent; r += gridDim.x * blockDim.x)
+  {
+    unsigned off[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      off[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+    {
+      const unsigned long long b = tab[(int64_t)r * 9 + i];
+      if (b != 0ull)
+      {
+        unsigned h = bk_val_hash(b);
+        while (vset[h] != b)
+          h = (h + 1) & (BK_VAL_HASH - 1);
+        off[i] = (unsigned)vcode[h] * 8u;
+      }
+    }
+    uint4v q0, q1;
+    q0.x = off[0] | (off[1] << 16), q0.y = off[2] | (off[3] << 16), q0.z = off[4] | (off[5] << 16), q0.w = off[6] | (off[7] << 16);
+    q1.x = off[8], q1.y = 0u, q1.z = 0u, q1.w = 0u;
+    reinterpret_cast<uint4v*>(rows16)[2 * (int64_t)r] = q0;
+    reinterpret_cast<uint4v*>(rows16)[2 * (int64_t)r + 1] = q1;
   }
 }
 
@@ -373,11 +500,14 @@ __device__ inline unsigned bk_code16(const uint4v& a, const uint4v& b, int e)
   return (f & 1) ? wd >> 16 : wd & 0xffffu;
 }
 
-template <bool DOT, bool SR, bool NT>
+// FORM 1: the table's rows (nine doubles) in LDS; FORM 2: the rows as nine 16-bit byte offsets in memory (p_rows16, 32 B per
+// row: L2-resident), the values they point at in LDS (p_tab = the dictionary then, a.ntab its entries)
+template <bool DOT, bool SR, bool NT, int FORM>
 __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __restrict__ p_desc, const int32_t* __restrict__ p_meta,
                                                                const int32_t* __restrict__ p_flags,
                                                                const uint16_t* __restrict__ p_bcode,
                                                                const uint16_t* __restrict__ p_ccode, const double* __restrict__ p_tab,
+                                                               const uint16_t* __restrict__ p_rows16,
                                                                const double* __restrict__ p_x, double* __restrict__ p_y,
                                                                const double* __restrict__ p_rvec, const int32_t* __restrict__ p_list,
                                                                BlkArgs a)
@@ -390,7 +520,7 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
     return;
   {
     // the table into LDS: eight entries per thread requested before any is stored
-    const int n9 = a.ntab * 9;
+    const int n9 = FORM == 1 ? a.ntab * 9 : a.ntab;
     for (int k0 = 0; k0 < n9; k0 += BK_THREADS * 8)
     {
       double t[8];
@@ -422,11 +552,37 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
   const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(SR ? p_rvec : p_x), 0, a.nnodes * 24, 0x00020000);
 
   double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
-  for (int64_t it = lo + (int64_t)(blockIdx.x >> 3) * (BK_THREADS / 64) + wv; it < hi; it += stride)
+  // One slice of look-ahead: while a slice is summed, the descriptor, the first chunk's flags and codes of the wavefront's next
+  // slice are in flight (a slice is a chain list -> descriptor -> flags / bases -> codes -> x; without the look-ahead a
+  // wavefront's five slices at C4 are five such chains end to end).  Two named stages, the body exists twice: no register that
+  // a load is still writing is copied.
+  struct Stage
   {
-    const int s = __builtin_amdgcn_readfirstlane(p_list ? p_list[it] : (int)it);
-    const int2 ds = p_desc[s];
-    const int c0 = __builtin_amdgcn_readfirstlane(ds.x), nch = __builtin_amdgcn_readfirstlane(ds.y);
+    int s, c0, nch, fl; // s < 0: no slice
+    uint4v b0, b1; // (the column codes of a chunk that is not affine -- the mesh's rim -- are loaded when it is worked on)
+  };
+  auto fetch = [&](int64_t it, Stage& S) {
+    S.s = -1;
+    S.nch = 0;
+    S.c0 = 0;
+    S.fl = 0;
+    if (it < hi)
+    {
+      S.s = __builtin_amdgcn_readfirstlane(p_list ? p_list[it] : (int)it);
+      const int2 ds = p_desc[S.s];
+      S.c0 = __builtin_amdgcn_readfirstlane(ds.x);
+      S.nch = __builtin_amdgcn_readfirstlane(ds.y);
+      if (S.nch > 0)
+      {
+        S.fl = __builtin_amdgcn_readfirstlane(p_flags[S.c0]);
+        const uint4v* __restrict__ bp = reinterpret_cast<const uint4v*>(p_bcode + (int64_t)S.c0 * 1024) + 2 * lane;
+        S.b0 = bk_ld<NT>(bp);
+        S.b1 = bk_ld<NT>(bp + 1);
+      }
+    }
+  };
+  auto body = [&](Stage& S, int64_t it_next, Stage& N) {
+    const int s = S.s;
     const int node24 = (s * 64 + lane) * 24;
     double xr0 = 0.0, xr1 = 0.0, xr2 = 0.0, rr0 = 0.0, rr1 = 0.0, rr2 = 0.0;
     if (DOT)
@@ -446,10 +602,24 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
       }
     }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int j = 0; j < nch; ++j)
+    for (int j = 0; j < S.nch; ++j)
     {
-      const int c = c0 + j;
-      const int fl = __builtin_amdgcn_readfirstlane(p_flags[c]);
+      const int c = S.c0 + j;
+      int fl = S.fl;
+      uint4v b0 = S.b0, b1 = S.b1, q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
+      if (j > 0) // (a slice of more than 16 blocks per node: P2 / P3, irregular meshes)
+      {
+        fl = __builtin_amdgcn_readfirstlane(p_flags[c]);
+        const uint4v* __restrict__ bp = reinterpret_cast<const uint4v*>(p_bcode + (int64_t)c * 1024) + 2 * lane;
+        b0 = bk_ld<NT>(bp);
+        b1 = bk_ld<NT>(bp + 1);
+      }
+      if (!(fl & 0x100))
+      {
+        const uint4v* __restrict__ cp = reinterpret_cast<const uint4v*>(p_ccode + (int64_t)c * 1024) + 2 * lane;
+        q0 = bk_ld<NT>(cp);
+        q1 = bk_ld<NT>(cp + 1);
+      }
       const int width = fl & 31;
       const bool affine = (fl & 0x100) != 0;
       const int32_t* __restrict__ mb = p_meta + (int64_t)c * BK_META + (affine ? BK_SLOTS : 0);
@@ -457,24 +627,29 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
 #pragma unroll
       for (int e = 0; e < BK_SLOTS; ++e)
         base[e] = mb[e];
-      const uint4v* __restrict__ bp = reinterpret_cast<const uint4v*>(p_bcode + (int64_t)c * 1024) + 2 * lane;
-      const uint4v b0 = bk_ld<NT>(bp), b1 = bk_ld<NT>(bp + 1);
-      uint4v q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
-      if (!affine)
-      {
-        const uint4v* __restrict__ cp = reinterpret_cast<const uint4v*>(p_ccode + (int64_t)c * 1024) + 2 * lane;
-        q0 = bk_ld<NT>(cp);
-        q1 = bk_ld<NT>(cp + 1);
-      }
-      // eight slots at a time: their x values requested, then block by block nine table reads, nine mul + add in column order
-      auto half = [&](auto htag) {
-        constexpr int H = decltype(htag)::value;
-        double x0[8], x1[8], x2[8];
+      // G slots at a time (8; form 2: 4 -- its table rows are in registers too): their x values (and rows) requested, then block
+      // by block the nine values, nine mul + add in column order
+      auto group = [&](auto stag, auto gtag, bool ahead) {
+        constexpr int START = decltype(stag)::value, G = decltype(gtag)::value;
+        double x0[G], x1[G], x2[G];
+        uint4v rw0[FORM == 2 ? G : 1];
+        unsigned rw1[FORM == 2 ? G : 1];
 #pragma unroll
-        for (int f = 0; f < 8; ++f)
+        for (int f = 0; f < G; ++f)
         {
-          const int e = 8 * H + f;
+          const int e = START + f;
           x0[f] = x1[f] = x2[f] = 0.0;
+          if (FORM == 2)
+          {
+            rw0[f] = uint4v{0u, 0u, 0u, 0u};
+            rw1[f] = 0u;
+            if (e < width)
+            {
+              const uint16_t* __restrict__ rp = p_rows16 + (size_t)bk_code16(b0, b1, e) * 16u;
+              rw0[f] = *reinterpret_cast<const uint4v*>(rp);
+              rw1[f] = *reinterpret_cast<const unsigned*>(rp + 8);
+            }
+          }
           if (e < width)
           {
             const int col = base[e] + (affine ? lane : (int)bk_code16(q0, q1, e));
@@ -486,14 +661,32 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
             x2[f] = __hiloint2double((int)u2[1], (int)u2[0]);
           }
         }
-#pragma unroll
-        for (int f = 0; f < 8; ++f)
+        if (ahead) // the next slice's stream goes out behind this slice's last gathers
         {
-          const int e = 8 * H + f;
+          __builtin_amdgcn_sched_barrier(0);
+          fetch(it_next, N);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int f = 0; f < G; ++f)
+        {
+          const int e = START + f;
           if (e < width)
           {
-            const double* __restrict__ t = bk_lds + bk_code16(b0, b1, e) * 9u;
-            const double v0 = t[0], v1 = t[1], v2 = t[2], v3 = t[3], v4 = t[4], v5 = t[5], v6 = t[6], v7 = t[7], v8 = t[8];
+            double v0, v1, v2, v3, v4, v5, v6, v7, v8;
+            if (FORM == 1)
+            {
+              const double* __restrict__ t = bk_lds + bk_code16(b0, b1, e) * 9u;
+              v0 = t[0], v1 = t[1], v2 = t[2], v3 = t[3], v4 = t[4], v5 = t[5], v6 = t[6], v7 = t[7], v8 = t[8];
+            }
+            else
+            {
+              const uint4v r0 = rw0[f];
+              const unsigned r1 = rw1[f];
+              auto at = [&](unsigned off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(bk_lds) + off); };
+              v0 = at(r0.x & 0xffffu), v1 = at(r0.x >> 16), v2 = at(r0.y & 0xffffu), v3 = at(r0.y >> 16), v4 = at(r0.z & 0xffffu);
+              v5 = at(r0.z >> 16), v6 = at(r0.w & 0xffffu), v7 = at(r0.w >> 16), v8 = at(r1 & 0xffffu);
+            }
             a0 += v0 * x0[f];
             a0 += v1 * x1[f];
             a0 += v2 * x2[f];
@@ -506,10 +699,30 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
           }
         }
       };
-      half(std::integral_constant<int, 0>());
-      if (width > 8)
-        half(std::integral_constant<int, 1>());
+      const bool last = j + 1 == S.nch;
+      using I0 = std::integral_constant<int, 0>;
+      using I4 = std::integral_constant<int, 4>;
+      using I8 = std::integral_constant<int, 8>;
+      using I12 = std::integral_constant<int, 12>;
+      if (FORM == 1)
+      {
+        group(I0(), I8(), last && width <= 8);
+        if (width > 8)
+          group(I8(), I8(), last);
+      }
+      else
+      {
+        group(I0(), I4(), last && width <= 4);
+        if (width > 4)
+          group(I4(), I4(), last && width <= 8);
+        if (width > 8)
+          group(I8(), I4(), last && width <= 12);
+        if (width > 12)
+          group(I12(), I4(), last);
+      }
     }
+    if (S.nch == 0)
+      fetch(it_next, N);
     {
       uint4v o;
       o.x = (unsigned)__double2loint(a0), o.y = (unsigned)__double2hiint(a0);
@@ -533,6 +746,23 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
         dot_nn += a.nn_is_rr ? rr1 * rr1 : xr1 * xr1;
         dot_nn += a.nn_is_rr ? rr2 * rr2 : xr2 * xr2;
       }
+    }
+  };
+  {
+    Stage A, B;
+    // consecutive slices of the XCD's eighth go to consecutive WORKGROUPS (= CUs), a wavefront's next slice lies 16 x that
+    // many on: the remainder of slices / wavefronts then spreads over the CUs one by one (with consecutive slices in one
+    // workgroup a few CUs took a whole extra round of sixteen slices: 96 against 81 at C4 -- and the CU's LDS is the bound)
+    int64_t it = lo + (blockIdx.x >> 3) + (int64_t)wgs_in_xcd * wv;
+    fetch(it, A);
+    while (A.s >= 0)
+    {
+      body(A, it + stride, B);
+      it += stride;
+      if (B.s < 0)
+        break;
+      body(B, it + stride, A);
+      it += stride;
     }
   }
   if (DOT)
@@ -567,6 +797,10 @@ int sellp_blk_build(zzz_ctx* ctx)
     return ZZZ_OK;
   if ((double)(ctx->n_owned + ctx->n_ghost) * 24.0 >= 2147483647.0)
     return ZZZ_OK; // (32-bit byte offsets into x)
+  // ZZZ_SELLP_BLK: 0 never, 1 (default) from 100 000 nodes on -- below that the generic product is as fast or faster (a few
+  // slices per wavefront, the table copy per workgroup: 30^3 sub-cubes 13.7 against 8.9 us, 50^3 15.6 against 16.6), 2 always
+  if (ctx->sellp_blk == 1 && ctx->nrows / 3 < 100000)
+    return ZZZ_OK;
   hipStream_t s = ctx->stream;
   const int nnodes = (int)(ctx->nrows / 3);
   const int64_t nsl = ((int64_t)nnodes + 63) / 64;
@@ -578,7 +812,7 @@ int sellp_blk_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bk_hash_tag.alloc((size_t)BK_HASH));
   ZZZ_HIP(ctx, ctx->bk_hash_owner.alloc((size_t)BK_HASH));
   ZZZ_HIP(ctx, ctx->bk_slot_code.alloc((size_t)BK_HASH));
-  ZZZ_HIP(ctx, ctx->bk_tab.alloc((size_t)BK_TAB_MAX * 9));
+  ZZZ_HIP(ctx, ctx->bk_tab.alloc((size_t)BK_CODE_MAX * 9));
   ZZZ_HIP(ctx, ctx->bk_gflag.alloc((size_t)nsl));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_hash_tag.p, 0, sizeof(unsigned long long) * BK_HASH, s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_hash_owner.p, 0xff, sizeof(unsigned long long) * BK_HASH, s));
@@ -587,7 +821,7 @@ int sellp_blk_build(zzz_ctx* ctx)
   const unsigned grid = (unsigned)std::min<int64_t>((nsl + 3) / 4, 256 * 16);
   hipLaunchKernelGGL(k_bk_count, dim3(grid), dim3(256), 0, s, ctx->rowptr.p, vals, nnodes, nsl, ctx->bk_nch.p, info.p);
   hipLaunchKernelGGL(k_bk_insert, dim3(grid), dim3(256), 0, s, ctx->rowptr.p, vals, nnodes, nsl, ctx->bk_hash_tag.p,
-                     ctx->bk_hash_owner.p, info.p, BK_TAB_MAX);
+                     ctx->bk_hash_owner.p, info.p, BK_CODE_MAX);
   hipLaunchKernelGGL(k_bk_number, dim3(1), dim3(1024), 0, s, ctx->bk_hash_tag.p, ctx->bk_hash_owner.p, ctx->rowptr.p, vals,
                      ctx->bk_slot_code.p, reinterpret_cast<unsigned long long*>(ctx->bk_tab.p), info.p);
   {
@@ -602,8 +836,33 @@ int sellp_blk_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipMemcpyAsync(&total, ctx->bk_c0.p + nsl, sizeof(total), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  if (h[1] || h[2] <= 0 || h[2] > BK_TAB_MAX || total <= 0)
+  if (h[1] || h[2] <= 0 || h[2] > BK_CODE_MAX || total <= 0)
     return ZZZ_OK;
+  ctx->bk_form = h[2] <= BK_TAB_MAX ? 1 : 2;
+  ctx->bk_ndict = 0;
+  if (ctx->bk_form == 2)
+  {
+    // more blocks than the LDS table holds: their distinct VALUES into a dictionary for LDS, the rows as offsets into it
+    ZZZ_HIP(ctx, ctx->bk_vset.alloc((size_t)BK_VAL_HASH));
+    ZZZ_HIP(ctx, ctx->bk_vcode.alloc((size_t)BK_VAL_HASH));
+    ZZZ_HIP(ctx, ctx->bk_vdict.alloc((size_t)BK_VAL_MAX));
+    ZZZ_HIP(ctx, ctx->bk_rows16.alloc((size_t)h[2] * 16));
+    ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_vset.p, 0xff, sizeof(unsigned long long) * BK_VAL_HASH, s));
+    const unsigned long long* tabb = reinterpret_cast<const unsigned long long*>(ctx->bk_tab.p);
+    hipLaunchKernelGGL(k_bk_val_insert, dim3((unsigned)std::min<int64_t>(((int64_t)h[2] * 9 + 255) / 256, 2048)), dim3(256), 0, s, tabb,
+                       h[2] * 9, ctx->bk_vset.p, info.p);
+    hipLaunchKernelGGL(k_bk_val_number, dim3(1), dim3(1024), 0, s, ctx->bk_vset.p, ctx->bk_vcode.p,
+                       reinterpret_cast<unsigned long long*>(ctx->bk_vdict.p), info.p);
+    hipLaunchKernelGGL(k_bk_rows16, dim3((unsigned)std::min<int64_t>((h[2] + 255) / 256, 2048)), dim3(256), 0, s, tabb, h[2],
+                       ctx->bk_vset.p, ctx->bk_vcode.p, ctx->bk_rows16.p, info.p);
+    ZZZ_HIP(ctx, hipGetLastError());
+    int32_t h2[8];
+    ZZZ_HIP(ctx, hipMemcpyAsync(h2, info.p, sizeof(h2), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    if (h2[1] || h2[3] <= 0 || h2[3] > BK_VAL_MAX)
+      return ZZZ_OK;
+    ctx->bk_ndict = h2[3];
+  }
   // (the chunk index times 1024 codes stays below 2^31 elements only as int64: the kernels index with 64 bits)
   ZZZ_HIP(ctx, ctx->bk_desc.alloc(2 * (size_t)nsl + 2));
   ZZZ_HIP(ctx, ctx->bk_meta.alloc((size_t)total * BK_META));
@@ -646,11 +905,11 @@ int sellp_blk_build(zzz_ctx* ctx)
   ctx->bk_entries = h[2];
   ctx->bk_chunks = total;
   ctx->bk_slices = nsl;
-  ctx->bk_bytes = (int64_t)bytes + (int64_t)h[2] * 72;
+  ctx->bk_bytes = (int64_t)bytes + (ctx->bk_form == 1 ? (int64_t)h[2] * 72 : (int64_t)h[2] * 32 + (int64_t)ctx->bk_ndict * 8);
   if (!ctx->bk_lds_attr)
   {
 #define ZZZ_BK_ATTR(DOT, SR, NT)                                                                                                   \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_blk3_kernel<DOT, SR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_blk3_kernel<DOT, SR, NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             BK_TAB_MAX * 72)
     ZZZ_BK_ATTR(true, true, true);
     ZZZ_BK_ATTR(true, true, false);
@@ -684,7 +943,8 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
   if (!sellp_blk_serves(ctx))
     return false;
   BlkArgs a;
-  a.ntab = ctx->bk_entries;
+  const bool f1 = ctx->bk_form == 1;
+  a.ntab = f1 ? ctx->bk_entries : ctx->bk_ndict;
   a.nnodes = (int)(ctx->nrows / 3);
   a.nslices = (int)ctx->bk_slices;
   a.nx8 = (int)((ctx->n_owned + ctx->n_ghost) * 24);
@@ -693,11 +953,20 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
   a.nlist = nlist;
   a.pstride = SPMV_PSTRIDE;
   a.nn_is_rr = nn_is_rr;
-  const size_t lds = (size_t)ctx->bk_entries * 72;
-#define ZZZ_BK_GO(DOT, SR, NT)                                                                                                     \
-  hipLaunchKernelGGL((spmv_blk3_kernel<DOT, SR, NT>), dim3(grid), dim3(BK_THREADS), lds, ctx->stream,                              \
+  const size_t lds = f1 ? (size_t)ctx->bk_entries * 72 : (size_t)ctx->bk_ndict * 8;
+  const double* tabp = f1 ? ctx->bk_tab.p : ctx->bk_vdict.p;
+#define ZZZ_BK_GO2(DOT, SR, NT, FORM)                                                                                              \
+  hipLaunchKernelGGL((spmv_blk3_kernel<DOT, SR, NT, FORM>), dim3(grid), dim3(BK_THREADS), lds, ctx->stream,                        \
                      reinterpret_cast<const int2*>(ctx->bk_desc.p), ctx->bk_meta.p, ctx->bk_flags.p, ctx->bk_code.p, ctx->bk_ccode.p,  \
-                     ctx->bk_tab.p, x, y, rvec, list, a)
+                     tabp, ctx->bk_rows16.p, x, y, rvec, list, a)
+#define ZZZ_BK_GO(DOT, SR, NT)                                                                                                     \
+  do                                                                                                                               \
+  {                                                                                                                                \
+    if (f1)                                                                                                                        \
+      ZZZ_BK_GO2(DOT, SR, NT, 1);                                                                                                  \
+    else                                                                                                                           \
+      ZZZ_BK_GO2(DOT, SR, NT, 2);                                                                                                  \
+  } while (0)
   if (dot && rvec)
   {
     if (nt)
@@ -719,6 +988,7 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
     else
       ZZZ_BK_GO(false, false, false);
   }
+#undef ZZZ_BK_GO2
 #undef ZZZ_BK_GO
   return true;
 }

@@ -16,7 +16,7 @@ def run(n, order=1, check=True):
     dims = n if isinstance(n, tuple) else (n, n, n)
     P = zzz.Part("elasticity", order, *dims)
     out = {}
-    for blk in ("1", "0"):
+    for blk in ("2", "0"):
         os.environ["ZZZ_SELLP_BLK"] = blk
         with zzz.Context(0) as ctx:
             ctx.upload_part(P)
@@ -36,14 +36,14 @@ def run(n, order=1, check=True):
             it2, _, _ = ctx.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=True)
             u = ctx.vec_download(zzz.VEC_U)
             out[blk] = (y, vi, t, it, ts, pm, it2, u)
-            if blk == "1" and check:
+            if blk == "2" and check:
                 rp, cl, v = ctx.csr_download()
                 zo.set_num_threads(8)
                 oy = zo.spmv(rp.astype(np.int64), cl, v, x)
                 print(f"  n={dims} order={order}: product == serial CSR loop: {np.array_equal(oy, y)}  max|diff|={np.abs(oy - y).max():.3e}")
-    y1, vi1, t1, it1, ts1, pm1, sr1, u1 = out["1"]
+    y1, vi1, t1, it1, ts1, pm1, sr1, u1 = out["2"]
     y0, vi0, t0_, it0, ts0, pm0, sr0, u0 = out["0"]
-    print(f"n={dims} order={order} rows={P.n_owned * 3}: block rows {vi1['block_rows']} table {vi1['block_table_entries']} chunks {vi1['block_chunks']} "
+    print(f"n={dims} order={order} rows={P.n_owned * 3}: block rows {vi1['block_rows']} form {vi1['block_form']} table {vi1['block_table_entries']} chunks {vi1['block_chunks']} "
           f"bytes {vi1['bytes_per_product']} (generic {vi0['bytes_per_product']});  same bits as generic: {np.array_equal(y0, y1)}")
     print(f"   product ms: block {t1:.4f}  generic {t0_:.4f};  in-solve {pm1[0]:.4f} / {pm0[0]:.4f};  solve {ts1 * 1e3:.1f} ms ({it1} its, sr {sr1}) / "
           f"{ts0 * 1e3:.1f} ms ({it0} its, sr {sr0});  |u1-u0|/|u0| = {np.linalg.norm(u1 - u0) / np.linalg.norm(u0):.2e}")
