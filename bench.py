@@ -84,7 +84,7 @@ def pmc_traffic(nrows, nnz, streamed=None):
     round wins."""
     import glob
 
-    best = (None, None)
+    best = (None, None, {})
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
         try:
             d = json.load(open(path))
@@ -96,7 +96,11 @@ def pmc_traffic(nrows, nnz, streamed=None):
                 continue
             # (traffic_bytes: the calibrated count of tools/profile_summarise.py -- the x2 of FETCH_SIZE does not hold for
             # every access pattern; older profiles carry the two counters only)
-            best = (k.get("traffic_bytes", 2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024), os.path.relpath(path, ROOT))
+            best = (k.get("traffic_bytes", 2 * k["FETCH_SIZE_KiB"] * 1024 + k["WRITE_SIZE_KiB"] * 1024), os.path.relpath(path, ROOT),
+                    {"traffic_low": k.get("traffic_low", (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024),
+                     "traffic_high": k.get("traffic_high", (2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024),
+                     "traffic_kernel": k.get("kernel"), "kernel_rocprof_us": k.get("kernel_rocprof_us"),
+                     "traffic_dispatches": k.get("dispatches")})
         except Exception:
             continue
     return best
@@ -286,7 +290,15 @@ def run_other_config(name, steps=3, unstructured=None):
             "krylov_iterations": it, "relative_residual": rn / r0 if r0 else 0.0, "solution_norm": unorm,
             "product_ms": spmv_ms, "product_launches_timed": spmv_n, "product_bytes_per_launch": bytes_pl,
             "product_GBs": phys, "roofline_frac": phys / HBM_PEAK_GBS,
-            "operator": ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")
+            # the same launch time against SURVEY 8(d)'s reference-format byte count (12 B per pattern entry + 4 (n + 1) + 16 n: what
+            # a plain CSR product would have to move): above 1 means the form in use moves fewer bytes than CSR could at the peak
+            "reference_format_bytes": spmv_algorithmic_bytes(nrows, nnz),
+            "reference_format_over_peak": (spmv_algorithmic_bytes(nrows, nnz) / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if spmv_ms > 0 else 0.0,
+            "operator": (f"block rows (block size 3: one lane per node, 16-bit codes into a table of {values['block_table_entries']} distinct "
+                         f"3 x 3 blocks, " + ("the table's rows in LDS" if values["block_form"] == 1 else
+                                               "rows of value offsets in memory and the values in LDS")
+                         + f"; {values['block_chunks']} chunks of 16 block slots per node; csrc/zzz_sellp_blk.hip)") if values.get("block_rows") else
+                        ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")
                          + (", values as 16-bit codes into per-slice dictionaries" if values["form"] == "slice dictionaries" else
                             f", values as codes into a {values['form']} of {values['distinct_values']} distinct values"
                             if values["form"] != "doubles" else "")) if sinfo[5] else "CSR tile kernel",
@@ -825,10 +837,12 @@ def main():
         achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         streamed, sinfo = physical_bytes_per_product(ctx, nrows, nnz, single_reduction)
         kernel_name = ("spmv_tile_kernel (CG SpMV + <p,Ap> partials)" if not sinfo[5] else
+                       "spmv_blk3_kernel (CG SpMV of a block-size-3 matrix in block-row form, one lane per node, + <p,Ap> partials)"
+                       if ctx.spmv_values_info().get("block_rows") else
                        "spmv_one_kernel (CG SpMV on the operator stream's one-chunk slices, two rows per lane, + <p,Ap> partials)"
                        if ctx.spmv_values_info()["one_chunk_kernel"] else
                        "spmv_sellp_kernel (CG SpMV on the sliced-ELL operator stream + <p,Ap> partials)")
-        traffic, traffic_src = pmc_traffic(nrows, nnz, streamed)
+        traffic, traffic_src, traffic_more = pmc_traffic(nrows, nnz, streamed)
         phys = streamed / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         avg = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
         out = {
@@ -869,6 +883,10 @@ def main():
                          "frac": phys / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": streamed, "avg_launch_ms": spmv_ms, "launches_timed": spmv_n,
                          "traffic_over_bytes": (traffic / streamed) if traffic else None,
+                         # the same PMC passes read both ways, per launch of THIS kernel name (tools/profile_summarise.py):
+                         # low = FETCH_SIZE + WRITE_SIZE as counted, high = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950
+                         # correction; `traffic` is this one); kernel_rocprof_us = its average duration in the kernel-trace pass
+                         **traffic_more,
                          "algorithmic_equivalent_bytes_per_launch": alg_bytes,
                          "algorithmic_equivalent_GBs": achieved,
                          "algorithmic_equivalent_over_peak": achieved / HBM_PEAK_GBS},

@@ -1504,19 +1504,23 @@ int launch_assemble_vector(zzz_ctx* ctx, int form)
     // the cells' records first (|det J| and the coefficient's vertex sum: k_cell_load_p1), then the row walk
     ZZZ_HIP(ctx, ctx->cell_geom.alloc((size_t)(ctx->ncells * (bs == 1 ? 2 : 4))));
     const int cper = bs == 1 ? 1024 : 256; // cells per workgroup and round (k_cell_load_p1: U)
-    const dim3 cgrid((unsigned)std::min<int64_t>((ctx->ncells + cper - 1) / cper, 16384));
+    // (a partition without cells: no cell pass -- a grid of 0 workgroups is an invalid configuration and the kernel clamps
+    // cell numbers to ncells - 1; the row walk below then meets empty adjacency lists only)
+    const dim3 cgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((ctx->ncells + cper - 1) / cper, 16384)));
     if (bs == 1)
     {
-      hipLaunchKernelGGL(k_cell_load_p1<1>, cgrid, dim3(256), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->coeff[0].p,
-                         ctx->facet_mask.p, ctx->ncells, ctx->cell_geom.p);
+      if (ctx->ncells > 0)
+        hipLaunchKernelGGL(k_cell_load_p1<1>, cgrid, dim3(256), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->coeff[0].p,
+                           ctx->facet_mask.p, ctx->ncells, ctx->cell_geom.p);
       hipLaunchKernelGGL(asm_vector_p1<1>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p,
                          ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p, ctx->coeff[1].p, ctx->cell_geom.p, ctx->b.p,
                          nrows);
     }
     else
     {
-      hipLaunchKernelGGL(k_cell_load_p1<3>, cgrid, dim3(256), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->coeff[0].p,
-                         (const uint8_t*)nullptr, ctx->ncells, ctx->cell_geom.p);
+      if (ctx->ncells > 0)
+        hipLaunchKernelGGL(k_cell_load_p1<3>, cgrid, dim3(256), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->coeff[0].p,
+                           (const uint8_t*)nullptr, ctx->ncells, ctx->cell_geom.p);
       hipLaunchKernelGGL(asm_vector_p1<3>, grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p, ctx->adjT_off.p, ctx->adjT_cells.p,
                          ctx->adj_li.p, ctx->bc.p, ctx->facet_mask.p, ctx->coeff[0].p, (const double*)nullptr, ctx->cell_geom.p,
                          ctx->b.p, nrows);

@@ -1,0 +1,602 @@
+"""GPU parity tests, part 2: the FORMS of the CG product (operator stream, dictionaries, x windows, one-chunk kernel, CSR tile
+kernel) pinned to the serial CSR loop and to each other."""
+from _gpu_helpers import *  # noqa: F401,F403 -- helpers, fixtures (ctx), np / os / zzz / zo
+
+pytestmark = pytest.mark.gpu  # noqa: F405
+
+
+@pytest.mark.parametrize("problem,order,dims,form", [("poisson", 1, (24, 22, 23), "dictionary in LDS"),
+                                                     ("elasticity", 1, (10, 9, 11), "dictionary in LDS"),
+                                                     ("poisson", 2, (9, 8, 7), "dictionary in LDS"),
+                                                     ("poisson", 3, (15, 14, 13), "dictionary in memory"),
+                                                     ("poisson", 3, (15, 14, 13), "slice dictionaries"),
+                                                     ("elasticity", 3, (5, 4, 5), "slice dictionaries"),
+                                                     ("spoke", 1, 6, "doubles")])
+def test_value_dictionary_of_the_operator_stream(problem, order, dims, form):
+    """The operator stream with its values as 16-bit codes into a dictionary of the matrix's distinct values (LDS copy per
+    workgroup for small dictionaries, memory for larger ones, plain doubles when a matrix has more than 65 535 distinct values:
+    the unstructured mesh) or into per-slice dictionaries (long rows whose matrix-wide dictionary does not fit LDS): the same
+    doubles in the same order -- the product is the serial CSR loop's bit for bit, the solve is the undictionaried stream's
+    iteration for iteration and bit for bit."""
+    P = zzz.Part.spoke("poisson", order, dims) if problem == "spoke" else zzz.Part(problem, order, *dims)
+    x = np.random.default_rng(4).standard_normal(P.n_owned * P.bs)
+    res = {}
+    old = os.environ.get("ZZZ_SELLP_DICT")
+    try:
+        forced = "3" if form == "slice dictionaries" else "2"
+        for knob in ("0", forced):
+            os.environ["ZZZ_SELLP_DICT"] = knob
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                y = c.spmv(x)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                res[knob] = (y, it, c.vec_download(zzz.VEC_U), c.spmv_values_info(), c.csr_download(), c.spmv_info_raw()[5])
+                # new values on the same pattern (MatSetValues + assembly again): the dictionary follows them
+                c.csr_upload_values(2.0 * res[knob][4][2])
+                np.testing.assert_array_equal(c.spmv(x), 2.0 * y)
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_SELLP_DICT", None)
+        else:
+            os.environ["ZZZ_SELLP_DICT"] = old
+    assert res["0"][5] and res[forced][5], "the product must run on the operator stream in this test"
+    rp, cl, v = res[forced][4]
+    np.testing.assert_array_equal(res[forced][0], zo.spmv(rp.astype(np.int64), cl, v, x))
+    np.testing.assert_array_equal(res[forced][0], res["0"][0])
+    assert res[forced][1] == res["0"][1]
+    vi = res[forced][3]
+    if vi["one_chunk_kernel"]:
+        # a stream of one-chunk slices on coded values runs on its own kernel (zzz_sellp_pipe.hip: two rows per lane) with
+        # another persistent grid: the products keep their bits (above), the workgroups' partial sums of <p, A p> are added
+        # in another order -- as MPI_Allreduce's order is the run's (src/cg.h:65); the solve agrees to rounding
+        assert vi["workgroups_per_cu"] < 8
+        np.testing.assert_allclose(res[forced][2], res["0"][2], rtol=0, atol=1e-12 * np.abs(res["0"][2]).max())
+    else:
+        np.testing.assert_array_equal(res[forced][2], res["0"][2])
+    assert res["0"][3]["form"] == "doubles" and vi["form"] == form, vi
+    if form == "slice dictionaries":
+        assert vi["bytes_per_product"] < vi["bytes_per_product_as_doubles"]  # (slices of more than 1 023 values stay doubles)
+    elif form != "doubles":
+        nd_ = np.unique(v[v != 0.0]).size + 1
+        assert vi["distinct_values"] <= nd_ and vi["distinct_values"] >= 2  # (dropped zeros and padding share code 0)
+        assert vi["bytes_per_product"] < 0.5 * vi["bytes_per_product_as_doubles"]
+        assert (vi["distinct_values"] <= 2048) == (form == "dictionary in LDS")
+
+
+def test_non_finite_vector_through_the_product():
+    """Inf/NaN in x (include/zzz_abi.h, zzz_spmv): the operator stream drops exact zeros and pads aligned slices, so
+    NaN propagates through NONZERO couplings always, through exact-zero couplings only with ZZZ_SELLP_DROP=0 and
+    without the aligned placement (ZZZ_SELLP_FORMS=5) -- and then exactly as in the serial CSR loop."""
+    zo.set_num_threads(1)
+    P = zzz.Part("poisson", 1, 150, 4, 3)
+    rng = np.random.default_rng(21)
+    xv = rng.standard_normal(P.n_owned)
+    bad = rng.choice(P.n_owned, size=25, replace=False)
+    xv[bad[:15]] = np.nan
+    xv[bad[15:]] = np.inf
+    saved = {k: os.environ.get(k) for k in ("ZZZ_SELLP_DROP", "ZZZ_SELLP_FORMS")}
+    try:
+        for exact in (False, True):
+            for k in saved:
+                if exact:
+                    os.environ[k] = "0" if k == "ZZZ_SELLP_DROP" else "5"  # (forms: affine and periodic, not aligned)
+                else:
+                    os.environ.pop(k, None)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                rp, cl, v = c.csr_download()
+                y = c.spmv(xv)
+                yo = zo.spmv(rp.astype(np.int64), cl, v, xv)
+                # rows that meet a non-finite x through a nonzero value
+                nz = v != 0.0
+                hit = np.zeros(P.n_owned, bool)
+                rows = np.repeat(np.arange(P.n_owned), np.diff(rp))
+                hit[rows[nz & ~np.isfinite(xv[cl])]] = True
+                assert np.all(~np.isfinite(y[hit]))
+                fin = np.isfinite(yo)
+                assert np.array_equal(y[fin & np.isfinite(y)], yo[fin & np.isfinite(y)])
+                if exact:
+                    np.testing.assert_array_equal(np.isnan(y), np.isnan(yo))
+                    np.testing.assert_array_equal(y[fin], yo[fin])
+                else:
+                    assert np.count_nonzero(~np.isfinite(y)) >= np.count_nonzero(hit)
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ZZZ_TEST_SEEDS", "24"))))
+def test_knob_combinations_keep_results(seed):
+    """The environment knobs select among code paths that are each tested alone; here RANDOM
+    COMBINATIONS of them run four small problems end to end: CSR indices and values identical to the default build's
+    (bit for bit: no knob may change what is assembled), the product within round-off of it (knobs that regroup row sums
+    are in the draw), Jacobi and Chebyshev-Jacobi solves with the default's iteration count +-2 and solution to 1e-7.
+    ZZZ_TEST_SEEDS=<n> draws more combinations (a soak run of 400 passes)."""
+    rng = np.random.default_rng(1000 + seed)
+    # (the knobs of the PRODUCT library; the tools build's extra ones -- ZZZ_CG_FUSED, ZZZ_SPMV_TILE, pipelined tiles,
+    # ZZZ_ASM_LPR, ZZZ_VGRID_PER, ZZZ_TAIL -- have tests of their own that load that build)
+    # (ZZZ_SELLP_FORMS: a mask of the code-free chunk forms, 1 affine, 2 aligned, 4 periodic; ZZZ_SELLP=4: the long-row packer)
+    knobs = {"ZZZ_SPMV_VARIANT": ["1", "8", "9", "16", "17"], "ZZZ_SELLP": ["0", "2", "3", "4"], "ZZZ_SELLP_DROP": ["0"],
+             "ZZZ_SELLP_FORMS": ["0", "1", "3", "4", "5", "6"], "ZZZ_SELLP_PIPE": ["0"],
+             "ZZZ_SPMV_LPR": ["1", "2", "4"], "ZZZ_COLS16": ["0", "11", "13"],
+             "ZZZ_PATTERN": ["host"], "ZZZ_RENUMBER": ["0", "2"], "ZZZ_CHEB_FUSED": ["0"],
+             "ZZZ_ASM_SEARCH": ["1"],
+             "ZZZ_SELLP_WIN": ["0", "1024", "8064"], "ZZZ_MF_NC": ["256", "512"], "ZZZ_MF_T": ["128", "256"],
+             "ZZZ_SELLP_DICT": ["0", "2", "3"], "ZZZ_CG_DINV_CODES": ["0", "2", "2"]}
+    names = sorted(knobs)
+    chosen = {k: str(rng.choice(knobs[k])) for k in names if rng.random() < 0.3}
+    problems = [("poisson", 1, (9, 8, 10)), ("poisson", 3, (3, 4, 3)), ("elasticity", 2, (3, 3, 4)),
+                ("elasticity", 1, (6, 5, 7))]  # (the last one: the one-pass packer with x windows when the knob asks)
+
+    def run_all():
+        out = []
+        for problem, order, dims in problems:
+            G = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(G)
+                c.pattern_build()
+                c.assemble_matrix(G.form)
+                c.assemble_vector(G.form)
+                rp, cl, v = c.csr_download()
+                x = np.cos(0.61 * np.arange(G.n_owned * G.bs))
+                y = c.spmv(x)
+                itj, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                uj = c.vec_download(zzz.VEC_U)
+                itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9)
+                uc = c.vec_download(zzz.VEC_U)
+                out.append((rp, cl, v, c.vec_download(zzz.VEC_B), y, itj, uj, itc, uc))
+        return out
+
+    saved = {k: os.environ.get(k) for k in names}
+    try:
+        for k in names:
+            os.environ.pop(k, None)
+        ref = run_all()
+        os.environ.update(chosen)
+        got = run_all()
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    for (rp0, cl0, v0, b0, y0, itj0, uj0, itc0, uc0), (rp, cl, v, b, y, itj, uj, itc, uc) in zip(ref, got):
+        assert np.array_equal(rp, rp0) and np.array_equal(cl, cl0), chosen
+        assert np.array_equal(v, v0) and np.array_equal(b, b0), chosen
+        assert np.abs(y - y0).max() <= 1e-13 * np.abs(y0).max(), chosen
+        assert abs(itj - itj0) <= 2 and abs(itc - itc0) <= 2, (chosen, itj, itj0, itc, itc0)
+        assert np.linalg.norm(uj - uj0) <= 1e-7 * np.linalg.norm(uj0), chosen
+        assert np.linalg.norm(uc - uc0) <= 1e-7 * np.linalg.norm(uc0), chosen
+
+
+@pytest.mark.parametrize("order,dims", [(1, (12, 11, 13)), (2, (5, 4, 5))])
+def test_x_windows_of_the_operator_stream_keep_every_bit(order, dims):
+    """Block size 3: the columns a group of 256 rows reaches are loaded into LDS once per group and the stream's codes
+    are window indices (k_sp_windows, spmv_sellp_kernel<..., WIN>).  Same entries, same ascending-column order: the
+    product, the CG history and the Chebyshev-Jacobi solve must be BIT-identical with and without windows, for a
+    single rank and partitioned (ghost columns sit in segments of their own)."""
+    G = zzz.Part("elasticity", order, *dims)
+    x = np.cos(0.37 * np.arange(G.n_owned * G.bs))
+    res = {}
+    for win in ("0", "2048", "8192"):
+        os.environ["ZZZ_SELLP_WIN"] = win
+        try:
+            with zzz.Context(0) as c:
+                c.upload_part(G)
+                c.pattern_build()
+                c.assemble_matrix(G.form)
+                c.assemble_vector(G.form)
+                y = c.spmv(x)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                u = c.vec_download(zzz.VEC_U)
+                hist = c.cg_history(it + 1)
+                its, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9, single_reduction=True)
+                us = c.vec_download(zzz.VEC_U)
+                itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9)
+                uc = c.vec_download(zzz.VEC_U)
+                res[win] = (y, it, hist, u, its, us, itc, uc, c.spmv_x_windows(), c.spmv_operator_form())
+        finally:
+            del os.environ["ZZZ_SELLP_WIN"]
+    assert res["0"][8] == (0, 0) and res["0"][9] == 1
+    if order == 1:  # (P2 rows are too long for the one-pass packer: its stream is built without windows)
+        assert any(res[w][8][0] > 0 and res[w][8][1] > 0 for w in ("2048", "8192")), [res[w][8] for w in res]
+    for w in ("2048", "8192"):
+        for a, b in zip(res["0"][:8], res[w][:8]):
+            assert np.array_equal(a, b), w
+    rp, cl, v = None, None, None
+    with zzz.Context(0) as c:
+        c.upload_part(G)
+        c.pattern_build()
+        c.assemble_matrix(G.form)
+        rp, cl, v = c.csr_download()
+    assert np.array_equal(res["2048"][0], zo.spmv(rp.astype(np.int64), cl, v, x))  # and the serial CSR loop's bits
+
+
+@pytest.mark.parametrize("variant", [0, 1, 8, 9, 16, 17])
+def test_spmv_kernel_variants_are_bit_exact(variant):
+    """Every SpMV kernel variant of the product library (plain / non-temporal loads, the operator stream, int32 instead
+    of packed 16-bit columns) adds a row's products in the same column order: bit-identical y, identical solve."""
+    _spmv_variant_case(variant, 2048)
+
+
+@in_tools_build
+def test_spmv_kernel_variants_of_the_tools_build_are_bit_exact():
+    """... and the ones the tools build keeps for re-measurement (pipelined tile loop, 4096-nonzero tiles)."""
+    for variant, tile in ((2, 2048), (3, 2048), (19, 2048), (0, 4096), (1, 4096), (3, 4096), (17, 4096)):
+        _spmv_variant_case(variant, tile)
+
+
+@pytest.mark.parametrize("cols16", ["0", "10", "11", "12", "13", "auto"])
+def test_packed_column_stream(cols16):
+    """The SpMV's 16-bit band-coded column stream is lossless: for every code width, with and without
+    tiles that fall back to int32 columns, y = A x is bit-identical to the oracle's CSR loop.
+    Cases: the structured feed (a few narrow bands per tile: everything packs), high-order and
+    vector-valued rows, a partition-style far band, and a RANDOM dof numbering (columns of a tile
+    scattered over > 65536 dofs: tiles must fall back, not mis-decode)."""
+    old = os.environ.get("ZZZ_COLS16")
+    if cols16 == "auto":
+        os.environ.pop("ZZZ_COLS16", None)
+    else:
+        os.environ["ZZZ_COLS16"] = cols16
+    # the packed columns belong to the CSR tile kernel: keep the product off the operator stream, or nothing here would
+    # run through them (and zzz_spmv_info would, rightly, not even encode them)
+    os.environ["ZZZ_SELLP"] = "0"
+    try:
+        zo.set_num_threads(4)
+        rng = np.random.default_rng(3)
+        with zzz.Context(0) as c:
+            for problem, order, dims in (("poisson", 1, (30, 28, 26)), ("poisson", 3, (7, 6, 8)),
+                                         ("elasticity", 2, (5, 6, 5))):
+                P = zzz.Part(problem, order, *dims)
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                packed, offb, nfb, ntiles = c.spmv_info()
+                assert packed == (cols16 != "0") and 0 <= nfb <= ntiles
+                if cols16 == "auto":
+                    assert nfb == 0, "structured feed: every tile must pack"
+                elif cols16 != "0":
+                    assert offb == int(cols16)
+                rp, cl, v = c.csr_download()
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+            # random global numbering of a 97 k-dof P1 problem, KEPT by the library (ZZZ_RENUMBER=0: without it the dofs
+            # would be put back into lattice order behind the ABI and no tile would need int32 columns)
+            os.environ["ZZZ_RENUMBER"] = "0"
+            O = zo.Problem("poisson", 1, 45, 45, 45)
+            perm = rng.permutation(O.n).astype(np.int32)
+            cell_dofs = np.ascontiguousarray(perm[O.cell_dofs])
+            bc = np.zeros_like(O.bc)
+            bc[perm] = O.bc
+            f, g = np.zeros_like(O.f), np.zeros_like(O.g)
+            f[perm], g[perm] = O.f, O.g
+            c.upload_mesh(O.x, O.cells)
+            c.upload_dofmap(1, 1, cell_dofs, O.nblock, 0)
+            c.upload_bc(np.nonzero(bc)[0].astype(np.int32))
+            c.upload_facets(O.facets)
+            c.upload_coeff(zzz.COEFF_F, f)
+            c.upload_coeff(zzz.COEFF_G, g)
+            c.pattern_build()
+            c.assemble_matrix(zzz.FORM_POISSON)
+            c.assemble_vector(zzz.FORM_POISSON)
+            packed, offb, nfb, ntiles = c.spmv_info()
+            if cols16 != "0":
+                assert packed and nfb > ntiles // 2, (nfb, ntiles)
+            rp, cl, v = c.csr_download()
+            orp, ocl = zo.pattern(O.nblock, cell_dofs, 1)
+            np.testing.assert_array_equal(rp, orp)
+            np.testing.assert_array_equal(cl, ocl)
+            xv = rng.standard_normal(O.n)
+            np.testing.assert_array_equal(c.spmv(xv), zo.spmv(orp, ocl, v, xv))
+            it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+            u = c.vec_download(zzz.VEC_U)
+            # same problem in the natural numbering: same solution, permuted
+            O.assemble()
+            oit, ou, _, _ = zo.pcg(O.rowptr, O.cols, O.vals, O.b, rtol=1e-8)
+            assert abs(it - oit) <= 2
+            assert np.linalg.norm(u[perm] - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
+        os.environ.pop("ZZZ_SELLP", None)
+        if old is None:
+            os.environ.pop("ZZZ_COLS16", None)
+        else:
+            os.environ["ZZZ_COLS16"] = old
+
+
+@pytest.mark.parametrize("lpr", ["auto", "2", "4", "8", "16"])
+def test_spmv_lanes_per_row(lpr):
+    """Row sums with several lanes per row (chosen automatically for rows of >= 128 nonzeros on average,
+    forced here through ZZZ_SPMV_LPR): bit-identical to the oracle's restatement of that summation order
+    (zo_spmv_chunked), round-off close to the serial order, and the solve is unaffected."""
+    old = os.environ.get("ZZZ_SPMV_LPR")
+    if lpr == "auto":
+        os.environ.pop("ZZZ_SPMV_LPR", None)
+    else:
+        os.environ["ZZZ_SPMV_LPR"] = lpr
+    try:
+        zo.set_num_threads(4)
+        rng = np.random.default_rng(int(lpr) if lpr != "auto" else 1)
+        with zzz.Context(0) as c:
+            for problem, order, dims in (("elasticity", 3, (5, 5, 6)), ("poisson", 3, (5, 4, 5)), ("poisson", 1, (9, 8, 7))):
+                P = zzz.Part(problem, order, *dims)
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                lanes = c.spmv_lanes_per_row()
+                rp, cl, v = c.csr_download()
+                rp = rp.astype(np.int64)
+                if lpr != "auto":
+                    assert lanes == int(lpr)
+                elif c.spmv_operator_form():
+                    assert lanes == 1  # the operator stream sums a row serially
+                else:
+                    assert lanes == (8 if cl.shape[0] / (rp.shape[0] - 1) >= 128 else 1)
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                y = c.spmv(xv)
+                np.testing.assert_array_equal(y, zo.spmv_chunked(rp, cl, v, xv, lanes))
+                ys = zo.spmv(rp, cl, v, xv)
+                assert np.abs(y - ys).max() <= 4e-15 * np.abs(ys).max()
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                oit, ou, _, _ = zo.pcg(rp, cl, v, c.vec_download(zzz.VEC_B), rtol=1e-8)
+                assert abs(it - oit) <= 2
+                assert np.linalg.norm(c.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+    finally:
+        if old is None:
+            os.environ.pop("ZZZ_SPMV_LPR", None)
+        else:
+            os.environ["ZZZ_SPMV_LPR"] = old
+
+
+def test_spmv_kernel_selection(ctx):
+    """Matrices whose rows have similar lengths run on the sliced-ELL operator stream (exact zeros dropped, natural
+    row order), very long rows of mixed lengths on its length-sorted form, the rest on the CSR tile kernel -- and
+    all of them give the oracle's bits (the stream sums a row serially in column order: zo.spmv)."""
+    rng = np.random.default_rng(8)
+    for problem, order, dims, form in (("poisson", 1, (30, 31, 29), 1), ("elasticity", 1, (12, 13, 11), 1),
+                                       ("poisson", 3, (8, 7, 8), None), ("poisson", 2, (9, 8, 10), None)):
+        P = zzz.Part(problem, order, *dims)
+        ctx.upload_part(P)
+        ctx.pattern_build()
+        assert ctx.spmv_operator_form() == 0  # the stream is packed from the assembled values
+        ctx.assemble_matrix(P.form)
+        if form is not None:  # small high-order boxes are mostly boundary: whichever form the cost rule picks
+            assert ctx.spmv_operator_form() == form, (problem, order)
+        rp, cl, v = ctx.csr_download()
+        xv = rng.standard_normal(P.n_owned * P.bs)
+        np.testing.assert_array_equal(ctx.spmv(xv), zo.spmv_chunked(rp.astype(np.int64), cl, v, xv, ctx.spmv_lanes_per_row()))
+
+
+@pytest.mark.parametrize("mode,drop", [(2, 1), (3, 1), (2, 0), (3, 0)])
+def test_operator_stream_forms_are_bit_exact(mode, drop):
+    """The operator stream in natural and in length-sorted row order, with and without the exact zeros of the
+    pattern, gives the bits of the serial CSR loop for every element family -- also where a chunk's columns do
+    not fit 16 bits (random renumbering: int32 chunks) and for rows that are entirely zero."""
+    old = {k: os.environ.get(k) for k in ("ZZZ_SELLP", "ZZZ_SELLP_DROP")}
+    os.environ["ZZZ_SELLP"], os.environ["ZZZ_SELLP_DROP"] = str(mode), str(drop)
+    try:
+        zo.set_num_threads(1)
+        rng = np.random.default_rng(100 * mode + drop)
+        for problem, order, dims in (("poisson", 1, (13, 9, 11)), ("elasticity", 1, (5, 6, 4)), ("poisson", 2, (5, 4, 6)),
+                                     ("elasticity", 2, (3, 3, 4)), ("poisson", 3, (3, 4, 3)), ("elasticity", 3, (2, 3, 2))):
+            P = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                assert c.spmv_operator_form() == (2 if mode == 3 else 1)
+                rp, cl, v = c.csr_download()
+                info = c.spmv_info_raw()
+                kept = np.count_nonzero(v) if drop else v.size
+                assert kept <= info[7] <= 8 * 64 * ((rp.size - 1 + 63) // 64) * ((np.diff(rp).max() + 7) // 8)
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                oit, ou, _, _ = zo.pcg(rp.astype(np.int64), cl, v, c.vec_download(zzz.VEC_B), rtol=1e-8)
+                assert abs(it - oit) <= 2
+                assert np.linalg.norm(c.vec_download(zzz.VEC_U) - ou) <= 1e-6 * np.linalg.norm(ou)
+                # values uploaded by the caller: a matrix with whole zero rows and wide column ranges
+                v2 = v.copy()
+                zero_rows = rng.choice(rp.size - 1, size=max(1, (rp.size - 1) // 7), replace=False)
+                for r in zero_rows:
+                    v2[rp[r]:rp[r + 1]] = 0.0
+                v2[rng.random(v2.size) < 0.3] = 0.0
+                c.csr_upload_values(v2)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v2, xv))
+        # random global numbering of a 97 k-dof P1 problem, kept by the library (ZZZ_RENUMBER=0): the columns of a slot
+        # span more than 16 bits
+        os.environ["ZZZ_RENUMBER"] = "0"
+        O = zo.Problem("poisson", 1, 45, 45, 45)
+        perm = rng.permutation(O.n).astype(np.int32)
+        cell_dofs = np.ascontiguousarray(perm[O.cell_dofs])
+        bc = np.zeros_like(O.bc)
+        bc[perm] = O.bc
+        with zzz.Context(0) as c:
+            c.upload_mesh(O.x, O.cells)
+            c.upload_dofmap(1, 1, cell_dofs, O.nblock, 0)
+            c.upload_bc(np.nonzero(bc)[0].astype(np.int32))
+            c.pattern_build()
+            c.assemble_matrix(zzz.FORM_POISSON)
+            assert c.spmv_operator_form() == (2 if mode == 3 else 1)
+            rp, cl, v = c.csr_download()
+            xv = rng.standard_normal(O.n)
+            np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+    finally:
+        os.environ.pop("ZZZ_RENUMBER", None)
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+@pytest.mark.parametrize("problem,dims,knob", [("poisson", (200, 3, 3), 1), ("poisson", (150, 4, 3), 2), ("elasticity", (100, 3, 3), 4)],
+                         ids=["affine", "aligned", "periodic"])
+def test_code_free_chunks_of_the_operator_stream_keep_every_bit(problem, dims, knob):
+    """Chunks whose columns are base + lane in every slot (scalar rows), or T[slot][row mod 3] + 3 (row div 3) (block
+    size 3), carry no column codes (zzz_sellp.hip); with the aligned placement the entries of a one-chunk slice are placed by
+    column, so that the short boundary rows at the end of a mesh line fit that form too (holes of value +0.0 inside a
+    row).  The small boxes of the tests above have mesh lines shorter than a
+    64-row slice, so none of their chunks qualifies; a long thin box has many.  Same bits as the serial CSR loop with and
+    without the code-free forms, and the code-free stream is the smaller one."""
+    zo.set_num_threads(1)
+    rng = np.random.default_rng(77)
+    P = zzz.Part(problem, 1, *dims)
+    knobs = ("ZZZ_SELLP_FORMS",)  # a mask: 1 affine chunks, 2 aligned one-chunk slices, 4 periodic chunks (default 7)
+    saved = {k: os.environ.get(k) for k in knobs}
+    res = {}
+    try:
+        for on in ("0", "1"):
+            os.environ["ZZZ_SELLP_FORMS"] = str(7 if on == "1" else 7 & ~knob)  # the form under test builds on the others
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                assert c.spmv_operator_form() == 1
+                rp, cl, v = c.csr_download()
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                y = c.spmv(xv)
+                np.testing.assert_array_equal(y, zo.spmv(rp.astype(np.int64), cl, v, xv))
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                res[on] = (c.spmv_info_raw()[6], it, c.vec_download(zzz.VEC_U))
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    assert res["1"][0] < res["0"][0], (res["1"][0], res["0"][0])  # fewer bytes per product
+    assert res["1"][1] == res["0"][1]
+    np.testing.assert_array_equal(res["1"][2], res["0"][2])  # the solve does not see the encoding
+
+
+def test_long_row_packing_path_keeps_every_bit():
+    """Rows too long for the one-pass LDS packer (P3 at scale) are packed through a compacted copy (k_sp_count_sweep,
+    k_sp_compact, k_sp_fill_c).  ZZZ_SELLP=4 sends small matrices down that path: same bits as the serial CSR
+    loop, also with whole zero rows and scattered zeros (values uploaded by the caller)."""
+    zo.set_num_threads(1)
+    rng = np.random.default_rng(78)
+    old = {k: os.environ.get(k) for k in ("ZZZ_SELLP",)}
+    os.environ["ZZZ_SELLP"] = "4"
+    try:
+        for problem, order, dims in (("poisson", 3, (4, 5, 3)), ("elasticity", 2, (3, 4, 3)), ("elasticity", 3, (2, 3, 2)),
+                                     ("poisson", 1, (70, 3, 3))):
+            P = zzz.Part(problem, order, *dims)
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                assert c.spmv_operator_form() == 1
+                rp, cl, v = c.csr_download()
+                xv = rng.standard_normal(P.n_owned * P.bs)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v, xv))
+                v2 = v.copy()
+                for r in rng.choice(rp.size - 1, size=max(1, (rp.size - 1) // 9), replace=False):
+                    v2[rp[r]:rp[r + 1]] = 0.0
+                v2[rng.random(v2.size) < 0.4] = 0.0
+                c.csr_upload_values(v2)
+                np.testing.assert_array_equal(c.spmv(xv), zo.spmv(rp.astype(np.int64), cl, v2, xv))
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem,order,n", _SWEEP, ids=[f"{p}-P{o}-{n}" for p, o, n in _SWEEP])
+def test_size_sweep_across_the_form_selection_rules(problem, order, n):
+    """The library picks the product's form from sizes: value dictionary from 48 MB of stream, slice dictionaries for long rows
+    when they take the stream below 60 %, x windows for block size 3 beyond 300 MB of values, the kernel for one-chunk slices,
+    non-temporal loads and the coded inverse diagonal once an iteration's bytes exceed the Infinity Cache.  Every rule has a size either side of it here (the last case asserts that both sides were seen); at
+    every size the default product is the serial CSR loop's bit for bit (zo.spmv on the assembled matrix the library holds)
+    and the default solve is that of the plain stream (no dictionaries, no windows, generic kernel) iteration for iteration,
+    to rounding in the solution; the default product takes no more than 1.15 x the plain stream's time (the persistent grids differ, so do the orders of the partial sums: src/cg.h:65)."""
+    knobs = {"ZZZ_SELLP_DICT": "0", "ZZZ_SELLP_WIN": "0", "ZZZ_SELLP_PIPE": "0", "ZZZ_CG_DINV_CODES": "0", "ZZZ_SELLP_BLK": "0"}
+    saved = {k: os.environ.get(k) for k in knobs}
+    res = {}
+    try:
+        for which in ("default", "plain"):
+            for k, v in knobs.items():
+                if which == "plain":
+                    os.environ[k] = v
+                else:
+                    os.environ.pop(k, None)
+            with zzz.Context(0) as c:
+                info = c.cube_generate(problem, order, n, n - 1, n + 1, 1, 0)
+                c.pattern_build()
+                c.assemble_matrix(zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON)
+                c.assemble_vector(zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON)
+                nrows = (c.n_owned) * c.bs
+                x = np.random.default_rng(n).standard_normal(nrows)
+                y = c.spmv(x)
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-30, max_it=40)
+                vi, cg = c.spmv_values_info(), c.cg_info()
+                t_ms = min(c.spmv_time(100) for _ in range(3))
+                res[which] = dict(t=t_ms, y=y, it=it, rn=rn, u=c.vec_download(zzz.VEC_U), values=vi["form"], one=vi["one_chunk_kernel"],
+                                  windows=c.spmv_x_windows()[0] > 0, fused=cg["fused"], dinv=cg["dinv_codes"] > 0,
+                                  stream=bool(c.spmv_info_raw()[5]), blk=vi["block_rows"])
+                if which == "default":
+                    rp, cl, v = c.csr_download()
+                    np.testing.assert_array_equal(y, zo.spmv_chunked(rp.astype(np.int64), cl, v, x, c.spmv_lanes_per_row()))
+                    del rp, cl, v
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    d, p = res["default"], res["plain"]
+    assert p["values"] in ("doubles",) and not p["one"] and not p["windows"] and not p["dinv"] and not p["blk"]
+    np.testing.assert_array_equal(d["y"], p["y"])
+    assert d["it"] == p["it"] == 40
+    assert abs(d["rn"] - p["rn"]) <= 1e-10 * p["rn"], (d["rn"], p["rn"])
+    np.testing.assert_allclose(d["u"], p["u"], rtol=0, atol=1e-11 * np.abs(p["u"]).max())
+    # the form the size rules pick should be no slower than the plain one beyond noise (a rule on the wrong side of its
+    # threshold would show here; + 2 us: launches of 10 us at the small end).  Wall-clock on a shared or throttled GPU is no
+    # correctness criterion: a warning, not a failure; tools/ab_sellp.py is the place for the measurement
+    if d["t"] > 1.15 * p["t"] + 0.002:
+        import warnings
+
+        warnings.warn(f"default product {d['t']:.4f} ms against the plain stream's {p['t']:.4f} ms at {problem} P{order} n={n} "
+                      f"({d['values']}, one-chunk {d['one']}, windows {d['windows']}, block rows {d['blk']})")
+
+
+@pytest.mark.gpu
+def test_size_sweep_straddles_every_form_selection_rule():
+    """The sweep above has a size either side of every rule: each choice is taken at some of its sizes and not at others.
+    (Computed here from the forms themselves -- assembly and a look at what the library picked, no solve -- so that it holds
+    under -k, xdist or any order of the cases.)"""
+    seen_all = {}
+    for problem, order, n in _SWEEP:
+        with zzz.Context(0) as c:
+            c.cube_generate(problem, order, n, n - 1, n + 1, 1, 0)
+            c.pattern_build()
+            c.assemble_matrix(zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON)
+            c.assemble_vector(zzz.FORM_ELASTICITY if problem == "elasticity" else zzz.FORM_POISSON)
+            c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-30, max_it=2)
+            vi, cg = c.spmv_values_info(), c.cg_info()
+            seen_all[(problem, order, n)] = dict(values=vi["form"], one=vi["one_chunk_kernel"], windows=c.spmv_x_windows()[0] > 0,
+                                                 fused=cg["fused"], dinv=cg["dinv_codes"] > 0, stream=bool(c.spmv_info_raw()[5]),
+                                                 blk=vi["block_rows"])
+    seen = lambda key, pred=lambda k: True: {s[key] for k, s in seen_all.items() if pred(k)}  # noqa: E731
+    assert seen("values", lambda k: k[1] == 1 and k[0] == "poisson") >= {"doubles", "dictionary in LDS"}, seen_all
+    assert "slice dictionaries" in seen("values", lambda k: k[1] == 3) and len(seen("values", lambda k: k[1] == 3)) >= 2, seen_all
+    assert seen("one", lambda k: k[1] == 1 and k[0] == "poisson") == {False, True}, seen_all
+    assert seen("windows", lambda k: k[0] == "elasticity") == {False, True}, seen_all
+    assert seen("blk", lambda k: k[0] == "elasticity") == {False, True}, seen_all  # (block rows from 100 000 nodes on)
+    assert seen("blk", lambda k: k[0] != "elasticity") == {False}, seen_all
+    assert seen("fused") == {False} and seen("dinv") == {False, True}, seen_all  # (the fused direction kernel: by knob only)
+    assert seen("stream") == {True}, seen_all
