@@ -139,6 +139,7 @@ int zzz_ctx_create(int device, zzz_ctx** out)
       zzz::preload_sellp_dict();
       zzz::preload_sellp_pipe();
       zzz::preload_sellp_blk();
+      zzz::preload_sellp_win();
       zzz::preload_sellp();
       zzz::preload_spmv();
       zzz::preload_cg();
@@ -174,6 +175,8 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_drop = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_DICT"))
     ctx->sellp_dict = atoi(e);
+  if (const char* e = getenv("ZZZ_SELLP_BWIN")) // long scalar rows, x from LDS windows: 0 never, 1 from 2 000 000 rows on, 2 always
+    ctx->sellp_bwin = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_BLK")) // 0: block size 3 stays on the generic product (A/B against the block-row form)
     ctx->sellp_blk = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_PIPE")) // 0: the generic product kernel always (A/B against the pipelined one)
@@ -415,6 +418,8 @@ int zzz_csr_pattern_build(zzz_ctx* ctx)
   if (ctx->order == 0)
     return fail(ctx, ZZZ_ERR_ARG, "zzz_csr_pattern_build before zzz_dofmap_upload");
   ctx->have_pattern = ctx->have_matrix = false;
+  ++ctx->pattern_version;
+  ctx->bw_on = false;
   ctx->have_adj_li = false;
   ctx->have_asm_pos = false;
   ++ctx->mat_version;
@@ -1019,10 +1024,13 @@ int zzz_spmv_values_info2(zzz_ctx* ctx, int n, int64_t* out)
     info[1] = ctx->sp_dict_on ? ctx->sp_dict_n : 0;
     info[2] = sellp_stream_bytes(ctx);
     info[3] = ctx->sp_bytes + ctx->nslices * 8;
-    info[6] = blk ? 1 : 0;
-    info[7] = blk ? ctx->bk_entries : 0;
-    info[8] = blk ? ctx->bk_chunks : 0;
-    info[9] = blk ? ctx->bk_form : 0;
+    const bool win = zzz::sellp_win_serves(ctx);
+    info[6] = blk ? 1 : (win ? 2 : 0);
+    info[7] = blk ? ctx->bk_entries : (win ? ctx->bw_window_entries : 0);
+    info[8] = blk ? ctx->bk_chunks : (win ? ctx->bw_chunks : 0);
+    info[9] = blk ? ctx->bk_form : (win ? ctx->bw_nblk : 0);
+    if (win)
+      info[4] = 0, info[5] = 1;
   }
   for (int i = 0; i < std::min(n, 10); ++i)
     out[i] = info[i];

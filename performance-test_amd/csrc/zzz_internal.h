@@ -295,6 +295,18 @@ struct zzz_ctx
   bool have_sell = false;    // stream built
   bool sell_current = false; // ... from the current CSR values
   zzz::DevBuf<int32_t> groups_interior, groups_boundary; // groups of 4 slices without / with ghost columns
+  // block-window form of the product for long scalar rows (zzz_sellp_win.hip): rows in the Morton order of their nodes, blocks of
+  // 4 096 with the columns they reach as a window in LDS and a dictionary of their values
+  zzz::DevBuf<int32_t> bw_order, bw_perm, bw_desc, bw_wlist, bw_blk_chunks, bw_blk_wn, bw_dnum, bw_info, bw_list_interior, bw_list_boundary;
+  zzz::DevBuf<int64_t> bw_chunk0, bw_woff;
+  zzz::DevBuf<uint16_t> bw_ccode, bw_vcode;
+  zzz::DevBuf<double> bw_dict;
+  zzz::DevBuf<uint8_t> bw_gflag;
+  bool bw_on = false, bw_struct_ok = false, bw_have_split = false, bw_lds_attr = false;
+  int sellp_bwin = 1; // ZZZ_SELLP_BWIN: 0 never, 1 from 2 000 000 rows on, 2 always
+  int32_t bw_nblk = 0;
+  int64_t bw_chunks = 0, bw_window_entries = 0, bw_dict_entries = 0, bw_bytes = 0, bw_n_interior = 0, bw_n_boundary = 0;
+  uint64_t pattern_version = 0, bw_struct_version = ~0ull; // pattern_version counts zzz_csr_pattern_build calls
   // block-row form of the product for block size 3 (zzz_sellp_blk.hip): one lane per node, 16-bit codes into a table of the
   // matrix's distinct 3 x 3 blocks (copied into LDS by every workgroup), 16 block slots per node and chunk
   zzz::DevBuf<int32_t> bk_desc, bk_meta, bk_flags, bk_nch, bk_c0, bk_slot_code, bk_info, bk_list_interior, bk_list_boundary;
@@ -420,6 +432,7 @@ void preload_sellp_dict();
 void preload_sellp_pack();
 void preload_sellp_pipe();
 void preload_sellp_blk();
+void preload_sellp_win();
 void preload_spmv();
 
 // api
@@ -431,6 +444,7 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
 int ensure_cols16(zzz_ctx* ctx); // encodes the 16-bit column stream of the CSR tile kernel on first use
 int asm_tile_nnz(const zzz_ctx* ctx); // nonzeros an assembly tile may hold (LDS budget of the matrix kernels)
 int build_adjT(zzz_ctx* ctx);
+int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx); // zzz_nullspace.hip
 int build_adjT_offsets(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);
 int ensure_p1_coords(zzz_ctx* ctx); // P1 only; a no-op for P2/P3

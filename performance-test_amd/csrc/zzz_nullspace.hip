@@ -143,6 +143,29 @@ int nn_dot(zzz_ctx* ctx, const double* a, const double* b, int64_t n_owned_scala
 ZZZ_PRELOAD_TU(nullspace)
 } // namespace zzz
 
+namespace zzz
+{
+// coordinates of every block dof (owned + ghost), [dof][3]: V.tabulate_dof_coordinates as described above.  Also used by the
+// block-window product (zzz_sellp_win.hip) to order rows in space.
+int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx)
+{
+  hipStream_t s = ctx->stream;
+  const int64_t nblock = ctx->n_owned + ctx->n_ghost, nc = ctx->ncells;
+  const int g = (int)std::max<int64_t>(1, std::min<int64_t>((nc * ctx->nd + 255) / 256, 8192));
+  DevBuf<int32_t> first;
+  ZZZ_HIP(ctx, first.alloc((size_t)nblock));
+  ZZZ_HIP(ctx, dofx.alloc((size_t)(3 * nblock)));
+  ZZZ_HIP(ctx, hipMemsetAsync(first.p, 0x7f, (size_t)nblock * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(dofx.p, 0, (size_t)(3 * nblock) * sizeof(double), s));
+  hipLaunchKernelGGL(k_nn_first_cell, dim3(g), dim3(256), 0, s, ctx->cell_dofs.p, ctx->nd, nc, first.p);
+  hipLaunchKernelGGL(k_nn_dof_coords, dim3(g), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p, ctx->order, ctx->nd, nc,
+                     first.p, dofx.p);
+  ZZZ_HIP(ctx, hipGetLastError());
+  ZZZ_HIP(ctx, hipStreamSynchronize(s)); // (`first` is released on return)
+  return ZZZ_OK;
+}
+} // namespace zzz
+
 using namespace zzz;
 
 extern "C" {

@@ -73,6 +73,12 @@ int sellp_pipe_wgs(const zzz_ctx* ctx, bool sr); // workgroups per CU if spmv_on
 int sellp_pairs_build(zzz_ctx* ctx); // marks the affine slice pairs of a stream of one-chunk slices (spmv_one_kernel)
 bool launch_sellp_pipe(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
                        const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr);
+// block-window form for long scalar rows (zzz_sellp_win.hip)
+int sellp_win_build(zzz_ctx* ctx);
+bool sellp_win_serves(const zzz_ctx* ctx);
+int sellp_win_grid(const zzz_ctx* ctx, int64_t items);
+bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
+                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr);
 // block-row form for block size 3 (zzz_sellp_blk.hip)
 int sellp_blk_build(zzz_ctx* ctx);
 bool sellp_blk_serves(const zzz_ctx* ctx);

@@ -636,7 +636,17 @@ bool sellp_active(zzz_ctx* ctx)
     // block size 3: the block-row form beside the stream (zzz_sellp_blk.hip); a failed build leaves the stream as it is
     if (sellp_blk_build(ctx) != ZZZ_OK)
     {
+      if (getenv("ZZZ_DEBUG_SYNC"))
+        fprintf(stderr, "[zzz dbg] sellp_blk_build: %s\n", ctx->err.c_str());
       ctx->bk_on = false;
+      (void)hipGetLastError();
+    }
+    // long scalar rows: the block-window form (zzz_sellp_win.hip), likewise
+    if (sellp_win_build(ctx) != ZZZ_OK)
+    {
+      if (getenv("ZZZ_DEBUG_SYNC"))
+        fprintf(stderr, "[zzz dbg] sellp_win_build: %s\n", ctx->err.c_str());
+      ctx->bw_on = false;
       (void)hipGetLastError();
     }
   }
@@ -649,6 +659,8 @@ int64_t sellp_stream_bytes(const zzz_ctx* ctx)
 {
   if (sellp_blk_serves(ctx))
     return ctx->bk_bytes; // (descriptors and table included)
+  if (sellp_win_serves(ctx))
+    return ctx->bw_bytes;
   return (ctx->sp_sd_on ? ctx->sp_sd_bytes : (ctx->sp_dict_on ? ctx->sp_dict_bytes : ctx->sp_bytes)) + ctx->nslices * 8; // (x windows: sp_win_bytes, reported apart)
 }
 
@@ -683,15 +695,18 @@ static int sp_grid(const zzz_ctx* ctx, int64_t ngroups, bool sr, bool plain)
 template <bool DOT>
 static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, double* partials, const int* stop,
                        const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr,
-                       const TailArgs& tail = TailArgs(), const ChebEpi* epi = nullptr, bool blk = false)
+                       const TailArgs& tail = TailArgs(), const ChebEpi* epi = nullptr, int special = 0)
 {
   // load policy by stream size, as for the tile kernel: a stream that stays in the 256 MiB Infinity Cache from
   // one CG iteration to the next is read with plain loads, a larger one with non-temporal loads
   bool nt = sp_stream_nt(ctx);
   if (!ctx->spmv_auto)
     nt = (ctx->spmv_variant & 1) != 0;
-  // blk: the caller sized the grid and chose the slice list for the block-row kernel (block size 3)
-  if (blk && launch_sellp_blk(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
+  // special: the caller sized the grid and chose the list for the block-row kernel (1: block size 3) or the block-window kernel
+  // (2: long scalar rows)
+  if (special == 1 && launch_sellp_blk(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
+    return;
+  if (special == 2 && launch_sellp_win(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
     return;
   if (!epi && !tail.parts && launch_sellp_pipe(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
     return;
@@ -762,8 +777,9 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   const bool plain = !epi && !(partials && ctx->tail_armed);
-  const bool blk = plain && sellp_blk_serves(ctx);
-  const int gs = blk ? sellp_blk_grid(ctx, ctx->bk_slices) : sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec), plain);
+  const int blk = plain ? (sellp_blk_serves(ctx) ? 1 : (sellp_win_serves(ctx) ? 2 : 0)) : 0;
+  const int gs = blk == 1 ? sellp_blk_grid(ctx, ctx->bk_slices) : blk == 2 ? sellp_win_grid(ctx, ctx->bw_nblk)
+                          : sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec), plain);
 #ifdef ZZZ_EXPERIMENTS
   const char* e = ctx->timing_only ? getenv("ZZZ_EXP_WIN") : nullptr; // timing probe, wrong results by construction (see
   if (e)                                                               // the kernel): inside zzz_spmv_time only
@@ -819,16 +835,18 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   const bool plain = !epi && !(partials && ctx->tail_armed);
-  const bool blk = plain && sellp_blk_serves(ctx) && ctx->bk_have_split;
-  const int64_t gi = blk ? ctx->bk_n_interior : ctx->n_groups_interior, gb = blk ? ctx->bk_n_boundary : ctx->n_groups_boundary;
-  const int32_t* list_in = blk ? ctx->bk_list_interior.p : ctx->groups_interior.p;
-  const int32_t* list_bd = blk ? ctx->bk_list_boundary.p : ctx->groups_boundary.p;
-  int g_in = gi ? (blk ? sellp_blk_grid(ctx, gi) : sp_grid(ctx, gi, (partials && rvec), plain)) : 0;
+  const int blk = !plain ? 0 : (sellp_blk_serves(ctx) && ctx->bk_have_split) ? 1 : (sellp_win_serves(ctx) && ctx->bw_have_split) ? 2 : 0;
+  const int64_t gi = blk == 1 ? ctx->bk_n_interior : blk == 2 ? ctx->bw_n_interior : ctx->n_groups_interior;
+  const int64_t gb = blk == 1 ? ctx->bk_n_boundary : blk == 2 ? ctx->bw_n_boundary : ctx->n_groups_boundary;
+  const int32_t* list_in = blk == 1 ? ctx->bk_list_interior.p : blk == 2 ? ctx->bw_list_interior.p : ctx->groups_interior.p;
+  const int32_t* list_bd = blk == 1 ? ctx->bk_list_boundary.p : blk == 2 ? ctx->bw_list_boundary.p : ctx->groups_boundary.p;
+  auto special_grid = [&](int64_t items) { return blk == 1 ? sellp_blk_grid(ctx, items) : sellp_win_grid(ctx, items); };
+  int g_in = gi ? (blk ? special_grid(gi) : sp_grid(ctx, gi, (partials && rvec), plain)) : 0;
   const int pw = plain ? sellp_pipe_wgs(ctx, partials && rvec) : 0;
   const int room = 256 * ((pw ? pw : 8) - 1); // (one workgroup slot per CU left to the exchange's kernel; the block-row
   if (!blk && g_in > room && ctx->nneigh > 0) //  kernel's one workgroup per CU leaves half the CU's wavefront slots free)
     g_in = room;
-  const int g_bd = gb ? (blk ? sellp_blk_grid(ctx, gb) : sp_grid(ctx, gb, (partials && rvec), plain)) : 0;
+  const int g_bd = gb ? (blk ? special_grid(gb) : sp_grid(ctx, gb, (partials && rvec), plain)) : 0;
   if (partials && (size_t)(g_in + g_bd) > (size_t)SPMV_PSTRIDE)
     return fail(ctx, ZZZ_ERR_ARG, "partials buffer too small");
   TailArgs Ti, Tb;

@@ -1255,6 +1255,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
   ctx->have_sell = ctx->sell_current = ctx->sp_pending = false;
   ctx->sp_dict_done = ctx->sp_dict_on = ctx->sp_sd_on = false; // (the values changed: the dictionaries are rebuilt at the stream's first use)
   ctx->bk_on = false;
+  ctx->bw_on = false;
   ctx->sp_win_max = 0; // (set again by the long-row packer when most groups get an x window)
   ctx->sp_win_bytes = 0;
   const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;

@@ -1,0 +1,789 @@
+// The CG product for LONG SCALAR ROWS (Poisson P2 / P3: BASELINE configs[4]) with x taken from LDS (round 6).
+//
+// Replaces PETSc MatMult inside KSPSolve (src/poisson_problem.cpp:168-177) like the other products of this library, with the
+// same arithmetic: a row's products are added in ascending column order, mul and add rounded separately -- bit-identical to
+// the serial CSR loop (zo_spmv) for finite x.
+//
+// Why.  On the operator stream (zzz_sellp.hip) a P3 row of ~48 entries costs one gather of x per entry and wavefront
+// instruction; slot e of 64 consecutive rows reaches 4-10 cache lines, and the product runs at the rate the CU's address path
+// retires those gathers (profiles/r05_sq_c5rank.json: 9 vector-memory instructions per chunk of 8 entries per row, 39 cycles
+// each, wavefronts waiting for memory 86 % of their cycles) -- 0.43 ms for 1.55 GB at 6.2 M rows, 0.45 of the HBM peak.  Fewer
+// bytes do not help it; fewer vector-memory instructions per entry do.  The columns a SET of rows reaches are few when the rows
+// are neighbours in SPACE (all entity types of a small brick of the mesh), not neighbours in the type-major numbering: 2 048
+// rows of P3 around one point reach ~4 500 columns.  So, privately to this product:
+//   * the rows are put into the Morton order of their nodes' coordinates (no lattice is assumed: whatever mesh) and cut into
+//     BLOCKS of 4 096; inside a block they are ordered by length, 64 to a slice, so that a slice pads little;
+//   * per block: the WINDOW = the distinct columns its rows reach (a list; at most 12 288), and a DICTIONARY of its distinct
+//     values (at most 6 144); per entry a 16-bit window index and a 16-bit value code: 4 B per entry, as on the stream;
+//   * one workgroup of 1 024 lanes per block: the window's x values and the dictionary go into LDS (two barriers per block),
+//     then a lane per row: per chunk of 8 entries two 16-B loads, eight LDS reads of x, eight of the dictionary, eight mul + add.
+//     Two vector-memory instructions per chunk instead of ten; y leaves through the row permutation.
+// Every entry of the pattern is kept (exact zeros too: 3-4 % at P3): the structure then depends on the PATTERN only and is
+// built once per zzz_csr_pattern_build's matrix; the value codes are refreshed at the first product after every assembly.
+//
+// When it applies: block size 1, natural row order of the stream, at least BW_MIN_AVG entries per row on average, every block
+// within the LDS budget, no Chebyshev epilogue / folded all-reduce on the launch (those stay on the generic kernel).
+// ZZZ_SELLP_BWIN: 0 never, 1 (default) from 2 000 000 rows on (488 blocks: two rounds of one workgroup per CU; with fewer blocks
+// than CUs the generic product wins: 24^3 sub-cubes of P3, 95 blocks, 0.036 against 0.046 ms -- but 0.027 with 2 048-row
+// blocks, so the limit is the block count, not the form), 2 always.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "zzz_sellp.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace zzz
+{
+constexpr int BW_R = 4096;        // rows per block
+constexpr int BW_THREADS = 1024;  // one workgroup per block: four rows per lane in the builders, four slices per wavefront in the product
+constexpr int BW_WCAP = 12288;    // window: distinct columns of a block at most (96 KiB of LDS in the product)
+constexpr int BW_WBITS = 15;
+constexpr int BW_WHASH = 1 << BW_WBITS; // ... and the slots of the set that finds them (build only)
+constexpr int BW_DCAP = 6144;     // distinct values of a block at most (+0.0 = code 0 included; 48 KiB)
+constexpr int BW_DBITS = 14;
+constexpr int BW_DHASH = 1 << BW_DBITS;
+constexpr int BW_MIN_AVG = 40;    // average row length from which the form is considered (P3: ~48; P2, ~27, measured slower: 0.203
+                                  // against 0.187 ms at 5 M dofs)
+constexpr int BW_SLICES = BW_R / 64;
+
+// ---- structure -----------------------------------------------------------------------------------------------------------
+// bounding box of the dof coordinates (one workgroup)
+__global__ __launch_bounds__(1024) void k_bw_bbox(const double* __restrict__ dofx, int64_t n, double* __restrict__ out)
+{
+  __shared__ double sh[6][16];
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t i = threadIdx.x; i < n; i += 1024)
+    for (int a = 0; a < 3; ++a)
+    {
+      const double v = dofx[3 * i + a];
+      lo[a] = fmin(lo[a], v);
+      hi[a] = fmax(hi[a], v);
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int o = 32; o; o >>= 1)
+    {
+      lo[a] = fmin(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = fmax(hi[a], __shfl_xor(hi[a], o));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; ++a)
+    {
+      sh[a][threadIdx.x >> 6] = lo[a];
+      sh[3 + a][threadIdx.x >> 6] = hi[a];
+    }
+  __syncthreads();
+  if (threadIdx.x < 3)
+  {
+    double l = 1e300, h = -1e300;
+    for (int w = 0; w < 16; ++w)
+    {
+      l = fmin(l, sh[threadIdx.x][w]);
+      h = fmax(h, sh[3 + threadIdx.x][w]);
+    }
+    out[threadIdx.x] = l;
+    out[3 + threadIdx.x] = h;
+  }
+}
+
+__device__ inline unsigned bw_part1by2(unsigned a)
+{
+  a &= 0x3ffu;
+  a = (a | (a << 16)) & 0x30000ffu;
+  a = (a | (a << 8)) & 0x300f00fu;
+  a = (a | (a << 4)) & 0x30c30c3u;
+  a = (a | (a << 2)) & 0x9249249u;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx, const double* __restrict__ bbox, int32_t n,
+                                                 uint32_t* __restrict__ key, int32_t* __restrict__ val)
+{
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+  {
+    unsigned q[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      const double l = bbox[a], h = bbox[3 + a];
+      const double t = h > l ? (dofx[3 * (int64_t)i + a] - l) / (h - l) : 0.0;
+      q[a] = (unsigned)fmin(1023.0, fmax(0.0, t * 1024.0));
+    }
+    key[i] = bw_part1by2(q[0]) | (bw_part1by2(q[1]) << 1) | (bw_part1by2(q[2]) << 2);
+    val[i] = i;
+  }
+}
+
+// info: [0] a block does not fit (window, values, a row of 2^11 entries or more), [1] blocks that reach a ghost column
+
+// One workgroup per block.  WRITE = false: chunks and window size of the block (scanned by the host); WRITE = true: the
+// block's part of the structure -- perm, slice descriptors, window list, window indices of every entry.
+template <bool WRITE>
+__global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restrict__ order, int32_t nrows, int32_t nblk,
+                                                         const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                         int32_t* __restrict__ blk_chunks, int32_t* __restrict__ blk_wn,
+                                                         const int64_t* __restrict__ chunk0, const int64_t* __restrict__ woff,
+                                                         int32_t* __restrict__ perm, int2* __restrict__ desc,
+                                                         int32_t* __restrict__ wlist, uint16_t* __restrict__ ccode,
+                                                         uint8_t* __restrict__ gflag, int* __restrict__ info,
+                                                         int32_t* __restrict__ hid_all)
+{
+  int32_t* const hid = hid_all + (int64_t)blockIdx.x * BW_WHASH; // slot -> window index (this workgroup's scratch: L2)
+  __shared__ int32_t hcol[BW_WHASH]; // the set of columns (-1: empty)
+  __shared__ uint32_t skey[BW_R];    // rows by (length descending, position ascending)
+  __shared__ int32_t sl_c0[BW_SLICES + 1];
+  __shared__ int wsum[BW_THREADS / 64];
+  __shared__ int n_win, any_ghost, bad;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x)
+  {
+    const int r0 = b * BW_R, nb = min(BW_R, nrows - r0);
+    for (int k = tid; k < BW_WHASH; k += BW_THREADS)
+      hcol[k] = -1;
+    if (tid == 0)
+      n_win = 0, any_ghost = 0, bad = 0;
+    __syncthreads();
+    // the rows' lengths; the sort key: longer rows first, ties in block order (a bitonic sort: deterministic)
+    for (int p = tid; p < BW_R; p += BW_THREADS)
+    {
+      unsigned len = 0;
+      if (p < nb)
+      {
+        const int32_t r = order[r0 + p];
+        len = (unsigned)(rowptr[r + 1] - rowptr[r]);
+        if (len > 2047u)
+        {
+          bad = 1;
+          len = 2047u;
+        }
+      }
+      skey[p] = ((2047u - len) << 12) | (unsigned)p; // (rows beyond the block's last: length 0, they sort last)
+    }
+    __syncthreads();
+    for (int k = 2; k <= BW_R; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1)
+      {
+        for (int i = tid; i < BW_R; i += BW_THREADS)
+        {
+          const int l = i ^ j;
+          if (l > i)
+          {
+            const uint32_t a = skey[i], c = skey[l];
+            const bool up = (i & k) == 0;
+            if ((a > c) == up)
+            {
+              skey[i] = c;
+              skey[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    // chunks per slice (its first row is its longest), their starts inside the block
+    if (tid < BW_SLICES)
+    {
+      const unsigned len = 2047u - (skey[tid * 64] >> 12);
+      sl_c0[tid] = (int)((len + 7u) / 8u);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      int acc = 0;
+      for (int s = 0; s < BW_SLICES; ++s)
+      {
+        const int v = sl_c0[s];
+        sl_c0[s] = acc;
+        acc += v;
+      }
+      sl_c0[BW_SLICES] = acc;
+    }
+    // the window: every column of every row into the set
+    for (int p = tid; p < nb; p += BW_THREADS)
+    {
+      const int32_t r = order[r0 + p];
+      for (rp_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+      {
+        const int32_t c = cols[k];
+        if (c >= nrows)
+          any_ghost = 1;
+        unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
+        for (int probe = 0; probe < BW_WHASH; ++probe)
+        {
+          int32_t cur = hcol[h];
+          if (cur == -1)
+          {
+            cur = atomicCAS(&hcol[h], -1, c);
+            if (cur == -1)
+            {
+              if (atomicAdd(&n_win, 1) >= BW_WCAP)
+                bad = 1;
+              break;
+            }
+          }
+          if (cur == c || bad)
+            break;
+          h = (h + 1) & (BW_WHASH - 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (bad)
+    {
+      if (tid == 0)
+        info[0] = 1;
+      __syncthreads();
+      continue;
+    }
+    if (!WRITE)
+    {
+      if (tid == 0)
+      {
+        blk_chunks[b] = sl_c0[BW_SLICES];
+        blk_wn[b] = n_win;
+        if (any_ghost)
+          atomicAdd(&info[1], 1);
+        gflag[b] = any_ghost ? 1 : 0;
+      }
+      __syncthreads();
+      continue;
+    }
+    // window indices: the occupied slots numbered in slot order
+    {
+      constexpr int PER = BW_WHASH / BW_THREADS;
+      int mine = 0;
+      for (int k = 0; k < PER; ++k)
+        mine += hcol[tid * PER + k] != -1 ? 1 : 0;
+      int incl = mine;
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d)
+          incl += t;
+      }
+      if (lane == 63)
+        wsum[wv] = incl;
+      __syncthreads();
+      int off = 0;
+      for (int q = 0; q < wv; ++q)
+        off += wsum[q];
+      int id = off + incl - mine;
+      const int64_t w0 = woff[b];
+      for (int k = 0; k < PER; ++k)
+      {
+        const int h = tid * PER + k;
+        if (hcol[h] != -1)
+        {
+          hid[h] = id;
+          wlist[w0 + id] = hcol[h];
+          ++id;
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t cb = chunk0[b];
+    if (tid < BW_SLICES)
+      desc[(int64_t)b * BW_SLICES + tid] = make_int2((int)(cb + sl_c0[tid]), sl_c0[tid + 1] - sl_c0[tid]);
+    for (int q = tid; q < BW_R; q += BW_THREADS)
+    {
+      const int p = (int)(skey[q] & 4095u);
+      const bool real = p < nb;
+      const int32_t r = real ? order[r0 + p] : -1;
+      perm[(int64_t)b * BW_R + q] = r;
+      if (!real)
+        continue;
+      const int s = q >> 6, ln = q & 63;
+      const int64_t c0 = cb + sl_c0[s];
+      const rp_t a = rowptr[r];
+      const int len = (int)(rowptr[r + 1] - a);
+      for (int k = 0; k < len; ++k)
+      {
+        const int32_t c = cols[a + k];
+        unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
+        while (hcol[h] != c)
+          h = (h + 1) & (BW_WHASH - 1);
+        ccode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)hid[h];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- values (after every assembly) ---------------------------------------------------------------------------------------
+// One workgroup per block: the block's distinct values into a set in LDS, numbered as they arrive (code 0 = +0.0); the table
+// and every entry's 16-bit code.  info[2]: a block holds more values than the table.
+__global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restrict__ perm, int32_t nblk, const rp_t* __restrict__ rowptr,
+                                                          const unsigned long long* __restrict__ vals, const int2* __restrict__ desc,
+                                                          uint16_t* __restrict__ vcode, unsigned long long* __restrict__ dict,
+                                                          int32_t* __restrict__ dnum, int* __restrict__ info,
+                                                          uint16_t* __restrict__ hcode_all)
+{
+  uint16_t* const hcode = hcode_all + (int64_t)blockIdx.x * BW_DHASH; // slot -> code (this workgroup's scratch: L2)
+  __shared__ unsigned long long hval[BW_DHASH];
+  __shared__ int n_val, bad;
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x)
+  {
+    for (int k = tid; k < BW_DHASH; k += BW_THREADS)
+      hval[k] = ~0ull;
+    if (tid == 0)
+      n_val = 1, bad = 0; // (entry 0 is +0.0)
+    __syncthreads();
+    unsigned long long* const tab = dict + (int64_t)b * BW_DCAP;
+    if (tid == 0)
+      tab[0] = 0ull;
+    for (int q = tid; q < BW_R; q += BW_THREADS)
+    {
+      const int32_t r = perm[(int64_t)b * BW_R + q];
+      if (r < 0)
+        continue;
+      unsigned long long last = 0ull;
+      for (rp_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+      {
+        const unsigned long long v = vals[k];
+        if (v == 0ull || v == last)
+          continue;
+        last = v;
+        if (v == ~0ull)
+        {
+          bad = 1;
+          continue;
+        }
+        unsigned h = (unsigned)(((v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
+        for (int probe = 0; probe < BW_DHASH; ++probe)
+        {
+          unsigned long long cur = hval[h];
+          if (cur == ~0ull)
+          {
+            cur = atomicCAS(&hval[h], ~0ull, v);
+            if (cur == ~0ull)
+            {
+              const int c = atomicAdd(&n_val, 1);
+              if (c >= BW_DCAP)
+                bad = 1;
+              else
+              {
+                hcode[h] = (uint16_t)c;
+                tab[c] = v;
+              }
+              break;
+            }
+          }
+          if (cur == v || bad)
+            break;
+          h = (h + 1) & (BW_DHASH - 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (bad)
+    {
+      if (tid == 0)
+        info[2] = 1;
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0)
+      dnum[b] = n_val;
+    for (int q = tid; q < BW_R; q += BW_THREADS)
+    {
+      const int32_t r = perm[(int64_t)b * BW_R + q];
+      if (r < 0)
+        continue;
+      const int s = q >> 6, ln = q & 63;
+      const int64_t c0 = desc[(int64_t)b * BW_SLICES + s].x;
+      const rp_t a = rowptr[r];
+      const int len = (int)(rowptr[r + 1] - a);
+      unsigned long long last = 0ull;
+      unsigned last_code = 0;
+      for (int k = 0; k < len; ++k)
+      {
+        const unsigned long long v = vals[a + k];
+        unsigned code = 0;
+        if (v != 0ull)
+        {
+          if (v != last)
+          {
+            unsigned h = (unsigned)(((v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
+            while (hval[h] != v)
+              h = (h + 1) & (BW_DHASH - 1);
+            last = v;
+            last_code = hcode[h];
+          }
+          code = last_code;
+        }
+        vcode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)code;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- the product -----------------------------------------------------------------------------------------------------------
+struct WinArgs
+{
+  int nblk, nrows;
+  double* partials;
+  const int* stop_flag;
+  int64_t nlist;
+  int pstride, nn_is_rr;
+};
+
+template <bool DOT, bool SR, bool NT>
+__global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __restrict__ p_perm, const int2* __restrict__ p_desc,
+                                                              const int64_t* __restrict__ p_woff, const int32_t* __restrict__ p_wlist,
+                                                              const uint16_t* __restrict__ p_ccode, const uint16_t* __restrict__ p_vcode,
+                                                              const double* __restrict__ p_dict, const int32_t* __restrict__ p_dnum,
+                                                              const double* __restrict__ p_x, double* __restrict__ p_y,
+                                                              const double* __restrict__ p_rvec, const int32_t* __restrict__ p_list,
+                                                              WinArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double bw_lds[]; // [0, BW_WCAP): the window's x; behind it the dictionary
+  __shared__ double red[BW_THREADS / 64];
+  double* const xwin = bw_lds;
+  double* const dtab = bw_lds + BW_WCAP;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (a.stop_flag && *a.stop_flag) // CG already converged: the host is a few iterations ahead
+    return;
+  const int64_t nitems = p_list ? a.nlist : (int64_t)a.nblk;
+  double dot = 0.0, dot_rx = 0.0, dot_nn = 0.0;
+  for (int i = 0;; ++i)
+  {
+    const int64_t t = xcd_stride_item(nitems, i);
+    if (t < 0)
+      break;
+    const int b = p_list ? p_list[t] : (int)t;
+    const int64_t w0 = p_woff[b];
+    const int wn = (int)(p_woff[b + 1] - w0), dn = p_dnum[b];
+    __syncthreads(); // the previous block's lookups are done
+    // window and dictionary into LDS: every thread's (at most eight + four) entries requested before any is stored
+    {
+      int32_t wc[BW_WCAP / BW_THREADS];
+      double xv[BW_WCAP / BW_THREADS], dv[BW_DCAP / BW_THREADS];
+#pragma unroll
+      for (int k = 0; k < BW_WCAP / BW_THREADS; ++k)
+        wc[k] = tid + k * BW_THREADS < wn ? p_wlist[w0 + tid + k * BW_THREADS] : 0;
+#pragma unroll
+      for (int k = 0; k < BW_DCAP / BW_THREADS; ++k)
+        dv[k] = tid + k * BW_THREADS < dn ? p_dict[(int64_t)b * BW_DCAP + tid + k * BW_THREADS] : 0.0;
+#pragma unroll
+      for (int k = 0; k < BW_WCAP / BW_THREADS; ++k)
+        xv[k] = tid + k * BW_THREADS < wn ? p_x[wc[k]] : 0.0;
+#pragma unroll
+      for (int k = 0; k < BW_DCAP / BW_THREADS; ++k)
+        if (tid + k * BW_THREADS < dn)
+          dtab[tid + k * BW_THREADS] = dv[k];
+#pragma unroll
+      for (int k = 0; k < BW_WCAP / BW_THREADS; ++k)
+        if (tid + k * BW_THREADS < wn)
+          xwin[tid + k * BW_THREADS] = xv[k];
+    }
+    __syncthreads();
+    for (int s = wv; s < BW_SLICES; s += BW_THREADS / 64)
+    {
+      const int2 ds = p_desc[(int64_t)b * BW_SLICES + s];
+      const int64_t c0 = ds.x;
+      const int nch = __builtin_amdgcn_readfirstlane(ds.y);
+      if (nch == 0)
+        continue; // (slices are ordered by length: the rest of the block is empty too, but other wavefronts' are not)
+      const int32_t r = p_perm[(int64_t)b * BW_R + s * 64 + lane];
+      double xr = 0.0, rr = 0.0;
+      if (DOT && r >= 0)
+      {
+        xr = p_x[r];
+        if (SR)
+          rr = p_rvec[r];
+      }
+      double sum = 0.0;
+      for (int j = 0; j < nch; ++j)
+      {
+        const uint4v vq = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p_vcode + (c0 + j) * 512) + lane)
+                             : reinterpret_cast<const uint4v*>(p_vcode + (c0 + j) * 512)[lane];
+        const uint4v cq = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p_ccode + (c0 + j) * 512) + lane)
+                             : reinterpret_cast<const uint4v*>(p_ccode + (c0 + j) * 512)[lane];
+        const unsigned vc[8] = {vq.x & 0xffffu, vq.x >> 16, vq.y & 0xffffu, vq.y >> 16, vq.z & 0xffffu, vq.z >> 16, vq.w & 0xffffu, vq.w >> 16};
+        const unsigned cc[8] = {cq.x & 0xffffu, cq.x >> 16, cq.y & 0xffffu, cq.y >> 16, cq.z & 0xffffu, cq.z >> 16, cq.w & 0xffffu, cq.w >> 16};
+        double xe[8], ve[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+        {
+          xe[e] = xwin[cc[e]];
+          ve[e] = dtab[vc[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          sum += ve[e] * xe[e]; // (entries beyond a row's last carry code 0 = +0.0 and window index 0: + 0 * x)
+      }
+      if (r >= 0)
+      {
+        p_y[r] = sum;
+        if (DOT)
+        {
+          dot += sum * xr;
+          if (SR)
+          {
+            dot_rx += rr * xr;
+            dot_nn += a.nn_is_rr ? rr * rr : xr * xr;
+          }
+        }
+      }
+    }
+  }
+  if (DOT)
+  {
+    const double sres = block_reduce_sum(dot, red);
+    double s1 = 0.0, s2 = 0.0;
+    if (SR)
+    {
+      s1 = block_reduce_sum(dot_rx, red);
+      s2 = block_reduce_sum(dot_nn, red);
+    }
+    if (threadIdx.x == 0)
+    {
+      a.partials[blockIdx.x] = sres;
+      if (SR)
+      {
+        a.partials[a.pstride + blockIdx.x] = s1;
+        a.partials[2 * a.pstride + blockIdx.x] = s2;
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static int bw_structure(zzz_ctx* ctx)
+{
+  hipStream_t s = ctx->stream;
+  const int32_t nrows = (int32_t)ctx->nrows;
+  const int32_t nblk = (nrows + BW_R - 1) / BW_R;
+  ctx->bw_struct_ok = false;
+  // Morton order of the rows' nodes
+  DevBuf<double> dofx, bbox;
+  DevBuf<uint32_t> key, key2;
+  DevBuf<int32_t> val;
+  if (int rc = dof_coords_device(ctx, dofx))
+    return rc;
+  ZZZ_HIP(ctx, bbox.alloc(6));
+  ZZZ_HIP(ctx, key.alloc((size_t)nrows));
+  ZZZ_HIP(ctx, key2.alloc((size_t)nrows));
+  ZZZ_HIP(ctx, val.alloc((size_t)nrows));
+  ZZZ_HIP(ctx, ctx->bw_order.alloc((size_t)nrows));
+  hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, dofx.p, (int64_t)nrows, bbox.p);
+  hipLaunchKernelGGL(k_bw_keys, dim3((unsigned)std::min<int64_t>(((int64_t)nrows + 255) / 256, 4096)), dim3(256), 0, s, dofx.p, bbox.p,
+                     nrows, key.p, val.p);
+  {
+    size_t tb = 0;
+    ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, val.p, ctx->bw_order.p, (size_t)nrows, 0, 30, s));
+    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, rocprim::radix_sort_pairs(ctx->scr_tmp.p, tb, key.p, key2.p, val.p, ctx->bw_order.p, (size_t)nrows, 0, 30, s));
+  }
+  DevBuf<int32_t>& info = ctx->bw_info;
+  ZZZ_HIP(ctx, info.reserve(8));
+  ZZZ_HIP(ctx, hipMemsetAsync(info.p, 0, 8 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, ctx->bw_blk_chunks.alloc((size_t)nblk + 1));
+  ZZZ_HIP(ctx, ctx->bw_blk_wn.alloc((size_t)nblk + 1));
+  ZZZ_HIP(ctx, ctx->bw_chunk0.alloc((size_t)nblk + 1));
+  ZZZ_HIP(ctx, ctx->bw_woff.alloc((size_t)nblk + 1));
+  ZZZ_HIP(ctx, ctx->bw_gflag.alloc((size_t)nblk));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_chunks.p + nblk, 0, sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_wn.p + nblk, 0, sizeof(int32_t), s));
+  const unsigned grid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
+  DevBuf<int32_t> hid;
+  ZZZ_HIP(ctx, hid.alloc((size_t)grid * BW_WHASH));
+  hipLaunchKernelGGL(k_bw_block<false>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
+                     ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, (const int64_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                     (int2*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, ctx->bw_gflag.p, info.p, hid.p);
+  {
+    size_t tb = 0;
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
+    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
+    ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->bw_blk_wn.p, ctx->bw_woff.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
+  }
+  ZZZ_HIP(ctx, hipGetLastError());
+  int32_t h[8];
+  int64_t tot[2] = {0, 0};
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[0], ctx->bw_chunk0.p + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[1], ctx->bw_woff.p + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (getenv("ZZZ_DEBUG_SYNC"))
+    fprintf(stderr, "[zzz dbg] bw_structure pass 1: flag %d ghost blocks %d chunks %lld window %lld nblk %d\n", h[0], h[1], (long long)tot[0],
+            (long long)tot[1], nblk);
+  if (h[0] || tot[0] <= 0 || tot[1] <= 0)
+    return ZZZ_OK; // declined: a block beyond the LDS budget
+  ZZZ_HIP(ctx, ctx->bw_perm.alloc((size_t)nblk * BW_R));
+  ZZZ_HIP(ctx, ctx->bw_desc.alloc((size_t)nblk * BW_SLICES * 2));
+  ZZZ_HIP(ctx, ctx->bw_wlist.alloc((size_t)tot[1] + 8));
+  ZZZ_HIP(ctx, ctx->bw_ccode.alloc((size_t)tot[0] * 512));
+  ZZZ_HIP(ctx, ctx->bw_vcode.alloc((size_t)tot[0] * 512));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_ccode.p, 0, (size_t)tot[0] * 1024, s));
+  hipLaunchKernelGGL(k_bw_block<true>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
+                     ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, ctx->bw_chunk0.p, ctx->bw_woff.p, ctx->bw_perm.p,
+                     reinterpret_cast<int2*>(ctx->bw_desc.p), ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, hid.p);
+  ZZZ_HIP(ctx, hipGetLastError());
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (h[0])
+    return ZZZ_OK;
+  // interior / boundary blocks for the halo-compute overlap of a partitioned matrix
+  ctx->bw_n_interior = ctx->bw_n_boundary = 0;
+  ctx->bw_have_split = false;
+  if (ctx->n_ghost > 0 || ctx->have_group_split)
+  {
+    std::vector<uint8_t> gf((size_t)nblk);
+    ZZZ_HIP(ctx, hipMemcpyAsync(gf.data(), ctx->bw_gflag.p, gf.size(), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    std::vector<int32_t> in, bd;
+    for (int32_t q = 0; q < nblk; ++q)
+      (gf[(size_t)q] ? bd : in).push_back(q);
+    ZZZ_HIP(ctx, ctx->bw_list_interior.alloc(in.size()));
+    ZZZ_HIP(ctx, ctx->bw_list_boundary.alloc(bd.size()));
+    if (!in.empty())
+      ZZZ_HIP(ctx, hipMemcpyAsync(ctx->bw_list_interior.p, in.data(), in.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (!bd.empty())
+      ZZZ_HIP(ctx, hipMemcpyAsync(ctx->bw_list_boundary.p, bd.data(), bd.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    ctx->bw_n_interior = (int64_t)in.size();
+    ctx->bw_n_boundary = (int64_t)bd.size();
+    ctx->bw_have_split = true;
+  }
+  ctx->bw_nblk = nblk;
+  ctx->bw_chunks = tot[0];
+  ctx->bw_window_entries = tot[1];
+  ctx->bw_struct_ok = true;
+  return ZZZ_OK;
+}
+
+// Called at the stream's first use after an assembly (sellp_active).  Declined (bw_on stays false, nothing else changes): block
+// size 3, short rows, sorted stream, a block beyond the LDS budget, ZZZ_SELLP_BWIN=0.
+int sellp_win_build(zzz_ctx* ctx)
+{
+  ctx->bw_on = false;
+  // (ZZZ_SELLP_BWIN=2 also takes P2's rows of ~27 -- the tests of the form at small sizes -- but never P1's 15)
+  const int64_t min_avg = ctx->sellp_bwin == 2 ? 20 : BW_MIN_AVG;
+  if (!ctx->sellp_bwin || ctx->bs != 1 || ctx->sp_sorted || ctx->nrows <= 0 || ctx->nnz < min_avg * ctx->nrows)
+    return ZZZ_OK;
+  if (ctx->sellp_bwin == 1 && ctx->nrows < 2000000)
+    return ZZZ_OK;
+  if (getenv("ZZZ_DEBUG_SYNC"))
+    fprintf(stderr, "[zzz dbg] sellp_win_build: rows %lld nnz %lld knob %d\n", (long long)ctx->nrows, (long long)ctx->nnz, ctx->sellp_bwin);
+  if (ctx->nrows >= (int64_t)1 << 31 || ctx->order == 0 || ctx->ncells <= 0)
+    return ZZZ_OK;
+  hipStream_t s = ctx->stream;
+  if (ctx->bw_struct_version != ctx->pattern_version || !ctx->bw_struct_ok)
+  {
+    ctx->bw_struct_version = ctx->pattern_version;
+    if (int rc = bw_structure(ctx))
+      return rc;
+  }
+  if (getenv("ZZZ_DEBUG_SYNC"))
+    fprintf(stderr, "[zzz dbg] bw structure ok %d\n", (int)ctx->bw_struct_ok);
+  if (!ctx->bw_struct_ok)
+    return ZZZ_OK;
+  const int32_t nblk = ctx->bw_nblk;
+  ZZZ_HIP(ctx, ctx->bw_dict.alloc((size_t)nblk * BW_DCAP));
+  ZZZ_HIP(ctx, ctx->bw_dnum.alloc((size_t)nblk));
+  DevBuf<int32_t>& info = ctx->bw_info;
+  ZZZ_HIP(ctx, hipMemsetAsync(info.p, 0, 8 * sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_vcode.p, 0, (size_t)ctx->bw_chunks * 1024, s));
+  const unsigned vgrid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
+  DevBuf<uint16_t> hcode;
+  ZZZ_HIP(ctx, hcode.alloc((size_t)vgrid * BW_DHASH));
+  hipLaunchKernelGGL(k_bw_values, dim3(vgrid), dim3(BW_THREADS), 0, s, ctx->bw_perm.p, nblk,
+                     ctx->rowptr.p, reinterpret_cast<const unsigned long long*>(ctx->vals.p), reinterpret_cast<const int2*>(ctx->bw_desc.p),
+                     ctx->bw_vcode.p, reinterpret_cast<unsigned long long*>(ctx->bw_dict.p), ctx->bw_dnum.p, info.p, hcode.p);
+  ZZZ_HIP(ctx, hipStreamSynchronize(s)); // (hcode is released on return)
+  ZZZ_HIP(ctx, hipGetLastError());
+  int32_t h[8];
+  ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  ZZZ_HIP(ctx, hipStreamSynchronize(s));
+  if (getenv("ZZZ_DEBUG_SYNC"))
+    fprintf(stderr, "[zzz dbg] bw values: flag %d\n", h[2]);
+  if (h[2])
+    return ZZZ_OK; // a block with more distinct values than the table holds (an irregular mesh): the stream serves the product
+  if (!ctx->bw_lds_attr)
+  {
+#define ZZZ_BW_ATTR(DOT, SR, NT)                                                                                                   \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_win_kernel<DOT, SR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (BW_WCAP + BW_DCAP) * 8)
+    ZZZ_BW_ATTR(true, true, true);
+    ZZZ_BW_ATTR(true, true, false);
+    ZZZ_BW_ATTR(true, false, true);
+    ZZZ_BW_ATTR(true, false, false);
+    ZZZ_BW_ATTR(false, false, true);
+    ZZZ_BW_ATTR(false, false, false);
+#undef ZZZ_BW_ATTR
+    ZZZ_HIP(ctx, hipGetLastError());
+    ctx->bw_lds_attr = true;
+  }
+  // bytes a product reads: codes, descriptors, permutation, window lists and their x (L2), dictionaries
+  ctx->bw_bytes = ctx->bw_chunks * 2048 + (int64_t)nblk * BW_SLICES * 8 + (int64_t)nblk * BW_R * 4 + ctx->bw_window_entries * 4
+                  + (int64_t)nblk * 16;
+  {
+    std::vector<int32_t> dn((size_t)nblk);
+    ZZZ_HIP(ctx, hipMemcpyAsync(dn.data(), ctx->bw_dnum.p, dn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipStreamSynchronize(s));
+    int64_t t = 0;
+    for (int32_t v : dn)
+      t += v;
+    ctx->bw_bytes += t * 8;
+    ctx->bw_dict_entries = t;
+  }
+  ctx->bw_on = true;
+  return ZZZ_OK;
+}
+
+bool sellp_win_serves(const zzz_ctx* ctx) { return ctx->bw_on && ctx->sellp_bwin && ctx->bs == 1 && !ctx->sp_sorted; }
+
+int sellp_win_grid(const zzz_ctx* ctx, int64_t items)
+{
+  (void)ctx;
+  const int64_t g = (items + 7) / 8 * 8;
+  return (int)std::max<int64_t>(8, std::min<int64_t>(g, 256));
+}
+
+bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
+                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr)
+{
+  if (!sellp_win_serves(ctx))
+    return false;
+  WinArgs a;
+  a.nblk = ctx->bw_nblk;
+  a.nrows = (int)ctx->nrows;
+  a.partials = partials;
+  a.stop_flag = stop;
+  a.nlist = nlist;
+  a.pstride = SPMV_PSTRIDE;
+  a.nn_is_rr = nn_is_rr;
+  const size_t lds = (size_t)(BW_WCAP + BW_DCAP) * 8;
+#define ZZZ_BW_GO(DOT, SR, NT)                                                                                                     \
+  hipLaunchKernelGGL((spmv_win_kernel<DOT, SR, NT>), dim3(grid), dim3(BW_THREADS), lds, ctx->stream, ctx->bw_perm.p,               \
+                     reinterpret_cast<const int2*>(ctx->bw_desc.p), ctx->bw_woff.p, ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_vcode.p, \
+                     ctx->bw_dict.p, ctx->bw_dnum.p, x, y, rvec, list, a)
+  if (dot && rvec)
+  {
+    if (nt)
+      ZZZ_BW_GO(true, true, true);
+    else
+      ZZZ_BW_GO(true, true, false);
+  }
+  else if (dot)
+  {
+    if (nt)
+      ZZZ_BW_GO(true, false, true);
+    else
+      ZZZ_BW_GO(true, false, false);
+  }
+  else
+  {
+    if (nt)
+      ZZZ_BW_GO(false, false, true);
+    else
+      ZZZ_BW_GO(false, false, false);
+  }
+#undef ZZZ_BW_GO
+  return true;
+}
+ZZZ_PRELOAD_TU(sellp_win)
+} // namespace zzz

@@ -579,11 +579,12 @@ class Context:
         info = (C.c_int64 * 10)()
         if os.environ.get("ZZZ_AB_OLD") and not hasattr(self.L, "zzz_spmv_values_info2"):
             return dict(form="doubles", distinct_values=0, bytes_per_product=0, bytes_per_product_as_doubles=0,
-                        one_chunk_kernel=False, workgroups_per_cu=8, block_rows=False, block_table_entries=0, block_chunks=0, block_form=0)
+                        one_chunk_kernel=False, workgroups_per_cu=8, block_rows=False, row_windows=False, special_form="", block_table_entries=0, block_chunks=0, block_form=0)
         self._ck(self.L.zzz_spmv_values_info2(self.h, 10, info))
         return dict(form=("doubles", "dictionary in memory", "dictionary in LDS", "slice dictionaries")[int(info[0])], distinct_values=int(info[1]),
                     bytes_per_product=int(info[2]), bytes_per_product_as_doubles=int(info[3]),
-                    one_chunk_kernel=bool(info[4]), workgroups_per_cu=int(info[5]), block_rows=bool(info[6]),
+                    one_chunk_kernel=bool(info[4]), workgroups_per_cu=int(info[5]), block_rows=int(info[6]) == 1, row_windows=int(info[6]) == 2,
+                    special_form=("", "block rows", "block windows")[int(info[6])],
                     block_table_entries=int(info[7]), block_chunks=int(info[8]), block_form=int(info[9]))
 
     def spmv_x_windows(self):

@@ -78,7 +78,7 @@ def test_block_row_product_is_the_serial_csr_loop(order, dims):
     np.testing.assert_array_equal(a["y"], oy)
     np.testing.assert_array_equal(a["y"], b["y"])
     for k in ("it", "its", "itc"):
-        assert abs(a[k] - b[k]) <= 1, (k, a[k], b[k])
+        assert abs(a[k] - b[k]) <= 2, (k, a[k], b[k])  # (the workgroups' partial sums of <p, A p> are added in another order)
     for k in ("u", "us", "uc"):
         assert np.linalg.norm(a[k] - b[k]) <= 1e-9 * np.linalg.norm(b[k]), k
     assert a["rel"] <= 1e-8
@@ -186,3 +186,126 @@ def test_pattern_build_when_the_connectivity_ends_on_a_page_boundary(problem, or
     orp, ocl = zo.pattern(P.n_owned, P.cell_dofs, P.bs)
     np.testing.assert_array_equal(rp, orp)
     np.testing.assert_array_equal(cl, ocl)
+
+
+# ---- long scalar rows: the block-window product (csrc/zzz_sellp_win.hip) ------------------------------------------------------
+def _run_poisson(P, x, **env):
+    with _Env(**env):
+        with zzz.Context(0) as c:
+            c.upload_part(P)
+            c.pattern_build()
+            c.assemble_matrix(P.form)
+            c.assemble_vector(P.form)
+            y = c.spmv(x)
+            vi = c.spmv_values_info()
+            it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+            u = c.vec_download(zzz.VEC_U)
+            its, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=True)
+            us = c.vec_download(zzz.VEC_U)
+            itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-8)
+            uc = c.vec_download(zzz.VEC_U)
+            rp, cl, v = c.csr_download()
+            # a second set of values on the same pattern: the structure (row order, windows) is kept, the value codes refreshed
+            v2 = -3.0 * v  # (as few distinct values as before: the block dictionaries must still hold them)
+            c.csr_upload_values(v2)
+            y2 = c.spmv(x)
+            vi2 = c.spmv_values_info()
+    return dict(y=y, vi=vi, it=it, u=u, its=its, us=us, itc=itc, uc=uc, csr=(rp, cl, v), rel=rn / r0, y2=y2, v2=v2, vi2=vi2)
+
+
+@pytest.mark.parametrize("order,dims", [(3, (4, 3, 5)), (3, (12, 12, 12)), (3, (20, 6, 9)), (2, (10, 9, 11)), (2, (24, 24, 24))])
+def test_block_window_product_is_the_serial_csr_loop(order, dims):
+    """Poisson P2 / P3 with the product forced into the block-window form (rows in Morton blocks of 4 096, x from a window in LDS,
+    values from a dictionary in LDS): == zo.spmv bit for bit == the generic stream's product (ZZZ_SELLP_BWIN=0), also after new
+    values arrive on the same pattern; CG (classical, single reduction) agrees with the generic kernel's solve and the oracle."""
+    zo.set_num_threads(4)
+    P = zzz.Part("poisson", order, *dims)
+    x = np.random.default_rng(21).standard_normal(P.n_owned)
+    a = _run_poisson(P, x, ZZZ_SELLP_BWIN=2, ZZZ_SELLP=2)
+    b = _run_poisson(P, x, ZZZ_SELLP_BWIN=0, ZZZ_SELLP=2)
+    assert a["vi"]["row_windows"] and not b["vi"]["row_windows"], (a["vi"], b["vi"])
+    assert a["vi"]["block_table_entries"] >= P.n_owned and a["vi"]["block_chunks"] >= 1 and a["vi"]["block_form"] == -(-P.n_owned // 4096)
+    rp, cl, v = a["csr"]
+    np.testing.assert_array_equal(a["y"], zo.spmv(rp.astype(np.int64), cl, v, x))
+    np.testing.assert_array_equal(a["y"], b["y"])
+    assert a["vi2"]["row_windows"]
+    np.testing.assert_array_equal(a["y2"], zo.spmv(rp.astype(np.int64), cl, a["v2"], x))
+    for k in ("it", "its", "itc"):
+        assert abs(a[k] - b[k]) <= 2, (k, a[k], b[k])
+    for k in ("u", "us", "uc"):
+        assert np.linalg.norm(a[k] - b[k]) <= 1e-9 * np.linalg.norm(b[k]), k
+    assert a["rel"] <= 1e-8
+    if P.n_owned <= 60000:
+        ob = zo.assemble_vector(P.form, order, P.x, P.cells, P.cell_dofs, P.f, P.g, P.facets, P.bc_marker())
+        oit, ou, _, _ = zo.pcg(rp.astype(np.int64), cl, v, ob, rtol=1e-8)
+        assert abs(a["it"] - oit) <= 2 and np.linalg.norm(a["u"] - ou) <= 1e-6 * np.linalg.norm(ou)
+
+
+def test_block_window_form_on_a_mesh_that_is_no_lattice_and_on_short_rows():
+    """The ring-with-spurs mesh (P3): rows ordered by their nodes' coordinates whatever the mesh; if a block's distinct values
+    exceed the dictionary the generic stream serves the product -- the same bits either way.  P1 (15 entries per row) never
+    takes the form."""
+    zo.set_num_threads(8)
+    U = zzz.Part.spoke("poisson", 3, 3)
+    xu = np.random.default_rng(22).standard_normal(U.n_owned)
+    w = _run_poisson(U, xu, ZZZ_SELLP_BWIN=2, ZZZ_SELLP=2)
+    rp, cl, v = w["csr"]
+    np.testing.assert_array_equal(w["y"], zo.spmv(rp.astype(np.int64), cl, v, xu))
+    np.testing.assert_array_equal(w["y2"], zo.spmv(rp.astype(np.int64), cl, w["v2"], xu))
+    P1 = zzz.Part("poisson", 1, 20, 18, 19)
+    x1 = np.random.default_rng(23).standard_normal(P1.n_owned)
+    q = _run_poisson(P1, x1, ZZZ_SELLP_BWIN=2, ZZZ_SELLP=2)
+    assert not q["vi"]["row_windows"]
+
+
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_block_windows_on_a_partition(nparts):
+    """z-slab partitions through the host-mediated communicator on one GPU: interior / boundary BLOCK lists of the block-window
+    kernel, halo overlap, all-reduced scalars; product of a global vector to round-off of the single-rank one, solves +-1 / 1e-9."""
+    import threading
+
+    dims = (5, 5, 12)
+    G = zzz.Part("poisson", 3, *dims)
+    xg = np.random.default_rng(6).standard_normal(G.n_owned)
+    g = _run_poisson(G, xg, ZZZ_SELLP_BWIN=2, ZZZ_SELLP=2)
+    assert g["vi"]["row_windows"]
+    grp = zzz.LocalGroup(nparts)
+    out, err = [None] * nparts, []
+
+    def run(rank):
+        try:
+            P = zzz.Part("poisson", 3, *dims, nparts, rank)
+            with zzz.Context(0) as c:
+                c.comm_init_local(grp.h, rank)
+                c.upload_part(P)
+                c.upload_halo(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                lo, hi = P.own_offset, P.own_offset + P.n_owned
+                y = c.spmv(xg[lo:hi])
+                win = c.spmv_values_info()["row_windows"]
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8)
+                u = c.vec_download(zzz.VEC_U)
+                its, _, _ = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-8, single_reduction=True)
+                out[rank] = (P.own_offset, y, win, it, u, its, c.vec_download(zzz.VEC_U))
+        except Exception as e:  # noqa: BLE001
+            err.append((rank, repr(e)))
+
+    with _Env(ZZZ_SELLP_BWIN=2, ZZZ_SELLP=2):
+        th = [threading.Thread(target=run, args=(r,)) for r in range(nparts)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+    grp.close()
+    assert not err, err
+    assert all(o is not None and o[2] for o in out), [o and o[2] for o in out]
+    y = np.concatenate([o[1] for o in out])
+    u = np.concatenate([o[4] for o in out])
+    us = np.concatenate([o[6] for o in out])
+    assert np.abs(y - g["y"]).max() <= 1e-13 * np.abs(g["y"]).max()
+    assert len({o[3] for o in out}) == 1 and abs(out[0][3] - g["it"]) <= 1
+    assert len({o[5] for o in out}) == 1 and abs(out[0][5] - g["its"]) <= 1
+    assert np.linalg.norm(u - g["u"]) <= 1e-9 * np.linalg.norm(g["u"])
+    assert np.linalg.norm(us - g["us"]) <= 1e-9 * np.linalg.norm(g["us"])
