@@ -298,6 +298,10 @@ def run_other_config(name, steps=3, unstructured=None):
                          f"3 x 3 blocks, " + ("the table's rows in LDS" if values["block_form"] == 1 else
                                                "rows of value offsets in memory and the values in LDS")
                          + f"; {values['block_chunks']} chunks of 16 block slots per node; csrc/zzz_sellp_blk.hip)") if values.get("block_rows") else
+                        (f"block windows (long scalar rows: {values['block_form']} blocks of 4 096 rows in the Morton order of their nodes, "
+                         f"x from a window in LDS ({values['block_table_entries']} window entries in all), values as 16-bit codes into block "
+                         f"dictionaries in LDS; {values['block_chunks']} chunks of 8 entries per row; csrc/zzz_sellp_win.hip)")
+                        if values.get("row_windows") else
                         ("sliced-ELL operator stream" + (" with x windows in LDS" if ctx_windows else "")
                          + (", values as 16-bit codes into per-slice dictionaries" if values["form"] == "slice dictionaries" else
                             f", values as codes into a {values['form']} of {values['distinct_values']} distinct values"
@@ -839,6 +843,8 @@ def main():
         kernel_name = ("spmv_tile_kernel (CG SpMV + <p,Ap> partials)" if not sinfo[5] else
                        "spmv_blk3_kernel (CG SpMV of a block-size-3 matrix in block-row form, one lane per node, + <p,Ap> partials)"
                        if ctx.spmv_values_info().get("block_rows") else
+                       "spmv_win_kernel (CG SpMV of long scalar rows, x from LDS windows, + <p,Ap> partials)"
+                       if ctx.spmv_values_info().get("row_windows") else
                        "spmv_one_kernel (CG SpMV on the operator stream's one-chunk slices, two rows per lane, + <p,Ap> partials)"
                        if ctx.spmv_values_info()["one_chunk_kernel"] else
                        "spmv_sellp_kernel (CG SpMV on the sliced-ELL operator stream + <p,Ap> partials)")

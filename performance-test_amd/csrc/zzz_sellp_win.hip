@@ -45,8 +45,8 @@ constexpr int BW_WHASH = 1 << BW_WBITS; // ... and the slots of the set that fin
 constexpr int BW_DCAP = 6144;     // distinct values of a block at most (+0.0 = code 0 included; 48 KiB)
 constexpr int BW_DBITS = 14;
 constexpr int BW_DHASH = 1 << BW_DBITS;
-constexpr int BW_MIN_AVG = 40;    // average row length from which the form is considered (P3: ~48; P2, ~27, measured slower: 0.203
-                                  // against 0.187 ms at 5 M dofs)
+constexpr int BW_MIN_AVG = 24;    // average row length from which the form is considered (P2: ~27, 0.187 -> 0.172 ms at 5 M dofs; P3: ~48,
+                                  // 0.44 -> 0.30 ms at 6.2 M; P1's 15 never)
 constexpr int BW_SLICES = BW_R / 64;
 
 // ---- structure -----------------------------------------------------------------------------------------------------------
@@ -274,10 +274,56 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
         const int h = tid * PER + k;
         if (hcol[h] != -1)
         {
-          hid[h] = id;
           wlist[w0 + id] = hcol[h];
           ++id;
         }
+      }
+    }
+    __syncthreads();
+    // ... and put into ASCENDING COLUMN order: neighbouring lanes of a slice (rows of one entity type, neighbours in space) then
+    // read neighbouring window slots -- fewer LDS bank conflicts in the product -- and the product's window load gathers x along
+    // runs of consecutive columns instead of at random.  The list is sorted in the set's own LDS (a bitonic sort of 16 384
+    // entries, the unused ones INT_MAX) and the set rebuilt from the sorted list with the positions as indices.
+    {
+      constexpr int SB = 16384;
+      static_assert(BW_WCAP <= SB && SB <= BW_WHASH, "the sort buffer lives in the set's array");
+      const int64_t w0 = woff[b];
+      const int nw = n_win;
+      for (int i = tid; i < SB; i += BW_THREADS)
+        hcol[i] = i < nw ? wlist[w0 + i] : INT_MAX;
+      __syncthreads();
+      for (int k = 2; k <= SB; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+          for (int i = tid; i < SB; i += BW_THREADS)
+          {
+            const int l = i ^ j;
+            if (l > i)
+            {
+              const int32_t a = hcol[i], c = hcol[l];
+              const bool up = (i & k) == 0;
+              if ((a > c) == up)
+              {
+                hcol[i] = c;
+                hcol[l] = a;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      for (int i = tid; i < nw; i += BW_THREADS)
+        wlist[w0 + i] = hcol[i];
+      __syncthreads();
+      for (int k = tid; k < BW_WHASH; k += BW_THREADS)
+        hcol[k] = -1;
+      __syncthreads();
+      for (int i = tid; i < nw; i += BW_THREADS)
+      {
+        const int32_t c = wlist[w0 + i];
+        unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
+        while (atomicCAS(&hcol[h], -1, c) != -1)
+          h = (h + 1) & (BW_WHASH - 1);
+        hid[h] = i;
       }
     }
     __syncthreads();
@@ -385,6 +431,52 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
     }
     if (tid == 0)
       dnum[b] = n_val;
+    // the table in ASCENDING order of the values' bit patterns (+0.0 stays code 0): the lanes of a slice -- rows of one entity
+    // type -- hold the same mathematical value in a slot, as a few bit patterns that then sit side by side in LDS (broadcasts
+    // and neighbouring banks instead of random ones).  Sorted in the set's own LDS, the set rebuilt with the positions as codes.
+    {
+      constexpr int SB = 8192;
+      static_assert(BW_DCAP <= SB && SB <= BW_DHASH, "the sort buffer lives in the set's array");
+      const int nv = n_val;
+      __syncthreads();
+      for (int i = tid; i < SB; i += BW_THREADS)
+        hval[i] = i < nv ? tab[i] : ~0ull;
+      __syncthreads();
+      for (int k = 2; k <= SB; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+          for (int i = tid; i < SB; i += BW_THREADS)
+          {
+            const int l = i ^ j;
+            if (l > i)
+            {
+              const unsigned long long a = hval[i], c = hval[l];
+              const bool up = (i & k) == 0;
+              if ((a > c) == up)
+              {
+                hval[i] = c;
+                hval[l] = a;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      for (int i = tid; i < nv; i += BW_THREADS)
+        tab[i] = hval[i];
+      __syncthreads();
+      for (int k = tid; k < BW_DHASH; k += BW_THREADS)
+        hval[k] = ~0ull;
+      __syncthreads();
+      for (int i = tid + 1; i < nv; i += BW_THREADS) // (entry 0, +0.0, is not looked up)
+      {
+        const unsigned long long v = tab[i];
+        unsigned h = (unsigned)(((v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
+        while (atomicCAS(&hval[h], ~0ull, v) != ~0ull)
+          h = (h + 1) & (BW_DHASH - 1);
+        hcode[h] = (uint16_t)i;
+      }
+      __syncthreads();
+    }
     for (int q = tid; q < BW_R; q += BW_THREADS)
     {
       const int32_t r = perm[(int64_t)b * BW_R + q];

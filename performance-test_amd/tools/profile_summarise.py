@@ -17,8 +17,8 @@ import sys
 # Round 6: the product kernels are tallied PER KERNEL NAME (template arguments included): "spmv:<name>".  The headline kernel's
 # record ("spmv" in the merged profile) is the instantiation the timed solve launches -- not a blend with the full-pattern
 # product, the Chebyshev epilogue products of alt_preconditioner or the plain products of zzz_spmv (judge, round 5).
-SPMV_RE = re.compile(r"(spmv_(?:sellp|tile|one|blk3)_kernel<[^>]*>)")
-KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel|spmv_one_kernel|spmv_blk3_kernel"), ("k_sp_pack", r"k_sp_pack"), ("k_sp_fill", r"k_sp_fill"), ("k_sp_count", r"k_sp_count"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
+SPMV_RE = re.compile(r"(spmv_(?:sellp|tile|one|blk3|win)_kernel<[^>]*>)")
+KEYS = [("spmv", r"spmv_sellp_kernel|spmv_tile_kernel|spmv_one_kernel|spmv_blk3_kernel|spmv_win_kernel"), ("k_sp_pack", r"k_sp_pack"), ("k_sp_fill", r"k_sp_fill"), ("k_sp_count", r"k_sp_count"), ("k_update_p", r"k_update_p\b"), ("k_update_xr", r"k_update_xr"),
         ("k_sr_update", r"k_sr_update"), ("asm_matrix", r"asm_matrix"), ("asm_vector", r"asm_vector"),
         ("k_row_pattern", r"k_row_pattern"), ("k_row_copy", r"k_row_copy"), ("k_tile_encode_cols", r"k_tile_encode_cols"),
         ("k_adjT_fill", r"k_adjT_fill"), ("k_make_pairs", r"k_make_pairs"), ("radix_sort", r"radix_sort_onesweep_iteration"),
