@@ -21,7 +21,8 @@
 // Every entry of the pattern is kept (exact zeros too: 3-4 % at P3): the structure then depends on the PATTERN only and is
 // built once per zzz_csr_pattern_build's matrix; the value codes are refreshed at the first product after every assembly.
 //
-// When it applies: block size 1, natural row order of the stream, at least BW_MIN_AVG entries per row on average, every block
+// When it applies: scalar matrices and those of block size 3 the block-row form declined (elasticity P2 / P3: their scalar rows
+// are long rows like any), natural row order of the stream, at least BW_MIN_AVG entries per row on average, every block
 // within the LDS budget, no Chebyshev epilogue / folded all-reduce on the launch (those stay on the generic kernel).
 // ZZZ_SELLP_BWIN: 0 never, 1 (default) from 2 000 000 rows on (488 blocks: two rounds of one workgroup per CU; with fewer blocks
 // than CUs the generic product wins: 24^3 sub-cubes of P3, 95 blocks, 0.036 against 0.046 ms -- but 0.027 with 2 048-row
@@ -98,7 +99,8 @@ __device__ inline unsigned bw_part1by2(unsigned a)
   return a;
 }
 
-__global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx, const double* __restrict__ bbox, int32_t n,
+// (row i belongs to node i / bs: the scalar rows of a vector-valued space are ordered by their nodes, components side by side)
+__global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx, const double* __restrict__ bbox, int32_t n, int bs,
                                                  uint32_t* __restrict__ key, int32_t* __restrict__ val)
 {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx
     for (int a = 0; a < 3; ++a)
     {
       const double l = bbox[a], h = bbox[3 + a];
-      const double t = h > l ? (dofx[3 * (int64_t)i + a] - l) / (h - l) : 0.0;
+      const double t = h > l ? (dofx[3 * (int64_t)(i / bs) + a] - l) / (h - l) : 0.0;
       q[a] = (unsigned)fmin(1023.0, fmax(0.0, t * 1024.0));
     }
     key[i] = bw_part1by2(q[0]) | (bw_part1by2(q[1]) << 1) | (bw_part1by2(q[2]) << 2);
@@ -660,9 +662,9 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, key2.alloc((size_t)nrows));
   ZZZ_HIP(ctx, val.alloc((size_t)nrows));
   ZZZ_HIP(ctx, ctx->bw_order.alloc((size_t)nrows));
-  hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, dofx.p, (int64_t)nrows, bbox.p);
+  hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, dofx.p, (int64_t)ctx->n_owned, bbox.p);
   hipLaunchKernelGGL(k_bw_keys, dim3((unsigned)std::min<int64_t>(((int64_t)nrows + 255) / 256, 4096)), dim3(256), 0, s, dofx.p, bbox.p,
-                     nrows, key.p, val.p);
+                     nrows, ctx->bs, key.p, val.p);
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, val.p, ctx->bw_order.p, (size_t)nrows, 0, 30, s));
@@ -754,7 +756,8 @@ int sellp_win_build(zzz_ctx* ctx)
   ctx->bw_on = false;
   // (ZZZ_SELLP_BWIN=2 also takes P2's rows of ~27 -- the tests of the form at small sizes -- but never P1's 15)
   const int64_t min_avg = ctx->sellp_bwin == 2 ? 20 : BW_MIN_AVG;
-  if (!ctx->sellp_bwin || ctx->bs != 1 || ctx->sp_sorted || ctx->nrows <= 0 || ctx->nnz < min_avg * ctx->nrows)
+  // (block size 3: the block-row form first -- elasticity P1, 2.4 x; where it declines, P2 / P3, the scalar rows are long rows like any)
+  if (!ctx->sellp_bwin || ctx->bk_on || ctx->sp_sorted || ctx->nrows <= 0 || ctx->nnz < min_avg * ctx->nrows)
     return ZZZ_OK;
   if (ctx->sellp_bwin == 1 && ctx->nrows < 2000000)
     return ZZZ_OK;
@@ -826,7 +829,7 @@ int sellp_win_build(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-bool sellp_win_serves(const zzz_ctx* ctx) { return ctx->bw_on && ctx->sellp_bwin && ctx->bs == 1 && !ctx->sp_sorted; }
+bool sellp_win_serves(const zzz_ctx* ctx) { return ctx->bw_on && ctx->sellp_bwin && !ctx->sp_sorted; }
 
 int sellp_win_grid(const zzz_ctx* ctx, int64_t items)
 {

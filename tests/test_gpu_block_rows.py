@@ -309,3 +309,23 @@ def test_block_windows_on_a_partition(nparts):
     assert len({o[5] for o in out}) == 1 and abs(out[0][5] - g["its"]) <= 1
     assert np.linalg.norm(u - g["u"]) <= 1e-9 * np.linalg.norm(g["u"])
     assert np.linalg.norm(us - g["us"]) <= 1e-9 * np.linalg.norm(g["us"])
+
+
+@pytest.mark.parametrize("order,dims", [(2, (8, 8, 8)), (3, (5, 5, 4))])
+def test_block_windows_serve_the_vector_valued_spaces_the_block_rows_decline(order, dims):
+    """Elasticity P2 / P3: more distinct values than the block-row form's dictionary holds -- their scalar rows (80-170 entries)
+    then take the block-window form like any long rows (ordered by their nodes).  == zo.spmv bit for bit."""
+    zo.set_num_threads(4)
+    P = zzz.Part("elasticity", order, *dims)
+    x = np.random.default_rng(31).standard_normal(P.n_owned * 3)
+    a = _run(P, x, ZZZ_SELLP_BLK=2, ZZZ_SELLP_BWIN=2, ZZZ_SELLP=2)
+    b = _run(P, x, ZZZ_SELLP_BLK=0, ZZZ_SELLP_BWIN=0, ZZZ_SELLP=2)
+    assert a["vi"]["block_rows"] or a["vi"]["row_windows"], a["vi"]
+    assert not b["vi"]["block_rows"] and not b["vi"]["row_windows"]
+    rp, cl, v = a["csr"]
+    np.testing.assert_array_equal(a["y"], zo.spmv(rp.astype(np.int64), cl, v, x))
+    np.testing.assert_array_equal(a["y"], b["y"])
+    for k in ("it", "its", "itc"):
+        assert abs(a[k] - b[k]) <= 2, (k, a[k], b[k])
+    for k in ("u", "us", "uc"):
+        assert np.linalg.norm(a[k] - b[k]) <= 1e-9 * np.linalg.norm(b[k]), k
