@@ -13,8 +13,8 @@
 // rows of P3 around one point reach ~4 500 columns.  So, privately to this product:
 //   * the rows are put into the Morton order of their nodes' coordinates (no lattice is assumed: whatever mesh) and cut into
 //     BLOCKS of 4 096; inside a block they are ordered by length, 64 to a slice, so that a slice pads little;
-//   * per block: the WINDOW = the distinct columns its rows reach (a list; at most 12 288), and a DICTIONARY of its distinct
-//     values (at most 6 144); per entry a 16-bit window index and a 16-bit value code: 4 B per entry, as on the stream;
+//   * per block: the WINDOW = the distinct columns its rows reach (a list; at most 11 264), and a DICTIONARY of its distinct
+//     values (at most 8 192); per entry a 16-bit window index and a 16-bit value code: 4 B per entry, as on the stream;
 //   * one workgroup of 1 024 lanes per block: the window's x values and the dictionary go into LDS (two barriers per block),
 //     then a lane per row: per chunk of 8 entries two 16-B loads, eight LDS reads of x, eight of the dictionary, eight mul + add.
 //     Two vector-memory instructions per chunk instead of ten; y leaves through the row permutation.
@@ -40,10 +40,12 @@ namespace zzz
 {
 constexpr int BW_R = 4096;        // rows per block
 constexpr int BW_THREADS = 1024;  // one workgroup per block: four rows per lane in the builders, four slices per wavefront in the product
-constexpr int BW_WCAP = 12288;    // window: distinct columns of a block at most (96 KiB of LDS in the product)
+constexpr int BW_WCAP = 11264;    // window: distinct columns of a block at most (88 KiB of LDS in the product; P3: 7 600 on average,
+                                  // 10 500 the largest met)
 constexpr int BW_WBITS = 15;
 constexpr int BW_WHASH = 1 << BW_WBITS; // ... and the slots of the set that finds them (build only)
-constexpr int BW_DCAP = 6144;     // distinct values of a block at most (+0.0 = code 0 included; 48 KiB)
+constexpr int BW_DCAP = 8192;     // distinct values of a block at most (+0.0 = code 0 included; 64 KiB; P3: 2 600 on average, 4 100 the
+                                  // largest at 61^3 sub-cubes, 7 100 at 122^3)
 constexpr int BW_DBITS = 14;
 constexpr int BW_DHASH = 1 << BW_DBITS;
 constexpr int BW_MIN_AVG = 24;    // average row length from which the form is considered (P2: ~27, 0.187 -> 0.172 ms at 5 M dofs; P3: ~48,
@@ -99,17 +101,58 @@ __device__ inline unsigned bw_part1by2(unsigned a)
   return a;
 }
 
+// sum over the cells of their extent along each axis (max - min of the four vertices): out[6..8]; the mean is the axis' cell size
+__global__ __launch_bounds__(256) void k_bw_cellsize(const double* __restrict__ x, const int32_t* __restrict__ cell_verts, int64_t ncells,
+                                                     double* __restrict__ out)
+{
+  __shared__ double sh[4];
+  double e[3] = {0.0, 0.0, 0.0};
+  for (int64_t c = blockIdx.x * 256ll + threadIdx.x; c < ncells; c += gridDim.x * 256ll)
+  {
+    const int4 v = *reinterpret_cast<const int4*>(cell_verts + 4 * c);
+    const int vv[4] = {v.x, v.y, v.z, v.w};
+    for (int a = 0; a < 3; ++a)
+    {
+      double lo = 1e300, hi = -1e300;
+      for (int k = 0; k < 4; ++k)
+      {
+        const double t = x[3 * (int64_t)vv[k] + a];
+        lo = fmin(lo, t);
+        hi = fmax(hi, t);
+      }
+      e[a] += hi - lo;
+    }
+  }
+  for (int a = 0; a < 3; ++a)
+  {
+    const double t = block_reduce_sum(e[a], sh);
+    if (threadIdx.x == 0)
+      atomicAdd(&out[6 + a], t);
+  }
+}
+
 // (row i belongs to node i / bs: the scalar rows of a vector-valued space are ordered by their nodes, components side by side)
-__global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx, const double* __restrict__ bbox, int32_t n, int bs,
+__global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx, const double* __restrict__ bbox, int64_t ncells, int32_t n,
+                                                 int bs,
                                                  uint32_t* __restrict__ key, int32_t* __restrict__ val)
 {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
   {
+    // Coordinates in units of the axis' mean CELL SIZE (bbox[6..8], summed over ncells), then ONE scale for the three axes: the
+    // cells of the Morton curve are cubes in the mesh's own metric, i.e. a block's rows are neighbours in the GRAPH.  (With each
+    // axis scaled to the box, or with physical lengths on a mesh of flat cells -- 122 x 122 x 16 sub-cubes of the unit cube --
+    // the blocks are 7.6 x wider than high and their windows do not fit: 14 700 columns against 7 600.)
+    double units[3], most = 0.0;
+    for (int a = 0; a < 3; ++a)
+    {
+      const double h = bbox[6 + a] / (double)ncells;
+      units[a] = h > 0.0 ? 1.0 / h : 0.0;
+      most = fmax(most, (bbox[3 + a] - bbox[a]) * units[a]);
+    }
     unsigned q[3];
     for (int a = 0; a < 3; ++a)
     {
-      const double l = bbox[a], h = bbox[3 + a];
-      const double t = h > l ? (dofx[3 * (int64_t)(i / bs) + a] - l) / (h - l) : 0.0;
+      const double t = most > 0.0 ? (dofx[3 * (int64_t)(i / bs) + a] - bbox[a]) * units[a] / most : 0.0;
       q[a] = (unsigned)fmin(1023.0, fmax(0.0, t * 1024.0));
     }
     key[i] = bw_part1by2(q[0]) | (bw_part1by2(q[1]) << 1) | (bw_part1by2(q[2]) << 2);
@@ -230,6 +273,12 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
       }
     }
     __syncthreads();
+    if (tid == 0)
+    {
+      atomicMax(&info[3], n_win); // (diagnostics: the largest window met, blocks that did not fit)
+      if (bad)
+        atomicAdd(&info[4], 1);
+    }
     if (bad)
     {
       if (tid == 0)
@@ -424,6 +473,12 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
       }
     }
     __syncthreads();
+    if (tid == 0)
+    {
+      atomicMax(&info[3], n_val); // (diagnostics: the largest dictionary met, blocks that did not fit)
+      if (bad)
+        atomicAdd(&info[4], 1);
+    }
     if (bad)
     {
       if (tid == 0)
@@ -657,14 +712,17 @@ static int bw_structure(zzz_ctx* ctx)
   DevBuf<int32_t> val;
   if (int rc = dof_coords_device(ctx, dofx))
     return rc;
-  ZZZ_HIP(ctx, bbox.alloc(6));
+  ZZZ_HIP(ctx, bbox.alloc(9));
+  ZZZ_HIP(ctx, hipMemsetAsync(bbox.p, 0, 9 * sizeof(double), s));
   ZZZ_HIP(ctx, key.alloc((size_t)nrows));
   ZZZ_HIP(ctx, key2.alloc((size_t)nrows));
   ZZZ_HIP(ctx, val.alloc((size_t)nrows));
   ZZZ_HIP(ctx, ctx->bw_order.alloc((size_t)nrows));
   hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, dofx.p, (int64_t)ctx->n_owned, bbox.p);
+  hipLaunchKernelGGL(k_bw_cellsize, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((ctx->ncells + 255) / 256, 2048))), dim3(256), 0, s,
+                     ctx->x.p, ctx->cell_verts.p, ctx->ncells, bbox.p);
   hipLaunchKernelGGL(k_bw_keys, dim3((unsigned)std::min<int64_t>(((int64_t)nrows + 255) / 256, 4096)), dim3(256), 0, s, dofx.p, bbox.p,
-                     nrows, ctx->bs, key.p, val.p);
+                     ctx->ncells, nrows, ctx->bs, key.p, val.p);
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, val.p, ctx->bw_order.p, (size_t)nrows, 0, 30, s));
@@ -702,8 +760,8 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemcpyAsync(&tot[1], ctx->bw_woff.p + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   if (getenv("ZZZ_DEBUG_SYNC"))
-    fprintf(stderr, "[zzz dbg] bw_structure pass 1: flag %d ghost blocks %d chunks %lld window %lld nblk %d\n", h[0], h[1], (long long)tot[0],
-            (long long)tot[1], nblk);
+    fprintf(stderr, "[zzz dbg] bw_structure pass 1: flag %d ghost blocks %d chunks %lld window %lld nblk %d max window %d bad blocks %d\n",
+            h[0], h[1], (long long)tot[0], (long long)tot[1], nblk, h[3], h[4]);
   if (h[0] || tot[0] <= 0 || tot[1] <= 0)
     return ZZZ_OK; // declined: a block beyond the LDS budget
   ZZZ_HIP(ctx, ctx->bw_perm.alloc((size_t)nblk * BW_R));
@@ -794,7 +852,7 @@ int sellp_win_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   if (getenv("ZZZ_DEBUG_SYNC"))
-    fprintf(stderr, "[zzz dbg] bw values: flag %d\n", h[2]);
+    fprintf(stderr, "[zzz dbg] bw values: flag %d max dictionary %d bad blocks %d of %d\n", h[2], h[3], h[4], nblk);
   if (h[2])
     return ZZZ_OK; // a block with more distinct values than the table holds (an irregular mesh): the stream serves the product
   if (!ctx->bw_lds_attr)
