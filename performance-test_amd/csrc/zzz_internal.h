@@ -299,7 +299,10 @@ struct zzz_ctx
   // 4 096 with the columns they reach as a window in LDS and a dictionary of their values
   zzz::DevBuf<int32_t> bw_order, bw_perm, bw_desc, bw_wlist, bw_blk_chunks, bw_blk_wn, bw_dnum, bw_info, bw_list_interior, bw_list_boundary;
   zzz::DevBuf<int64_t> bw_chunk0, bw_woff;
-  zzz::DevBuf<uint16_t> bw_ccode, bw_vcode;
+  zzz::DevBuf<uint16_t> bw_ccode, bw_vcode, bw_hcode;
+  zzz::DevBuf<uint32_t> bw_key, bw_key2;
+  zzz::DevBuf<int32_t> bw_val, bw_hid, bw_first; // (scratch of the builders, kept: hipFree waits for the whole device)
+  zzz::DevBuf<double> bw_dofx, bw_bbox;
   zzz::DevBuf<double> bw_dict;
   zzz::DevBuf<uint8_t> bw_gflag;
   bool bw_on = false, bw_struct_ok = false, bw_have_split = false, bw_lds_attr = false;
@@ -444,7 +447,7 @@ int build_tiles_device(zzz_ctx* ctx, int max_block_cols);
 int ensure_cols16(zzz_ctx* ctx); // encodes the 16-bit column stream of the CSR tile kernel on first use
 int asm_tile_nnz(const zzz_ctx* ctx); // nonzeros an assembly tile may hold (LDS budget of the matrix kernels)
 int build_adjT(zzz_ctx* ctx);
-int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx); // zzz_nullspace.hip
+int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx, DevBuf<int32_t>& first); // zzz_nullspace.hip
 int build_adjT_offsets(zzz_ctx* ctx);
 int ensure_tables(zzz_ctx* ctx);
 int ensure_p1_coords(zzz_ctx* ctx); // P1 only; a no-op for P2/P3

@@ -147,12 +147,11 @@ namespace zzz
 {
 // coordinates of every block dof (owned + ghost), [dof][3]: V.tabulate_dof_coordinates as described above.  Also used by the
 // block-window product (zzz_sellp_win.hip) to order rows in space.
-int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx)
+int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx, DevBuf<int32_t>& first)
 {
   hipStream_t s = ctx->stream;
   const int64_t nblock = ctx->n_owned + ctx->n_ghost, nc = ctx->ncells;
   const int g = (int)std::max<int64_t>(1, std::min<int64_t>((nc * ctx->nd + 255) / 256, 8192));
-  DevBuf<int32_t> first;
   ZZZ_HIP(ctx, first.alloc((size_t)nblock));
   ZZZ_HIP(ctx, dofx.alloc((size_t)(3 * nblock)));
   ZZZ_HIP(ctx, hipMemsetAsync(first.p, 0x7f, (size_t)nblock * sizeof(int32_t), s));
@@ -161,7 +160,6 @@ int dof_coords_device(zzz_ctx* ctx, DevBuf<double>& dofx)
   hipLaunchKernelGGL(k_nn_dof_coords, dim3(g), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, ctx->cell_dofs.p, ctx->order, ctx->nd, nc,
                      first.p, dofx.p);
   ZZZ_HIP(ctx, hipGetLastError());
-  ZZZ_HIP(ctx, hipStreamSynchronize(s)); // (`first` is released on return)
   return ZZZ_OK;
 }
 } // namespace zzz

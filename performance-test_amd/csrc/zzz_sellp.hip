@@ -613,27 +613,13 @@ bool sellp_active(zzz_ctx* ctx)
     // at the first product of a solve, and hipFree waits for the whole device -- with two ranks on ONE GPU (the tests' and
     // the driver's --comm local) the other rank may already be polling its all-reduce mailbox for this one: a release here
     // was a dead wait until the poll's time-out (round 5, found by tools/soak_driver.sh: elasticity P2, two ranks).
-    if (sp_dict_build(ctx) != ZZZ_OK)
-    {
-      ctx->sp_dict_on = false;
-      (void)hipGetLastError();
-      ctx->sp_vcode.release();
-      ctx->sp_dict_table.release();
-      ctx->sp_dict_slot.release();
-    }
-    if (sp_sd_build(ctx) != ZZZ_OK)
-    {
-      ctx->sp_sd_on = ctx->sp_sd_all = false;
-      (void)hipGetLastError();
-      ctx->sp_vcode8.release();
-      ctx->sp_sd_vals.release();
-      ctx->sp_sd_info.release();
-      ctx->sp_sd_off.release();
-    }
-    ctx->sp_pairs_ok = false;
-    if (ctx->sp_one_chunk && ctx->sp_dict_on && ctx->bs == 1 && !ctx->sp_sorted)
-      ctx->sp_pairs_ok = sellp_pairs_build(ctx) == ZZZ_OK;
-    // block size 3: the block-row form beside the stream (zzz_sellp_blk.hip); a failed build leaves the stream as it is
+    // The special forms first (block rows for block size 3, zzz_sellp_blk.hip; block windows for long scalar rows,
+    // zzz_sellp_win.hip): where one of them serves the product, the stream's value dictionaries are not built -- the launches
+    // that still take the generic kernel (a Chebyshev epilogue, a folded all-reduce) read its values as doubles.  7.6 ms per
+    // assembly at 6.2 M rows of P3, 3 ms at C4.  A failed build leaves the stream as it is.
+    ctx->sp_dict_done = true;
+    ctx->sp_dict_on = ctx->sp_sd_on = ctx->sp_sd_all = false;
+    ctx->sp_dict_n = 0;
     if (sellp_blk_build(ctx) != ZZZ_OK)
     {
       if (getenv("ZZZ_DEBUG_SYNC"))
@@ -641,7 +627,6 @@ bool sellp_active(zzz_ctx* ctx)
       ctx->bk_on = false;
       (void)hipGetLastError();
     }
-    // long scalar rows: the block-window form (zzz_sellp_win.hip), likewise
     if (sellp_win_build(ctx) != ZZZ_OK)
     {
       if (getenv("ZZZ_DEBUG_SYNC"))
@@ -649,6 +634,29 @@ bool sellp_active(zzz_ctx* ctx)
       ctx->bw_on = false;
       (void)hipGetLastError();
     }
+    if (!sellp_blk_serves(ctx) && !sellp_win_serves(ctx))
+    {
+      if (sp_dict_build(ctx) != ZZZ_OK)
+      {
+        ctx->sp_dict_on = false;
+        (void)hipGetLastError();
+        ctx->sp_vcode.release();
+        ctx->sp_dict_table.release();
+        ctx->sp_dict_slot.release();
+      }
+      if (sp_sd_build(ctx) != ZZZ_OK)
+      {
+        ctx->sp_sd_on = ctx->sp_sd_all = false;
+        (void)hipGetLastError();
+        ctx->sp_vcode8.release();
+        ctx->sp_sd_vals.release();
+        ctx->sp_sd_info.release();
+        ctx->sp_sd_off.release();
+      }
+    }
+    ctx->sp_pairs_ok = false;
+    if (ctx->sp_one_chunk && ctx->sp_dict_on && ctx->bs == 1 && !ctx->sp_sorted)
+      ctx->sp_pairs_ok = sellp_pairs_build(ctx) == ZZZ_OK;
   }
   return true;
 }

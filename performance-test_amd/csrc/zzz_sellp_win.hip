@@ -336,10 +336,12 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
     // runs of consecutive columns instead of at random.  The list is sorted in the set's own LDS (a bitonic sort of 16 384
     // entries, the unused ones INT_MAX) and the set rebuilt from the sorted list with the positions as indices.
     {
-      constexpr int SB = 16384;
-      static_assert(BW_WCAP <= SB && SB <= BW_WHASH, "the sort buffer lives in the set's array");
+      static_assert(BW_WCAP <= 16384 && 16384 <= BW_WHASH, "the sort buffer lives in the set's array");
       const int64_t w0 = woff[b];
       const int nw = n_win;
+      int SB = 1024; // (the next power of two: most P3 windows are below 8 192)
+      while (SB < nw)
+        SB <<= 1;
       for (int i = tid; i < SB; i += BW_THREADS)
         hcol[i] = i < nw ? wlist[w0 + i] : INT_MAX;
       __syncthreads();
@@ -488,52 +490,8 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
     }
     if (tid == 0)
       dnum[b] = n_val;
-    // the table in ASCENDING order of the values' bit patterns (+0.0 stays code 0): the lanes of a slice -- rows of one entity
-    // type -- hold the same mathematical value in a slot, as a few bit patterns that then sit side by side in LDS (broadcasts
-    // and neighbouring banks instead of random ones).  Sorted in the set's own LDS, the set rebuilt with the positions as codes.
-    {
-      constexpr int SB = 8192;
-      static_assert(BW_DCAP <= SB && SB <= BW_DHASH, "the sort buffer lives in the set's array");
-      const int nv = n_val;
-      __syncthreads();
-      for (int i = tid; i < SB; i += BW_THREADS)
-        hval[i] = i < nv ? tab[i] : ~0ull;
-      __syncthreads();
-      for (int k = 2; k <= SB; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1)
-        {
-          for (int i = tid; i < SB; i += BW_THREADS)
-          {
-            const int l = i ^ j;
-            if (l > i)
-            {
-              const unsigned long long a = hval[i], c = hval[l];
-              const bool up = (i & k) == 0;
-              if ((a > c) == up)
-              {
-                hval[i] = c;
-                hval[l] = a;
-              }
-            }
-          }
-          __syncthreads();
-        }
-      for (int i = tid; i < nv; i += BW_THREADS)
-        tab[i] = hval[i];
-      __syncthreads();
-      for (int k = tid; k < BW_DHASH; k += BW_THREADS)
-        hval[k] = ~0ull;
-      __syncthreads();
-      for (int i = tid + 1; i < nv; i += BW_THREADS) // (entry 0, +0.0, is not looked up)
-      {
-        const unsigned long long v = tab[i];
-        unsigned h = (unsigned)(((v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
-        while (atomicCAS(&hval[h], ~0ull, v) != ~0ull)
-          h = (h + 1) & (BW_DHASH - 1);
-        hcode[h] = (uint16_t)i;
-      }
-      __syncthreads();
-    }
+    // (the table stays in arrival order: sorting it by bit pattern -- neighbouring lanes then read neighbouring slots -- was
+    // measured and bought nothing, 0.3013 against 0.3023 ms at 6.2 M rows of P3: the product is bound by its bytes, not by LDS)
     for (int q = tid; q < BW_R; q += BW_THREADS)
     {
       const int32_t r = perm[(int64_t)b * BW_R + q];
@@ -707,10 +665,11 @@ static int bw_structure(zzz_ctx* ctx)
   const int32_t nblk = (nrows + BW_R - 1) / BW_R;
   ctx->bw_struct_ok = false;
   // Morton order of the rows' nodes
-  DevBuf<double> dofx, bbox;
-  DevBuf<uint32_t> key, key2;
-  DevBuf<int32_t> val;
-  if (int rc = dof_coords_device(ctx, dofx))
+  // (scratch kept in the context: hipFree waits for the whole device -- other ranks' kernels on a shared GPU included)
+  DevBuf<double>&dofx = ctx->bw_dofx, &bbox = ctx->bw_bbox;
+  DevBuf<uint32_t>&key = ctx->bw_key, &key2 = ctx->bw_key2;
+  DevBuf<int32_t>& val = ctx->bw_val;
+  if (int rc = dof_coords_device(ctx, dofx, ctx->bw_first))
     return rc;
   ZZZ_HIP(ctx, bbox.alloc(9));
   ZZZ_HIP(ctx, hipMemsetAsync(bbox.p, 0, 9 * sizeof(double), s));
@@ -718,7 +677,8 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, key2.alloc((size_t)nrows));
   ZZZ_HIP(ctx, val.alloc((size_t)nrows));
   ZZZ_HIP(ctx, ctx->bw_order.alloc((size_t)nrows));
-  hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, dofx.p, (int64_t)ctx->n_owned, bbox.p);
+  // (the nodes of a Lagrange space lie in the convex hull of their cells' vertices: the vertices' box will do, and they are few)
+  hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, ctx->x.p, ctx->nverts, bbox.p);
   hipLaunchKernelGGL(k_bw_cellsize, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((ctx->ncells + 255) / 256, 2048))), dim3(256), 0, s,
                      ctx->x.p, ctx->cell_verts.p, ctx->ncells, bbox.p);
   hipLaunchKernelGGL(k_bw_keys, dim3((unsigned)std::min<int64_t>(((int64_t)nrows + 255) / 256, 4096)), dim3(256), 0, s, dofx.p, bbox.p,
@@ -740,7 +700,7 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_chunks.p + nblk, 0, sizeof(int32_t), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_wn.p + nblk, 0, sizeof(int32_t), s));
   const unsigned grid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
-  DevBuf<int32_t> hid;
+  DevBuf<int32_t>& hid = ctx->bw_hid;
   ZZZ_HIP(ctx, hid.alloc((size_t)grid * BW_WHASH));
   hipLaunchKernelGGL(k_bw_block<false>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
                      ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, (const int64_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
@@ -841,12 +801,11 @@ int sellp_win_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemsetAsync(info.p, 0, 8 * sizeof(int32_t), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_vcode.p, 0, (size_t)ctx->bw_chunks * 1024, s));
   const unsigned vgrid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
-  DevBuf<uint16_t> hcode;
+  DevBuf<uint16_t>& hcode = ctx->bw_hcode;
   ZZZ_HIP(ctx, hcode.alloc((size_t)vgrid * BW_DHASH));
   hipLaunchKernelGGL(k_bw_values, dim3(vgrid), dim3(BW_THREADS), 0, s, ctx->bw_perm.p, nblk,
                      ctx->rowptr.p, reinterpret_cast<const unsigned long long*>(ctx->vals.p), reinterpret_cast<const int2*>(ctx->bw_desc.p),
                      ctx->bw_vcode.p, reinterpret_cast<unsigned long long*>(ctx->bw_dict.p), ctx->bw_dnum.p, info.p, hcode.p);
-  ZZZ_HIP(ctx, hipStreamSynchronize(s)); // (hcode is released on return)
   ZZZ_HIP(ctx, hipGetLastError());
   int32_t h[8];
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
