@@ -113,11 +113,12 @@ def merge(pdir, tag, cfg="c2"):
             kern["spmv"]["bytes_streamed"] = st
             kern["spmv"]["corrected_over_streamed"] = kern["spmv"]["hbm_bytes_corrected"] / st
             # Both readings of the counters, and what the kernel must move at least (`bytes_streamed`: what it addresses).
-            # MI355X_MICROARCH.md prescribes 2 x FETCH_SIZE + WRITE_SIZE for gfx950 ("calibrate on a known byte count in your
-            # own access pattern"): that holds for the wide coalesced streams of the CG vector kernels (k_update_xr / k_update_p
-            # above reproduce their 26 / 42 B per row with it).  For spmv_one_kernel's 16-B loads at 8-B alignment the
-            # UNCORRECTED sum lies below the bytes the kernel addresses (the counter under-reports) and the corrected one above:
-            # the truth is bracketed, traffic_low <= HBM bytes <= traffic_high, and both are within ~1.2x of the compulsory bytes.
+            # MI355X_MICROARCH.md prescribes 2 x FETCH_SIZE + WRITE_SIZE for gfx950, "calibrated on a known byte count in your own
+            # access pattern": tools/micro/fetch_calib.hip does that for every read shape of this library's kernels (wide 16-B / 8-B
+            # streams, non-temporal or not, 16-B loads at 8-B alignment as spmv_one_kernel's x loads, 24-B records as
+            # spmv_blk3_kernel's) -- 2.00 bytes per FETCH_SIZE byte for all of them, WRITE_SIZE counts bytes
+            # (profiles/r06_fetch_calibration.txt).  So `traffic` = traffic_high; traffic_low (the counters as printed) is kept
+            # because round 5 reported it for spmv_one_kernel.
             raw = kern["spmv"]["hbm_bytes_uncorrected"]
             kern["spmv"]["uncorrected_over_streamed"] = raw / st
             kern["spmv"]["traffic_low"] = raw
