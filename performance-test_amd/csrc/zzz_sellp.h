@@ -78,11 +78,11 @@ int sellp_win_build(zzz_ctx* ctx);
 bool sellp_win_serves(const zzz_ctx* ctx);
 int sellp_win_grid(const zzz_ctx* ctx, int64_t items);
 bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
-                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr);
+                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr, const ChebEpi* epi = nullptr);
 // block-row form for block size 3 (zzz_sellp_blk.hip)
 int sellp_blk_build(zzz_ctx* ctx);
 bool sellp_blk_serves(const zzz_ctx* ctx);
 int sellp_blk_grid(const zzz_ctx* ctx, int64_t items);
 bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
-                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr);
+                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr, const ChebEpi* epi = nullptr);
 } // namespace zzz

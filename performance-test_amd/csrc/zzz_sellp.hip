@@ -615,7 +615,7 @@ bool sellp_active(zzz_ctx* ctx)
     // was a dead wait until the poll's time-out (round 5, found by tools/soak_driver.sh: elasticity P2, two ranks).
     // The special forms first (block rows for block size 3, zzz_sellp_blk.hip; block windows for long scalar rows,
     // zzz_sellp_win.hip): where one of them serves the product, the stream's value dictionaries are not built -- the launches
-    // that still take the generic kernel (a Chebyshev epilogue, a folded all-reduce) read its values as doubles.  7.6 ms per
+    // that still take the generic kernel (a folded all-reduce: tools build only) read its values as doubles.  7.6 ms per
     // assembly at 6.2 M rows of P3, 3 ms at C4.  A failed build leaves the stream as it is.
     ctx->sp_dict_done = true;
     ctx->sp_dict_on = ctx->sp_sd_on = ctx->sp_sd_all = false;
@@ -712,9 +712,9 @@ static void launch_one(zzz_ctx* ctx, int grid, const double* x, double* y, doubl
     nt = (ctx->spmv_variant & 1) != 0;
   // special: the caller sized the grid and chose the list for the block-row kernel (1: block size 3) or the block-window kernel
   // (2: long scalar rows)
-  if (special == 1 && launch_sellp_blk(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
+  if (special == 1 && launch_sellp_blk(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr, epi))
     return;
-  if (special == 2 && launch_sellp_win(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
+  if (special == 2 && launch_sellp_win(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr, epi))
     return;
   if (!epi && !tail.parts && launch_sellp_pipe(ctx, DOT, nt, grid, x, y, partials, stop, group_list, nlist, rvec, nn_is_rr))
     return;
@@ -785,7 +785,8 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr; // CgState::converged
   const bool plain = !epi && !(partials && ctx->tail_armed);
-  const int blk = plain ? (sellp_blk_serves(ctx) ? 1 : (sellp_win_serves(ctx) ? 2 : 0)) : 0;
+  const bool no_tail = !(partials && ctx->tail_armed); // (the special forms carry the Chebyshev epilogue, not the folded all-reduce)
+  const int blk = no_tail ? (sellp_blk_serves(ctx) ? 1 : (sellp_win_serves(ctx) ? 2 : 0)) : 0;
   const int gs = blk == 1 ? sellp_blk_grid(ctx, ctx->bk_slices) : blk == 2 ? sellp_win_grid(ctx, ctx->bw_nblk)
                           : sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec), plain);
 #ifdef ZZZ_EXPERIMENTS
@@ -843,7 +844,8 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
 {
   const int* stop = partials ? reinterpret_cast<const int*>(ctx->state.p) : nullptr;
   const bool plain = !epi && !(partials && ctx->tail_armed);
-  const int blk = !plain ? 0 : (sellp_blk_serves(ctx) && ctx->bk_have_split) ? 1 : (sellp_win_serves(ctx) && ctx->bw_have_split) ? 2 : 0;
+  const bool no_tail = !(partials && ctx->tail_armed);
+  const int blk = !no_tail ? 0 : (sellp_blk_serves(ctx) && ctx->bk_have_split) ? 1 : (sellp_win_serves(ctx) && ctx->bw_have_split) ? 2 : 0;
   const int64_t gi = blk == 1 ? ctx->bk_n_interior : blk == 2 ? ctx->bw_n_interior : ctx->n_groups_interior;
   const int64_t gb = blk == 1 ? ctx->bk_n_boundary : blk == 2 ? ctx->bw_n_boundary : ctx->n_groups_boundary;
   const int32_t* list_in = blk == 1 ? ctx->bk_list_interior.p : blk == 2 ? ctx->bw_list_interior.p : ctx->groups_interior.p;

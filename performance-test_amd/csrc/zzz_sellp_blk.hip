@@ -22,8 +22,8 @@
 // valid or out-of-range x (buffer loads return 0 there).
 //
 // When it applies: block size 3, natural row order, at most BK_TAB_MAX distinct blocks (the LDS copy), 16-bit column codes
-// suffice, no Chebyshev epilogue / folded all-reduce on the launch (those stay on the generic kernel, like spmv_one_kernel's
-// exceptions).  Otherwise nothing changes.  ZZZ_SELLP_BLK=0 switches it off (A/B, parity tests), 2 forces it below 100 000 nodes.
+// suffice, no folded all-reduce on the launch (tools build; that stays on the generic kernel).  The Chebyshev-Jacobi polynomial's
+// terms ride on it as epilogues exactly as on the generic kernel (CHEB: C4's solve with -pc_type chebyshev_jacobi 419 -> 191 ms).  Otherwise nothing changes.  ZZZ_SELLP_BLK=0 switches it off (A/B, parity tests), 2 forces it below 100 000 nodes.
 // Built at the stream's first use after an assembly (sellp_active), from the CSR matrix of record, on the device.
 #include <algorithm>
 #include <cstdlib>
@@ -502,7 +502,7 @@ __device__ inline unsigned bk_code16(const uint4v& a, const uint4v& b, int e)
 
 // FORM 1: the table's rows (nine doubles) in LDS; FORM 2: the rows as nine 16-bit byte offsets in memory (p_rows16, 32 B per
 // row: L2-resident), the values they point at in LDS (p_tab = the dictionary then, a.ntab its entries)
-template <bool DOT, bool SR, bool NT, int FORM>
+template <bool DOT, bool SR, bool NT, int FORM, bool CHEB = false>
 __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __restrict__ p_desc, const int32_t* __restrict__ p_meta,
                                                                const int32_t* __restrict__ p_flags,
                                                                const uint16_t* __restrict__ p_bcode,
@@ -510,8 +510,9 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
                                                                const uint16_t* __restrict__ p_rows16,
                                                                const double* __restrict__ p_x, double* __restrict__ p_y,
                                                                const double* __restrict__ p_rvec, const int32_t* __restrict__ p_list,
-                                                               BlkArgs a)
+                                                               BlkArgs a, ChebEpi epi)
 {
+  static_assert(!(CHEB && SR), "a Chebyshev term has no residual vector of its own");
   extern __shared__ __attribute__((aligned(16))) double bk_lds[]; // the block table: [entry][9]
   __shared__ double red[BK_THREADS / 64];
   const int lane = threadIdx.x & 63;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
     const int s = S.s;
     const int node24 = (s * 64 + lane) * 24;
     double xr0 = 0.0, xr1 = 0.0, xr2 = 0.0, rr0 = 0.0, rr1 = 0.0, rr2 = 0.0;
-    if (DOT)
+    if (DOT || CHEB)
     {
       const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs_x, node24, 0, 0);
       const auto u2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, node24 + 16, 0, 0);
@@ -723,6 +724,37 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
     }
     if (S.nch == 0)
       fetch(it_next, N);
+    if (CHEB)
+    {
+      // a term of the Chebyshev-Jacobi polynomial as the epilogue (ChebEpi, zzz_internal.h; the generic kernel's arithmetic
+      // row by row): x is d, y the next d; DOT marks the last term (sums of <r,z> and the norm, nothing else stored but z)
+      if (s * 64 + lane < a.nnodes)
+      {
+        const int r0 = (s * 64 + lane) * 3;
+        const double sum[3] = {a0, a1, a2}, xr[3] = {xr0, xr1, xr2};
+        double dn[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+        {
+          const double gi = -1.0 * (epi.dinv[r0 + c] * sum[c]) + epi.g[r0 + c];
+          dn[c] = epi.c1 * xr[c] + epi.c2 * gi;
+          const double zi = epi.z[r0 + c] + dn[c];
+          epi.z[r0 + c] = zi;
+          if (DOT)
+          {
+            const double ri = epi.r[r0 + c];
+            dot_rx += ri * zi;
+            dot_nn += a.nn_is_rr ? ri * ri : zi * zi;
+          }
+          else
+          {
+            epi.g[r0 + c] = gi;
+            p_y[r0 + c] = dn[c];
+          }
+        }
+      }
+    }
+    else
     {
       uint4v o;
       o.x = (unsigned)__double2loint(a0), o.y = (unsigned)__double2hiint(a0);
@@ -732,7 +764,7 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
       o2.x = (unsigned)__double2loint(a2), o2.y = (unsigned)__double2hiint(a2);
       __builtin_amdgcn_raw_buffer_store_b64(o2, rs_y, node24 + 16, 0, 0);
     }
-    if (DOT && s * 64 + lane < a.nnodes)
+    if (!CHEB && DOT && s * 64 + lane < a.nnodes)
     {
       dot += a0 * xr0;
       dot += a1 * xr1;
@@ -767,17 +799,18 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
   }
   if (DOT)
   {
-    const double sres = block_reduce_sum(dot, red);
+    const double sres = CHEB ? 0.0 : block_reduce_sum(dot, red);
     double s1 = 0.0, s2 = 0.0;
-    if (SR)
+    if (SR || CHEB)
     {
       s1 = block_reduce_sum(dot_rx, red);
       s2 = block_reduce_sum(dot_nn, red);
     }
     if (threadIdx.x == 0)
     {
-      a.partials[blockIdx.x] = sres;
-      if (SR)
+      if (!CHEB)
+        a.partials[blockIdx.x] = sres;
+      if (SR || CHEB)
       {
         a.partials[a.pstride + blockIdx.x] = s1;
         a.partials[2 * a.pstride + blockIdx.x] = s2;
@@ -917,6 +950,14 @@ int sellp_blk_build(zzz_ctx* ctx)
     ZZZ_BK_ATTR(true, false, false);
     ZZZ_BK_ATTR(false, false, true);
     ZZZ_BK_ATTR(false, false, false);
+#define ZZZ_BK_ATTRC(DOT, NT)                                                                                                      \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_blk3_kernel<DOT, false, NT, 1, true>),                            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BK_TAB_MAX * 72)
+    ZZZ_BK_ATTRC(true, true);
+    ZZZ_BK_ATTRC(true, false);
+    ZZZ_BK_ATTRC(false, true);
+    ZZZ_BK_ATTRC(false, false);
+#undef ZZZ_BK_ATTRC
 #undef ZZZ_BK_ATTR
     ZZZ_HIP(ctx, hipGetLastError());
     ctx->bk_lds_attr = true;
@@ -938,7 +979,7 @@ int sellp_blk_grid(const zzz_ctx* ctx, int64_t items)
 }
 
 bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
-                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr)
+                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr, const ChebEpi* epi)
 {
   if (!sellp_blk_serves(ctx))
     return false;
@@ -955,10 +996,11 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
   a.nn_is_rr = nn_is_rr;
   const size_t lds = f1 ? (size_t)ctx->bk_entries * 72 : (size_t)ctx->bk_ndict * 8;
   const double* tabp = f1 ? ctx->bk_tab.p : ctx->bk_vdict.p;
-#define ZZZ_BK_GO2(DOT, SR, NT, FORM)                                                                                              \
-  hipLaunchKernelGGL((spmv_blk3_kernel<DOT, SR, NT, FORM>), dim3(grid), dim3(BK_THREADS), lds, ctx->stream,                        \
+#define ZZZ_BK_GO3(DOT, SR, NT, FORM, CHEB, EPI)                                                                                   \
+  hipLaunchKernelGGL((spmv_blk3_kernel<DOT, SR, NT, FORM, CHEB>), dim3(grid), dim3(BK_THREADS), lds, ctx->stream,                  \
                      reinterpret_cast<const int2*>(ctx->bk_desc.p), ctx->bk_meta.p, ctx->bk_flags.p, ctx->bk_code.p, ctx->bk_ccode.p,  \
-                     tabp, ctx->bk_rows16.p, x, y, rvec, list, a)
+                     tabp, ctx->bk_rows16.p, x, y, rvec, list, a, EPI)
+#define ZZZ_BK_GO2(DOT, SR, NT, FORM) ZZZ_BK_GO3(DOT, SR, NT, FORM, false, ChebEpi())
 #define ZZZ_BK_GO(DOT, SR, NT)                                                                                                     \
   do                                                                                                                               \
   {                                                                                                                                \
@@ -967,7 +1009,32 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
     else                                                                                                                           \
       ZZZ_BK_GO2(DOT, SR, NT, 2);                                                                                                  \
   } while (0)
-  if (dot && rvec)
+#define ZZZ_BK_GOC(DOT, NT)                                                                                                        \
+  do                                                                                                                               \
+  {                                                                                                                                \
+    if (f1)                                                                                                                        \
+      ZZZ_BK_GO3(DOT, false, NT, 1, true, *epi);                                                                                   \
+    else                                                                                                                           \
+      ZZZ_BK_GO3(DOT, false, NT, 2, true, *epi);                                                                                   \
+  } while (0)
+  if (epi)
+  {
+    if (dot)
+    {
+      if (nt)
+        ZZZ_BK_GOC(true, true);
+      else
+        ZZZ_BK_GOC(true, false);
+    }
+    else
+    {
+      if (nt)
+        ZZZ_BK_GOC(false, true);
+      else
+        ZZZ_BK_GOC(false, false);
+    }
+  }
+  else if (dot && rvec)
   {
     if (nt)
       ZZZ_BK_GO(true, true, true);
@@ -988,6 +1055,8 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
     else
       ZZZ_BK_GO(false, false, false);
   }
+#undef ZZZ_BK_GOC
+#undef ZZZ_BK_GO3
 #undef ZZZ_BK_GO2
 #undef ZZZ_BK_GO
   return true;

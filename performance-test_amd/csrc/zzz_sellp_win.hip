@@ -23,7 +23,7 @@
 //
 // When it applies: scalar matrices and those of block size 3 the block-row form declined (elasticity P2 / P3: their scalar rows
 // are long rows like any), natural row order of the stream, at least BW_MIN_AVG entries per row on average, every block
-// within the LDS budget, no Chebyshev epilogue / folded all-reduce on the launch (those stay on the generic kernel).
+// within the LDS budget, no folded all-reduce on the launch (tools build).  Chebyshev-Jacobi terms ride on it as epilogues (CHEB).
 // ZZZ_SELLP_BWIN: 0 never, 1 (default) from 2 000 000 rows on (488 blocks: two rounds of one workgroup per CU; with fewer blocks
 // than CUs the generic product wins: 24^3 sub-cubes of P3, 95 blocks, 0.036 against 0.046 ms -- but 0.027 with 2 048-row
 // blocks, so the limit is the block count, not the form), 2 always.
@@ -536,15 +536,16 @@ struct WinArgs
   int pstride, nn_is_rr;
 };
 
-template <bool DOT, bool SR, bool NT>
+template <bool DOT, bool SR, bool NT, bool CHEB = false>
 __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __restrict__ p_perm, const int2* __restrict__ p_desc,
                                                               const int64_t* __restrict__ p_woff, const int32_t* __restrict__ p_wlist,
                                                               const uint16_t* __restrict__ p_ccode, const uint16_t* __restrict__ p_vcode,
                                                               const double* __restrict__ p_dict, const int32_t* __restrict__ p_dnum,
                                                               const double* __restrict__ p_x, double* __restrict__ p_y,
                                                               const double* __restrict__ p_rvec, const int32_t* __restrict__ p_list,
-                                                              WinArgs a)
+                                                              WinArgs a, ChebEpi epi)
 {
+  static_assert(!(CHEB && SR), "a Chebyshev term has no residual vector of its own");
   extern __shared__ __attribute__((aligned(16))) double bw_lds[]; // [0, BW_WCAP): the window's x; behind it the dictionary
   __shared__ double red[BW_THREADS / 64];
   double* const xwin = bw_lds;
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
         continue; // (slices are ordered by length: the rest of the block is empty too, but other wavefronts' are not)
       const int32_t r = p_perm[(int64_t)b * BW_R + s * 64 + lane];
       double xr = 0.0, rr = 0.0;
-      if (DOT && r >= 0)
+      if ((DOT || CHEB) && r >= 0)
       {
         xr = p_x[r];
         if (SR)
@@ -621,7 +622,29 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
         for (int e = 0; e < 8; ++e)
           sum += ve[e] * xe[e]; // (entries beyond a row's last carry code 0 = +0.0 and window index 0: + 0 * x)
       }
-      if (r >= 0)
+      if (CHEB)
+      {
+        // a term of the Chebyshev-Jacobi polynomial as the epilogue (ChebEpi; the generic kernel's arithmetic): x is d, y the next d
+        if (r >= 0)
+        {
+          const double gi = -1.0 * (epi.dinv[r] * sum) + epi.g[r];
+          const double dn = epi.c1 * xr + epi.c2 * gi;
+          const double zi = epi.z[r] + dn;
+          epi.z[r] = zi;
+          if (DOT)
+          {
+            const double ri = epi.r[r];
+            dot_rx += ri * zi;
+            dot_nn += a.nn_is_rr ? ri * ri : zi * zi;
+          }
+          else
+          {
+            epi.g[r] = gi;
+            p_y[r] = dn;
+          }
+        }
+      }
+      else if (r >= 0)
       {
         p_y[r] = sum;
         if (DOT)
@@ -638,17 +661,18 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
   }
   if (DOT)
   {
-    const double sres = block_reduce_sum(dot, red);
+    const double sres = CHEB ? 0.0 : block_reduce_sum(dot, red);
     double s1 = 0.0, s2 = 0.0;
-    if (SR)
+    if (SR || CHEB)
     {
       s1 = block_reduce_sum(dot_rx, red);
       s2 = block_reduce_sum(dot_nn, red);
     }
     if (threadIdx.x == 0)
     {
-      a.partials[blockIdx.x] = sres;
-      if (SR)
+      if (!CHEB)
+        a.partials[blockIdx.x] = sres;
+      if (SR || CHEB)
       {
         a.partials[a.pstride + blockIdx.x] = s1;
         a.partials[2 * a.pstride + blockIdx.x] = s2;
@@ -773,7 +797,9 @@ int sellp_win_build(zzz_ctx* ctx)
 {
   ctx->bw_on = false;
   // (ZZZ_SELLP_BWIN=2 also takes P2's rows of ~27 -- the tests of the form at small sizes -- but never P1's 15)
-  const int64_t min_avg = ctx->sellp_bwin == 2 ? 20 : BW_MIN_AVG;
+  // (block size 3 and rows of ~44: elasticity P1 where the block-row form declined -- the generic product with its x windows is
+  // faster there, 324 against 427 ms per C4 solve; its P2 / P3, rows of 80-170, take the form)
+  const int64_t min_avg = ctx->sellp_bwin == 2 ? 20 : (ctx->bs == 3 ? 64 : BW_MIN_AVG);
   // (block size 3: the block-row form first -- elasticity P1, 2.4 x; where it declines, P2 / P3, the scalar rows are long rows like any)
   if (!ctx->sellp_bwin || ctx->bk_on || ctx->sp_sorted || ctx->nrows <= 0 || ctx->nnz < min_avg * ctx->nrows)
     return ZZZ_OK;
@@ -825,6 +851,14 @@ int sellp_win_build(zzz_ctx* ctx)
     ZZZ_BW_ATTR(true, false, false);
     ZZZ_BW_ATTR(false, false, true);
     ZZZ_BW_ATTR(false, false, false);
+#define ZZZ_BW_ATTRC(DOT, NT)                                                                                                      \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_win_kernel<DOT, false, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (BW_WCAP + BW_DCAP) * 8)
+    ZZZ_BW_ATTRC(true, true);
+    ZZZ_BW_ATTRC(true, false);
+    ZZZ_BW_ATTRC(false, true);
+    ZZZ_BW_ATTRC(false, false);
+#undef ZZZ_BW_ATTRC
 #undef ZZZ_BW_ATTR
     ZZZ_HIP(ctx, hipGetLastError());
     ctx->bw_lds_attr = true;
@@ -856,7 +890,7 @@ int sellp_win_grid(const zzz_ctx* ctx, int64_t items)
 }
 
 bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
-                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr)
+                      const int32_t* list, int64_t nlist, const double* rvec, int nn_is_rr, const ChebEpi* epi)
 {
   if (!sellp_win_serves(ctx))
     return false;
@@ -869,11 +903,29 @@ bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
   a.pstride = SPMV_PSTRIDE;
   a.nn_is_rr = nn_is_rr;
   const size_t lds = (size_t)(BW_WCAP + BW_DCAP) * 8;
-#define ZZZ_BW_GO(DOT, SR, NT)                                                                                                     \
-  hipLaunchKernelGGL((spmv_win_kernel<DOT, SR, NT>), dim3(grid), dim3(BW_THREADS), lds, ctx->stream, ctx->bw_perm.p,               \
+#define ZZZ_BW_GO4(DOT, SR, NT, CHEB, EPI)                                                                                         \
+  hipLaunchKernelGGL((spmv_win_kernel<DOT, SR, NT, CHEB>), dim3(grid), dim3(BW_THREADS), lds, ctx->stream, ctx->bw_perm.p,         \
                      reinterpret_cast<const int2*>(ctx->bw_desc.p), ctx->bw_woff.p, ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_vcode.p, \
-                     ctx->bw_dict.p, ctx->bw_dnum.p, x, y, rvec, list, a)
-  if (dot && rvec)
+                     ctx->bw_dict.p, ctx->bw_dnum.p, x, y, rvec, list, a, EPI)
+#define ZZZ_BW_GO(DOT, SR, NT) ZZZ_BW_GO4(DOT, SR, NT, false, ChebEpi())
+  if (epi)
+  {
+    if (dot)
+    {
+      if (nt)
+        ZZZ_BW_GO4(true, false, true, true, *epi);
+      else
+        ZZZ_BW_GO4(true, false, false, true, *epi);
+    }
+    else
+    {
+      if (nt)
+        ZZZ_BW_GO4(false, false, true, true, *epi);
+      else
+        ZZZ_BW_GO4(false, false, false, true, *epi);
+    }
+  }
+  else if (dot && rvec)
   {
     if (nt)
       ZZZ_BW_GO(true, true, true);
@@ -894,6 +946,7 @@ bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
     else
       ZZZ_BW_GO(false, false, false);
   }
+#undef ZZZ_BW_GO4
 #undef ZZZ_BW_GO
   return true;
 }
