@@ -273,6 +273,15 @@ def run_other_config(name, steps=3, unstructured=None):
         ctx_windows = ctx.spmv_x_windows()[0] > 0
         values = ctx.spmv_values_info()
         unorm = ctx.vec_norm(zzz.VEC_U)
+        if name in ("c4_total", "c5_rank"):
+            # beside the measurement: one solve with the library's polynomial preconditioner on the same system (its terms ride on
+            # the same product kernel as epilogues)
+            ctx.sync()
+            tc = time.perf_counter()
+            itc, rnc, r0c = ctx.cg_solve(variant=zzz.CG_PETSC, pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-8, max_it=10000)
+            ctx.sync()
+            extra["alt_preconditioner"] = {"pc_type": "chebyshev_jacobi (degree 3, ratio 60)", "ZZZ Solve ms": (time.perf_counter() - tc) * 1e3,
+                                           "krylov_iterations": itc, "relative_residual": rnc / r0c if r0c else 0.0}
         if unstructured:
             # what the structured feed's luck was worth: entries kept in the stream, and the matrix-free action here
             extra["stream_entries_over_pattern"] = sinfo[7] / nnz
