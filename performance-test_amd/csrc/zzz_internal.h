@@ -300,6 +300,9 @@ struct zzz_ctx
   zzz::DevBuf<int32_t> bw_order, bw_perm, bw_desc, bw_wlist, bw_blk_chunks, bw_blk_wn, bw_dnum, bw_info, bw_list_interior, bw_list_boundary;
   zzz::DevBuf<int64_t> bw_chunk0, bw_woff;
   zzz::DevBuf<uint16_t> bw_ccode, bw_vcode, bw_hcode;
+  zzz::DevBuf<uint32_t> bw_cpack, bw_vpack; // the same codes packed, 12 B per lane and chunk (where the block's flag says so)
+  zzz::DevBuf<uint8_t> bw_cflag, bw_vflag;
+  int64_t bw_packed_planes = 0;
   zzz::DevBuf<uint32_t> bw_key, bw_key2;
   zzz::DevBuf<int32_t> bw_val, bw_hid, bw_first; // (scratch of the builders, kept: hipFree waits for the whole device)
   zzz::DevBuf<double> bw_dofx, bw_bbox;

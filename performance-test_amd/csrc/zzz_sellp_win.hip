@@ -172,14 +172,15 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
                                                          int32_t* __restrict__ perm, int2* __restrict__ desc,
                                                          int32_t* __restrict__ wlist, uint16_t* __restrict__ ccode,
                                                          uint8_t* __restrict__ gflag, int* __restrict__ info,
-                                                         int32_t* __restrict__ hid_all)
+                                                         int32_t* __restrict__ hid_all, uint32_t* __restrict__ cpack,
+                                                         uint8_t* __restrict__ cflag)
 {
   int32_t* const hid = hid_all + (int64_t)blockIdx.x * BW_WHASH; // slot -> window index (this workgroup's scratch: L2)
   __shared__ int32_t hcol[BW_WHASH]; // the set of columns (-1: empty)
   __shared__ uint32_t skey[BW_R];    // rows by (length descending, position ascending)
   __shared__ int32_t sl_c0[BW_SLICES + 1];
   __shared__ int wsum[BW_THREADS / 64];
-  __shared__ int n_win, any_ghost, bad;
+  __shared__ int n_win, any_ghost, bad, max_delta;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int b = blockIdx.x; b < nblk; b += gridDim.x)
   {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
     for (int k = tid; k < BW_WHASH; k += BW_THREADS)
       hcol[k] = -1;
     if (tid == 0)
-      n_win = 0, any_ghost = 0, bad = 0;
+      n_win = 0, any_ghost = 0, bad = 0, max_delta = 0;
     __syncthreads();
     // the rows' lengths; the sort key: longer rows first, ties in block order (a bitonic sort: deterministic)
     for (int p = tid; p < BW_R; p += BW_THREADS)
@@ -395,15 +396,59 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
       const int64_t c0 = cb + sl_c0[s];
       const rp_t a = rowptr[r];
       const int len = (int)(rowptr[r + 1] - a);
+      // Every entry's window index twice: as 16 bits (ccode), and PACKED, 12 B per lane and chunk (cpack: the chunk's first
+      // index in 16 bits, then seven differences of 10 bits -- the window is in ascending column order, as a row's entries are:
+      // differences are positive and small, 69 % of P3's chunks below 256, all below 1 024).  The product reads the packed form
+      // where every difference of the block fits (cflag); entries beyond the row's last repeat the last index (difference 0).
+      unsigned w0 = 0, w1 = 0, w2 = 0;
+      int prev = 0, dmax = 0;
       for (int k = 0; k < len; ++k)
       {
         const int32_t c = cols[a + k];
         unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
         while (hcol[h] != c)
           h = (h + 1) & (BW_WHASH - 1);
-        ccode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)hid[h];
+        const int id = hid[h];
+        ccode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)id;
+        const int e = k & 7;
+        if (e == 0)
+          w0 = (unsigned)id, w1 = 0, w2 = 0;
+        else
+        {
+          const int d = id - prev;
+          dmax = max(dmax, d);
+          const unsigned long long dd = (unsigned long long)(unsigned)(d & 1023);
+          const int bit = 16 + 10 * (e - 1); // 16, 26, 36, 46, 56, 66, 76
+          if (bit < 32)
+          {
+            w0 |= (unsigned)(dd << bit);
+            if (bit + 10 > 32)
+              w1 |= (unsigned)(dd >> (32 - bit));
+          }
+          else if (bit < 64)
+          {
+            w1 |= (unsigned)(dd << (bit - 32));
+            if (bit + 10 > 64)
+              w2 |= (unsigned)(dd >> (64 - bit));
+          }
+          else
+            w2 |= (unsigned)(dd << (bit - 64));
+        }
+        prev = id;
+        if (e == 7 || k + 1 == len)
+        {
+          uint32_t* dst = cpack + ((c0 + (k >> 3)) * 64 + ln) * 3;
+          dst[0] = w0;
+          dst[1] = w1;
+          dst[2] = w2;
+        }
       }
+      if (dmax)
+        atomicMax(&max_delta, dmax);
     }
+    __syncthreads();
+    if (tid == 0)
+      cflag[b] = max_delta < 1024 ? 1 : 0;
     __syncthreads();
   }
 }
@@ -415,7 +460,8 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
                                                           const unsigned long long* __restrict__ vals, const int2* __restrict__ desc,
                                                           uint16_t* __restrict__ vcode, unsigned long long* __restrict__ dict,
                                                           int32_t* __restrict__ dnum, int* __restrict__ info,
-                                                          uint16_t* __restrict__ hcode_all)
+                                                          uint16_t* __restrict__ hcode_all, uint32_t* __restrict__ vpack,
+                                                          uint8_t* __restrict__ vflag)
 {
   uint16_t* const hcode = hcode_all + (int64_t)blockIdx.x * BW_DHASH; // slot -> code (this workgroup's scratch: L2)
   __shared__ unsigned long long hval[BW_DHASH];
@@ -489,7 +535,11 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
       continue;
     }
     if (tid == 0)
+    {
       dnum[b] = n_val;
+      vflag[b] = n_val <= 4096 ? 1 : 0; // the codes fit 12 bits: the product reads them packed, 12 B per lane and chunk (vpack)
+    }
+    const bool vp = n_val <= 4096;
     // (the table stays in arrival order: sorting it by bit pattern -- neighbouring lanes then read neighbouring slots -- was
     // measured and bought nothing, 0.3013 against 0.3023 ms at 6.2 M rows of P3: the product is bound by its bytes, not by LDS)
     for (int q = tid; q < BW_R; q += BW_THREADS)
@@ -502,7 +552,7 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
       const rp_t a = rowptr[r];
       const int len = (int)(rowptr[r + 1] - a);
       unsigned long long last = 0ull;
-      unsigned last_code = 0;
+      unsigned last_code = 0, p0 = 0, p1 = 0, p2 = 0;
       for (int k = 0; k < len; ++k)
       {
         const unsigned long long v = vals[a + k];
@@ -520,6 +570,34 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
           code = last_code;
         }
         vcode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)code;
+        if (vp)
+        {
+          const int e = k & 7, bit = 12 * e; // 0, 12, 24, 36, 48, 60, 72, 84
+          const unsigned long long cc = (unsigned long long)(code & 4095u);
+          if (e == 0)
+            p0 = p1 = p2 = 0;
+          if (bit < 32)
+          {
+            p0 |= (unsigned)(cc << bit);
+            if (bit + 12 > 32)
+              p1 |= (unsigned)(cc >> (32 - bit));
+          }
+          else if (bit < 64)
+          {
+            p1 |= (unsigned)(cc << (bit - 32));
+            if (bit + 12 > 64)
+              p2 |= (unsigned)(cc >> (64 - bit));
+          }
+          else
+            p2 |= (unsigned)(cc << (bit - 64));
+          if (e == 7 || k + 1 == len)
+          {
+            uint32_t* dst = vpack + ((c0 + (k >> 3)) * 64 + ln) * 3;
+            dst[0] = p0;
+            dst[1] = p1;
+            dst[2] = p2;
+          }
+        }
       }
     }
     __syncthreads();
@@ -540,6 +618,8 @@ template <bool DOT, bool SR, bool NT, bool CHEB = false>
 __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __restrict__ p_perm, const int2* __restrict__ p_desc,
                                                               const int64_t* __restrict__ p_woff, const int32_t* __restrict__ p_wlist,
                                                               const uint16_t* __restrict__ p_ccode, const uint16_t* __restrict__ p_vcode,
+                                                              const uint32_t* __restrict__ p_cpack, const uint32_t* __restrict__ p_vpack,
+                                                              const uint8_t* __restrict__ p_cflag, const uint8_t* __restrict__ p_vflag,
                                                               const double* __restrict__ p_dict, const int32_t* __restrict__ p_dnum,
                                                               const double* __restrict__ p_x, double* __restrict__ p_y,
                                                               const double* __restrict__ p_rvec, const int32_t* __restrict__ p_list,
@@ -563,6 +643,7 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
     const int b = p_list ? p_list[t] : (int)t;
     const int64_t w0 = p_woff[b];
     const int wn = (int)(p_woff[b + 1] - w0), dn = p_dnum[b];
+    const bool cpk = __builtin_amdgcn_readfirstlane((int)p_cflag[b]) != 0, vpk = __builtin_amdgcn_readfirstlane((int)p_vflag[b]) != 0;
     __syncthreads(); // the previous block's lookups are done
     // window and dictionary into LDS: every thread's (at most eight + four) entries requested before any is stored
     {
@@ -603,14 +684,66 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
           rr = p_rvec[r];
       }
       double sum = 0.0;
-      for (int j = 0; j < nch; ++j)
+      // The chunk's eight value codes and eight window indices: packed (12 B per lane each: 12-bit codes; a 16-bit first index
+      // and seven 10-bit differences) where the block allows, else 16 bits each.  One chunk of look-ahead: the raw words of
+      // chunk j + 1 are requested before chunk j is decoded and summed (two named stages, the body twice: no register that a
+      // load is still writing is copied) -- a slice is otherwise a chain load -> decode -> LDS -> sums per chunk.
+      struct Raw
       {
-        const uint4v vq = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p_vcode + (c0 + j) * 512) + lane)
-                             : reinterpret_cast<const uint4v*>(p_vcode + (c0 + j) * 512)[lane];
-        const uint4v cq = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p_ccode + (c0 + j) * 512) + lane)
-                             : reinterpret_cast<const uint4v*>(p_ccode + (c0 + j) * 512)[lane];
-        const unsigned vc[8] = {vq.x & 0xffffu, vq.x >> 16, vq.y & 0xffffu, vq.y >> 16, vq.z & 0xffffu, vq.z >> 16, vq.w & 0xffffu, vq.w >> 16};
-        const unsigned cc[8] = {cq.x & 0xffffu, cq.x >> 16, cq.y & 0xffffu, cq.y >> 16, cq.z & 0xffffu, cq.z >> 16, cq.w & 0xffffu, cq.w >> 16};
+        uint4v v, c; // (.w unused by the packed forms)
+      };
+      auto request = [&](int jj, Raw& R) {
+        if (vpk)
+        {
+          const uint32_t* __restrict__ vp = p_vpack + ((c0 + jj) * 64 + lane) * 3;
+          R.v.x = NT ? __builtin_nontemporal_load(vp) : vp[0];
+          R.v.y = NT ? __builtin_nontemporal_load(vp + 1) : vp[1];
+          R.v.z = NT ? __builtin_nontemporal_load(vp + 2) : vp[2];
+        }
+        else
+          R.v = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p_vcode + (c0 + jj) * 512) + lane)
+                   : reinterpret_cast<const uint4v*>(p_vcode + (c0 + jj) * 512)[lane];
+        if (cpk)
+        {
+          const uint32_t* __restrict__ cp = p_cpack + ((c0 + jj) * 64 + lane) * 3;
+          R.c.x = NT ? __builtin_nontemporal_load(cp) : cp[0];
+          R.c.y = NT ? __builtin_nontemporal_load(cp + 1) : cp[1];
+          R.c.z = NT ? __builtin_nontemporal_load(cp + 2) : cp[2];
+        }
+        else
+          R.c = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p_ccode + (c0 + jj) * 512) + lane)
+                   : reinterpret_cast<const uint4v*>(p_ccode + (c0 + jj) * 512)[lane];
+      };
+      auto consume = [&](const Raw& R) {
+        unsigned vc[8], cc[8];
+        if (vpk)
+        {
+          const unsigned a0 = R.v.x, a1 = R.v.y, a2 = R.v.z;
+          vc[0] = a0 & 4095u, vc[1] = (a0 >> 12) & 4095u, vc[2] = ((a0 >> 24) | (a1 << 8)) & 4095u, vc[3] = (a1 >> 4) & 4095u;
+          vc[4] = (a1 >> 16) & 4095u, vc[5] = ((a1 >> 28) | (a2 << 4)) & 4095u, vc[6] = (a2 >> 8) & 4095u, vc[7] = a2 >> 20;
+        }
+        else
+        {
+          vc[0] = R.v.x & 0xffffu, vc[1] = R.v.x >> 16, vc[2] = R.v.y & 0xffffu, vc[3] = R.v.y >> 16;
+          vc[4] = R.v.z & 0xffffu, vc[5] = R.v.z >> 16, vc[6] = R.v.w & 0xffffu, vc[7] = R.v.w >> 16;
+        }
+        if (cpk)
+        {
+          const unsigned b0 = R.c.x, b1 = R.c.y, b2 = R.c.z;
+          cc[0] = b0 & 0xffffu;
+          cc[1] = cc[0] + ((b0 >> 16) & 1023u);
+          cc[2] = cc[1] + (((b0 >> 26) | (b1 << 6)) & 1023u);
+          cc[3] = cc[2] + ((b1 >> 4) & 1023u);
+          cc[4] = cc[3] + ((b1 >> 14) & 1023u);
+          cc[5] = cc[4] + (((b1 >> 24) | (b2 << 8)) & 1023u);
+          cc[6] = cc[5] + ((b2 >> 2) & 1023u);
+          cc[7] = cc[6] + ((b2 >> 12) & 1023u);
+        }
+        else
+        {
+          cc[0] = R.c.x & 0xffffu, cc[1] = R.c.x >> 16, cc[2] = R.c.y & 0xffffu, cc[3] = R.c.y >> 16;
+          cc[4] = R.c.z & 0xffffu, cc[5] = R.c.z >> 16, cc[6] = R.c.w & 0xffffu, cc[7] = R.c.w >> 16;
+        }
         double xe[8], ve[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -620,7 +753,24 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          sum += ve[e] * xe[e]; // (entries beyond a row's last carry code 0 = +0.0 and window index 0: + 0 * x)
+          sum += ve[e] * xe[e]; // (entries beyond a row's last carry code 0 = +0.0 and repeat an index: + 0 * x)
+      };
+      {
+        Raw A, B;
+        A.v = A.c = B.v = B.c = uint4v{0u, 0u, 0u, 0u};
+        request(0, A);
+        for (int jj = 0; jj < nch; jj += 2)
+        {
+          if (jj + 1 < nch)
+            request(jj + 1, B);
+          consume(A);
+          if (jj + 1 < nch)
+          {
+            if (jj + 2 < nch)
+              request(jj + 2, A);
+            consume(B);
+          }
+        }
       }
       if (CHEB)
       {
@@ -728,7 +878,7 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hid.alloc((size_t)grid * BW_WHASH));
   hipLaunchKernelGGL(k_bw_block<false>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
                      ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, (const int64_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
-                     (int2*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, ctx->bw_gflag.p, info.p, hid.p);
+                     (int2*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, ctx->bw_gflag.p, info.p, hid.p, (uint32_t*)nullptr, (uint8_t*)nullptr);
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
@@ -754,9 +904,15 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bw_ccode.alloc((size_t)tot[0] * 512));
   ZZZ_HIP(ctx, ctx->bw_vcode.alloc((size_t)tot[0] * 512));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_ccode.p, 0, (size_t)tot[0] * 1024, s));
+  ZZZ_HIP(ctx, ctx->bw_cpack.alloc((size_t)tot[0] * 192)); // the packed forms: 12 B per lane and chunk
+  ZZZ_HIP(ctx, ctx->bw_vpack.alloc((size_t)tot[0] * 192));
+  ZZZ_HIP(ctx, ctx->bw_cflag.alloc((size_t)nblk));
+  ZZZ_HIP(ctx, ctx->bw_vflag.alloc((size_t)nblk));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_cpack.p, 0, (size_t)tot[0] * 768, s));
   hipLaunchKernelGGL(k_bw_block<true>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
                      ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, ctx->bw_chunk0.p, ctx->bw_woff.p, ctx->bw_perm.p,
-                     reinterpret_cast<int2*>(ctx->bw_desc.p), ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, hid.p);
+                     reinterpret_cast<int2*>(ctx->bw_desc.p), ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, hid.p, ctx->bw_cpack.p,
+                     ctx->bw_cflag.p);
   ZZZ_HIP(ctx, hipGetLastError());
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
@@ -826,12 +982,14 @@ int sellp_win_build(zzz_ctx* ctx)
   DevBuf<int32_t>& info = ctx->bw_info;
   ZZZ_HIP(ctx, hipMemsetAsync(info.p, 0, 8 * sizeof(int32_t), s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_vcode.p, 0, (size_t)ctx->bw_chunks * 1024, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_vpack.p, 0, (size_t)ctx->bw_chunks * 768, s));
   const unsigned vgrid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
   DevBuf<uint16_t>& hcode = ctx->bw_hcode;
   ZZZ_HIP(ctx, hcode.alloc((size_t)vgrid * BW_DHASH));
   hipLaunchKernelGGL(k_bw_values, dim3(vgrid), dim3(BW_THREADS), 0, s, ctx->bw_perm.p, nblk,
                      ctx->rowptr.p, reinterpret_cast<const unsigned long long*>(ctx->vals.p), reinterpret_cast<const int2*>(ctx->bw_desc.p),
-                     ctx->bw_vcode.p, reinterpret_cast<unsigned long long*>(ctx->bw_dict.p), ctx->bw_dnum.p, info.p, hcode.p);
+                     ctx->bw_vcode.p, reinterpret_cast<unsigned long long*>(ctx->bw_dict.p), ctx->bw_dnum.p, info.p, hcode.p, ctx->bw_vpack.p,
+                     ctx->bw_vflag.p);
   ZZZ_HIP(ctx, hipGetLastError());
   int32_t h[8];
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -864,17 +1022,25 @@ int sellp_win_build(zzz_ctx* ctx)
     ctx->bw_lds_attr = true;
   }
   // bytes a product reads: codes, descriptors, permutation, window lists and their x (L2), dictionaries
-  ctx->bw_bytes = ctx->bw_chunks * 2048 + (int64_t)nblk * BW_SLICES * 8 + (int64_t)nblk * BW_R * 4 + ctx->bw_window_entries * 4
-                  + (int64_t)nblk * 16;
+  ctx->bw_bytes = (int64_t)nblk * BW_SLICES * 8 + (int64_t)nblk * BW_R * 4 + ctx->bw_window_entries * 4 + (int64_t)nblk * 18;
   {
-    std::vector<int32_t> dn((size_t)nblk);
+    std::vector<int32_t> dn((size_t)nblk), bc((size_t)nblk);
+    std::vector<uint8_t> cf((size_t)nblk), vf((size_t)nblk);
     ZZZ_HIP(ctx, hipMemcpyAsync(dn.data(), ctx->bw_dnum.p, dn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipMemcpyAsync(bc.data(), ctx->bw_blk_chunks.p, bc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipMemcpyAsync(cf.data(), ctx->bw_cflag.p, cf.size(), hipMemcpyDeviceToHost, s));
+    ZZZ_HIP(ctx, hipMemcpyAsync(vf.data(), ctx->bw_vflag.p, vf.size(), hipMemcpyDeviceToHost, s));
     ZZZ_HIP(ctx, hipStreamSynchronize(s));
-    int64_t t = 0;
-    for (int32_t v : dn)
-      t += v;
-    ctx->bw_bytes += t * 8;
+    int64_t t = 0, codes = 0, packed = 0;
+    for (int32_t q = 0; q < nblk; ++q)
+    {
+      t += dn[(size_t)q];
+      codes += (int64_t)bc[(size_t)q] * ((cf[(size_t)q] ? 768 : 1024) + (vf[(size_t)q] ? 768 : 1024)); // bytes of codes per chunk
+      packed += (cf[(size_t)q] ? 1 : 0) + (vf[(size_t)q] ? 1 : 0);
+    }
+    ctx->bw_bytes += t * 8 + codes;
     ctx->bw_dict_entries = t;
+    ctx->bw_packed_planes = packed; // of 2 nblk
   }
   ctx->bw_on = true;
   return ZZZ_OK;
@@ -906,7 +1072,7 @@ bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
 #define ZZZ_BW_GO4(DOT, SR, NT, CHEB, EPI)                                                                                         \
   hipLaunchKernelGGL((spmv_win_kernel<DOT, SR, NT, CHEB>), dim3(grid), dim3(BW_THREADS), lds, ctx->stream, ctx->bw_perm.p,         \
                      reinterpret_cast<const int2*>(ctx->bw_desc.p), ctx->bw_woff.p, ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_vcode.p, \
-                     ctx->bw_dict.p, ctx->bw_dnum.p, x, y, rvec, list, a, EPI)
+                     ctx->bw_cpack.p, ctx->bw_vpack.p, ctx->bw_cflag.p, ctx->bw_vflag.p, ctx->bw_dict.p, ctx->bw_dnum.p, x, y, rvec, list, a, EPI)
 #define ZZZ_BW_GO(DOT, SR, NT) ZZZ_BW_GO4(DOT, SR, NT, false, ChebEpi())
   if (epi)
   {
