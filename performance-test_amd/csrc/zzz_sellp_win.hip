@@ -685,8 +685,8 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
       }
       double sum = 0.0;
       // The chunk's eight value codes and eight window indices: packed (12 B per lane each: 12-bit codes; a 16-bit first index
-      // and seven 10-bit differences) where the block allows, else 16 bits each.  One chunk of look-ahead: the raw words of
-      // chunk j + 1 are requested before chunk j is decoded and summed (two named stages, the body twice: no register that a
+      // and seven 10-bit differences) where the block allows, else 16 bits each.  Two chunks of look-ahead: the raw words of
+      // chunk j + 2 are requested before chunk j is decoded and summed (three named stages, the body three times: no register that a
       // load is still writing is copied) -- a slice is otherwise a chain load -> decode -> LDS -> sums per chunk.
       struct Raw
       {
@@ -756,19 +756,27 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
           sum += ve[e] * xe[e]; // (entries beyond a row's last carry code 0 = +0.0 and repeat an index: + 0 * x)
       };
       {
-        Raw A, B;
-        A.v = A.c = B.v = B.c = uint4v{0u, 0u, 0u, 0u};
+        Raw A, B, C;
+        A.v = A.c = B.v = B.c = C.v = C.c = uint4v{0u, 0u, 0u, 0u};
         request(0, A);
-        for (int jj = 0; jj < nch; jj += 2)
+        if (nch > 1)
+          request(1, B);
+        for (int jj = 0; jj < nch; jj += 3)
         {
-          if (jj + 1 < nch)
-            request(jj + 1, B);
+          if (jj + 2 < nch)
+            request(jj + 2, C);
           consume(A);
           if (jj + 1 < nch)
           {
-            if (jj + 2 < nch)
-              request(jj + 2, A);
+            if (jj + 3 < nch)
+              request(jj + 3, A);
             consume(B);
+          }
+          if (jj + 2 < nch)
+          {
+            if (jj + 4 < nch)
+              request(jj + 4, B);
+            consume(C);
           }
         }
       }
