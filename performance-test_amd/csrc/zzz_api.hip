@@ -175,7 +175,7 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_drop = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_DICT"))
     ctx->sellp_dict = atoi(e);
-  if (const char* e = getenv("ZZZ_SELLP_BWIN")) // long scalar rows, x from LDS windows: 0 never, 1 from 2 000 000 rows on, 2 always
+  if (const char* e = getenv("ZZZ_SELLP_BWIN")) // long scalar rows, x from LDS windows: 0 never, 1 by size, 2 always
     ctx->sellp_bwin = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_BLK")) // 0: block size 3 stays on the generic product (A/B against the block-row form)
     ctx->sellp_blk = atoi(e);

@@ -309,7 +309,7 @@ struct zzz_ctx
   zzz::DevBuf<double> bw_dict;
   zzz::DevBuf<uint8_t> bw_gflag;
   bool bw_on = false, bw_struct_ok = false, bw_have_split = false, bw_lds_attr = false;
-  int sellp_bwin = 1; // ZZZ_SELLP_BWIN: 0 never, 1 from 2 000 000 rows on, 2 always
+  int sellp_bwin = 1; // ZZZ_SELLP_BWIN: 0 never, 1 by size (zzz_sellp_win.hip), 2 always
   int32_t bw_nblk = 0;
   int64_t bw_chunks = 0, bw_window_entries = 0, bw_dict_entries = 0, bw_bytes = 0, bw_n_interior = 0, bw_n_boundary = 0;
   uint64_t pattern_version = 0, bw_struct_version = ~0ull; // pattern_version counts zzz_csr_pattern_build calls

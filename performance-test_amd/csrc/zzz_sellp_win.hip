@@ -24,9 +24,8 @@
 // When it applies: scalar matrices and those of block size 3 the block-row form declined (elasticity P2 / P3: their scalar rows
 // are long rows like any), natural row order of the stream, at least BW_MIN_AVG entries per row on average, every block
 // within the LDS budget, no folded all-reduce on the launch (tools build).  Chebyshev-Jacobi terms ride on it as epilogues (CHEB).
-// ZZZ_SELLP_BWIN: 0 never, 1 (default) from 2 000 000 rows on (488 blocks: two rounds of one workgroup per CU; with fewer blocks
-// than CUs the generic product wins: 24^3 sub-cubes of P3, 95 blocks, 0.036 against 0.046 ms -- but 0.027 with 2 048-row
-// blocks, so the limit is the block count, not the form), 2 always.
+// ZZZ_SELLP_BWIN: 0 never, 1 (default) by size (rows of ~48 entries from 300 000 rows on, of ~27 from 800 000: below, the generic
+// product is as fast or faster -- a few blocks for 256 CUs), 2 always.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -967,7 +966,9 @@ int sellp_win_build(zzz_ctx* ctx)
   // (block size 3: the block-row form first -- elasticity P1, 2.4 x; where it declines, P2 / P3, the scalar rows are long rows like any)
   if (!ctx->sellp_bwin || ctx->bk_on || ctx->sp_sorted || ctx->nrows <= 0 || ctx->nnz < min_avg * ctx->nrows)
     return ZZZ_OK;
-  if (ctx->sellp_bwin == 1 && ctx->nrows < 2000000)
+  // size rule (one MI355X, P3 / P2 cubes): rows of ~48 win from 390 k rows on (0.028 against 0.046 ms; 0.033 against 0.072 at 0.9 M;
+  // about equal at 118 k), rows of ~27 from 0.9 M on (0.027 against 0.031; 0.022 against 0.016 at 275 k)
+  if (ctx->sellp_bwin == 1 && ctx->nrows < (ctx->nnz >= 40 * ctx->nrows ? 300000 : 800000))
     return ZZZ_OK;
   if (getenv("ZZZ_DEBUG_SYNC"))
     fprintf(stderr, "[zzz dbg] sellp_win_build: rows %lld nnz %lld knob %d\n", (long long)ctx->nrows, (long long)ctx->nnz, ctx->sellp_bwin);
