@@ -70,3 +70,33 @@ def test_operator_stream_kernel_keeps_full_occupancy(tmp_path):
     # values as doubles, as codes into a dictionary in memory, as codes into a dictionary in LDS, as 8-bit codes into
     # per-slice dictionaries
     assert seen == 88  # (slice dictionaries and x windows exclude each other)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src_name,kernel_re,lds_budget,variants", [
+    ("zzz_sellp_blk.hip", r"_ZN3zzz16spmv_blk3_kernelILb[01]ELb[01]ELb[01]ELi[12]ELb[01]EEE", 2200 * 72, 20),
+    ("zzz_sellp_win.hip", r"_ZN3zzz15spmv_win_kernelILb[01]ELb[01]ELb[01]ELb[01]EEE", (11264 + 8192) * 8, 10)])
+def test_special_product_kernels_fit_one_workgroup_of_1024_lanes_per_cu(tmp_path, src_name, kernel_re, lds_budget, variants):
+    """The block-row and block-window products (round 6) run ONE workgroup of 1 024 lanes per CU: sixteen wavefronts, four per SIMD,
+    i.e. at most 128 VGPRs per lane, with (nearly) no scratch; their dynamic LDS (block table / window + dictionary) plus the static
+    part must fit the CU's 160 KB."""
+    src = os.path.join(ROOT, "performance-test_amd", "csrc", src_name)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I" + os.path.dirname(src),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "performance-test_amd", "host"), "-c", src, "-o",
+           str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if not re.match(kernel_re, name):
+            continue
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vgprs <= 128 and occ >= 4 and scratch <= 64, (name, vgprs, occ, scratch)
+        assert lds + lds_budget <= 160 * 1024, (name, lds)
+        seen += 1
+    assert seen == variants, seen  # (dot / single reduction / load policy [/ table form], and the Chebyshev-epilogue variants)
