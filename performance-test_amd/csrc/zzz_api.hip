@@ -177,6 +177,10 @@ int zzz_ctx_create(int device, zzz_ctx** out)
     ctx->sellp_dict = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_BWIN")) // long scalar rows, x from LDS windows: 0 never, 1 by size, 2 always
     ctx->sellp_bwin = atoi(e);
+  if (const char* e = getenv("ZZZ_SELLP_EARLY")) // 0: generic stream at every assembly, special forms at the first product (A/B)
+    ctx->sellp_early = atoi(e) != 0;
+  if (const char* e = getenv("ZZZ_ASM_NODE3")) // 0: elasticity P1 matrix assembly with a thread per scalar row (A/B)
+    ctx->asm_node3 = atoi(e) != 0;
   if (const char* e = getenv("ZZZ_SELLP_BLK")) // 0: block size 3 stays on the generic product (A/B against the block-row form)
     ctx->sellp_blk = atoi(e);
   if (const char* e = getenv("ZZZ_SELLP_PIPE")) // 0: the generic product kernel always (A/B against the pipelined one)

@@ -457,8 +457,187 @@ __global__ __launch_bounds__(BLK) void asm_matrix_p1(const double* __restrict__ 
     vals[s + k] = vals_s[k];
 }
 
+// ---- matrix, P1, block size 3 (Elasticity a1, src/Elasticity.py:39), ONE THREAD PER NODE (round 6)
+// asm_matrix_p1<3> gives every scalar row a thread: the three rows of a node walk the same cells and each derives the cell's
+// geometry, searches the same four block columns and fetches the same connectivity, coordinates and flags -- and a tile of 4 096
+// nonzeros holds 91 rows, so 165 of the workgroup's 256 lanes idle (3.85 ms at 1.33 M nodes, C4).  Here a lane owns a NODE: per
+// (node, cell) pair one geometry, one search of the node's BLOCK columns (15 per node in LDS instead of 135 scalar columns),
+// then the 3 x 4 x 3 entries of the pair, the same expression per entry as before (values bit-identical to asm_matrix_p1<3>).  A
+// tile is ~63 nodes = 8 704 nonzeros (68 KiB of LDS: two one-wavefront workgroups per CU); the software pipeline over the
+// node's cells (adjacency -> connectivity -> coordinates and flags, one link ahead each) is the one of asm_matrix_p1.
+// The three rows of a node must have the same columns (they do: the pattern is built on block dofs).
+constexpr int ASM_NNZ_NODE3 = 8704;
+template <int NNZ>
+__global__ __launch_bounds__(64) void asm_matrix_p1_node3(const double* __restrict__ xq, const int32_t* __restrict__ cell_dofs,
+                                                          const int32_t* __restrict__ adjT_off, const int32_t* __restrict__ adjT_cells,
+                                                          const uint8_t* __restrict__ adj_li, const uint8_t* __restrict__ bc,
+                                                          const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                          double* __restrict__ vals, const int32_t* __restrict__ tiles, int64_t ntiles)
+{
+  constexpr int BS = 3, BLK = 64;
+  __shared__ double vals_s[NNZ];
+  __shared__ int32_t bcols_s[NNZ / 9 + 1 + 32]; // block columns of the tile's nodes (+ 32: find_pos4 reads past a row's end)
+  const int64_t tile = xcd_item(ntiles);
+  if (tile < 0)
+    return;
+  const int d0 = tiles[tile], d1 = tiles[tile + 1];
+  const int64_t s = rowptr[(int64_t)d0 * BS];
+  const int e = (int)(rowptr[(int64_t)d1 * BS] - s); // entries of the tile's CSR segment (fits LDS)
+  for (int k = threadIdx.x; k < e; k += BLK)
+    vals_s[k] = 0.0;
+  // block columns: entry q of the tile's block rows = column / 3 of the first scalar row's entry 3 q'
+  for (int i = d0 + (int)threadIdx.x; i < d1; i += BLK)
+  {
+    const int64_t a = rowptr[(int64_t)i * BS];
+    const int blen = (int)(rowptr[(int64_t)i * BS + 1] - a) / BS;
+    const int b0 = (int)((a - s) / 9);
+    for (int k = 0; k < blen; ++k)
+      bcols_s[b0 + k] = cols[a + 3 * k] / BS;
+  }
+  __syncthreads();
+  constexpr double Ey = 1.0e6, nu = 0.3; // src/Elasticity.py:12-15
+  constexpr double mu = Ey / (2.0 * (1.0 + nu));
+  constexpr double lmbda = Ey * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+  for (int i = d0 + (int)threadIdx.x; i < d1; i += BLK)
+  {
+    const int64_t ra = rowptr[(int64_t)i * BS];
+    const int a0 = (int)(ra - s), len = (int)(rowptr[(int64_t)i * BS + 1] - ra), blen = len / BS;
+    const int b0 = a0 / 9;
+    bool bcr[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c)
+      bcr[c] = bc[(int64_t)i * BS + c] != 0;
+    const AdjIter adj(adjT_off, adjT_cells, adj_li, i);
+    struct Conn
+    {
+      int cell, li;
+      int4 dd;
+    };
+    struct Data
+    {
+      double p[4][3];
+      uint8_t bcj[4 * BS];
+    };
+    const int alen = adj.len;
+    auto adj_at = [&](int a, int& cell, int& li) {
+      const int ac = min(a, alen - 1);
+      const int cc = adj.cell(ac);
+      cell = a < alen ? cc : -1;
+      li = adj.li(ac);
+    };
+    auto conn_at = [&](int cell, int li, Conn& K) {
+      K.cell = cell;
+      K.li = li;
+      K.dd = *reinterpret_cast<const int4*>(cell_dofs + 4 * (int64_t)max(cell, 0));
+    };
+    auto data_at = [&](const Conn& K, Data& D) {
+      load_cell_q(xq, K.dd, D.p);
+      const int dj[4] = {K.dd.x, K.dd.y, K.dd.z, K.dd.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < BS; ++d)
+          D.bcj[j * BS + d] = bc[dj[j] * BS + d];
+    };
+    Conn K0, K1;
+    Data DA, DB;
+    int c2, l2;
+    auto iter = [&](int a, const Data& D0, Data& D1) {
+      Conn K2;
+      int c3, l3;
+      data_at(K1, D1);
+      conn_at(c2, l2, K2);
+      adj_at(a + 3, c3, l3);
+      const int li = K0.li;
+      const int dofs[4] = {K0.dd.x, K0.dd.y, K0.dd.z, K0.dd.w};
+      double g[4][3];
+      Geom G;
+      geometry(D0.p, G);
+      p1_grads(G, g);
+      const double w = G.adet / 6.0; // reference volume
+      double gi[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k == li)
+        {
+          gi[0] = g[k][0];
+          gi[1] = g[k][1];
+          gi[2] = g[k][2];
+        }
+      int pos4[4];
+      find_pos4(bcols_s + b0, blen, dofs, pos4);
+      if (K0.cell >= 0) // the cell's four block columns are distinct entries of the block row: read all 36, add, write all
+      {                 // (one LDS round trip per pair instead of twelve dependent ones: a lane is alone on its SIMD here)
+        double acc[4][BS][BS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < BS; ++c)
+#pragma unroll
+            for (int d = 0; d < BS; ++d)
+              acc[j][c][d] = vals_s[a0 + c * len + BS * pos4[j] + d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          const double gg = gi[0] * g[j][0] + gi[1] * g[j][1] + gi[2] * g[j][2];
+#pragma unroll
+          for (int c = 0; c < BS; ++c)
+          {
+            const double gic = gi[c], gjc = g[j][c];
+#pragma unroll
+            for (int d = 0; d < BS; ++d)
+            {
+              // mu (delta_cd g_i.g_j + d_d phi_i d_c phi_j) + lambda d_c phi_i d_d phi_j
+              const double v = w * (mu * ((c == d ? gg : 0.0) + gi[d] * gjc) + lmbda * gic * g[j][d]);
+              acc[j][c][d] += (bcr[c] || D0.bcj[j * BS + d]) ? 0.0 : v;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < BS; ++c)
+#pragma unroll
+            for (int d = 0; d < BS; ++d)
+              vals_s[a0 + c * len + BS * pos4[j] + d] = acc[j][c][d];
+      }
+      K0 = K1;
+      K1 = K2;
+      c2 = c3;
+      l2 = l3;
+    };
+    if (alen > 0)
+    {
+      {
+        int ca, la;
+        adj_at(0, ca, la);
+        conn_at(ca, la, K0);
+        data_at(K0, DA);
+        adj_at(1, ca, la);
+        conn_at(ca, la, K1);
+        adj_at(2, c2, l2);
+      }
+      int a = 0;
+      for (; a + 1 < alen; a += 2)
+      {
+        iter(a, DA, DB);
+        iter(a + 1, DB, DA);
+      }
+      if (a < alen)
+        iter(a, DA, DB);
+    }
+#pragma unroll
+    for (int c = 0; c < BS; ++c)
+      if (bcr[c]) // fem::set_diagonal: 1.0 on constrained rows
+        vals_s[a0 + c * len + BS * find_pos(bcols_s + b0, blen, i) + c] = 1.0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < e; k += BLK)
+    vals[s + k] = vals_s[k];
+}
+
 // ---- vector, P1: Poisson L1 = f v dx + g v ds (src/Poisson.py:32), Elasticity L1 = f.v dx (:40)
-// Round 5: two passes.  What a (row, cell) pair of the cell term needs from its cell is the same for the cell's four rows:
+// Round 5: two passes. What a (row, cell) pair of the cell term needs from its cell is the same for the cell's four rows:
 // |det J| and the sum of the coefficient over the cell's vertices (per component).  k_cell_load_p1 evaluates both once per
 // cell (dense, one thread per cell: connectivity, four vertices, four coefficients, one determinant) into a record of
 // 1 + BS doubles; the row walk then fetches ONE record per pair -- a chain of two dependent loads (adjacency -> record)
@@ -1031,6 +1210,8 @@ int asm_tile_nnz(const zzz_ctx* ctx)
 {
   if (ctx->bs == 1 && ctx->order == 1)
     return ASM_NNZ_P1;
+  if (ctx->bs == 3 && ctx->order == 1 && ctx->asm_node3)
+    return ASM_NNZ_NODE3; // (one thread per node: asm_matrix_p1_node3)
 #ifdef ZZZ_EXPERIMENTS
   if (const char* e = getenv("ZZZ_ASM_CAP")) // measurement knob, tools build only
     if (atoi(e) >= 1024 && atoi(e) <= 8192)
@@ -1449,6 +1630,10 @@ int launch_assemble_matrix(zzz_ctx* ctx, int form)
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
                          ctx->asm_tile.p, ctx->n_asm_tiles);
     }
+    else if (ctx->asm_node3)
+      hipLaunchKernelGGL((asm_matrix_p1_node3<ASM_NNZ_NODE3>), grid, dim3(64), 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
+                         ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,
+                         ctx->asm_tile.p, ctx->n_asm_tiles);
     else
       hipLaunchKernelGGL((asm_matrix_p1<3, ASM_NNZ, ASM_BLOCK>), grid, block, 0, ctx->stream, ctx->xq, ctx->cell_dofs.p,
                          ctx->adjT_off.p, ctx->adjT_cells.p, ctx->adj_li.p, ctx->bc.p, ctx->rowptr.p, ctx->cols.p, ctx->vals.p,

@@ -275,6 +275,10 @@ struct zzz_ctx
   bool sp_sd_all = false; // every slice has its table (none stays doubles)
   int64_t sp_sd_bytes = 0;
   bool sp_dict_done = false, sp_dict_on = false;
+  bool sp_generic = false;       // the generic operator stream is packed for the current values (not when a special form was chosen at
+                                 // assembly time: sell_update; packed late by sellp_need_generic if a launch asks for it)
+  bool sp_special_tried = false; // the special forms were built or declined for the current values
+  bool sellp_early = true;       // ZZZ_SELLP_EARLY=0: pack the generic stream at every assembly, special forms at the first product (A/B)
   int sellp_dict = 1;       // ZZZ_SELLP_DICT=0: no value dictionary
   // Jacobi's inverse diagonal as 16-bit codes (zzz_cg.hip, DinvCodes)
   zzz::DevBuf<unsigned long long> dd_table;
@@ -303,13 +307,14 @@ struct zzz_ctx
   zzz::DevBuf<uint32_t> bw_cpack, bw_vpack; // the same codes packed, 12 B per lane and chunk (where the block's flag says so)
   zzz::DevBuf<uint8_t> bw_cflag, bw_vflag;
   int64_t bw_packed_planes = 0;
-  zzz::DevBuf<uint32_t> bw_key, bw_key2;
+  zzz::DevBuf<uint32_t> bw_key, bw_key2, bw_skey; // (bw_skey: a block's rows by length, pass 1 to pass 2 of the structure)
   zzz::DevBuf<int32_t> bw_val, bw_hid, bw_first; // (scratch of the builders, kept: hipFree waits for the whole device)
   zzz::DevBuf<double> bw_dofx, bw_bbox;
   zzz::DevBuf<double> bw_dict;
   zzz::DevBuf<uint8_t> bw_gflag;
   bool bw_on = false, bw_struct_ok = false, bw_have_split = false, bw_lds_attr = false;
   int sellp_bwin = 1; // ZZZ_SELLP_BWIN: 0 never, 1 by size (zzz_sellp_win.hip), 2 always
+  bool asm_node3 = true; // ZZZ_ASM_NODE3=0: elasticity P1 matrix by the thread-per-scalar-row kernel (A/B against asm_matrix_p1_node3)
   int32_t bw_nblk = 0;
   int64_t bw_chunks = 0, bw_window_entries = 0, bw_dict_entries = 0, bw_bytes = 0, bw_n_interior = 0, bw_n_boundary = 0;
   uint64_t pattern_version = 0, bw_struct_version = ~0ull; // pattern_version counts zzz_csr_pattern_build calls

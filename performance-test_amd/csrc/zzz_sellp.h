@@ -73,6 +73,10 @@ int sellp_pipe_wgs(const zzz_ctx* ctx, bool sr); // workgroups per CU if spmv_on
 int sellp_pairs_build(zzz_ctx* ctx); // marks the affine slice pairs of a stream of one-chunk slices (spmv_one_kernel)
 bool launch_sellp_pipe(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x, double* y, double* partials, const int* stop,
                        const int32_t* group_list, int64_t nlist, const double* rvec, int nn_is_rr);
+// special forms (block rows, block windows): build what applies; true if one of them serves the products of this matrix
+bool sellp_special_build(zzz_ctx* ctx);
+int sell_pack_generic(zzz_ctx* ctx); // the generic operator stream of the current values (zzz_sellp_pack.hip)
+int sellp_need_generic(zzz_ctx* ctx); // ... packed now if a launch needs it and sell_update left it out
 // block-window form for long scalar rows (zzz_sellp_win.hip)
 int sellp_win_build(zzz_ctx* ctx);
 bool sellp_win_serves(const zzz_ctx* ctx);

@@ -597,6 +597,26 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void spmv_sellp_dir_kernel(
 #endif // ZZZ_EXPERIMENTS
 
 // ---- host side ------------------------------------------------------------------------------------------
+// A failed build leaves its form off (and the stream, where there is one, as it is).
+bool sellp_special_build(zzz_ctx* ctx)
+{
+  if (sellp_blk_build(ctx) != ZZZ_OK)
+  {
+    if (getenv("ZZZ_DEBUG_SYNC"))
+      fprintf(stderr, "[zzz dbg] sellp_blk_build: %s\n", ctx->err.c_str());
+    ctx->bk_on = false;
+    (void)hipGetLastError();
+  }
+  if (sellp_win_build(ctx) != ZZZ_OK)
+  {
+    if (getenv("ZZZ_DEBUG_SYNC"))
+      fprintf(stderr, "[zzz dbg] sellp_win_build: %s\n", ctx->err.c_str());
+    ctx->bw_on = false;
+    (void)hipGetLastError();
+  }
+  return sellp_blk_serves(ctx) || sellp_win_serves(ctx);
+}
+
 bool sellp_active(zzz_ctx* ctx)
 {
   if (ctx->sp_pending)
@@ -620,19 +640,10 @@ bool sellp_active(zzz_ctx* ctx)
     ctx->sp_dict_done = true;
     ctx->sp_dict_on = ctx->sp_sd_on = ctx->sp_sd_all = false;
     ctx->sp_dict_n = 0;
-    if (sellp_blk_build(ctx) != ZZZ_OK)
+    if (!ctx->sp_special_tried)
     {
-      if (getenv("ZZZ_DEBUG_SYNC"))
-        fprintf(stderr, "[zzz dbg] sellp_blk_build: %s\n", ctx->err.c_str());
-      ctx->bk_on = false;
-      (void)hipGetLastError();
-    }
-    if (sellp_win_build(ctx) != ZZZ_OK)
-    {
-      if (getenv("ZZZ_DEBUG_SYNC"))
-        fprintf(stderr, "[zzz dbg] sellp_win_build: %s\n", ctx->err.c_str());
-      ctx->bw_on = false;
-      (void)hipGetLastError();
+      (void)sellp_special_build(ctx);
+      ctx->sp_special_tried = true;
     }
     if (!sellp_blk_serves(ctx) && !sellp_win_serves(ctx))
     {
@@ -787,6 +798,9 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
   const bool plain = !epi && !(partials && ctx->tail_armed);
   const bool no_tail = !(partials && ctx->tail_armed); // (the special forms carry the Chebyshev epilogue, not the folded all-reduce)
   const int blk = no_tail ? (sellp_blk_serves(ctx) ? 1 : (sellp_win_serves(ctx) ? 2 : 0)) : 0;
+  if (!blk)
+    if (int rc = sellp_need_generic(ctx))
+      return rc;
   const int gs = blk == 1 ? sellp_blk_grid(ctx, ctx->bk_slices) : blk == 2 ? sellp_win_grid(ctx, ctx->bw_nblk)
                           : sp_grid(ctx, (ctx->nslices + 3) / 4, (partials && rvec), plain);
 #ifdef ZZZ_EXPERIMENTS
@@ -794,7 +808,7 @@ int launch_sellp(zzz_ctx* ctx, const double* x, double* y, double* partials, int
   if (e)                                                               // the kernel): inside zzz_spmv_time only
   {
     const int wlen = atoi(e) & ~1;
-    if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows && ctx->sp_win_max == 0)
+    if (wlen >= 256 && wlen <= 8192 && !ctx->sp_sorted && !epi && wlen < ctx->nrows && ctx->sp_win_max == 0 && !blk)
     {
       const int lds_slots = getenv("ZZZ_EXP_WIN_SLOTS") ? atoi(getenv("ZZZ_EXP_WIN_SLOTS")) : 8;
       const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)wlen * 8 + 512))));
@@ -846,6 +860,9 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
   const bool plain = !epi && !(partials && ctx->tail_armed);
   const bool no_tail = !(partials && ctx->tail_armed);
   const int blk = !no_tail ? 0 : (sellp_blk_serves(ctx) && ctx->bk_have_split) ? 1 : (sellp_win_serves(ctx) && ctx->bw_have_split) ? 2 : 0;
+  if (!blk)
+    if (int rc = sellp_need_generic(ctx))
+      return rc;
   const int64_t gi = blk == 1 ? ctx->bk_n_interior : blk == 2 ? ctx->bw_n_interior : ctx->n_groups_interior;
   const int64_t gb = blk == 1 ? ctx->bk_n_boundary : blk == 2 ? ctx->bw_n_boundary : ctx->n_groups_boundary;
   const int32_t* list_in = blk == 1 ? ctx->bk_list_interior.p : blk == 2 ? ctx->bw_list_interior.p : ctx->groups_interior.p;
@@ -903,6 +920,8 @@ int launch_sellp_overlapped(zzz_ctx* ctx, double* x, double* y, double* partials
 int launch_sellp_dir(zzz_ctx* ctx, double* z, const double* p_old, double* p_new, double* xsol, double* y, double* partials,
                      int* npartials, int it, const CgParams& P, const double* pa, const double* pb, int np, bool overlap)
 {
+  if (int rc = sellp_need_generic(ctx))
+    return rc;
   const bool nt = ctx->spmv_auto ? sp_stream_nt(ctx) : (ctx->spmv_variant & 1) != 0;
   const int2* off = reinterpret_cast<const int2*>(ctx->sp_desc.p);
   const int ncols = (int)ctx->nloc();

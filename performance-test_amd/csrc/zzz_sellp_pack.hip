@@ -1256,6 +1256,7 @@ int sell_update(zzz_ctx* ctx, bool structure)
   ctx->sp_dict_done = ctx->sp_dict_on = ctx->sp_sd_on = false; // (the values changed: the dictionaries are rebuilt at the stream's first use)
   ctx->bk_on = false;
   ctx->bw_on = false;
+  ctx->sp_generic = ctx->sp_special_tried = false;
   ctx->sp_win_max = 0; // (set again by the long-row packer when most groups get an x window)
   ctx->sp_win_bytes = 0;
   const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
@@ -1271,6 +1272,47 @@ int sell_update(zzz_ctx* ctx, bool structure)
     if (rc)
       return rc;
   }
+  // The special forms first (block rows for block size 3, block windows for long scalar rows): where one of them serves this
+  // matrix's products the generic stream is not packed at all (4.9 ms per assembly at C4, 2 ms at C5's per-GPU share).  Only
+  // where no launch can need the generic kernel: automatic mode, no partition (the overlapped launches of a partitioned matrix
+  // take their group split from the generic stream).  A launch that asks for the generic kernel after all (the tools build's
+  // folded all-reduce) packs it then: sellp_need_generic.
+  if (ctx->sellp_mode == 1 && !forced && ctx->sellp_early && ctx->n_ghost == 0 && !ctx->comm)
+  {
+    ctx->sp_sorted = false;
+    const bool serves = sellp_special_build(ctx);
+    ctx->sp_special_tried = true;
+    if (serves)
+    {
+      ctx->sp_dict_done = true;
+      ctx->sp_dict_n = 0;
+      ctx->sp_pairs_ok = ctx->sp_one_chunk = ctx->sp_pipe_ok = false;
+      ctx->sp_bytes = ctx->sp_chunks = ctx->sp_kept = 0;
+      ctx->have_sell = ctx->sell_current = true;
+      return ZZZ_OK;
+    }
+  }
+  return sell_pack_generic(ctx);
+}
+
+int sellp_need_generic(zzz_ctx* ctx)
+{
+  if (ctx->sp_generic)
+    return ZZZ_OK;
+  int rc = sell_pack_generic(ctx);
+  if (!rc)
+    rc = sellp_resolve(ctx);
+  if (!rc && !(ctx->sp_generic && ctx->have_sell && ctx->sell_current))
+    return fail(ctx, ZZZ_ERR_LIMIT, "this launch needs the generic operator stream, which this matrix does not get");
+  ctx->have_sell = ctx->sell_current = true;
+  return rc;
+}
+
+int sell_pack_generic(zzz_ctx* ctx)
+{
+  const bool forced = (ctx->spmv_variant & 8) != 0 && !ctx->spmv_auto;
+  ctx->sp_generic = true;
+  ctx->have_sell = ctx->sell_current = false; // (until a stream is packed below)
   hipStream_t s = ctx->stream;
   const int nrows = (int)ctx->nrows;
   const int64_t nsl = ctx->nslices;

@@ -41,7 +41,7 @@ constexpr int BW_R = 4096;        // rows per block
 constexpr int BW_THREADS = 1024;  // one workgroup per block: four rows per lane in the builders, four slices per wavefront in the product
 constexpr int BW_WCAP = 11264;    // window: distinct columns of a block at most (88 KiB of LDS in the product; P3: 7 600 on average,
                                   // 10 500 the largest met)
-constexpr int BW_WBITS = 15;
+constexpr int BW_WBITS = 14;     // (load factor at most 0.69, 0.46 on average at P3)
 constexpr int BW_WHASH = 1 << BW_WBITS; // ... and the slots of the set that finds them (build only)
 constexpr int BW_DCAP = 8192;     // distinct values of a block at most (+0.0 = code 0 included; 64 KiB; P3: 2 600 on average, 4 100 the
                                   // largest at 61^3 sub-cubes, 7 100 at 122^3)
@@ -159,37 +159,26 @@ __global__ __launch_bounds__(256) void k_bw_keys(const double* __restrict__ dofx
   }
 }
 
-// info: [0] a block does not fit (window, values, a row of 2^11 entries or more), [1] blocks that reach a ghost column
+// info: [0] a block does not fit (window, values, a row of 2^11 entries or more), [1] blocks that reach a ghost column,
+// [6..7] (one 64-bit counter) window entries of all blocks
 
-// One workgroup per block.  WRITE = false: chunks and window size of the block (scanned by the host); WRITE = true: the
-// block's part of the structure -- perm, slice descriptors, window list, window indices of every entry.
-template <bool WRITE>
-__global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restrict__ order, int32_t nrows, int32_t nblk,
-                                                         const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                         int32_t* __restrict__ blk_chunks, int32_t* __restrict__ blk_wn,
-                                                         const int64_t* __restrict__ chunk0, const int64_t* __restrict__ woff,
-                                                         int32_t* __restrict__ perm, int2* __restrict__ desc,
-                                                         int32_t* __restrict__ wlist, uint16_t* __restrict__ ccode,
-                                                         uint8_t* __restrict__ gflag, int* __restrict__ info,
-                                                         int32_t* __restrict__ hid_all, uint32_t* __restrict__ cpack,
-                                                         uint8_t* __restrict__ cflag)
+// Pass 1, one workgroup per block: the block's rows by (length descending, position ascending) -- a bitonic sort, deterministic
+// --, kept in memory for pass 2 (skey_all); the block's chunks (a slice's first row is its longest); the start of its window list
+// (every block gets BW_WCAP entries of room: no pass over the columns is needed to place it).
+__global__ __launch_bounds__(BW_THREADS) void k_bw_sort(const int32_t* __restrict__ order, int32_t nrows, int32_t nblk,
+                                                        const rp_t* __restrict__ rowptr, uint32_t* __restrict__ skey_all,
+                                                        int32_t* __restrict__ blk_chunks, int64_t* __restrict__ woff, int* __restrict__ info)
 {
-  int32_t* const hid = hid_all + (int64_t)blockIdx.x * BW_WHASH; // slot -> window index (this workgroup's scratch: L2)
-  __shared__ int32_t hcol[BW_WHASH]; // the set of columns (-1: empty)
-  __shared__ uint32_t skey[BW_R];    // rows by (length descending, position ascending)
-  __shared__ int32_t sl_c0[BW_SLICES + 1];
-  __shared__ int wsum[BW_THREADS / 64];
-  __shared__ int n_win, any_ghost, bad, max_delta;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ uint32_t skey[BW_R];
+  __shared__ int32_t sl_n[BW_SLICES];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
   for (int b = blockIdx.x; b < nblk; b += gridDim.x)
   {
     const int r0 = b * BW_R, nb = min(BW_R, nrows - r0);
-    for (int k = tid; k < BW_WHASH; k += BW_THREADS)
-      hcol[k] = -1;
     if (tid == 0)
-      n_win = 0, any_ghost = 0, bad = 0, max_delta = 0;
+      bad = 0;
     __syncthreads();
-    // the rows' lengths; the sort key: longer rows first, ties in block order (a bitonic sort: deterministic)
     for (int p = tid; p < BW_R; p += BW_THREADS)
     {
       unsigned len = 0;
@@ -225,7 +214,77 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
         }
         __syncthreads();
       }
-    // chunks per slice (its first row is its longest), their starts inside the block
+    for (int q = tid; q < BW_R; q += BW_THREADS)
+      skey_all[(int64_t)b * BW_R + q] = skey[q];
+    if (tid < BW_SLICES)
+    {
+      const unsigned len = 2047u - (skey[tid * 64] >> 12);
+      sl_n[tid] = (int)((len + 7u) / 8u);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      int acc = 0;
+      for (int s = 0; s < BW_SLICES; ++s)
+        acc += sl_n[s];
+      blk_chunks[b] = acc;
+      woff[b] = (int64_t)b * BW_WCAP;
+      if (b == nblk - 1)
+        woff[nblk] = (int64_t)nblk * BW_WCAP;
+      if (bad)
+        info[0] = 1;
+    }
+    __syncthreads();
+  }
+}
+
+// a lane's next eight entries of a row (k0 .. k0 + 7; those at or beyond len come back as `fill`): two 16-B loads where the row
+// has them, single loads at its end
+template <typename T>
+__device__ inline void bw_load8(const T* __restrict__ p, int k0, int len, T fill, T (&v)[8])
+{
+  if (k0 + 8 <= len)
+  {
+    __builtin_memcpy(v, p + k0, 8 * sizeof(T));
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    v[e] = k0 + e < len ? p[k0 + e] : fill;
+}
+
+// Pass 2, one workgroup per block: the block's part of the structure -- perm, slice descriptors, window list, the window index of
+// every entry.  The columns are read ONCE: a lane walks its rows chunk by chunk (16-B loads), puts each column into the set and
+// parks the SLOT it landed in -- 16 bits, in the entry's own place in ccode; when the set is complete its slots are sorted by
+// column (indirectly: 16-bit slot numbers, compared through the set), which numbers the window in ascending column order --
+// neighbouring lanes of a slice then read neighbouring window slots, the product's window load gathers x along runs of columns,
+// and a row's window indices ascend (cpack's differences are positive) --, and a second walk over the parked slots (its own
+// 16-B pieces, no column is read again) turns them into window indices.  Everything the lookups need is in LDS:
+// set 64 KiB + slot -> index 32 KiB + sort buffer 32 KiB.  (Until round 6's last third: three walks over the columns by 4-B
+// loads, the slot -> index map in memory: 3.0 + 9.5 ms per pattern at 6.2 M rows of P3.)
+__global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restrict__ order, int32_t nrows, int32_t nblk,
+                                                         const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                         const uint32_t* __restrict__ skey_all, int32_t* __restrict__ blk_wn,
+                                                         const int64_t* __restrict__ chunk0, int32_t* __restrict__ perm,
+                                                         int2* __restrict__ desc, int32_t* __restrict__ wlist,
+                                                         uint16_t* __restrict__ ccode, uint8_t* __restrict__ gflag, int* __restrict__ info,
+                                                         uint32_t* __restrict__ cpack, uint8_t* __restrict__ cflag)
+{
+  __shared__ int32_t hcol[BW_WHASH];  // the set of columns (-1: empty)
+  __shared__ uint16_t hid[BW_WHASH];  // slot -> window index
+  __shared__ uint16_t sbuf[BW_WHASH]; // occupied slots, sorted by their column
+  __shared__ int32_t sl_c0[BW_SLICES + 1];
+  __shared__ int wsum[BW_THREADS / 64];
+  __shared__ int n_win, any_ghost, bad, max_delta;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x)
+  {
+    const int r0 = b * BW_R, nb = min(BW_R, nrows - r0);
+    const uint32_t* __restrict__ skey = skey_all + (int64_t)b * BW_R;
+    for (int k = tid; k < BW_WHASH; k += BW_THREADS)
+      hcol[k] = -1;
+    if (tid == 0)
+      n_win = 0, any_ghost = 0, bad = 0, max_delta = 0;
     if (tid < BW_SLICES)
     {
       const unsigned len = 2047u - (skey[tid * 64] >> 12);
@@ -243,33 +302,60 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
       }
       sl_c0[BW_SLICES] = acc;
     }
-    // the window: every column of every row into the set
-    for (int p = tid; p < nb; p += BW_THREADS)
+    __syncthreads();
+    const int64_t cb = chunk0[b];
+    // first walk: every column into the set, its slot parked in ccode
+    for (int q = tid; q < BW_R; q += BW_THREADS)
     {
-      const int32_t r = order[r0 + p];
-      for (rp_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+      const int p = (int)(skey[q] & 4095u);
+      const bool real = p < nb;
+      const int32_t r = real ? order[r0 + p] : -1;
+      perm[(int64_t)b * BW_R + q] = r;
+      if (!real)
+        continue;
+      const int s = q >> 6, ln = q & 63;
+      const int64_t c0 = cb + sl_c0[s];
+      const rp_t a = rowptr[r];
+      const int len = (int)(rowptr[r + 1] - a);
+      for (int k0 = 0; k0 < len; k0 += 8)
       {
-        const int32_t c = cols[k];
-        if (c >= nrows)
-          any_ghost = 1;
-        unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
-        for (int probe = 0; probe < BW_WHASH; ++probe)
+        int32_t c[8];
+        bw_load8(cols + a, k0, len, (int32_t)-1, c);
+        unsigned slot[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
         {
-          int32_t cur = hcol[h];
-          if (cur == -1)
+          slot[e] = 0xffffu;
+          if (c[e] < 0)
+            continue;
+          if (c[e] >= nrows)
+            any_ghost = 1;
+          unsigned h = ((unsigned)c[e] * 2654435761u) >> (32 - BW_WBITS);
+          for (int probe = 0; probe < BW_WHASH; ++probe)
           {
-            cur = atomicCAS(&hcol[h], -1, c);
+            int32_t cur = hcol[h];
             if (cur == -1)
             {
-              if (atomicAdd(&n_win, 1) >= BW_WCAP)
-                bad = 1;
-              break;
+              cur = atomicCAS(&hcol[h], -1, c[e]);
+              if (cur == -1)
+              {
+                if (atomicAdd(&n_win, 1) >= BW_WCAP)
+                  bad = 1;
+                break;
+              }
             }
+            if (cur == c[e] || bad)
+              break;
+            h = (h + 1) & (BW_WHASH - 1);
           }
-          if (cur == c || bad)
-            break;
-          h = (h + 1) & (BW_WHASH - 1);
+          slot[e] = h;
         }
+        uint4v pk;
+        pk.x = slot[0] | (slot[1] << 16);
+        pk.y = slot[2] | (slot[3] << 16);
+        pk.z = slot[4] | (slot[5] << 16);
+        pk.w = slot[6] | (slot[7] << 16);
+        *reinterpret_cast<uint4v*>(ccode + ((c0 + (k0 >> 3)) * 64 + ln) * 8) = pk;
       }
     }
     __syncthreads();
@@ -286,20 +372,11 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
       __syncthreads();
       continue;
     }
-    if (!WRITE)
-    {
-      if (tid == 0)
-      {
-        blk_chunks[b] = sl_c0[BW_SLICES];
-        blk_wn[b] = n_win;
-        if (any_ghost)
-          atomicAdd(&info[1], 1);
-        gflag[b] = any_ghost ? 1 : 0;
-      }
-      __syncthreads();
-      continue;
-    }
-    // window indices: the occupied slots numbered in slot order
+    // the occupied slots, compacted in slot order, then sorted by column
+    const int nw = n_win;
+    int SB = 1024; // (the next power of two: most P3 windows are below 8 192)
+    while (SB < nw)
+      SB <<= 1;
     {
       constexpr int PER = BW_WHASH / BW_THREADS;
       int mine = 0;
@@ -319,128 +396,109 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
       for (int q = 0; q < wv; ++q)
         off += wsum[q];
       int id = off + incl - mine;
-      const int64_t w0 = woff[b];
       for (int k = 0; k < PER; ++k)
       {
         const int h = tid * PER + k;
         if (hcol[h] != -1)
-        {
-          wlist[w0 + id] = hcol[h];
-          ++id;
-        }
+          sbuf[id++] = (uint16_t)h;
       }
+      for (int i = nw + tid; i < SB; i += BW_THREADS)
+        sbuf[i] = 0xffffu;
     }
     __syncthreads();
-    // ... and put into ASCENDING COLUMN order: neighbouring lanes of a slice (rows of one entity type, neighbours in space) then
-    // read neighbouring window slots -- fewer LDS bank conflicts in the product -- and the product's window load gathers x along
-    // runs of consecutive columns instead of at random.  The list is sorted in the set's own LDS (a bitonic sort of 16 384
-    // entries, the unused ones INT_MAX) and the set rebuilt from the sorted list with the positions as indices.
-    {
-      static_assert(BW_WCAP <= 16384 && 16384 <= BW_WHASH, "the sort buffer lives in the set's array");
-      const int64_t w0 = woff[b];
-      const int nw = n_win;
-      int SB = 1024; // (the next power of two: most P3 windows are below 8 192)
-      while (SB < nw)
-        SB <<= 1;
-      for (int i = tid; i < SB; i += BW_THREADS)
-        hcol[i] = i < nw ? wlist[w0 + i] : INT_MAX;
-      __syncthreads();
-      for (int k = 2; k <= SB; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1)
+    for (int k = 2; k <= SB; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1)
+      {
+        for (int i = tid; i < SB; i += BW_THREADS)
         {
-          for (int i = tid; i < SB; i += BW_THREADS)
+          const int l = i ^ j;
+          if (l > i)
           {
-            const int l = i ^ j;
-            if (l > i)
+            const unsigned sa = sbuf[i], sc = sbuf[l];
+            const int32_t a = sa == 0xffffu ? INT_MAX : hcol[sa], c = sc == 0xffffu ? INT_MAX : hcol[sc];
+            const bool up = (i & k) == 0;
+            if ((a > c) == up)
             {
-              const int32_t a = hcol[i], c = hcol[l];
-              const bool up = (i & k) == 0;
-              if ((a > c) == up)
-              {
-                hcol[i] = c;
-                hcol[l] = a;
-              }
+              sbuf[i] = (uint16_t)sc;
+              sbuf[l] = (uint16_t)sa;
             }
           }
-          __syncthreads();
         }
-      for (int i = tid; i < nw; i += BW_THREADS)
-        wlist[w0 + i] = hcol[i];
-      __syncthreads();
-      for (int k = tid; k < BW_WHASH; k += BW_THREADS)
-        hcol[k] = -1;
-      __syncthreads();
-      for (int i = tid; i < nw; i += BW_THREADS)
-      {
-        const int32_t c = wlist[w0 + i];
-        unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
-        while (atomicCAS(&hcol[h], -1, c) != -1)
-          h = (h + 1) & (BW_WHASH - 1);
-        hid[h] = i;
+        __syncthreads();
       }
+    const int64_t w0 = (int64_t)b * BW_WCAP;
+    for (int i = tid; i < nw; i += BW_THREADS)
+    {
+      const unsigned sl = sbuf[i];
+      wlist[w0 + i] = hcol[sl];
+      hid[sl] = (uint16_t)i;
     }
-    __syncthreads();
-    const int64_t cb = chunk0[b];
     if (tid < BW_SLICES)
       desc[(int64_t)b * BW_SLICES + tid] = make_int2((int)(cb + sl_c0[tid]), sl_c0[tid + 1] - sl_c0[tid]);
+    if (tid == 0)
+    {
+      blk_wn[b] = nw;
+      gflag[b] = any_ghost ? 1 : 0;
+      if (any_ghost)
+        atomicAdd(&info[1], 1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(info + 6), (unsigned long long)nw);
+    }
+    __syncthreads();
+    // second walk: the parked slots become window indices.  Every entry's index twice: as 16 bits (ccode), and PACKED, 12 B per
+    // lane and chunk (cpack: the chunk's first index in 16 bits, then seven differences of 10 bits -- the window is in ascending
+    // column order, as a row's entries are: differences are positive and small, 69 % of P3's chunks below 256, all below 1 024).
+    // The product reads the packed form where every difference of the block fits (cflag); entries beyond the row's last have
+    // index 0 in ccode and repeat the last index (difference 0) in cpack.
     for (int q = tid; q < BW_R; q += BW_THREADS)
     {
       const int p = (int)(skey[q] & 4095u);
-      const bool real = p < nb;
-      const int32_t r = real ? order[r0 + p] : -1;
-      perm[(int64_t)b * BW_R + q] = r;
-      if (!real)
+      if (p >= nb)
         continue;
+      const int32_t r = order[r0 + p];
       const int s = q >> 6, ln = q & 63;
       const int64_t c0 = cb + sl_c0[s];
-      const rp_t a = rowptr[r];
-      const int len = (int)(rowptr[r + 1] - a);
-      // Every entry's window index twice: as 16 bits (ccode), and PACKED, 12 B per lane and chunk (cpack: the chunk's first
-      // index in 16 bits, then seven differences of 10 bits -- the window is in ascending column order, as a row's entries are:
-      // differences are positive and small, 69 % of P3's chunks below 256, all below 1 024).  The product reads the packed form
-      // where every difference of the block fits (cflag); entries beyond the row's last repeat the last index (difference 0).
-      unsigned w0 = 0, w1 = 0, w2 = 0;
-      int prev = 0, dmax = 0;
-      for (int k = 0; k < len; ++k)
+      const int len = (int)(rowptr[r + 1] - rowptr[r]);
+      int dmax = 0;
+      for (int k0 = 0; k0 < len; k0 += 8)
       {
-        const int32_t c = cols[a + k];
-        unsigned h = ((unsigned)c * 2654435761u) >> (32 - BW_WBITS);
-        while (hcol[h] != c)
-          h = (h + 1) & (BW_WHASH - 1);
-        const int id = hid[h];
-        ccode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)id;
-        const int e = k & 7;
-        if (e == 0)
-          w0 = (unsigned)id, w1 = 0, w2 = 0;
-        else
+        uint16_t* const cc = ccode + ((c0 + (k0 >> 3)) * 64 + ln) * 8;
+        const uint4v pk = *reinterpret_cast<const uint4v*>(cc);
+        const unsigned sl[8] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16, pk.z & 0xffffu, pk.z >> 16, pk.w & 0xffffu, pk.w >> 16};
+        unsigned id[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          id[e] = sl[e] == 0xffffu ? 0xffffu : (unsigned)hid[sl[e]];
+        unsigned long long lo = id[0]; // bits 0..15 first index, then seven differences of 10 bits: bits 16..85
+        unsigned w2 = 0;
+        unsigned prev = id[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e)
         {
-          const int d = id - prev;
+          const unsigned cur = id[e] == 0xffffu ? prev : id[e];
+          const int d = (int)cur - (int)prev;
           dmax = max(dmax, d);
           const unsigned long long dd = (unsigned long long)(unsigned)(d & 1023);
           const int bit = 16 + 10 * (e - 1); // 16, 26, 36, 46, 56, 66, 76
-          if (bit < 32)
+          if (bit < 64)
           {
-            w0 |= (unsigned)(dd << bit);
-            if (bit + 10 > 32)
-              w1 |= (unsigned)(dd >> (32 - bit));
-          }
-          else if (bit < 64)
-          {
-            w1 |= (unsigned)(dd << (bit - 32));
+            lo |= dd << bit;
             if (bit + 10 > 64)
               w2 |= (unsigned)(dd >> (64 - bit));
           }
           else
             w2 |= (unsigned)(dd << (bit - 64));
+          prev = cur;
         }
-        prev = id;
-        if (e == 7 || k + 1 == len)
-        {
-          uint32_t* dst = cpack + ((c0 + (k >> 3)) * 64 + ln) * 3;
-          dst[0] = w0;
-          dst[1] = w1;
-          dst[2] = w2;
-        }
+        uint4v out;
+        out.x = (id[0] == 0xffffu ? 0u : id[0]) | ((id[1] == 0xffffu ? 0u : id[1]) << 16);
+        out.y = (id[2] == 0xffffu ? 0u : id[2]) | ((id[3] == 0xffffu ? 0u : id[3]) << 16);
+        out.z = (id[4] == 0xffffu ? 0u : id[4]) | ((id[5] == 0xffffu ? 0u : id[5]) << 16);
+        out.w = (id[6] == 0xffffu ? 0u : id[6]) | ((id[7] == 0xffffu ? 0u : id[7]) << 16);
+        *reinterpret_cast<uint4v*>(cc) = out;
+        uint32_t* dst = cpack + ((c0 + (k0 >> 3)) * 64 + ln) * 3;
+        dst[0] = (unsigned)lo;
+        dst[1] = (unsigned)(lo >> 32);
+        dst[2] = w2;
       }
       if (dmax)
         atomicMax(&max_delta, dmax);
@@ -453,19 +511,21 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
 }
 
 // ---- values (after every assembly) ---------------------------------------------------------------------------------------
-// One workgroup per block: the block's distinct values into a set in LDS, numbered as they arrive (code 0 = +0.0); the table
-// and every entry's 16-bit code.  info[2]: a block holds more values than the table.
+// One workgroup per block: the block's distinct values into a set in LDS; the table and every entry's code (code 0 = +0.0).
+// The values are read ONCE (16-B loads): a lane parks the set's SLOT of each entry in the entry's place in vcode; the occupied
+// slots are then numbered in slot order (deterministic: the dictionary's order does not depend on which lane came first), the
+// table written, the numbers put into the set's own slots, and a second walk over the parked slots turns them into codes.
+// info[2]: a block holds more values than the table.
 __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restrict__ perm, int32_t nblk, const rp_t* __restrict__ rowptr,
                                                           const unsigned long long* __restrict__ vals, const int2* __restrict__ desc,
                                                           uint16_t* __restrict__ vcode, unsigned long long* __restrict__ dict,
                                                           int32_t* __restrict__ dnum, int* __restrict__ info,
-                                                          uint16_t* __restrict__ hcode_all, uint32_t* __restrict__ vpack,
-                                                          uint8_t* __restrict__ vflag)
+                                                          uint32_t* __restrict__ vpack, uint8_t* __restrict__ vflag)
 {
-  uint16_t* const hcode = hcode_all + (int64_t)blockIdx.x * BW_DHASH; // slot -> code (this workgroup's scratch: L2)
   __shared__ unsigned long long hval[BW_DHASH];
+  __shared__ int wsum[BW_THREADS / 64];
   __shared__ int n_val, bad;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int b = blockIdx.x; b < nblk; b += gridDim.x)
   {
     for (int k = tid; k < BW_DHASH; k += BW_THREADS)
@@ -474,73 +534,6 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
       n_val = 1, bad = 0; // (entry 0 is +0.0)
     __syncthreads();
     unsigned long long* const tab = dict + (int64_t)b * BW_DCAP;
-    if (tid == 0)
-      tab[0] = 0ull;
-    for (int q = tid; q < BW_R; q += BW_THREADS)
-    {
-      const int32_t r = perm[(int64_t)b * BW_R + q];
-      if (r < 0)
-        continue;
-      unsigned long long last = 0ull;
-      for (rp_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
-      {
-        const unsigned long long v = vals[k];
-        if (v == 0ull || v == last)
-          continue;
-        last = v;
-        if (v == ~0ull)
-        {
-          bad = 1;
-          continue;
-        }
-        unsigned h = (unsigned)(((v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
-        for (int probe = 0; probe < BW_DHASH; ++probe)
-        {
-          unsigned long long cur = hval[h];
-          if (cur == ~0ull)
-          {
-            cur = atomicCAS(&hval[h], ~0ull, v);
-            if (cur == ~0ull)
-            {
-              const int c = atomicAdd(&n_val, 1);
-              if (c >= BW_DCAP)
-                bad = 1;
-              else
-              {
-                hcode[h] = (uint16_t)c;
-                tab[c] = v;
-              }
-              break;
-            }
-          }
-          if (cur == v || bad)
-            break;
-          h = (h + 1) & (BW_DHASH - 1);
-        }
-      }
-    }
-    __syncthreads();
-    if (tid == 0)
-    {
-      atomicMax(&info[3], n_val); // (diagnostics: the largest dictionary met, blocks that did not fit)
-      if (bad)
-        atomicAdd(&info[4], 1);
-    }
-    if (bad)
-    {
-      if (tid == 0)
-        info[2] = 1;
-      __syncthreads();
-      continue;
-    }
-    if (tid == 0)
-    {
-      dnum[b] = n_val;
-      vflag[b] = n_val <= 4096 ? 1 : 0; // the codes fit 12 bits: the product reads them packed, 12 B per lane and chunk (vpack)
-    }
-    const bool vp = n_val <= 4096;
-    // (the table stays in arrival order: sorting it by bit pattern -- neighbouring lanes then read neighbouring slots -- was
-    // measured and bought nothing, 0.3013 against 0.3023 ms at 6.2 M rows of P3: the product is bound by its bytes, not by LDS)
     for (int q = tid; q < BW_R; q += BW_THREADS)
     {
       const int32_t r = perm[(int64_t)b * BW_R + q];
@@ -551,51 +544,147 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_values(const int32_t* __restr
       const rp_t a = rowptr[r];
       const int len = (int)(rowptr[r + 1] - a);
       unsigned long long last = 0ull;
-      unsigned last_code = 0, p0 = 0, p1 = 0, p2 = 0;
-      for (int k = 0; k < len; ++k)
+      unsigned last_slot = 0xffffu;
+      for (int k0 = 0; k0 < len; k0 += 8)
       {
-        const unsigned long long v = vals[a + k];
-        unsigned code = 0;
-        if (v != 0ull)
+        unsigned long long v[8];
+        bw_load8(vals + a, k0, len, 0ull, v);
+        unsigned slot[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
         {
-          if (v != last)
+          slot[e] = 0xffffu; // (+0.0: code 0)
+          if (v[e] == 0ull)
+            continue;
+          if (v[e] == last)
           {
-            unsigned h = (unsigned)(((v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
-            while (hval[h] != v)
-              h = (h + 1) & (BW_DHASH - 1);
-            last = v;
-            last_code = hcode[h];
+            slot[e] = last_slot;
+            continue;
           }
-          code = last_code;
+          if (v[e] == ~0ull)
+          {
+            bad = 1;
+            continue;
+          }
+          unsigned h = (unsigned)(((v[e] ^ (v[e] >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - BW_DBITS));
+          for (int probe = 0; probe < BW_DHASH; ++probe)
+          {
+            unsigned long long cur = hval[h];
+            if (cur == ~0ull)
+            {
+              cur = atomicCAS(&hval[h], ~0ull, v[e]);
+              if (cur == ~0ull)
+              {
+                if (atomicAdd(&n_val, 1) >= BW_DCAP)
+                  bad = 1;
+                break;
+              }
+            }
+            if (cur == v[e] || bad)
+              break;
+            h = (h + 1) & (BW_DHASH - 1);
+          }
+          slot[e] = h;
+          last = v[e];
+          last_slot = h;
         }
-        vcode[((c0 + (k >> 3)) * 64 + ln) * 8 + (k & 7)] = (uint16_t)code;
+        uint4v pk;
+        pk.x = slot[0] | (slot[1] << 16);
+        pk.y = slot[2] | (slot[3] << 16);
+        pk.z = slot[4] | (slot[5] << 16);
+        pk.w = slot[6] | (slot[7] << 16);
+        *reinterpret_cast<uint4v*>(vcode + ((c0 + (k0 >> 3)) * 64 + ln) * 8) = pk;
+      }
+    }
+    __syncthreads();
+    const int nv = n_val;
+    if (tid == 0)
+    {
+      atomicMax(&info[3], nv); // (diagnostics: the largest dictionary met, blocks that did not fit)
+      if (bad)
+        atomicAdd(&info[4], 1);
+    }
+    if (bad)
+    {
+      if (tid == 0)
+        info[2] = 1;
+      __syncthreads();
+      continue;
+    }
+    // codes: the occupied slots numbered in slot order from 1; the table; the code into the slot itself
+    {
+      constexpr int PER = BW_DHASH / BW_THREADS;
+      int mine = 0;
+      for (int k = 0; k < PER; ++k)
+        mine += hval[tid * PER + k] != ~0ull ? 1 : 0;
+      int incl = mine;
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d)
+          incl += t;
+      }
+      if (lane == 63)
+        wsum[wv] = incl;
+      __syncthreads();
+      int off = 0;
+      for (int q = 0; q < wv; ++q)
+        off += wsum[q];
+      int code = 1 + off + incl - mine;
+      for (int k = 0; k < PER; ++k)
+      {
+        const int h = tid * PER + k;
+        const unsigned long long v = hval[h];
+        if (v != ~0ull)
+        {
+          tab[code] = v;
+          hval[h] = (unsigned long long)code;
+          ++code;
+        }
+      }
+      if (tid == 0)
+      {
+        tab[0] = 0ull;
+        dnum[b] = nv;
+        vflag[b] = nv <= 4096 ? 1 : 0; // the codes fit 12 bits: the product reads them packed, 12 B per lane and chunk (vpack)
+      }
+    }
+    __syncthreads();
+    const bool vp = nv <= 4096;
+    for (int q = tid; q < BW_R; q += BW_THREADS)
+    {
+      const int32_t r = perm[(int64_t)b * BW_R + q];
+      if (r < 0)
+        continue;
+      const int s = q >> 6, ln = q & 63;
+      const int64_t c0 = desc[(int64_t)b * BW_SLICES + s].x;
+      const int len = (int)(rowptr[r + 1] - rowptr[r]);
+      for (int k0 = 0; k0 < len; k0 += 8)
+      {
+        uint16_t* const vc = vcode + ((c0 + (k0 >> 3)) * 64 + ln) * 8;
+        const uint4v pk = *reinterpret_cast<const uint4v*>(vc);
+        const unsigned sl[8] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16, pk.z & 0xffffu, pk.z >> 16, pk.w & 0xffffu, pk.w >> 16};
+        unsigned code[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          code[e] = sl[e] == 0xffffu ? 0u : (unsigned)hval[sl[e]];
+        uint4v out;
+        out.x = code[0] | (code[1] << 16);
+        out.y = code[2] | (code[3] << 16);
+        out.z = code[4] | (code[5] << 16);
+        out.w = code[6] | (code[7] << 16);
+        *reinterpret_cast<uint4v*>(vc) = out;
         if (vp)
         {
-          const int e = k & 7, bit = 12 * e; // 0, 12, 24, 36, 48, 60, 72, 84
-          const unsigned long long cc = (unsigned long long)(code & 4095u);
-          if (e == 0)
-            p0 = p1 = p2 = 0;
-          if (bit < 32)
-          {
-            p0 |= (unsigned)(cc << bit);
-            if (bit + 12 > 32)
-              p1 |= (unsigned)(cc >> (32 - bit));
-          }
-          else if (bit < 64)
-          {
-            p1 |= (unsigned)(cc << (bit - 32));
-            if (bit + 12 > 64)
-              p2 |= (unsigned)(cc >> (64 - bit));
-          }
-          else
-            p2 |= (unsigned)(cc << (bit - 64));
-          if (e == 7 || k + 1 == len)
-          {
-            uint32_t* dst = vpack + ((c0 + (k >> 3)) * 64 + ln) * 3;
-            dst[0] = p0;
-            dst[1] = p1;
-            dst[2] = p2;
-          }
+          // eight codes of 12 bits: bits 0..95
+          const unsigned long long lo = (unsigned long long)code[0] | ((unsigned long long)code[1] << 12) | ((unsigned long long)code[2] << 24)
+                                        | ((unsigned long long)code[3] << 36) | ((unsigned long long)code[4] << 48)
+                                        | ((unsigned long long)code[5] << 60);
+          const unsigned hi = (code[5] >> 4) | (code[6] << 8) | (code[7] << 20);
+          uint32_t* dst = vpack + ((c0 + (k0 >> 3)) * 64 + ln) * 3;
+          dst[0] = (unsigned)lo;
+          dst[1] = (unsigned)(lo >> 32);
+          dst[2] = hi;
         }
       }
     }
@@ -615,7 +704,8 @@ struct WinArgs
 
 template <bool DOT, bool SR, bool NT, bool CHEB = false>
 __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __restrict__ p_perm, const int2* __restrict__ p_desc,
-                                                              const int64_t* __restrict__ p_woff, const int32_t* __restrict__ p_wlist,
+                                                              const int64_t* __restrict__ p_woff, const int32_t* __restrict__ p_wn,
+                                                              const int32_t* __restrict__ p_wlist,
                                                               const uint16_t* __restrict__ p_ccode, const uint16_t* __restrict__ p_vcode,
                                                               const uint32_t* __restrict__ p_cpack, const uint32_t* __restrict__ p_vpack,
                                                               const uint8_t* __restrict__ p_cflag, const uint8_t* __restrict__ p_vflag,
@@ -641,7 +731,7 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
       break;
     const int b = p_list ? p_list[t] : (int)t;
     const int64_t w0 = p_woff[b];
-    const int wn = (int)(p_woff[b + 1] - w0), dn = p_dnum[b];
+    const int wn = p_wn[b], dn = p_dnum[b];
     const bool cpk = __builtin_amdgcn_readfirstlane((int)p_cflag[b]) != 0, vpk = __builtin_amdgcn_readfirstlane((int)p_vflag[b]) != 0;
     __syncthreads(); // the previous block's lookups are done
     // window and dictionary into LDS: every thread's (at most eight + four) entries requested before any is stored
@@ -878,36 +968,31 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bw_chunk0.alloc((size_t)nblk + 1));
   ZZZ_HIP(ctx, ctx->bw_woff.alloc((size_t)nblk + 1));
   ZZZ_HIP(ctx, ctx->bw_gflag.alloc((size_t)nblk));
+  ZZZ_HIP(ctx, ctx->bw_skey.alloc((size_t)nblk * BW_R));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_chunks.p + nblk, 0, sizeof(int32_t), s));
-  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_wn.p + nblk, 0, sizeof(int32_t), s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_blk_wn.p, 0, ((size_t)nblk + 1) * sizeof(int32_t), s));
   const unsigned grid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
-  DevBuf<int32_t>& hid = ctx->bw_hid;
-  ZZZ_HIP(ctx, hid.alloc((size_t)grid * BW_WHASH));
-  hipLaunchKernelGGL(k_bw_block<false>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
-                     ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, (const int64_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
-                     (int2*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, ctx->bw_gflag.p, info.p, hid.p, (uint32_t*)nullptr, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_bw_sort, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->bw_skey.p,
+                     ctx->bw_blk_chunks.p, ctx->bw_woff.p, info.p);
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
     ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
     ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
-    ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->bw_blk_wn.p, ctx->bw_woff.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
   }
   ZZZ_HIP(ctx, hipGetLastError());
   int32_t h[8];
   int64_t tot[2] = {0, 0};
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipMemcpyAsync(&tot[0], ctx->bw_chunk0.p + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  ZZZ_HIP(ctx, hipMemcpyAsync(&tot[1], ctx->bw_woff.p + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
   if (getenv("ZZZ_DEBUG_SYNC"))
-    fprintf(stderr, "[zzz dbg] bw_structure pass 1: flag %d ghost blocks %d chunks %lld window %lld nblk %d max window %d bad blocks %d\n",
-            h[0], h[1], (long long)tot[0], (long long)tot[1], nblk, h[3], h[4]);
-  if (h[0] || tot[0] <= 0 || tot[1] <= 0)
-    return ZZZ_OK; // declined: a block beyond the LDS budget
+    fprintf(stderr, "[zzz dbg] bw_structure pass 1: flag %d chunks %lld nblk %d\n", h[0], (long long)tot[0], nblk);
+  if (h[0] || tot[0] <= 0)
+    return ZZZ_OK; // declined: a row of 2^11 entries or more
   ZZZ_HIP(ctx, ctx->bw_perm.alloc((size_t)nblk * BW_R));
   ZZZ_HIP(ctx, ctx->bw_desc.alloc((size_t)nblk * BW_SLICES * 2));
-  ZZZ_HIP(ctx, ctx->bw_wlist.alloc((size_t)tot[1] + 8));
+  ZZZ_HIP(ctx, ctx->bw_wlist.alloc((size_t)nblk * BW_WCAP + 8));
   ZZZ_HIP(ctx, ctx->bw_ccode.alloc((size_t)tot[0] * 512));
   ZZZ_HIP(ctx, ctx->bw_vcode.alloc((size_t)tot[0] * 512));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_ccode.p, 0, (size_t)tot[0] * 1024, s));
@@ -916,15 +1001,22 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bw_cflag.alloc((size_t)nblk));
   ZZZ_HIP(ctx, ctx->bw_vflag.alloc((size_t)nblk));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_cpack.p, 0, (size_t)tot[0] * 768, s));
-  hipLaunchKernelGGL(k_bw_block<true>, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
-                     ctx->bw_blk_chunks.p, ctx->bw_blk_wn.p, ctx->bw_chunk0.p, ctx->bw_woff.p, ctx->bw_perm.p,
-                     reinterpret_cast<int2*>(ctx->bw_desc.p), ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, hid.p, ctx->bw_cpack.p,
-                     ctx->bw_cflag.p);
+  hipLaunchKernelGGL(k_bw_block, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
+                     ctx->bw_skey.p, ctx->bw_blk_wn.p, ctx->bw_chunk0.p, ctx->bw_perm.p, reinterpret_cast<int2*>(ctx->bw_desc.p),
+                     ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, ctx->bw_cpack.p, ctx->bw_cflag.p);
   ZZZ_HIP(ctx, hipGetLastError());
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
-  if (h[0])
-    return ZZZ_OK;
+  {
+    unsigned long long we = 0;
+    memcpy(&we, h + 6, sizeof(we));
+    tot[1] = (int64_t)we;
+  }
+  if (getenv("ZZZ_DEBUG_SYNC"))
+    fprintf(stderr, "[zzz dbg] bw_structure pass 2: flag %d ghost blocks %d window %lld max window %d bad blocks %d\n", h[0], h[1],
+            (long long)tot[1], h[3], h[4]);
+  if (h[0] || tot[1] <= 0)
+    return ZZZ_OK; // declined: a block beyond the LDS budget
   // interior / boundary blocks for the halo-compute overlap of a partitioned matrix
   ctx->bw_n_interior = ctx->bw_n_boundary = 0;
   ctx->bw_have_split = false;
@@ -993,11 +1085,9 @@ int sellp_win_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_vcode.p, 0, (size_t)ctx->bw_chunks * 1024, s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_vpack.p, 0, (size_t)ctx->bw_chunks * 768, s));
   const unsigned vgrid = (unsigned)std::min<int32_t>(nblk, 256 * 2);
-  DevBuf<uint16_t>& hcode = ctx->bw_hcode;
-  ZZZ_HIP(ctx, hcode.alloc((size_t)vgrid * BW_DHASH));
   hipLaunchKernelGGL(k_bw_values, dim3(vgrid), dim3(BW_THREADS), 0, s, ctx->bw_perm.p, nblk,
                      ctx->rowptr.p, reinterpret_cast<const unsigned long long*>(ctx->vals.p), reinterpret_cast<const int2*>(ctx->bw_desc.p),
-                     ctx->bw_vcode.p, reinterpret_cast<unsigned long long*>(ctx->bw_dict.p), ctx->bw_dnum.p, info.p, hcode.p, ctx->bw_vpack.p,
+                     ctx->bw_vcode.p, reinterpret_cast<unsigned long long*>(ctx->bw_dict.p), ctx->bw_dnum.p, info.p, ctx->bw_vpack.p,
                      ctx->bw_vflag.p);
   ZZZ_HIP(ctx, hipGetLastError());
   int32_t h[8];
@@ -1080,7 +1170,7 @@ bool launch_sellp_win(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
   const size_t lds = (size_t)(BW_WCAP + BW_DCAP) * 8;
 #define ZZZ_BW_GO4(DOT, SR, NT, CHEB, EPI)                                                                                         \
   hipLaunchKernelGGL((spmv_win_kernel<DOT, SR, NT, CHEB>), dim3(grid), dim3(BW_THREADS), lds, ctx->stream, ctx->bw_perm.p,         \
-                     reinterpret_cast<const int2*>(ctx->bw_desc.p), ctx->bw_woff.p, ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_vcode.p, \
+                     reinterpret_cast<const int2*>(ctx->bw_desc.p), ctx->bw_woff.p, ctx->bw_blk_wn.p, ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_vcode.p, \
                      ctx->bw_cpack.p, ctx->bw_vpack.p, ctx->bw_cflag.p, ctx->bw_vflag.p, ctx->bw_dict.p, ctx->bw_dnum.p, x, y, rvec, list, a, EPI)
 #define ZZZ_BW_GO(DOT, SR, NT) ZZZ_BW_GO4(DOT, SR, NT, false, ChebEpi())
   if (epi)
