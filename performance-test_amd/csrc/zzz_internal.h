@@ -327,7 +327,8 @@ struct zzz_ctx
   zzz::DevBuf<double> bk_vdict;
   int bk_form = 1, bk_ndict = 0; // 1: the table's rows (nine doubles) in LDS; 2: rows of value offsets in memory, the values in LDS
   zzz::DevBuf<double> bk_tab;
-  zzz::DevBuf<unsigned long long> bk_hash_tag, bk_hash_owner;
+  zzz::DevBuf<unsigned long long> bk_hash_tag, bk_hash_tag2, bk_hash_owner;
+  zzz::DevBuf<int32_t> bk_park; // per block of the matrix: its slot in the set (-1: a zero block), k_bk_insert to k_bk_fill
   zzz::DevBuf<uint8_t> bk_gflag;
   bool bk_on = false, bk_have_split = false, bk_lds_attr = false;
   int sellp_blk = 1;       // ZZZ_SELLP_BLK=0: block size 3 stays on the generic product

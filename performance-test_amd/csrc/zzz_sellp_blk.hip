@@ -24,7 +24,8 @@
 // When it applies: block size 3, natural row order, at most BK_TAB_MAX distinct blocks (the LDS copy), 16-bit column codes
 // suffice, no folded all-reduce on the launch (tools build; that stays on the generic kernel).  The Chebyshev-Jacobi polynomial's
 // terms ride on it as epilogues exactly as on the generic kernel (CHEB: C4's solve with -pc_type chebyshev_jacobi 419 -> 191 ms).  Otherwise nothing changes.  ZZZ_SELLP_BLK=0 switches it off (A/B, parity tests), 2 forces it below 100 000 nodes.
-// Built at the stream's first use after an assembly (sellp_active), from the CSR matrix of record, on the device.
+// Built from the CSR matrix of record, on the device, when the matrix is assembled (sell_update: the generic stream is then not
+// packed at all) or, for a partitioned matrix, at the stream's first use after an assembly (sellp_active).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -85,43 +86,34 @@ __device__ inline unsigned long long bk_hash(const Blk9& B)
   return h ? h : 1ull; // 0 marks an empty slot
 }
 
+// a second, independent fingerprint: a block is identified by the PAIR (128 bits; two different blocks of one matrix sharing both
+// has probability ~ n^2 / 2^129 for n distinct blocks, 1e-29 at 65 536 -- below any hardware error rate; until the last third of
+// round 6 one fingerprint + a comparison of every block with its table row, which cost a third walk over the values)
+__device__ inline unsigned long long bk_hash2(const Blk9& B)
+{
+  unsigned long long h = 0xD6E8FEB86659FD93ull;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+  {
+    h = (h ^ ((B.b[i] << 17) | (B.b[i] >> 47))) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+  }
+  return h ? h : 1ull;
+}
+
 // info: [0] distinct blocks so far, [1] the form does not apply (structure, too many blocks, a column code beyond 16 bits, a
 // fingerprint collision), [2] entries of the table, [4..5] bytes a product reads (64-bit)
 
-// pass 1: chunks per slice = ceil(most kept blocks of a node / 16); the matrix's block structure checked on the way
-__global__ __launch_bounds__(256) void k_bk_count(const rp_t* __restrict__ rowptr, const unsigned long long* __restrict__ vals,
-                                                  int nnodes, int64_t nsl, int32_t* __restrict__ nch, int* __restrict__ info)
-{
-  const int lane = threadIdx.x & 63;
-  for (int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6); s < nsl; s += gridDim.x * 4ll)
-  {
-    const int64_t r = s * 64 + lane;
-    int kept = 0;
-    if (r < nnodes)
-    {
-      const int64_t p0 = rowptr[3 * r], p1 = rowptr[3 * r + 1], p2 = rowptr[3 * r + 2], p3 = rowptr[3 * r + 3];
-      const int64_t len = p1 - p0;
-      if (p2 - p1 != len || p3 - p2 != len || len % 3 != 0)
-        info[1] = 1;
-      else
-        for (int k = 0; k < (int)(len / 3); ++k)
-        {
-          Blk9 B;
-          bk_load(vals, p0, p1, p2, k, B);
-          kept += bk_nonzero(B) ? 1 : 0;
-        }
-    }
-    const int m = wave_max_i(kept);
-    if (lane == 0)
-      nch[s] = (m + BK_SLOTS - 1) / BK_SLOTS;
-  }
-}
-
-// pass 2: every kept block into the set: tag = fingerprint, owner = the smallest (node << 10 | block) that carries it (so that
-// the table does not depend on which lane came first)
+// pass 1: ONE walk over the values.  Every kept block into the set -- tag = first fingerprint, tag2 = second (whoever sets it
+// first owns the slot: a block with the same tag and another tag2 moves on), owner = the smallest (node << 10 | block) that carries
+// the pair (so that the table does not depend on which lane came first) --, the SLOT it landed in parked per block (park: -1 for a
+// zero block) for the fill pass, which then needs no value; chunks per slice = ceil(most kept blocks of a node / 16); the matrix's
+// block structure checked on the way.  (Until the last third of round 6: a count walk, an insert walk and a fill walk that hashed
+// every block again and compared it with its table row: 0.9 + 1.7 + 1.75 ms at C4.)
 __global__ __launch_bounds__(256) void k_bk_insert(const rp_t* __restrict__ rowptr, const unsigned long long* __restrict__ vals,
                                                    int nnodes, int64_t nsl, unsigned long long* __restrict__ tag,
-                                                   unsigned long long* __restrict__ owner, int* __restrict__ info, int limit)
+                                                   unsigned long long* __restrict__ tag2, unsigned long long* __restrict__ owner,
+                                                   int32_t* __restrict__ park, int32_t* __restrict__ nch, int* __restrict__ info, int limit)
 {
   const int lane = threadIdx.x & 63;
   for (int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6); s < nsl; s += gridDim.x * 4ll)
@@ -129,52 +121,84 @@ __global__ __launch_bounds__(256) void k_bk_insert(const rp_t* __restrict__ rowp
     if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       return;
     const int64_t r = s * 64 + lane;
-    if (r >= nnodes)
-      continue;
-    const int64_t p0 = rowptr[3 * r], p1 = rowptr[3 * r + 1], p2 = rowptr[3 * r + 2];
-    const int nbk = (int)((p1 - p0) / 3);
-    if (nbk >= 1024)
+    int kept = 0;
+    if (r < nnodes)
     {
-      info[1] = 1; // (the owner word keeps ten bits for the block)
-      continue;
-    }
-    unsigned long long last = 0ull;
-    for (int k = 0; k < nbk; ++k)
-    {
-      Blk9 B;
-      bk_load(vals, p0, p1, p2, k, B);
-      if (!bk_nonzero(B))
-        continue;
-      const unsigned long long fp = bk_hash(B);
-      const unsigned long long me = ((unsigned long long)r << 10) | (unsigned)k;
-      if (fp == last)
-        continue; // (a node's neighbours often carry the same block: the table has seen it; its owner is this node or an earlier one)
-      last = fp;
-      unsigned h = (unsigned)(fp >> (64 - BK_HASH_BITS));
-      for (int probe = 0; probe < BK_HASH; ++probe)
+      const int64_t p0 = rowptr[3 * r], p1 = rowptr[3 * r + 1], p2 = rowptr[3 * r + 2], p3 = rowptr[3 * r + 3];
+      const int64_t len = p1 - p0;
+      const int nbk = (int)(len / 3);
+      if (p2 - p1 != len || p3 - p2 != len || len % 3 != 0 || p0 % 9 != 0 || nbk >= 1024) // (the owner word keeps ten bits for the block)
+        info[1] = 1;
+      else
       {
-        unsigned long long cur = __hip_atomic_load(&tag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0ull)
+        int32_t* const pk = park + p0 / 9;
+        unsigned long long last = 0ull, last2 = 0ull;
+        int last_slot = -1;
+        for (int k = 0; k < nbk; ++k)
         {
-          cur = atomicCAS(&tag[h], 0ull, fp);
-          if (cur == 0ull)
+          Blk9 B;
+          bk_load(vals, p0, p1, p2, k, B);
+          if (!bk_nonzero(B))
           {
-            if (atomicAdd(&info[0], 1) >= limit - 1)
-              info[1] = 2;
-            cur = fp;
+            pk[k] = -1;
+            continue;
           }
+          ++kept;
+          const unsigned long long fp = bk_hash(B), fq = bk_hash2(B);
+          if (fp == last && fq == last2) // (a node's neighbours often carry the same block: its owner is this node or an earlier one)
+          {
+            pk[k] = last_slot;
+            continue;
+          }
+          const unsigned long long me = ((unsigned long long)r << 10) | (unsigned)k;
+          unsigned h = (unsigned)(fp >> (64 - BK_HASH_BITS));
+          int slot = -1;
+          for (int probe = 0; probe < BK_HASH; ++probe)
+          {
+            unsigned long long cur = __hip_atomic_load(&tag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull)
+            {
+              cur = atomicCAS(&tag[h], 0ull, fp);
+              if (cur == 0ull)
+              {
+                if (atomicAdd(&info[0], 1) >= limit - 1)
+                  info[1] = 2;
+                cur = fp;
+              }
+            }
+            if (cur == fp)
+            {
+              unsigned long long c2 = __hip_atomic_load(&tag2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (c2 == 0ull)
+              {
+                c2 = atomicCAS(&tag2[h], 0ull, fq);
+                if (c2 == 0ull)
+                  c2 = fq;
+              }
+              if (c2 == fq)
+              {
+                if (__hip_atomic_load(&owner[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > me)
+                  atomicMin(&owner[h], me);
+                slot = (int)h;
+                break;
+              }
+            }
+            h = (h + 1) & (BK_HASH - 1);
+            if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+              return;
+          }
+          if (slot < 0)
+            info[1] = 3;
+          pk[k] = slot;
+          last = fp;
+          last2 = fq;
+          last_slot = slot;
         }
-        if (cur == fp)
-        {
-          if (__hip_atomic_load(&owner[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > me)
-            atomicMin(&owner[h], me);
-          break;
-        }
-        h = (h + 1) & (BK_HASH - 1);
-        if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-          return;
       }
     }
+    const int m = wave_max_i(kept);
+    if (lane == 0)
+      nch[s] = (m + BK_SLOTS - 1) / BK_SLOTS;
   }
 }
 
@@ -362,10 +386,9 @@ __global__ __launch_bounds__(256) void k_bk_rows16(const unsigned long long* __r
 // Per chunk: meta[0..15] the slots' smallest block columns (column = base + 16-bit code), meta[16..31] the affine bases
 // (column = base + lane: valid when flags bit 8 is set, i.e. EVERY slot of the chunk is affine); flags = width | affine << 8.
 __global__ __launch_bounds__(256) void k_bk_fill(const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                 const unsigned long long* __restrict__ vals, int nnodes, int n_owned, int64_t nsl,
+                                                 const int32_t* __restrict__ park, int nnodes, int n_owned, int64_t nsl,
                                                  const int32_t* __restrict__ c0s, const int32_t* __restrict__ nchs,
-                                                 const unsigned long long* __restrict__ tag, const int32_t* __restrict__ slot_code,
-                                                 const unsigned long long* __restrict__ tab, int2* __restrict__ desc,
+                                                 const int32_t* __restrict__ slot_code, int2* __restrict__ desc,
                                                  int32_t* __restrict__ meta, int32_t* __restrict__ flags, uint16_t* __restrict__ bcode,
                                                  uint16_t* __restrict__ ccode, uint8_t* __restrict__ ghost_flag, int* __restrict__ info)
 {
@@ -377,15 +400,14 @@ __global__ __launch_bounds__(256) void k_bk_fill(const rp_t* __restrict__ rowptr
   {
     const int64_t r = s * 64 + lane;
     const bool has = r < nnodes;
-    const int64_t p0 = has ? rowptr[3 * r] : 0, p1 = has ? rowptr[3 * r + 1] : 0, p2 = has ? rowptr[3 * r + 2] : 0;
+    const int64_t p0 = has ? rowptr[3 * r] : 0, p1 = has ? rowptr[3 * r + 1] : 0;
     const int nbk = has ? (int)((p1 - p0) / 3) : 0;
+    const int32_t* const pk = park + p0 / 9;
     const int c0 = c0s[s], nch = nchs[s];
     if (lane == 0)
       desc[s] = make_int2(c0, nch);
     int k = 0; // the lane's next block to look at
     bool ghost = false;
-    unsigned long long last_fp = 0ull;
-    unsigned last_code = 0;
     for (int j = 0; j < nch; ++j)
     {
       const int64_t c = (int64_t)c0 + j;
@@ -393,48 +415,23 @@ __global__ __launch_bounds__(256) void k_bk_fill(const rp_t* __restrict__ rowptr
       bool affine = true;
       for (int e = 0; e < BK_SLOTS; ++e)
       {
-        // the lane's next kept block
-        Blk9 B;
-        bool found = false;
+        // the lane's next kept block: its slot in the set was parked by k_bk_insert
+        int slot = -1;
         while (k < nbk)
         {
-          bk_load(vals, p0, p1, p2, k, B);
-          if (bk_nonzero(B))
-          {
-            found = true;
+          slot = pk[k];
+          if (slot >= 0)
             break;
-          }
           ++k;
         }
+        const bool found = k < nbk && slot >= 0;
         int col = INT_MAX;
         unsigned code = 0;
         if (found)
         {
           col = cols[p0 + 3 * k] / 3;
           ghost |= col >= n_owned;
-          const unsigned long long fp = bk_hash(B);
-          if (fp != last_fp)
-          {
-            unsigned h = (unsigned)(fp >> (64 - BK_HASH_BITS));
-            int probe = 0;
-            while (tag[h] != fp && probe < BK_HASH)
-            {
-              h = (h + 1) & (BK_HASH - 1);
-              ++probe;
-            }
-            last_fp = fp;
-            last_code = probe < BK_HASH ? (unsigned)slot_code[h] : 0u;
-            if (probe >= BK_HASH)
-              info[1] = 3;
-          }
-          code = last_code;
-          // the table's row must BE this block: two blocks with one fingerprint would otherwise share a code
-          bool same = true;
-#pragma unroll
-          for (int i = 0; i < 9; ++i)
-            same = same && tab[(int64_t)code * 9 + i] == B.b[i];
-          if (!same)
-            info[1] = 3;
+          code = (unsigned)slot_code[slot];
           ++k;
         }
         const bool any = __ballot(found) != 0ull;
@@ -823,6 +820,8 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
 // The block-row form of a freshly assembled matrix of block size 3 (called at the stream's first use, behind the dictionaries).
 // Declined (bk_on stays false, nothing else changes): another block size, sorted rows, more distinct blocks than the table
 // holds, columns beyond 16-bit codes, ZZZ_SELLP_BLK=0.
+// Set-up at C4 (1.33 M nodes): k_bk_insert 1.95 ms (the one walk over the values: lane per node, 1 080 B apart), k_bk_number
+// 0.37 ms, k_bk_fill 0.80 ms.
 int sellp_blk_build(zzz_ctx* ctx)
 {
   ctx->bk_on = false;
@@ -847,14 +846,16 @@ int sellp_blk_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bk_slot_code.alloc((size_t)BK_HASH));
   ZZZ_HIP(ctx, ctx->bk_tab.alloc((size_t)BK_CODE_MAX * 9));
   ZZZ_HIP(ctx, ctx->bk_gflag.alloc((size_t)nsl));
+  ZZZ_HIP(ctx, ctx->bk_hash_tag2.alloc((size_t)BK_HASH));
+  ZZZ_HIP(ctx, ctx->bk_park.alloc((size_t)(ctx->nnz / 9) + 1));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_hash_tag.p, 0, sizeof(unsigned long long) * BK_HASH, s));
+  ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_hash_tag2.p, 0, sizeof(unsigned long long) * BK_HASH, s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_hash_owner.p, 0xff, sizeof(unsigned long long) * BK_HASH, s));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bk_nch.p + nsl, 0, sizeof(int32_t), s)); // closes the scan
   const unsigned long long* vals = reinterpret_cast<const unsigned long long*>(ctx->vals.p);
   const unsigned grid = (unsigned)std::min<int64_t>((nsl + 3) / 4, 256 * 16);
-  hipLaunchKernelGGL(k_bk_count, dim3(grid), dim3(256), 0, s, ctx->rowptr.p, vals, nnodes, nsl, ctx->bk_nch.p, info.p);
   hipLaunchKernelGGL(k_bk_insert, dim3(grid), dim3(256), 0, s, ctx->rowptr.p, vals, nnodes, nsl, ctx->bk_hash_tag.p,
-                     ctx->bk_hash_owner.p, info.p, BK_CODE_MAX);
+                     ctx->bk_hash_tag2.p, ctx->bk_hash_owner.p, ctx->bk_park.p, ctx->bk_nch.p, info.p, BK_CODE_MAX);
   hipLaunchKernelGGL(k_bk_number, dim3(1), dim3(1024), 0, s, ctx->bk_hash_tag.p, ctx->bk_hash_owner.p, ctx->rowptr.p, vals,
                      ctx->bk_slot_code.p, reinterpret_cast<unsigned long long*>(ctx->bk_tab.p), info.p);
   {
@@ -902,9 +903,8 @@ int sellp_blk_build(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bk_flags.alloc((size_t)total + 1));
   ZZZ_HIP(ctx, ctx->bk_code.alloc((size_t)total * 1024));
   ZZZ_HIP(ctx, ctx->bk_ccode.alloc((size_t)total * 1024));
-  hipLaunchKernelGGL(k_bk_fill, dim3(grid), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, vals, nnodes, (int)ctx->n_owned, nsl,
-                     ctx->bk_c0.p, ctx->bk_nch.p, ctx->bk_hash_tag.p, ctx->bk_slot_code.p,
-                     reinterpret_cast<const unsigned long long*>(ctx->bk_tab.p), reinterpret_cast<int2*>(ctx->bk_desc.p), ctx->bk_meta.p,
+  hipLaunchKernelGGL(k_bk_fill, dim3(grid), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->bk_park.p, nnodes, (int)ctx->n_owned, nsl,
+                     ctx->bk_c0.p, ctx->bk_nch.p, ctx->bk_slot_code.p, reinterpret_cast<int2*>(ctx->bk_desc.p), ctx->bk_meta.p,
                      ctx->bk_flags.p, ctx->bk_code.p, ctx->bk_ccode.p, ctx->bk_gflag.p, info.p);
   ZZZ_HIP(ctx, hipGetLastError());
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));

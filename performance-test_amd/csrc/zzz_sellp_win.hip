@@ -19,7 +19,8 @@
 //     then a lane per row: per chunk of 8 entries two 16-B loads, eight LDS reads of x, eight of the dictionary, eight mul + add.
 //     Two vector-memory instructions per chunk instead of ten; y leaves through the row permutation.
 // Every entry of the pattern is kept (exact zeros too: 3-4 % at P3): the structure then depends on the PATTERN only and is
-// built once per zzz_csr_pattern_build's matrix; the value codes are refreshed at the first product after every assembly.
+// built once per zzz_csr_pattern_build's matrix; the value codes are refreshed after every assembly (sell_update; for a
+// partitioned matrix at the first product after it).
 //
 // When it applies: scalar matrices and those of block size 3 the block-row form declined (elasticity P2 / P3: their scalar rows
 // are long rows like any), natural row order of the stream, at least BW_MIN_AVG entries per row on average, every block
@@ -262,27 +263,42 @@ __device__ inline void bw_load8(const T* __restrict__ p, int k0, int len, T fill
 // 16-B pieces, no column is read again) turns them into window indices.  Everything the lookups need is in LDS:
 // set 64 KiB + slot -> index 32 KiB + sort buffer 32 KiB.  (Until round 6's last third: three walks over the columns by 4-B
 // loads, the slot -> index map in memory: 3.0 + 9.5 ms per pattern at 6.2 M rows of P3.)
+using BwSort = rocprim::block_radix_sort<int32_t, BW_THREADS, BW_WHASH / BW_THREADS, uint16_t>;
+// (out of line: inlined into k_bw_block the sort took hipcc 7.2's instruction selection down)
+__device__ __noinline__ void bw_sort_pairs(int32_t (&keys)[BW_WHASH / BW_THREADS], uint16_t (&slots)[BW_WHASH / BW_THREADS],
+                                           typename BwSort::storage_type& st, unsigned key_bits)
+{
+  BwSort().sort(keys, slots, st, 0, key_bits);
+}
 __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restrict__ order, int32_t nrows, int32_t nblk,
                                                          const rp_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                          const uint32_t* __restrict__ skey_all, int32_t* __restrict__ blk_wn,
                                                          const int64_t* __restrict__ chunk0, int32_t* __restrict__ perm,
                                                          int2* __restrict__ desc, int32_t* __restrict__ wlist,
                                                          uint16_t* __restrict__ ccode, uint8_t* __restrict__ gflag, int* __restrict__ info,
-                                                         uint32_t* __restrict__ cpack, uint8_t* __restrict__ cflag)
+                                                         uint32_t* __restrict__ cpack, uint8_t* __restrict__ cflag, int phases, int32_t ncols)
 {
-  __shared__ int32_t hcol[BW_WHASH];  // the set of columns (-1: empty)
-  __shared__ uint16_t hid[BW_WHASH];  // slot -> window index
-  __shared__ uint16_t sbuf[BW_WHASH]; // occupied slots, sorted by their column
+  // (phases: 4 = everything; the tools build stops a block after the first walk (1), the compaction (2), the sort (3) to time them)
+  __shared__ union
+  {
+    int32_t hcol[BW_WHASH]; // the set of columns (-1: empty)
+    typename BwSort::storage_type sort;
+  } u;
+  __shared__ uint16_t hid[BW_WHASH]; // slot -> window index
   __shared__ int32_t sl_c0[BW_SLICES + 1];
-  __shared__ int wsum[BW_THREADS / 64];
   __shared__ int n_win, any_ghost, bad, max_delta;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x;
+  // keys of the sort: the columns, and one value beyond them for the empty slots; key_bits = the bits that tell them apart
+  const int32_t pad_key = ncols;
+  int key_bits = 1;
+  while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)ncols)
+    ++key_bits;
   for (int b = blockIdx.x; b < nblk; b += gridDim.x)
   {
     const int r0 = b * BW_R, nb = min(BW_R, nrows - r0);
     const uint32_t* __restrict__ skey = skey_all + (int64_t)b * BW_R;
     for (int k = tid; k < BW_WHASH; k += BW_THREADS)
-      hcol[k] = -1;
+      u.hcol[k] = -1;
     if (tid == 0)
       n_win = 0, any_ghost = 0, bad = 0, max_delta = 0;
     if (tid < BW_SLICES)
@@ -305,6 +321,9 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
     __syncthreads();
     const int64_t cb = chunk0[b];
     // first walk: every column into the set, its slot parked in ccode
+    // (1.6 of the kernel's 2.9 ms at 6.2 M rows of P3.  Not the probes' LDS latency: a chunk's eight lookups side by side, one
+    // LDS round trip per probe round instead of one per entry, took 1.96 ms.  The rows of a block are neighbours in space, not
+    // in the CSR arrays: 4 096 separate segments of ~200 B per block, 0.7 TB/s.)
     for (int q = tid; q < BW_R; q += BW_THREADS)
     {
       const int p = (int)(skey[q] & 4095u);
@@ -333,10 +352,10 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
           unsigned h = ((unsigned)c[e] * 2654435761u) >> (32 - BW_WBITS);
           for (int probe = 0; probe < BW_WHASH; ++probe)
           {
-            int32_t cur = hcol[h];
+            int32_t cur = u.hcol[h];
             if (cur == -1)
             {
-              cur = atomicCAS(&hcol[h], -1, c[e]);
+              cur = atomicCAS(&u.hcol[h], -1, c[e]);
               if (cur == -1)
               {
                 if (atomicAdd(&n_win, 1) >= BW_WCAP)
@@ -372,66 +391,45 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_block(const int32_t* __restri
       __syncthreads();
       continue;
     }
-    // the occupied slots, compacted in slot order, then sorted by column
+    if (phases < 2)
+      continue;
+    // The window in ascending column order: every thread takes its sixteen slots of the set as (column, slot) pairs -- an empty
+    // slot's key is beyond every column --, the workgroup sorts the 16 384 pairs by key (rocPRIM's block radix sort, in the set's
+    // own LDS: the columns are in registers by then), and pair number i < n_win is window entry i.  (An indirect bitonic sort of
+    // the slot numbers through the set took 320 us per block, more than both walks: dependent LDS round trips per compare.)
     const int nw = n_win;
-    int SB = 1024; // (the next power of two: most P3 windows are below 8 192)
-    while (SB < nw)
-      SB <<= 1;
     {
       constexpr int PER = BW_WHASH / BW_THREADS;
-      int mine = 0;
-      for (int k = 0; k < PER; ++k)
-        mine += hcol[tid * PER + k] != -1 ? 1 : 0;
-      int incl = mine;
-      for (int d = 1; d < 64; d <<= 1)
-      {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d)
-          incl += t;
-      }
-      if (lane == 63)
-        wsum[wv] = incl;
-      __syncthreads();
-      int off = 0;
-      for (int q = 0; q < wv; ++q)
-        off += wsum[q];
-      int id = off + incl - mine;
+      int32_t keys[PER];
+      uint16_t slots[PER];
+#pragma unroll
       for (int k = 0; k < PER; ++k)
       {
         const int h = tid * PER + k;
-        if (hcol[h] != -1)
-          sbuf[id++] = (uint16_t)h;
+        const int32_t c = u.hcol[h];
+        keys[k] = c == -1 ? pad_key : c;
+        slots[k] = (uint16_t)h;
       }
-      for (int i = nw + tid; i < SB; i += BW_THREADS)
-        sbuf[i] = 0xffffu;
-    }
-    __syncthreads();
-    for (int k = 2; k <= SB; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1)
+      __syncthreads(); // (the set's LDS becomes the sort's)
+      if (phases < 3)
+        continue;
+      bw_sort_pairs(keys, slots, u.sort, (unsigned)key_bits);
+      if (phases < 4)
       {
-        for (int i = tid; i < SB; i += BW_THREADS)
-        {
-          const int l = i ^ j;
-          if (l > i)
-          {
-            const unsigned sa = sbuf[i], sc = sbuf[l];
-            const int32_t a = sa == 0xffffu ? INT_MAX : hcol[sa], c = sc == 0xffffu ? INT_MAX : hcol[sc];
-            const bool up = (i & k) == 0;
-            if ((a > c) == up)
-            {
-              sbuf[i] = (uint16_t)sc;
-              sbuf[l] = (uint16_t)sa;
-            }
-          }
-        }
         __syncthreads();
+        continue;
       }
-    const int64_t w0 = (int64_t)b * BW_WCAP;
-    for (int i = tid; i < nw; i += BW_THREADS)
-    {
-      const unsigned sl = sbuf[i];
-      wlist[w0 + i] = hcol[sl];
-      hid[sl] = (uint16_t)i;
+      const int64_t w0 = (int64_t)b * BW_WCAP;
+#pragma unroll
+      for (int k = 0; k < PER; ++k)
+      {
+        const int i = tid * PER + k;
+        if (i < nw)
+        {
+          wlist[w0 + i] = keys[k];
+          hid[slots[k]] = (uint16_t)i;
+        }
+      }
     }
     if (tid < BW_SLICES)
       desc[(int64_t)b * BW_SLICES + tid] = make_int2((int)(cb + sl_c0[tid]), sl_c0[tid + 1] - sl_c0[tid]);
@@ -1001,9 +999,14 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bw_cflag.alloc((size_t)nblk));
   ZZZ_HIP(ctx, ctx->bw_vflag.alloc((size_t)nblk));
   ZZZ_HIP(ctx, hipMemsetAsync(ctx->bw_cpack.p, 0, (size_t)tot[0] * 768, s));
+  int phases = 4;
+#ifdef ZZZ_EXPERIMENTS
+  if (const char* e = getenv("ZZZ_BW_PHASES")) // timing of the builder's phases (an incomplete structure: the form then declines)
+    phases = atoi(e);
+#endif
   hipLaunchKernelGGL(k_bw_block, dim3(grid), dim3(BW_THREADS), 0, s, ctx->bw_order.p, nrows, nblk, ctx->rowptr.p, ctx->cols.p,
                      ctx->bw_skey.p, ctx->bw_blk_wn.p, ctx->bw_chunk0.p, ctx->bw_perm.p, reinterpret_cast<int2*>(ctx->bw_desc.p),
-                     ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, ctx->bw_cpack.p, ctx->bw_cflag.p);
+                     ctx->bw_wlist.p, ctx->bw_ccode.p, ctx->bw_gflag.p, info.p, ctx->bw_cpack.p, ctx->bw_cflag.p, phases, (int32_t)ctx->nloc());
   ZZZ_HIP(ctx, hipGetLastError());
   ZZZ_HIP(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, s));
   ZZZ_HIP(ctx, hipStreamSynchronize(s));
@@ -1015,7 +1018,7 @@ static int bw_structure(zzz_ctx* ctx)
   if (getenv("ZZZ_DEBUG_SYNC"))
     fprintf(stderr, "[zzz dbg] bw_structure pass 2: flag %d ghost blocks %d window %lld max window %d bad blocks %d\n", h[0], h[1],
             (long long)tot[1], h[3], h[4]);
-  if (h[0] || tot[1] <= 0)
+  if (h[0] || tot[1] <= 0 || phases < 4)
     return ZZZ_OK; // declined: a block beyond the LDS budget
   // interior / boundary blocks for the halo-compute overlap of a partitioned matrix
   ctx->bw_n_interior = ctx->bw_n_boundary = 0;
@@ -1046,7 +1049,7 @@ static int bw_structure(zzz_ctx* ctx)
   return ZZZ_OK;
 }
 
-// Called at the stream's first use after an assembly (sellp_active).  Declined (bw_on stays false, nothing else changes): block
+// Called when the matrix is assembled (sell_update) or at the stream's first use after an assembly (sellp_active).  Declined (bw_on stays false, nothing else changes): block
 // size 3, short rows, sorted stream, a block beyond the LDS budget, ZZZ_SELLP_BWIN=0.
 int sellp_win_build(zzz_ctx* ctx)
 {
