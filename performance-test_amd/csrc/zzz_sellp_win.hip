@@ -731,20 +731,28 @@ __global__ __launch_bounds__(BW_THREADS) void spmv_win_kernel(const int32_t* __r
     const int64_t w0 = p_woff[b];
     const int wn = p_wn[b], dn = p_dnum[b];
     const bool cpk = __builtin_amdgcn_readfirstlane((int)p_cflag[b]) != 0, vpk = __builtin_amdgcn_readfirstlane((int)p_vflag[b]) != 0;
-    __syncthreads(); // the previous block's lookups are done
-    // window and dictionary into LDS: every thread's (at most eight + four) entries requested before any is stored
+    // window and dictionary into LDS: every thread's (at most eleven + eight) entries requested before any is stored, and before
+    // the barrier that waits for the previous block's lookups (the loads touch no LDS).
+    // (Loads at CLAMPED indices, not loads under a condition: `i < wn ? p[i] : 0` compiles to a branch per load with the wait
+    // for the load inside it -- eleven round trips one after the other for the window list, found in the disassembly in the
+    // last third of round 6; the entries beyond wn / dn are loaded twice and stored nowhere.  Worth nothing measurable: 0.2345-0.2398
+    // against 0.2338-0.2439 ms at 6.2 M rows of P3 -- those loads hit the L2.  Also measured there and dropped: the wavefront's four
+    // slices as ONE sequence of chunks, every request two unconditional 16-B loads so that the compiler's waits become
+    // vmcnt(4) / vmcnt(5) instead of vmcnt(0) and the look-ahead runs across slice ends and the window load: 0.2465 ms -- the
+    // cursors' scalar bookkeeping costs what the overlap gains; the kernel sits at the rate the memory system gives this mix.)
     {
       int32_t wc[BW_WCAP / BW_THREADS];
       double xv[BW_WCAP / BW_THREADS], dv[BW_DCAP / BW_THREADS];
 #pragma unroll
       for (int k = 0; k < BW_WCAP / BW_THREADS; ++k)
-        wc[k] = tid + k * BW_THREADS < wn ? p_wlist[w0 + tid + k * BW_THREADS] : 0;
+        wc[k] = p_wlist[w0 + min(tid + k * BW_THREADS, wn - 1)];
 #pragma unroll
       for (int k = 0; k < BW_DCAP / BW_THREADS; ++k)
-        dv[k] = tid + k * BW_THREADS < dn ? p_dict[(int64_t)b * BW_DCAP + tid + k * BW_THREADS] : 0.0;
+        dv[k] = p_dict[(int64_t)b * BW_DCAP + min(tid + k * BW_THREADS, dn - 1)];
 #pragma unroll
       for (int k = 0; k < BW_WCAP / BW_THREADS; ++k)
-        xv[k] = tid + k * BW_THREADS < wn ? p_x[wc[k]] : 0.0;
+        xv[k] = p_x[wc[k]];
+      __syncthreads(); // the previous block's lookups are done
 #pragma unroll
       for (int k = 0; k < BW_DCAP / BW_THREADS; ++k)
         if (tid + k * BW_THREADS < dn)
