@@ -1104,9 +1104,20 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restr
     Geom G;
     load_cell(x, v, p);
     geometry(p, G);
-    double acc = 0.0;
+    // (the cell's dofs, then the coefficient at them, as two rounds of loads side by side; as a loop over j it was ND dependent
+    // pairs of round trips)
+    int32_t cdv[ND];
+#pragma unroll
     for (int j = 0; j < ND; ++j)
-      acc += M_s[li * ND + j] * f[(int64_t)cd[j] * BS + c];
+      cdv[j] = cd[j];
+    double fv[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      fv[j] = f[(int64_t)cdv[j] * BS + c];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      acc += M_s[li * ND + j] * fv[j];
     sum += G.adet * acc;
     if (BS == 1)
     {
@@ -1130,7 +1141,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_vector_pk(const double* __restr
             const double scale = sqrt(cx * cx + cy * cy + cz * cz);
             double fa = 0.0;
             for (int j = 0; j < ND; ++j)
-              fa += F_s[(lf * ND + li) * ND + j] * gc[cd[j]]; // rows of dofs off the facet are zero
+              fa += F_s[(lf * ND + li) * ND + j] * gc[cdv[j]]; // rows of dofs off the facet are zero
             sum += scale * fa;
           }
       }
@@ -1377,26 +1388,33 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_matrix_pk_pos(const double* __r
       double g[NG];
       int pj[JM];
     };
+    // (Every load below is UNCONDITIONAL, at a clamped index: `in ? p[a] : -1` and `if (cell < 0) return` compiled to one branch
+    // per load with the wait for the load inside it -- a row's adjacency entry, geometry record and five positions were eight
+    // round trips one after the other per (row, cell) pair; found in the disassembly in the last third of round 6.  Beyond a
+    // row's last cell the walk loads cell 0 / the row's last position and uses neither.)
+    const int alast = max(adj.len - 1, 0), npairs = max(adj_off[i + 1] - adj_off[i], 1);
     auto adj_at = [&](int a, int& cell, int& li) {
-      const bool in = a < adj.len;
-      cell = in ? adj.cell(a) : -1;
-      li = in ? adj.li(a) : 0;
+      const int ac = min(a, alast);
+      const int cc = adj.cell(ac), ll = adj.li(ac);
+      cell = a < adj.len ? cc : -1;
+      li = a < adj.len ? ll : 0;
     };
     auto item_at = [&](int a, int cell, int li, Item& K) {
       K.cell = cell;
       K.li = li;
-      if (cell < 0)
-        return;
-      const double* __restrict__ gp = geom + (int64_t)cell * NG;
+      const double* __restrict__ gp = geom + (int64_t)max(cell, 0) * NG;
 #pragma unroll
       for (int t = 0; t < NG; ++t)
         K.g[t] = gp[t];
+      const uint16_t* __restrict__ pp = prow + min(a, npairs - 1) * ND;
 #pragma unroll
       for (int qq = 0; qq < JM; ++qq)
-        K.pj[qq] = lane + qq * LPR < ND ? prow[a * ND + lane + qq * LPR] : 0;
+        K.pj[qq] = pp[min(lane + qq * LPR, ND - 1)];
     };
     Item K0;
     int c1, l1;
+    K0.cell = -1;
+    if (adj.len > 0) // (a slice without cells has no adjacency entries to read)
     {
       int ca, la;
       adj_at(0, ca, la);

@@ -167,14 +167,27 @@ __device__ inline int row_unique_regs(const int32_t* __restrict__ cell_dofs, int
   int32_t x[NR];
 #pragma unroll
   for (int kk = 0; kk < NR; ++kk)
-  {
-    const int idx = kk * 64 + lane;
     x[kk] = INT_MAX;
-    if (idx < n)
+  if (n > 0) // (wave-uniform)
+  {
+    // the candidates in two rounds of UNCONDITIONAL loads at clamped indices -- all cells, then all dofs: `if (idx < n) x =
+    // dofs[cells[..]]` per register compiled to a branch per load with the wait inside it, up to sixteen round trips one after
+    // the other for a vertex row of P3 (disassembly, last third of round 6)
+    int32_t cv[NR];
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
+      cv[kk] = adj_cells[a0 + min(kk * 64 + lane, n - 1) / nd];
+    int32_t dv[NR];
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
     {
-      const int a = idx / nd, j = idx - a * nd;
-      x[kk] = cell_dofs[(int64_t)adj_cells[a0 + a] * nd + j];
+      const int idx = min(kk * 64 + lane, n - 1);
+      dv[kk] = cell_dofs[(int64_t)cv[kk] * nd + (idx - idx / nd * nd)];
     }
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
+      if (kk * 64 + lane < n)
+        x[kk] = dv[kk];
   }
   int32_t dmin = 0;
   if (POS)
