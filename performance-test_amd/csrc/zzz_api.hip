@@ -235,6 +235,8 @@ void zzz_ctx_destroy(zzz_ctx* ctx)
     (void)hipHostFree(ctx->adj_flag_host);
   if (ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
+  for (void* q : ctx->retired)
+    (void)hipFree(q);
   delete ctx;
 }
 

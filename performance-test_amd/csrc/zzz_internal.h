@@ -60,6 +60,29 @@ struct DevBuf
     }
     return alloc(count);
   }
+  // Scratch that may be asked for while ANOTHER context's kernel is waiting for this one (two ranks on one GPU: the other rank
+  // polls its all-reduce mailbox inside a kernel while this one still builds its product form): grows only, and a buffer that
+  // is too small is RETIRED -- handed to `retired`, freed with the context -- not freed: hipFree waits for every kernel on the
+  // device, i.e. for the poll's time-out (tools/r06/soak_new_forms.sh, elasticity P2 on two ranks: found in round 5 at the
+  // dictionaries' buffers, again in round 6 at the scans' scratch behind a pattern build's larger one).
+  hipError_t grow_keep(size_t count, std::vector<void*>& retired)
+  {
+    if (count == 0)
+      count = 1;
+    if (p && cap >= count)
+    {
+      n = count;
+      return hipSuccess;
+    }
+    if (p)
+      retired.push_back(p);
+    p = nullptr;
+    n = cap = 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess)
+      n = cap = count;
+    return e;
+  }
   hipError_t alloc(size_t count)
   {
     if (count == 0)
@@ -201,6 +224,7 @@ struct zzz_ctx
   int adj_runs_n = -1;
   int32_t* adj_flag_host = nullptr; // pinned: "a window did not fit" travels here behind the build's kernels
   zzz::DevBuf<unsigned char> scr_tmp;
+  std::vector<void*> retired; // device buffers replaced by larger ones while another context's kernel may be waiting (DevBuf::grow_keep)
   zzz::DevBuf<int32_t> adj_off, adj_cells; // owned block dof -> incident cells (ascending)
   zzz::DevBuf<int32_t> adjT_off, adjT_cells; // the same lists transposed in 64-row slices (dense wave reads)
   zzz::DevBuf<uint8_t> adj_li;             // local index of the dof in each of those cells, same layout

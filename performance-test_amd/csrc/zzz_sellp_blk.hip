@@ -861,7 +861,7 @@ int sellp_blk_build(zzz_ctx* ctx)
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->bk_nch.p, ctx->bk_c0.p, (int32_t)0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
-    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
     ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->bk_nch.p, ctx->bk_c0.p, (int32_t)0, (size_t)nsl + 1, rocprim::plus<int32_t>(), s));
   }
   ZZZ_HIP(ctx, hipGetLastError());

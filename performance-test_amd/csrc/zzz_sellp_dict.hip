@@ -493,7 +493,7 @@ int sp_sd_build(zzz_ctx* ctx)
     const auto even = rocprim::make_transform_iterator(ctx->sp_sd_info.p, Even2{}); // (tables start at even entries: 16-B aligned)
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, even, ctx->sp_sd_off.p, (int64_t)0, (size_t)nsl + 1, rocprim::plus<int64_t>(), s));
-    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
     ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, even, ctx->sp_sd_off.p, (int64_t)0, (size_t)nsl + 1, rocprim::plus<int64_t>(), s));
   }
   int64_t total = 0;

@@ -1101,7 +1101,7 @@ static int sp_build_sorted(zzz_ctx* ctx, int64_t* total_out, bool sorted = true)
   size_t tb = 0;
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->sp_nch.p, ctx->sp_chunk_off.p, 0, (size_t)nsl + 1,
                                        rocprim::plus<int32_t>(), s));
-  ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+  ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
   ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->sp_nch.p, ctx->sp_chunk_off.p, 0, (size_t)nsl + 1,
                                        rocprim::plus<int32_t>(), s));
   int32_t* tot = reinterpret_cast<int32_t*>(ctx->h_state + 4); // pinned scratch
@@ -1149,7 +1149,7 @@ static int sp_fill_sorted(zzz_ctx* ctx, int64_t total, bool sorted = true)
       size_t tb = 0;
       ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
                                            rocprim::plus<int64_t>(), s));
-      ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+      ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
       ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, padded, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
                                            rocprim::plus<int64_t>(), s));
       hipLaunchKernelGGL(k_sp_compact, dim3(grid_cap(nsl, 4, 8192)), dim3(256), 0, s, ctx->rowptr.p, ctx->cols.p, ctx->vals.p, nrows,
@@ -1210,7 +1210,7 @@ int sellp_capacity_rows(zzz_ctx* ctx)
   size_t tb = 0;
   ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->sp_crow.p, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
                                        rocprim::plus<int64_t>(), s));
-  ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+  ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
   ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->sp_crow.p, ctx->sp_crow.p, (int64_t)0, (size_t)nrows + 1,
                                        rocprim::plus<int64_t>(), s));
   ZZZ_HIP(ctx, hipGetLastError());

@@ -963,7 +963,7 @@ static int bw_structure(zzz_ctx* ctx)
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, val.p, ctx->bw_order.p, (size_t)nrows, 0, 30, s));
-    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
     ZZZ_HIP(ctx, rocprim::radix_sort_pairs(ctx->scr_tmp.p, tb, key.p, key2.p, val.p, ctx->bw_order.p, (size_t)nrows, 0, 30, s));
   }
   DevBuf<int32_t>& info = ctx->bw_info;
@@ -983,7 +983,7 @@ static int bw_structure(zzz_ctx* ctx)
   {
     size_t tb = 0;
     ZZZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
-    ZZZ_HIP(ctx, ctx->scr_tmp.alloc(tb));
+    ZZZ_HIP(ctx, ctx->scr_tmp.grow_keep(tb, ctx->retired));
     ZZZ_HIP(ctx, rocprim::exclusive_scan(ctx->scr_tmp.p, tb, ctx->bw_blk_chunks.p, ctx->bw_chunk0.p, (int64_t)0, (size_t)nblk + 1, rocprim::plus<int64_t>(), s));
   }
   ZZZ_HIP(ctx, hipGetLastError());
