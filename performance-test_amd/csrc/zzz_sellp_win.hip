@@ -103,7 +103,7 @@ __device__ inline unsigned bw_part1by2(unsigned a)
 
 // sum over the cells of their extent along each axis (max - min of the four vertices): out[6..8]; the mean is the axis' cell size
 __global__ __launch_bounds__(256) void k_bw_cellsize(const double* __restrict__ x, const int32_t* __restrict__ cell_verts, int64_t ncells,
-                                                     double* __restrict__ out)
+                                                     double* __restrict__ part)
 {
   __shared__ double sh[4];
   double e[3] = {0.0, 0.0, 0.0};
@@ -123,11 +123,26 @@ __global__ __launch_bounds__(256) void k_bw_cellsize(const double* __restrict__ 
       e[a] += hi - lo;
     }
   }
+  // per-workgroup partials, added in a FIXED order by k_bw_cellsum: an atomicAdd of doubles here made the mean cell size -- and
+  // with it the Morton keys of nodes on a key boundary, the rows' order inside their blocks and so the order in which a lane adds
+  // its dot-product terms -- depend on which workgroup came first: the product stayed bit-identical, but the CG history of a
+  // matrix in block-window form differed from run to run at rounding level (found by the early / late form test, elasticity P2)
   for (int a = 0; a < 3; ++a)
   {
     const double t = block_reduce_sum(e[a], sh);
     if (threadIdx.x == 0)
-      atomicAdd(&out[6 + a], t);
+      part[3 * blockIdx.x + a] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bw_cellsum(const double* __restrict__ part, int nparts, double* __restrict__ out)
+{
+  if (threadIdx.x < 3)
+  {
+    double t = 0.0;
+    for (int k = 0; k < nparts; ++k)
+      t += part[3 * k + threadIdx.x];
+    out[6 + threadIdx.x] = t;
   }
 }
 
@@ -948,7 +963,7 @@ static int bw_structure(zzz_ctx* ctx)
   DevBuf<int32_t>& val = ctx->bw_val;
   if (int rc = dof_coords_device(ctx, dofx, ctx->bw_first))
     return rc;
-  ZZZ_HIP(ctx, bbox.alloc(9));
+  ZZZ_HIP(ctx, bbox.alloc(16 + 3 * 2048)); // [0..5] box, [6..8] summed cell extents, [16..) the workgroups' partial sums of those
   ZZZ_HIP(ctx, hipMemsetAsync(bbox.p, 0, 9 * sizeof(double), s));
   ZZZ_HIP(ctx, key.alloc((size_t)nrows));
   ZZZ_HIP(ctx, key2.alloc((size_t)nrows));
@@ -956,8 +971,9 @@ static int bw_structure(zzz_ctx* ctx)
   ZZZ_HIP(ctx, ctx->bw_order.alloc((size_t)nrows));
   // (the nodes of a Lagrange space lie in the convex hull of their cells' vertices: the vertices' box will do, and they are few)
   hipLaunchKernelGGL(k_bw_bbox, dim3(1), dim3(1024), 0, s, ctx->x.p, ctx->nverts, bbox.p);
-  hipLaunchKernelGGL(k_bw_cellsize, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((ctx->ncells + 255) / 256, 2048))), dim3(256), 0, s,
-                     ctx->x.p, ctx->cell_verts.p, ctx->ncells, bbox.p);
+  const unsigned cs_grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ctx->ncells + 255) / 256, 2048));
+  hipLaunchKernelGGL(k_bw_cellsize, dim3(cs_grid), dim3(256), 0, s, ctx->x.p, ctx->cell_verts.p, ctx->ncells, bbox.p + 16);
+  hipLaunchKernelGGL(k_bw_cellsum, dim3(1), dim3(64), 0, s, bbox.p + 16, (int)cs_grid, bbox.p);
   hipLaunchKernelGGL(k_bw_keys, dim3((unsigned)std::min<int64_t>(((int64_t)nrows + 255) / 256, 4096)), dim3(256), 0, s, dofx.p, bbox.p,
                      ctx->ncells, nrows, ctx->bs, key.p, val.p);
   {

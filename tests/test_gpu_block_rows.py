@@ -329,3 +329,67 @@ def test_block_windows_serve_the_vector_valued_spaces_the_block_rows_decline(ord
         assert abs(a[k] - b[k]) <= 2, (k, a[k], b[k])
     for k in ("u", "us", "uc"):
         assert np.linalg.norm(a[k] - b[k]) <= 1e-9 * np.linalg.norm(b[k]), k
+
+
+@pytest.mark.parametrize("problem,order,dims,knobs", [("elasticity", 1, (20, 18, 22), dict(ZZZ_SELLP_BLK=2)),
+                                                       ("poisson", 3, (8, 7, 9), dict(ZZZ_SELLP_BWIN=2)),
+                                                       ("elasticity", 2, (6, 5, 6), dict(ZZZ_SELLP_BWIN=2))])
+def test_form_chosen_at_assembly_time_equals_form_chosen_at_the_first_product(problem, order, dims, knobs):
+    """Last third of round 6: an unpartitioned matrix gets its special form inside zzz_assemble and then no generic operator
+    stream at all (sell_update); ZZZ_SELLP_EARLY=0 packs the stream first and builds the form at the first product as before.
+    Same form, same product bit for bit (= the serial CSR loop), same solves; values uploaded afterwards take the same path;
+    the Chebyshev epilogue and the plain product API run on a matrix that has no generic stream."""
+    zo.set_num_threads(4)
+    P = zzz.Part(problem, order, *dims)
+    x = np.sin(0.41 * np.arange(P.n_owned * P.bs)) + 0.3
+    res = {}
+    for early in ("1", "0"):
+        with _Env(ZZZ_SELLP_EARLY=early, **knobs):
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                c.assemble_vector(P.form)
+                raw_before = c.spmv_info_raw()
+                y = c.spmv(x)
+                vi = c.spmv_values_info()
+                it, rn, r0 = c.cg_solve(pc=zzz.PC_JACOBI, rtol=1e-9)
+                u = c.vec_download(zzz.VEC_U)
+                itc, _, _ = c.cg_solve(pc=zzz.PC_CHEBYSHEV_JACOBI, rtol=1e-9)
+                uc = c.vec_download(zzz.VEC_U)
+                rp, cl, v = c.csr_download()
+                v2 = -2.5 * v
+                c.csr_upload_values(v2)
+                y2 = c.spmv(x)
+                vi2 = c.spmv_values_info()
+                res[early] = dict(y=y, vi=vi, it=it, u=u, itc=itc, uc=uc, y2=y2, vi2=vi2, entries=int(raw_before[7]))
+    a, b = res["1"], res["0"]
+    assert a["vi"]["special_form"] == b["vi"]["special_form"] != "", (a["vi"], b["vi"])
+    assert a["vi2"]["special_form"] == a["vi"]["special_form"]
+    assert a["entries"] == 0 and b["entries"] > 0  # (no generic stream was packed / one was)
+    np.testing.assert_array_equal(a["y"], zo.spmv(rp.astype(np.int64), cl, v, x))
+    np.testing.assert_array_equal(a["y"], b["y"])
+    np.testing.assert_array_equal(a["y2"], zo.spmv(rp.astype(np.int64), cl, v2, x))
+    np.testing.assert_array_equal(a["y2"], b["y2"])
+    assert a["it"] == b["it"] and a["itc"] == b["itc"]
+    np.testing.assert_array_equal(a["u"], b["u"])
+    np.testing.assert_array_equal(a["uc"], b["uc"])
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 1), (3, 2, 4), (12, 11, 13), (31, 17, 9)])
+def test_elasticity_p1_matrix_by_node_equals_matrix_by_row(dims):
+    """asm_matrix_p1_node3 (a thread per node: one geometry and one block-column search per (node, cell) pair) writes the values
+    asm_matrix_p1<3> (a thread per scalar row) writes, bit for bit, boundary rows and columns included (fem::assemble_matrix +
+    set_diagonal, src/elasticity_problem.cpp:199-213; against the oracle: the golden and medium-size cases of test_gpu_assembly.py
+    run the by-node kernel)."""
+    P = zzz.Part("elasticity", 1, *dims)
+    vals = {}
+    for k in ("1", "0"):
+        with _Env(ZZZ_ASM_NODE3=k):
+            with zzz.Context(0) as c:
+                c.upload_part(P)
+                c.pattern_build()
+                c.assemble_matrix(P.form)
+                vals[k] = c.csr_download()
+    for q in range(3):
+        np.testing.assert_array_equal(vals["1"][q], vals["0"][q])
