@@ -481,6 +481,7 @@ struct BlkArgs
   const int* stop_flag;
   int64_t nlist;
   int pstride, nn_is_rr;
+  int xprobe = 0; // (tools build: ZZZ_BK_XPROBE, a timing probe of a component-major x)
 };
 
 template <bool NT, typename T>
@@ -652,6 +653,19 @@ __global__ __launch_bounds__(BK_THREADS) void spmv_blk3_kernel(const int2* __res
           {
             const int col = base[e] + (affine ? lane : (int)bk_code16(q0, q1, e));
             const int off = col * 24;
+#ifdef ZZZ_EXPERIMENTS
+            if (a.xprobe) // timing probe (wrong results): x as three component planes, three dense 8-B loads per block
+            {
+              const int plane = a.nnodes * 8;
+              const auto w0 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, col * 8, 0, 0);
+              const auto w1 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, col * 8 + plane, 0, 0);
+              const auto w2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, col * 8 + 2 * plane, 0, 0);
+              x0[f] = __hiloint2double((int)w0[1], (int)w0[0]);
+              x1[f] = __hiloint2double((int)w1[1], (int)w1[0]);
+              x2[f] = __hiloint2double((int)w2[1], (int)w2[0]);
+              continue;
+            }
+#endif
             const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
             const auto u2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, off + 16, 0, 0);
             x0[f] = __hiloint2double((int)u[1], (int)u[0]);
@@ -994,6 +1008,9 @@ bool launch_sellp_blk(zzz_ctx* ctx, bool dot, bool nt, int grid, const double* x
   a.nlist = nlist;
   a.pstride = SPMV_PSTRIDE;
   a.nn_is_rr = nn_is_rr;
+#ifdef ZZZ_EXPERIMENTS
+  a.xprobe = ctx->timing_only && getenv("ZZZ_BK_XPROBE") ? atoi(getenv("ZZZ_BK_XPROBE")) : 0; // (inside zzz_spmv_time only)
+#endif
   const size_t lds = f1 ? (size_t)ctx->bk_entries * 72 : (size_t)ctx->bk_ndict * 8;
   const double* tabp = f1 ? ctx->bk_tab.p : ctx->bk_vdict.p;
 #define ZZZ_BK_GO3(DOT, SR, NT, FORM, CHEB, EPI)                                                                                   \
