@@ -1,7 +1,7 @@
 # block-row builders with one walk over the values (slots parked, 128-bit fingerprints): parity + timing at C4
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r06k
+O=$R/gpurun_out/r06k2
 mkdir -p $O
 cd $R
 timeout 1500 python3 -m pytest tests/test_gpu_block_rows.py tests/test_gpu_product.py tests/test_gpu_partitions.py -q -m gpu -x > $O/pytest.log 2>&1
