@@ -108,7 +108,9 @@ __device__ inline unsigned long long bk_hash2(const Blk9& B)
 // first owns the slot: a block with the same tag and another tag2 moves on), owner = the smallest (node << 10 | block) that carries
 // the pair (so that the table does not depend on which lane came first) --, the SLOT it landed in parked per block (park: -1 for a
 // zero block) for the fill pass, which then needs no value; chunks per slice = ceil(most kept blocks of a node / 16); the matrix's
-// block structure checked on the way.  (Until the last third of round 6: a count walk, an insert walk and a fill walk that hashed
+// block structure checked on the way.  (Staging a slice's contiguous run of values in LDS by dense loads, a wavefront per
+// workgroup, was measured: 1.89 against 1.95 ms at C4 -- the walk is not bound by its 1 080-B-strided loads; dropped.)
+// (Until the last third of round 6: a count walk, an insert walk and a fill walk that hashed
 // every block again and compared it with its table row: 0.9 + 1.7 + 1.75 ms at C4.)
 __global__ __launch_bounds__(256) void k_bk_insert(const rp_t* __restrict__ rowptr, const unsigned long long* __restrict__ vals,
                                                    int nnodes, int64_t nsl, unsigned long long* __restrict__ tag,
